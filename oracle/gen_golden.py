@@ -1,0 +1,162 @@
+"""Generate tests/golden/*.npz by running the REFERENCE ITSELF in this container.
+
+    python -m oracle.gen_golden            (needs /root/reference; see oracle/overlay.py)
+
+Every fixture stores inputs plus what the reference's own code produced for them:
+``medpy.graphcut.graph_from_voxels`` (generate.py:33-174) with the reference energy terms
+(energy_voxel.py) feeding the unmodified BK solver, then ``maxflow()`` and the
+``what_segment`` read-out of bin/medpy_graphcut_voxel.py:172-182.  The n-link weights are
+captured with a recording subclass of the reference ``GCGraph`` (the pattern of reference
+tests/graphcut_/energy_label.py:196-215) that also forwards to the real graph.
+
+The committed fixtures are what ``-m "not gpu"`` tests pin the oracle against and what the
+``-m gpu`` tests pin the HIP path against on the GPU box, where /root/reference is absent.
+TEST INFRASTRUCTURE ONLY.
+"""
+import os
+import sys
+
+import numpy as np
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+OUT = os.path.join(os.path.dirname(HERE), "tests", "golden")
+sys.path.insert(0, os.path.dirname(HERE))
+
+from oracle.overlay import import_reference_graphcut  # noqa: E402
+
+TERMS = ["difference_linear", "difference_exponential", "difference_division", "difference_power",
+         "maximum_linear", "maximum_exponential", "maximum_division", "maximum_power"]
+
+
+def run_reference(gc, fg, bg, term=None, image=None, sigma=None, spacing=False, prob=None, alpha=None):
+    """Returns dict(labels, flow, trcap, edges_i, edges_j, edges_w) from the reference pipeline."""
+    import medpy.graphcut.generate as gen
+    import medpy.graphcut.graph as graphmod
+
+    rec = {}
+
+    class Recorder(graphmod.GCGraph):
+        def set_nweight(self, a, b, w, wr):
+            graphmod.GCGraph.set_nweight(self, a, b, w, wr)
+            rec[(int(a), int(b))] = rec.get((int(a), int(b)), 0.0) + float(w)
+
+    orig = gen.GCGraph
+    gen.GCGraph = Recorder
+    try:
+        kw = {}
+        if term is not None:
+            fn = getattr(gc.energy_voxel, "boundary_" + term)
+            kw["boundary_term"] = fn
+            kw["boundary_term_args"] = (image, spacing) if term.endswith("linear") else (image, sigma, spacing)
+        if prob is not None:
+            kw["regional_term"] = gc.energy_voxel.regional_probability_map
+            kw["regional_term_args"] = (prob, alpha)
+        with np.errstate(all="ignore"):
+            g = gc.graph_from_voxels(fg, bg, **kw)
+    finally:
+        gen.GCGraph = orig
+    n = g.get_node_num()
+    trcap = np.array([g.get_trcap(i) for i in range(n)])
+    flow = g.maxflow()
+    labels = np.array([0 if g.termtype.SINK == g.what_segment(i) else 1 for i in range(n)], dtype=np.uint8)
+    keys = sorted(rec)
+    return {
+        "labels": labels.reshape(np.asarray(fg).shape),
+        "flow": np.float64(flow),
+        "trcap": trcap,
+        "edges_i": np.array([k[0] for k in keys], dtype=np.int64),
+        "edges_j": np.array([k[1] for k in keys], dtype=np.int64),
+        "edges_w": np.array([rec[k] for k in keys], dtype=np.float64),
+    }
+
+
+def pack(prefix, d, store):
+    for k, v in d.items():
+        store["%s/%s" % (prefix, k)] = v
+
+
+def main():
+    gc = import_reference_graphcut()
+    os.makedirs(OUT, exist_ok=True)
+
+    # ---- 1. the reference's own known-answer inputs (tests/graphcut_/cut.py:32-50,
+    #         tests/graphcut_/energy_voxel.py:55-66,110-149): inputs restated, outputs from the reference
+    store = {}
+    vol = np.asarray([[[1, 0, 1, 2, 3], [1, 0, 1, 4, 3], [0, 1, 1, 6, 4]]] * 2)
+    vfg = np.zeros(vol.shape, int); vfg[:, 2, 0] = 1
+    vbg = np.zeros(vol.shape, int); vbg[:, 0, 4] = 1
+    store["cut/image"], store["cut/fg"], store["cut/bg"] = vol, vfg, vbg
+    pack("cut", run_reference(gc, vfg, vbg, "difference_linear", vol), store)
+
+    img = np.asarray([[0, 0, 0, 0], [0, 0, 0, 0], [0, 0, 1, 1], [0, 0, 1, 1]], dtype=float)
+    grad = np.asarray([[0, 0, 0, 0], [0, 1, 1, 1], [0, 1, 0, 0], [0, 1, 0, 0]], dtype=float)
+    fg = np.zeros((4, 4), int); fg[3, 3] = 1
+    bg = np.zeros((4, 4), int); bg[0, 0] = 1
+    store["e2d/image"], store["e2d/gradient"], store["e2d/fg"], store["e2d/bg"] = img, grad, fg, bg
+    sig = {"exponential": 1.0, "division": 0.5, "power": 2.0, "linear": None}
+    for t in TERMS:
+        im = img if t.startswith("difference") else grad
+        pack("e2d/" + t, run_reference(gc, fg, bg, t, im, sig[t.split("_")[1]]), store)
+    pack("e2d/regional", run_reference(gc, fg, bg, prob=img / 2.0, alpha=1.0), store)
+
+    simg = np.zeros((5, 5)); simg[1:, 2] = 2
+    sfg = np.zeros((5, 5), bool); sfg[4, 2] = 1
+    sbg = np.zeros((5, 5), bool); sbg[0, 0] = sbg[0, 4] = 1
+    store["spacing/image"], store["spacing/fg"], store["spacing/bg"] = simg, sfg, sbg
+    pack("spacing", run_reference(gc, sfg, sbg, "difference_division", simg, 1.0, (1.0, 5.0)), store)
+    np.savez_compressed(os.path.join(OUT, "reference_kat.npz"), **store)
+
+    # ---- 2. seeded small volumes through all eight terms, several dtypes, spacing on/off, + regional
+    store = {}
+    rng = np.random.default_rng(1234)
+    cases = []
+    for idx, (shape, dtype) in enumerate([((5, 6, 7), np.float32), ((4, 9, 3), np.float64), ((6, 5, 8), np.uint16),
+                                          ((7, 1, 6), np.float32), ((3, 4, 5, 2), np.float64), ((9, 11), np.int16)]):
+        if np.issubdtype(dtype, np.floating):
+            image = (rng.normal(0, 20, shape) + 50 * (rng.random(shape) < 0.4)).astype(dtype)
+        elif dtype == np.uint16:
+            image = rng.integers(0, 6, shape).astype(dtype)
+        else:
+            image = rng.integers(-5, 6, shape).astype(dtype)
+        u = rng.random(shape)
+        fgm, bgm = u < 0.08, (u > 0.9)
+        spacing = False if idx % 2 == 0 else tuple(float(x) for x in rng.uniform(0.5, 3.0, len(shape)))
+        sigma = float(rng.uniform(0.5, 20.0))
+        name = "c%d" % idx
+        store[name + "/image"], store[name + "/fg"], store[name + "/bg"] = image, fgm, bgm
+        store[name + "/sigma"] = np.float64(sigma)
+        store[name + "/spacing"] = np.asarray(spacing if spacing else [], dtype=np.float64)
+        for t in TERMS:
+            pack("%s/%s" % (name, t), run_reference(gc, fgm, bgm, t, image, sigma, spacing), store)
+        cases.append(name)
+    # regional (+ boundary) with float32 and float64 maps; fg&bg overlap voxel to pin t-link merging (graph.h:416-425)
+    for idx, dtype in enumerate([np.float32, np.float64]):
+        shape = (5, 6, 4)
+        image = rng.normal(0, 10, shape).astype(np.float32)
+        prob = np.clip(rng.normal(0.5, 0.3, shape), 0, 1).astype(dtype)
+        fgm = rng.random(shape) < 0.1
+        bgm = rng.random(shape) < 0.1
+        fgm[0, 0, 0] = bgm[0, 0, 0] = True
+        name = "r%d" % idx
+        store[name + "/image"], store[name + "/fg"], store[name + "/bg"], store[name + "/prob"] = image, fgm, bgm, prob
+        store[name + "/sigma"], store[name + "/alpha"] = np.float64(7.5), np.float64(0.5)
+        pack(name + "/cut", run_reference(gc, fgm, bgm, "difference_exponential", image, 7.5, False, prob, 0.5), store)
+        pack(name + "/regional_only", run_reference(gc, fgm, bgm, prob=prob, alpha=0.5), store)
+    np.savez_compressed(os.path.join(OUT, "reference_small.npz"), **store)
+
+    # ---- 3. synthetic lattices of SURVEY 8(d) at small sizes: labels + flow from the reference pipeline
+    from medpy_amd import synthetic
+    store = {}
+    for gen_name, shape in [("sphere", (16, 16, 16)), ("sphere", (12, 20, 17)), ("hard", (16, 16, 16)), ("ties", (14, 14, 14))]:
+        s = getattr(synthetic, gen_name)(shape)
+        name = "%s_%s" % (gen_name, "x".join(map(str, shape)))
+        r = run_reference(gc, s["fg"], s["bg"], s["term"], s["image"], s["sigma"])
+        store[name + "/labels"], store[name + "/flow"] = np.packbits(r["labels"]), r["flow"]
+        store[name + "/shape"] = np.asarray(shape)
+    np.savez_compressed(os.path.join(OUT, "reference_synthetic.npz"), **store)
+    for f in sorted(os.listdir(OUT)):
+        print(f, os.path.getsize(os.path.join(OUT, f)))
+
+
+if __name__ == "__main__":
+    main()
