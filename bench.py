@@ -1,0 +1,160 @@
+#!/usr/bin/env python3
+"""bench.py -- Mvoxels/s of the voxel graph cut (build + solve) on MI355X.
+
+    python bench.py [--gpus N] [--steps K] [--warmup W] [--size 512]
+
+A "step" = one pass of the hot path over one synthetic volume: n-link/t-link construction
+(mgc_build) + max-flow solve (mgc_maxflow) with image and markers already resident in HBM and
+the label array left in HBM (SURVEY.md 8(d) "headline, device-resident").  Workload = the
+configuration BASELINE.json's metric is quoted on: 512^3 "sphere" volume, 6-connectivity,
+boundary_difference_exponential, sigma 15.
+
+Prints ONE JSON line (rank 0) with `roofline` (dominant kernel, HIP-event timed on the launch
+stream inside the library) and `cpu_baseline` (the reference's own BK solver, compiled in place
+as oracle/_ref, timed on a bounded sample on the host cores).
+
+N > 1: one process per GPU (torch.distributed launch contract), every rank cuts its own
+volume of the same size -- weak scaling over independent volumes; there is no data-path
+collective in that mode (the Z-slab split with RCCL halo exchange is not implemented yet, see
+DESIGN.md).
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+B_ALG_6CONN = 71.0  # algorithmic bytes per voxel, SURVEY.md 8(d): 4 + 2 + 2*(3*8 + 8) + 1
+HBM_PEAK_GBS = 8000.0  # /opt/skills/guides/MI355X_MICROARCH.md
+
+
+def cpu_baseline(sample_n):
+    """Reference BK (oracle/_ref, or the C restatement when it did not travel) on a bounded sample."""
+    from medpy_amd import synthetic
+    from oracle import bk, energy_numpy, pipeline
+    s = synthetic.sphere((sample_n,) * 3)
+    kind = bk.best_kind()
+    w = energy_numpy.boundary_weights(s["term"], s["image"], s["sigma"])  # NumPy part of the reference (not timed:
+    # the reference spends its build time in the per-edge insertion, which IS timed below)
+    best = None
+    for _ in range(2):
+        t0 = time.perf_counter()
+        g = pipeline.build_graph(s["fg"], s["bg"], weights=w, kind=kind)
+        t1 = time.perf_counter()
+        g.maxflow()
+        t2 = time.perf_counter()
+        del g
+        if best is None or (t2 - t0) < best[0]:
+            best = (t2 - t0, t1 - t0, t2 - t1)
+    n = sample_n ** 3
+    return {
+        "value": round(n / best[0] / 1e6, 4), "unit": "Mvoxels/s", "cores": 1,
+        "kind": "reference" if kind == "ref" else "port",
+        "sample": "%d^3 sphere volume, 6-conn, diff_exp sigma 15; bulk sum_edge build %.2fs + BK maxflow %.2fs, single thread "
+                  "(the reference is single-threaded), host has %d cores" % (sample_n, best[1], best[2], os.cpu_count()),
+    }
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=3)
+    ap.add_argument("--warmup", type=int, default=1)
+    ap.add_argument("--size", type=int, default=512)
+    ap.add_argument("--cpu-sample", type=int, default=160)
+    ap.add_argument("--no-cpu", action="store_true")
+    args = ap.parse_args()
+
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    dist = None
+    if world > 1:
+        import torch.distributed as dist  # plumbing only: rendezvous + barrier + max-reduce of the timing
+        dist.init_process_group("gloo", rank=rank, world_size=world)
+
+    from medpy_amd import _lib, synthetic
+    from medpy_amd.graphcut.graph import VoxelGraph
+
+    if _lib.device_count() < 1:
+        raise SystemExit("bench.py: no MI355X visible (the HIP path has no CPU fallback)")
+
+    n = args.size
+    shape = (n, n, n)
+    s = synthetic.sphere(shape, seed=rank)
+    g = VoxelGraph(shape, device=local_rank % max(_lib.device_count(), 1))
+    g._set_boundary("difference_exponential", s["image"], s["sigma"], False)  # H2D, outside the timed region
+    g._set_markers(s["fg"], s["bg"])
+
+    def step():
+        g._build()
+        return g.maxflow()
+
+    for _ in range(args.warmup):
+        step()
+    if dist:
+        dist.barrier()
+    t0 = time.perf_counter()
+    acc = {"build_ms": 0.0, "solve_ms": 0.0, "discharge_ms": 0.0, "relabel_ms": 0.0, "discharge_launches": 0,
+           "relabel_launches": 0, "discharge_tiles": 0, "relabel_tiles": 0, "global_relabels": 0, "phases": 0}
+    flow = 0.0
+    for _ in range(args.steps):
+        flow = step()  # synchronous: returns after the stream drained
+        st = g.stats()
+        for k in acc:
+            acc[k] += st[k]
+    elapsed = time.perf_counter() - t0
+    if dist:
+        import torch
+        t = torch.tensor([elapsed], dtype=torch.float64)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        dist.barrier()
+        elapsed = float(t[0])
+    labels = g.labels()
+    fg_fraction = float(labels.mean())
+
+    if rank == 0:
+        nvox = n ** 3
+        ms_per_step = elapsed / args.steps * 1e3
+        value = world * nvox / (elapsed / args.steps) / 1e6
+        # dominant kernel: k_discharge (tile region-discharge).  Units per launch = voxels of the tiles it visits.
+        launches = max(acc["discharge_launches"], 1)
+        avg_ms = acc["discharge_ms"] / launches
+        vox_per_launch = acc["discharge_tiles"] * 512.0 / launches
+        achieved = (B_ALG_6CONN * vox_per_launch) / (avg_ms * 1e-3) / 1e9 if avg_ms > 0 else 0.0
+        out = {
+            "metric": "Mvoxels/s graph-cut (build+solve), 512^3 6-conn; fraction of HBM roofline",
+            "value": round(value, 3), "unit": "Mvoxels/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+            "ms_per_step": round(ms_per_step, 3), "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+            "dtype": "f64", "data": "synthetic",
+            "config": {"workload": "%d^3 sphere volume (float32), 6-conn, boundary_difference_exponential sigma=15, "
+                                   "fg=inner ball, bg=6 faces" % n,
+                       "parallelism": "1 volume per GPU" if world > 1 else "single GPU",
+                       "fg_fraction": round(fg_fraction, 5), "flow": flow},
+            "phases_ms": {"build": round(acc["build_ms"] / args.steps, 3), "solve": round(acc["solve_ms"] / args.steps, 3),
+                          "discharge_kernels": round(acc["discharge_ms"] / args.steps, 3),
+                          "relabel_kernels": round(acc["relabel_ms"] / args.steps, 3),
+                          "global_relabels": acc["global_relabels"] / args.steps, "colour_phases": acc["phases"] / args.steps,
+                          "tile_discharges": acc["discharge_tiles"] / args.steps, "tile_relabels": acc["relabel_tiles"] / args.steps},
+            "job_roofline_frac": round(value * 1e6 / world * B_ALG_6CONN / (HBM_PEAK_GBS * 1e9), 6),
+            "roofline": {"bound": "hbm", "kernel": "k_discharge", "achieved": round(achieved, 2), "peak": HBM_PEAK_GBS,
+                         "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBS, 5), "traffic": None,
+                         "avg_launch_ms": round(avg_ms, 4), "launches_per_step": launches / args.steps,
+                         "voxels_per_launch": round(vox_per_launch, 1), "bytes_per_voxel": B_ALG_6CONN},
+        }
+        if not args.no_cpu and world == 1:
+            out["cpu_baseline"] = cpu_baseline(args.cpu_sample)
+        elif not args.no_cpu:
+            out["cpu_baseline"] = None
+        print(json.dumps(out))
+    if dist:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

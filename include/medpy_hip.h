@@ -1,0 +1,136 @@
+/*
+ * medpy_hip.h -- C ABI of libmedpyhip.so: MI355X (gfx950) voxel graph-cut.
+ *
+ * This is the drop-in boundary for the hot path
+ *     medpy.graphcut.graph_from_voxels  (reference medpy/graphcut/generate.py:33-174)
+ *   + medpy.graphcut.energy_voxel.*     (reference medpy/graphcut/energy_voxel.py:33-664)
+ *   + maxflow.GraphDouble               (reference lib/maxflow/src/wrapper.cpp:59-89 binding of
+ *                                        lib/maxflow/src/graph.h / maxflow.cpp)
+ * Plain C types only; a handle owns all device memory; every entry point returns an
+ * status code (never exit()s, unlike graph.cpp:22,71,95).  The Python host layer
+ * (medpy_amd/graphcut) binds these with ctypes and presents the reference's API;
+ * INTEGRATION.md shows the binding a MedPy maintainer would add.
+ *
+ * Node ids are C-order flat indices of the logical array shape, as in the reference
+ * (energy_voxel.py:667-677, generate.py:170-172).  All host arrays handed over must be
+ * C-contiguous; they are copied into HBM inside the call and may be freed on return.
+ */
+#ifndef MEDPY_HIP_H
+#define MEDPY_HIP_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef struct mgc_graph* mgc_handle;
+
+typedef enum mgc_status {
+    MGC_OK = 0,
+    MGC_ERR_INVALID = 1,     /* bad argument (shape, dtype, id out of range ...)          */
+    MGC_ERR_NO_DEVICE = 2,   /* no usable gfx950 device: the library never falls back     */
+    MGC_ERR_HIP = 3,         /* a HIP runtime call failed; see mgc_last_error             */
+    MGC_ERR_OOM = 4,
+    MGC_ERR_STATE = 5,       /* call order violated (e.g. maxflow before build)           */
+    MGC_ERR_UNSUPPORTED = 6, /* valid request outside the implemented path                */
+    MGC_ERR_NOT_CONVERGED = 7
+} mgc_status;
+
+/* boundary terms, reference energy_voxel.py:68-516 */
+typedef enum mgc_term {
+    MGC_TERM_NONE = 0,
+    MGC_TERM_DIFFERENCE_LINEAR = 1,      /* energy_voxel.py:117-191 */
+    MGC_TERM_DIFFERENCE_EXPONENTIAL = 2, /* energy_voxel.py:241-302 */
+    MGC_TERM_DIFFERENCE_DIVISION = 3,    /* energy_voxel.py:350-409 */
+    MGC_TERM_DIFFERENCE_POWER = 4,       /* energy_voxel.py:455-516 */
+    MGC_TERM_MAXIMUM_LINEAR = 5,         /* energy_voxel.py:68-114  */
+    MGC_TERM_MAXIMUM_EXPONENTIAL = 6,    /* energy_voxel.py:194-238 */
+    MGC_TERM_MAXIMUM_DIVISION = 7,       /* energy_voxel.py:305-347 (uses the difference skeleton, :347) */
+    MGC_TERM_MAXIMUM_POWER = 8           /* energy_voxel.py:412-452 */
+} mgc_term;
+
+typedef enum mgc_dtype {
+    MGC_U8 = 0, MGC_I8 = 1, MGC_U16 = 2, MGC_I16 = 3, MGC_U32 = 4, MGC_I32 = 5,
+    MGC_U64 = 6, MGC_I64 = 7, MGC_F32 = 8, MGC_F64 = 9
+} mgc_dtype;
+
+/* termtype of the reference, lib/maxflow/src/graph.h:57-61 */
+enum { MGC_SOURCE = 0, MGC_SINK = 1 };
+
+typedef struct mgc_stats {
+    double  build_ms;          /* device time of the last mgc_build                        */
+    double  solve_ms;          /* device time of the last mgc_maxflow                      */
+    double  discharge_ms;      /* ... of which tile-discharge kernels (HIP events)         */
+    double  relabel_ms;        /* ... of which global-relabel kernels                      */
+    int64_t discharge_launches;
+    int64_t relabel_launches;
+    int64_t discharge_tiles;   /* tile discharges executed                                 */
+    int64_t relabel_tiles;     /* tile relabels executed                                   */
+    int64_t global_relabels;
+    int64_t phases;
+    int64_t ntiles;
+    int64_t nvox;
+    int64_t device_bytes;      /* HBM held by the handle                                   */
+    int64_t reserved[3];
+} mgc_stats;
+
+/* number of usable devices (0 => every other call fails with MGC_ERR_NO_DEVICE) */
+int mgc_device_count(int* count);
+
+/* Replaces GCGraph.__init__ -> GraphDouble(nodes, edges) + add_node (graph.py:294-308,
+ * graph.cpp:12-31).  ndim 1..3; connectivity must be 2*ndim (the only neighbourhood the
+ * reference supports, generate.py:44-49). */
+int mgc_create(int ndim, const int64_t* shape, int connectivity, int device, mgc_handle* out);
+int mgc_destroy(mgc_handle h);
+const char* mgc_last_error(mgc_handle h); /* h may be NULL: error of the last failed mgc_create */
+
+/* Replaces boundary_<term>(graph, (image, sigma, spacing)) -> __skeleton_base
+ * (energy_voxel.py:611-664).  `image` has the handle's shape.  p0: sigma for
+ * exponential/division/power (for exponential pass sigma; the library squares it the way
+ * math.pow does), unused for linear (the intensity range is reduced on the device).
+ * spacing: ndim doubles or NULL (False). */
+int mgc_set_boundary(mgc_handle h, int term, const void* image, int dtype, double sigma, const double* spacing);
+
+/* Replaces regional_probability_map(graph, (probability_map, alpha)) (energy_voxel.py:33-65)
+ * -> set_tweights_all (graph.py:551-552).  dtype MGC_F32 or MGC_F64: products are evaluated in
+ * that dtype, as NumPy does for the reference. */
+int mgc_set_regional_probability(mgc_handle h, const void* probability_map, int dtype, double alpha);
+
+/* Replaces set_source_nodes / set_sink_nodes over marker masks (generate.py:169-172,
+ * graph.py:310-380): nonzero fg -> add_tweights(i, 65535, 0), nonzero bg -> add_tweights(i, 0, 65535). */
+int mgc_set_markers(mgc_handle h, const uint8_t* fg, const uint8_t* bg);
+
+/* Plug-in path (user supplied energy callables drive GCGraph.set_nweight / set_tweight,
+ * graph.py:382-440, 466-498).  Edges must join lattice neighbours; capacities accumulate like
+ * sum_edge (graph.h:457-480).  t-weights: tr[n] = merged residual per node, flow_const = the
+ * part add_tweights folds into the flow (graph.h:416-425); applied before the markers. */
+int mgc_add_edges(mgc_handle h, int64_t n, const int64_t* i, const int64_t* j, const double* cap, const double* rev);
+int mgc_set_tweights_merged(mgc_handle h, const double* tr, double flow_const);
+
+/* Runs the n-link / t-link kernels: the residual graph is now resident in HBM. */
+int mgc_build(mgc_handle h);
+
+/* Energy read-back for parity tests: axis weights in the layout of
+ * `neighbourhood_intensity_term` (energy_voxel.py:644-658); tr_cap per node (Graph::get_trcap). */
+int mgc_get_nweights(mgc_handle h, int axis, double* out);
+int mgc_get_tweights(mgc_handle h, double* out);
+int mgc_get_edge(mgc_handle h, int64_t i, int64_t j, double* out); /* Graph::get_edge, graph.h:482-498 */
+
+/* Replaces GraphDouble.maxflow() (maxflow.cpp:472-604).  flow = capacity of the minimum cut
+ * found (equals the reference's return value up to summation order, ~1e-12 relative). */
+int mgc_maxflow(mgc_handle h, double* flow);
+
+/* Replaces the per-voxel what_segment loop of bin/medpy_graphcut_voxel.py:177-181:
+ * out[i] = 0 if SINK == what_segment(i) else 1. */
+int mgc_labels(mgc_handle h, uint8_t* out);
+int mgc_what_segment(mgc_handle h, int64_t i, int* segment); /* Graph::what_segment, graph.h:561-571 */
+
+int mgc_get_node_num(mgc_handle h, int64_t* n);
+int mgc_set_param(mgc_handle h, const char* name, int64_t value); /* solver schedule knobs, see DESIGN.md */
+int mgc_get_stats(mgc_handle h, mgc_stats* out);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* MEDPY_HIP_H */

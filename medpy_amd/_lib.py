@@ -1,0 +1,103 @@
+"""ctypes binding of libmedpyhip.so (C ABI: include/medpy_hip.h).
+
+There is no CPU fallback: if the HIP library is missing or no MI355X is visible, calls raise.
+"""
+import ctypes as C
+import os
+
+import numpy as np
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "libmedpyhip.so")
+
+OK, ERR_INVALID, ERR_NO_DEVICE, ERR_HIP, ERR_OOM, ERR_STATE, ERR_UNSUPPORTED, ERR_NOT_CONVERGED = range(8)
+
+TERM_IDS = {
+    "none": 0,
+    "difference_linear": 1, "difference_exponential": 2, "difference_division": 3, "difference_power": 4,
+    "maximum_linear": 5, "maximum_exponential": 6, "maximum_division": 7, "maximum_power": 8,
+}
+
+DTYPE_IDS = {
+    np.dtype(np.uint8): 0, np.dtype(np.int8): 1, np.dtype(np.uint16): 2, np.dtype(np.int16): 3,
+    np.dtype(np.uint32): 4, np.dtype(np.int32): 5, np.dtype(np.uint64): 6, np.dtype(np.int64): 7,
+    np.dtype(np.float32): 8, np.dtype(np.float64): 9,
+}
+
+
+class Stats(C.Structure):
+    _fields_ = [
+        ("build_ms", C.c_double), ("solve_ms", C.c_double), ("discharge_ms", C.c_double), ("relabel_ms", C.c_double),
+        ("discharge_launches", C.c_int64), ("relabel_launches", C.c_int64), ("discharge_tiles", C.c_int64),
+        ("relabel_tiles", C.c_int64), ("global_relabels", C.c_int64), ("phases", C.c_int64), ("ntiles", C.c_int64),
+        ("nvox", C.c_int64), ("device_bytes", C.c_int64), ("reserved", C.c_int64 * 3),
+    ]
+
+    def as_dict(self):
+        return {k: getattr(self, k) for k, _ in self._fields_ if k != "reserved"}
+
+
+# every symbol include/medpy_hip.h declares: (restype, argtypes)
+_VP, _I64, _DBL, _INT = C.c_void_p, C.c_int64, C.c_double, C.c_int
+SIGNATURES = {
+    "mgc_device_count": (_INT, [C.POINTER(_INT)]),
+    "mgc_create": (_INT, [_INT, C.POINTER(_I64), _INT, _INT, C.POINTER(_VP)]),
+    "mgc_destroy": (_INT, [_VP]),
+    "mgc_last_error": (C.c_char_p, [_VP]),
+    "mgc_set_boundary": (_INT, [_VP, _INT, _VP, _INT, _DBL, C.POINTER(_DBL)]),
+    "mgc_set_regional_probability": (_INT, [_VP, _VP, _INT, _DBL]),
+    "mgc_set_markers": (_INT, [_VP, _VP, _VP]),
+    "mgc_add_edges": (_INT, [_VP, _I64, _VP, _VP, _VP, _VP]),
+    "mgc_set_tweights_merged": (_INT, [_VP, _VP, _DBL]),
+    "mgc_build": (_INT, [_VP]),
+    "mgc_get_nweights": (_INT, [_VP, _INT, _VP]),
+    "mgc_get_tweights": (_INT, [_VP, _VP]),
+    "mgc_get_edge": (_INT, [_VP, _I64, _I64, C.POINTER(_DBL)]),
+    "mgc_maxflow": (_INT, [_VP, C.POINTER(_DBL)]),
+    "mgc_labels": (_INT, [_VP, _VP]),
+    "mgc_what_segment": (_INT, [_VP, _I64, C.POINTER(_INT)]),
+    "mgc_get_node_num": (_INT, [_VP, C.POINTER(_I64)]),
+    "mgc_set_param": (_INT, [_VP, C.c_char_p, _I64]),
+    "mgc_get_stats": (_INT, [_VP, C.POINTER(Stats)]),
+}
+
+_lib = None
+
+
+class MedpyHipError(RuntimeError):
+    def __init__(self, code, message):
+        RuntimeError.__init__(self, "libmedpyhip error %d: %s" % (code, message))
+        self.code = code
+
+
+def load():
+    """Load the HIP library; raises ImportError with the build recipe when it is not there."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(LIB_PATH):
+        raise ImportError(
+            "medpy_amd: %s not found. Build it with `python -c 'import __graft_entry__ as g; g.build()'` "
+            "(hipcc --offload-arch=gfx950). There is no CPU fallback." % LIB_PATH)
+    lib = C.CDLL(LIB_PATH)
+    for name, (res, args) in SIGNATURES.items():
+        f = getattr(lib, name)
+        f.restype, f.argtypes = res, args
+    _lib = lib
+    return lib
+
+
+def device_count():
+    n = C.c_int(0)
+    load().mgc_device_count(C.byref(n))
+    return n.value
+
+
+def check(handle, rc):
+    if rc != OK:
+        msg = load().mgc_last_error(handle)
+        raise MedpyHipError(rc, (msg or b"").decode("utf-8", "replace"))
+
+
+def ptr(a):
+    return C.c_void_p(a.ctypes.data)

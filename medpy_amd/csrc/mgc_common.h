@@ -1,0 +1,114 @@
+/*
+ * mgc_common.h -- lattice layout shared by the HIP kernels, the host driver and the
+ * host-side simulator used by the CPU tests (tests/hostsim).
+ *
+ * The reference keeps an explicit adjacency-list graph (lib/maxflow/src/graph.h:290-315:
+ * 48 B per node + 2 x 32 B per edge = 240 B/voxel at 6-connectivity).  Here the voxel
+ * lattice is implicit: per voxel six residual capacities (f64), excess, residual sink
+ * capacity and a distance label, stored TILE-MAJOR: the volume is cut into 8x8x8 tiles and
+ * every per-voxel field of one tile is contiguous (512 elements), so a workgroup loads its
+ * whole tile with perfectly coalesced 4 KiB streams and keeps it in registers/LDS for many
+ * push/relabel sweeps.
+ *
+ * Axis naming: the logical array has shape (D0, D1, D2) in C order (D2 fastest), node id =
+ * (i0*D1 + i1)*D2 + i2 as the reference numbers voxels (energy_voxel.py:667-677).
+ * Internally x = axis 2, y = axis 1, z = axis 0.
+ */
+#ifndef MGC_COMMON_H
+#define MGC_COMMON_H
+
+#include <stdint.h>
+
+#if defined(__HIPCC__)
+#define MGC_HD __host__ __device__ __forceinline__
+#else
+#define MGC_HD inline
+#endif
+
+#define MGC_T 8                 /* tile edge                              */
+#define MGC_TV 512              /* voxels per tile                        */
+#define MGC_TF 64               /* voxels per tile face                   */
+#define MGC_HINF 0x3f3f3f3f     /* "cannot reach the sink"; memset-able   */
+
+/* direction d: 0 = -x, 1 = +x, 2 = -y, 3 = +y, 4 = -z, 5 = +z ; opposite = d ^ 1 ; axis = d >> 1 */
+#define MGC_NDIR 6
+#define MGC_MASK_SINK 0x40      /* rmask bit 6: residual capacity to the sink > 0 */
+
+struct MgcLattice {
+    /* logical volume */
+    int64_t dz, dy, dx;       /* D0, D1, D2                                         */
+    int64_t nvox;
+    /* tile grid */
+    int gz, gy, gx;           /* ceil(D / 8)                                        */
+    int ntiles;
+    /* per-tile state, tile-major */
+    double*   rcap;           /* [ntiles][6][512] residual n-link capacities        */
+    double*   cap0;           /* [ntiles][6][512] capacities as built (cut value, getters) */
+    double*   excess;         /* [ntiles][512]                                      */
+    double*   sink;           /* [ntiles][512] residual capacity voxel -> sink      */
+    int32_t*  height;         /* [ntiles][512] distance label, MGC_HINF = unreachable */
+    uint8_t*  rmask;          /* [ntiles][512] bit d: rcap[d] > 0 ; bit 6: sink > 0 */
+    double*   obox;           /* [ntiles][6][64] flow pushed across face f, not yet absorbed by the neighbour */
+    uint32_t* oflags;         /* [ntiles] bit f: obox[f] holds something            */
+    /* work lists: [0],[1] = discharge lists of colour 0 / 1 being consumed; [2],[3] = being produced;
+       [4],[5] = relabel list consumed / produced */
+    int32_t*  list[6];
+    int32_t*  count;          /* [8] list lengths (device resident)                 */
+    uint32_t* stamp;          /* [ntiles] de-duplication stamp for list appends (discharge) */
+    uint32_t* rstamp;         /* [ntiles] same for the relabel lists                */
+    uint32_t* status;         /* [ntiles] bit0: tile holds excess that can still reach the sink */
+};
+
+MGC_HD int mgc_tile_id(const MgcLattice& L, int tz, int ty, int tx) { return (tz * L.gy + ty) * L.gx + tx; }
+
+MGC_HD void mgc_tile_coords(const MgcLattice& L, int tile, int& tz, int& ty, int& tx)
+{
+    tx = tile % L.gx;
+    int r = tile / L.gx;
+    ty = r % L.gy;
+    tz = r / L.gy;
+}
+
+/* neighbour tile across face f, or -1 outside the grid */
+MGC_HD int mgc_tile_nbr(const MgcLattice& L, int tz, int ty, int tx, int f)
+{
+    switch (f) {
+    case 0: return tx > 0 ? mgc_tile_id(L, tz, ty, tx - 1) : -1;
+    case 1: return tx + 1 < L.gx ? mgc_tile_id(L, tz, ty, tx + 1) : -1;
+    case 2: return ty > 0 ? mgc_tile_id(L, tz, ty - 1, tx) : -1;
+    case 3: return ty + 1 < L.gy ? mgc_tile_id(L, tz, ty + 1, tx) : -1;
+    case 4: return tz > 0 ? mgc_tile_id(L, tz - 1, ty, tx) : -1;
+    default: return tz + 1 < L.gz ? mgc_tile_id(L, tz + 1, ty, tx) : -1;
+    }
+}
+
+MGC_HD int mgc_tile_colour(int tz, int ty, int tx) { return (tz + ty + tx) & 1; }
+
+/* local voxel index inside a tile */
+MGC_HD int mgc_local(int z, int y, int x) { return (z * MGC_T + y) * MGC_T + x; }
+
+/* index of local voxel (z,y,x) on the face normal to axis a (a = 0:x, 1:y, 2:z) */
+MGC_HD int mgc_face_index(int a, int z, int y, int x)
+{
+    return a == 0 ? (z * MGC_T + y) : (a == 1 ? (z * MGC_T + x) : (y * MGC_T + x));
+}
+
+/* local index of the k-th voxel of the face of direction f (the layer touching that face) */
+MGC_HD int mgc_face_voxel(int f, int k)
+{
+    const int a = f >> 1, u = k >> 3, v = k & 7, w = (f & 1) ? (MGC_T - 1) : 0;
+    return a == 0 ? mgc_local(u, v, w) : (a == 1 ? mgc_local(u, w, v) : mgc_local(w, u, v));
+}
+
+/* C-order node id -> (tile, local) and back */
+MGC_HD void mgc_node_to_tile(const MgcLattice& L, int64_t id, int& tile, int& loc)
+{
+    const int64_t x = id % L.dx;
+    const int64_t r = id / L.dx;
+    const int64_t y = r % L.dy;
+    const int64_t z = r / L.dy;
+    tile = mgc_tile_id(L, (int)(z >> 3), (int)(y >> 3), (int)(x >> 3));
+    loc = mgc_local((int)(z & 7), (int)(y & 7), (int)(x & 7));
+}
+
+#endif /* MGC_COMMON_H */

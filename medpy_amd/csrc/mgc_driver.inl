@@ -1,0 +1,112 @@
+/*
+ * mgc_driver.inl -- host-side orchestration of the lattice max-flow solve, written against a
+ * "device policy" so the HIP backend (mgc_kernels.hip: one kernel launch per call) and the
+ * host simulator of the CPU test tier (tests/hostsim) run the same schedule.
+ *
+ * Replaces (reference): the serial main loop of Graph::maxflow, lib/maxflow/src/maxflow.cpp:472-604.
+ *
+ * Schedule
+ *   outer:  absorb in-flight outboxes -> GLOBAL RELABEL (tile BFS passes to a fixpoint: exact
+ *           distance-to-sink labels, MGC_HINF = cannot reach the sink) -> collect tiles that hold
+ *           excess able to reach the sink; none => the preflow is maximum and the labels ARE the cut.
+ *   inner:  `rounds` rounds of two colour phases.  Tiles are 3-D checkerboard coloured, so the six
+ *           face neighbours of a discharging tile are idle: region discharge is race-free and
+ *           bit-reproducible without atomics on the flow data.
+ *
+ * Dev concept (every call is asynchronous on the device's stream unless it returns a value):
+ *   fill_heights_inf()  zero_count(i)  read_counts(int out[8])   absorb_all()
+ *   relabel_all(epoch, next_list)  relabel_list(list, epoch, next_list)
+ *   activate_all(phase)  discharge(list, phase, max_cycles, max_sweeps)
+ */
+#ifndef MGC_DRIVER_INL
+#define MGC_DRIVER_INL
+
+#include "mgc_common.h"
+
+struct MgcSolveParams {
+    int rounds_per_relabel; /* colour-phase rounds between two global relabels            */
+    int max_cycles;         /* label/push cycles per tile discharge                       */
+    int max_sweeps;         /* push sweeps per cycle                                      */
+    int max_outer;          /* safety cap on global relabels                              */
+};
+
+struct MgcSolveStats {
+    int64_t outer;            /* global relabels performed                                 */
+    int64_t relabel_passes;   /* tile-BFS passes over a work list                          */
+    int64_t relabel_tiles;    /* tiles visited by those passes                             */
+    int64_t phases;           /* colour phases launched                                    */
+    int64_t discharge_tiles;  /* tile discharges                                           */
+    int64_t converged;        /* 1 when the preflow is maximum                             */
+    int64_t last_active;      /* active tiles found by the last activation pass            */
+    int64_t reserved;
+};
+
+static inline MgcSolveParams mgc_default_params()
+{
+    MgcSolveParams p;
+    p.rounds_per_relabel = 8;
+    p.max_cycles = 8;
+    p.max_sweeps = 32;
+    p.max_outer = 100000;
+    return p;
+}
+
+template <class Dev>
+int mgc_solve(Dev& dev, const MgcLattice& L, const MgcSolveParams& P, MgcSolveStats& st)
+{
+    uint32_t phase = 4; /* stamps start at 0 */
+    uint32_t rep = 2;   /* relabel epoch     */
+    int cnt[8];
+    st = MgcSolveStats();
+
+    for (int outer = 0; outer < P.max_outer; ++outer) {
+        /* ---- global relabel ---- */
+        dev.absorb_all();
+        dev.fill_heights_inf();
+        dev.zero_count(4);
+        dev.zero_count(5);
+        dev.relabel_all(rep + 1, 4 + (int)((rep + 1) & 1u));
+        st.relabel_passes++;
+        st.relabel_tiles += L.ntiles;
+        for (;;) {
+            rep++;
+            const int cur = 4 + (int)(rep & 1u), nxt = 4 + (int)((rep + 1) & 1u);
+            dev.read_counts(cnt);
+            if (cnt[cur] == 0) break;
+            dev.zero_count(nxt);
+            dev.relabel_list(cur, rep + 1, nxt);
+            st.relabel_passes++;
+            st.relabel_tiles += cnt[cur];
+        }
+        st.outer++;
+
+        /* ---- who can still push towards the sink? ---- */
+        phase += 4; /* fresh stamps: anything queued before the relabel is void */
+        for (int i = 0; i < 4; ++i) dev.zero_count(i);
+        dev.zero_count(6);
+        dev.activate_all(phase);
+        dev.read_counts(cnt);
+        st.last_active = cnt[6];
+        if (cnt[6] == 0) {
+            st.converged = 1;
+            return 0;
+        }
+
+        /* ---- colour phases ---- */
+        for (int r = 0; r < P.rounds_per_relabel; ++r) {
+            for (int c = 0; c < 2; ++c) {
+                const int lst = (int)(phase & 3u);
+                st.discharge_tiles += cnt[lst];
+                dev.discharge(lst, phase, P.max_cycles, P.max_sweeps);
+                dev.zero_count(lst);
+                st.phases++;
+                phase++;
+                dev.read_counts(cnt);
+            }
+            if (cnt[phase & 3u] == 0 && cnt[(phase + 1) & 3u] == 0) break;
+        }
+    }
+    return 1; /* not converged within max_outer */
+}
+
+#endif /* MGC_DRIVER_INL */

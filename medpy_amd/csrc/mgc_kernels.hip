@@ -1,0 +1,999 @@
+/*
+ * mgc_kernels.hip -- HIP (gfx950 / CDNA4) kernels and the C ABI of libmedpyhip.so.
+ *
+ * Written for MI355X only: wave64, 8x8x8-voxel tiles = 512-thread workgroups (8 waves, one
+ * z-slice of the tile per wave), tile-major f64 state so every global access of the solver is
+ * a contiguous 4 KiB stream, LDS for the label halo and the push hand-off, device-resident
+ * work lists so only active tiles cost anything.  No MFMA: this is HBM/LDS-bound index and
+ * f64 add/min work.
+ *
+ * Kernels
+ *   k_minmax        intensity range for the *_linear terms (energy_voxel.py:101,174-176)
+ *   k_build         n-link weights g(|Ip-Iq|) / g(max) for the 6 neighbours of every voxel
+ *                   (energy_voxel.py:611-664) + merged t-links (energy_voxel.py:61-65,
+ *                   graph.h:416-425, generate.py:169-172) -> tile-major residual graph
+ *   k_absorb / k_relabel_all / k_relabel_list / k_activate / k_discharge
+ *                   the solver (bodies: mgc_tile_ops.inl; schedule: mgc_driver.inl)
+ *   k_labels        what_segment read-out (graph.h:561-571, bin/medpy_graphcut_voxel.py:177-181)
+ *   k_cut_value     capacity of the cut = the value maxflow() returns
+ *   k_get_*         energy read-back for the parity tests
+ */
+#include <hip/hip_runtime.h>
+
+#include <math.h>
+#include <stdarg.h>
+#include <stdio.h>
+#include <stdlib.h>
+#include <string.h>
+
+#include <string>
+
+#include "../../include/medpy_hip.h"
+#include "mgc_tile_ops.inl"
+#include "mgc_driver.inl"
+
+#define MGC_DBL_MIN 2.2250738585072014e-308 /* sys.float_info.min, energy_voxel.py:113,...,513 */
+#define MGC_MARKER_MAX 65535.0              /* GCGraph.MAX, graph.py:288-291 */
+
+/* ======================================================================================
+ * block executor for the single-source tile operations
+ * ==================================================================================== */
+struct GpuBlock {
+    template <class T>
+    struct Reg {
+        T v;
+        __device__ __forceinline__ T& operator[](int) { return v; }
+    };
+    MgcTileShared& S;
+    __device__ __forceinline__ explicit GpuBlock(MgcTileShared& s) : S(s) {}
+    template <class F>
+    __device__ __forceinline__ void par(F f)
+    {
+        f((int)threadIdx.x);
+        __syncthreads();
+    }
+    template <class F>
+    __device__ __forceinline__ bool any(F f)
+    {
+        return __syncthreads_or((int)f((int)threadIdx.x)) != 0;
+    }
+    __device__ __forceinline__ int atomic_add(int32_t* p, int v) { return atomicAdd(p, v); }
+    __device__ __forceinline__ uint32_t atomic_exch(uint32_t* p, uint32_t v) { return atomicExch(p, v); }
+    __device__ __forceinline__ void atomic_or(uint32_t* p, uint32_t v) { atomicOr(p, v); }
+    __device__ __forceinline__ void atomic_and(uint32_t* p, uint32_t v) { atomicAnd(p, v); }
+};
+
+__global__ __launch_bounds__(MGC_TV) void k_absorb(MgcLattice L)
+{
+    __shared__ MgcTileShared S;
+    GpuBlock x(S);
+    for (int tile = blockIdx.x; tile < L.ntiles; tile += gridDim.x) {
+        mgc_absorb_tile(x, L, tile);
+        __syncthreads();
+    }
+}
+
+__global__ __launch_bounds__(MGC_TV) void k_relabel_all(MgcLattice L, uint32_t epoch, int next_list)
+{
+    __shared__ MgcTileShared S;
+    GpuBlock x(S);
+    for (int tile = blockIdx.x; tile < L.ntiles; tile += gridDim.x) {
+        mgc_relabel_tile(x, L, tile, epoch, next_list);
+        __syncthreads();
+    }
+}
+
+__global__ __launch_bounds__(MGC_TV) void k_relabel_list(MgcLattice L, int lst, uint32_t epoch, int next_list)
+{
+    __shared__ MgcTileShared S;
+    GpuBlock x(S);
+    const int n = L.count[lst];
+    for (int i = blockIdx.x; i < n; i += gridDim.x) {
+        mgc_relabel_tile(x, L, L.list[lst][i], epoch, next_list);
+        __syncthreads();
+    }
+}
+
+__global__ __launch_bounds__(MGC_TV) void k_activate(MgcLattice L, uint32_t phase)
+{
+    __shared__ MgcTileShared S;
+    GpuBlock x(S);
+    for (int tile = blockIdx.x; tile < L.ntiles; tile += gridDim.x) {
+        mgc_activate_tile(x, L, tile, phase);
+        __syncthreads();
+    }
+}
+
+__global__ __launch_bounds__(MGC_TV) void k_discharge(MgcLattice L, int lst, uint32_t phase, int cycles, int sweeps)
+{
+    __shared__ MgcTileShared S;
+    GpuBlock x(S);
+    const int n = L.count[lst];
+    for (int i = blockIdx.x; i < n; i += gridDim.x) {
+        mgc_discharge_tile(x, L, L.list[lst][i], phase, cycles, sweeps);
+        __syncthreads();
+    }
+}
+
+/* ======================================================================================
+ * graph construction
+ * ==================================================================================== */
+struct MgcBuildArgs {
+    const void* image;   /* C-order, handle shape, any mgc_dtype; NULL when term == NONE */
+    int img_dtype;
+    int term;
+    double p0;           /* linear: M ; exponential: sigma^2 ; division / power: sigma */
+    double inv_axis[3];  /* divisor per axis x,y,z (spacing) -- only used when has_spacing */
+    int has_spacing;
+    const void* prob;    /* regional probability map or NULL */
+    int prob_dtype;
+    double alpha;
+    const uint8_t* fg;   /* marker masks or NULL */
+    const uint8_t* bg;
+    const double* tr_in; /* merged explicit t-links (plug-in path) or NULL */
+    double* tr0;         /* out: merged tr_cap per voxel, tile-major */
+    double* fpart;       /* out: per-tile partial of the flow constant */
+};
+
+__device__ __forceinline__ double mgc_load_as_double(const void* p, int dtype, int64_t i, bool take_abs)
+{
+    double v;
+    switch (dtype) {
+    case MGC_U8: v = (double)((const uint8_t*)p)[i]; break;
+    case MGC_I8: { int x = ((const int8_t*)p)[i]; v = (double)(take_abs && x < 0 ? -x : x); take_abs = false; } break;
+    case MGC_U16: v = (double)((const uint16_t*)p)[i]; break;
+    case MGC_I16: { int x = ((const int16_t*)p)[i]; v = (double)(take_abs && x < 0 ? -x : x); take_abs = false; } break;
+    case MGC_U32: v = (double)((const uint32_t*)p)[i]; break;
+    case MGC_I32: { int64_t x = ((const int32_t*)p)[i]; v = (double)(take_abs && x < 0 ? -x : x); take_abs = false; } break;
+    case MGC_U64: v = (double)((const uint64_t*)p)[i]; break;
+    case MGC_I64: { int64_t x = ((const int64_t*)p)[i]; v = (double)(take_abs && x < 0 ? -x : x); take_abs = false; } break;
+    case MGC_F32: v = (double)((const float*)p)[i]; break;
+    default: v = ((const double*)p)[i]; break;
+    }
+    return take_abs ? fabs(v) : v;
+}
+
+/* g(.) of the eight boundary terms, operation for operation as NumPy evaluates them in the
+ * reference (energy_voxel.py:103-114, 226-236, 337-345, 444-452 and the difference twins). */
+__device__ __forceinline__ double mgc_boundary_g(int term, double a, double b, double p0)
+{
+    const bool use_max = (term == MGC_TERM_MAXIMUM_LINEAR || term == MGC_TERM_MAXIMUM_EXPONENTIAL ||
+                          term == MGC_TERM_MAXIMUM_POWER); /* MAXIMUM_DIVISION: difference skeleton, :347 */
+    double x = use_max ? fmax(a, b) : fabs(a - b);
+    switch (term) {
+    case MGC_TERM_DIFFERENCE_LINEAR:
+    case MGC_TERM_MAXIMUM_LINEAR:
+        x = x / p0;
+        x = 1.0 - x;
+        if (x == 0.0) x = MGC_DBL_MIN;
+        return x;
+    case MGC_TERM_DIFFERENCE_EXPONENTIAL:
+    case MGC_TERM_MAXIMUM_EXPONENTIAL:
+        x = x * x;   /* numpy.power(x, 2) */
+        x = x / p0;  /* /= math.pow(sigma, 2) */
+        x = -x;      /* *= -1 */
+        x = exp(x);
+        if (x <= 0.0) x = MGC_DBL_MIN;
+        return x;
+    case MGC_TERM_DIFFERENCE_DIVISION:
+    case MGC_TERM_MAXIMUM_DIVISION:
+        x = x / p0;
+        x = 1.0 / (x + 1.0);
+        if (x <= 0.0) x = MGC_DBL_MIN;
+        return x;
+    default: /* power */
+        x = 1.0 / (x + 1.0);
+        x = pow(x, p0);
+        if (x <= 0.0) x = MGC_DBL_MIN;
+        return x;
+    }
+}
+
+/* Graph::add_tweights, graph.h:416-425 */
+__device__ __forceinline__ void mgc_add_tweights(double& tr, double& fconst, double cs, double ck)
+{
+    const double delta = tr;
+    if (delta > 0) cs += delta;
+    else           ck -= delta;
+    fconst += (cs < ck) ? cs : ck;
+    tr = cs - ck;
+}
+
+/* deterministic block sum of one double per lane (fixed tree), result valid in lane 0 */
+__device__ __forceinline__ double mgc_block_sum(double v, double* scratch)
+{
+    const int t = threadIdx.x;
+    scratch[t] = v;
+    __syncthreads();
+    for (int s = MGC_TV / 2; s > 0; s >>= 1) {
+        if (t < s) scratch[t] += scratch[t + s];
+        __syncthreads();
+    }
+    return scratch[0];
+}
+
+__global__ __launch_bounds__(MGC_TV) void k_build(MgcLattice L, MgcBuildArgs A)
+{
+    __shared__ double img[1000]; /* 10x10x10: tile + one-voxel halo, already |.|'d for the maximum terms */
+    __shared__ double scratch[MGC_TV];
+    const int t = threadIdx.x;
+    const bool take_abs = (A.term == MGC_TERM_MAXIMUM_LINEAR || A.term == MGC_TERM_MAXIMUM_EXPONENTIAL ||
+                           A.term == MGC_TERM_MAXIMUM_POWER);
+    for (int tile = blockIdx.x; tile < L.ntiles; tile += gridDim.x) {
+        int tz, ty, tx;
+        mgc_tile_coords(L, tile, tz, ty, tx);
+        const int64_t z0 = (int64_t)tz * 8, y0 = (int64_t)ty * 8, x0 = (int64_t)tx * 8;
+        if (A.term != MGC_TERM_NONE) {
+            for (int k = t; k < 1000; k += MGC_TV) {
+                const int64_t gz = z0 + k / 100 - 1, gy = y0 + (k / 10) % 10 - 1, gx = x0 + k % 10 - 1;
+                double v = 0.0;
+                if (gz >= 0 && gz < L.dz && gy >= 0 && gy < L.dy && gx >= 0 && gx < L.dx)
+                    v = mgc_load_as_double(A.image, A.img_dtype, (gz * L.dy + gy) * L.dx + gx, take_abs);
+                img[k] = v;
+            }
+        }
+        __syncthreads();
+        const int lz = t >> 6, ly = (t >> 3) & 7, lx = t & 7;
+        const int64_t gz = z0 + lz, gy = y0 + ly, gx = x0 + lx;
+        const bool valid = gz < L.dz && gy < L.dy && gx < L.dx;
+        const int64_t id = (gz * L.dy + gy) * L.dx + gx;
+        const int me = mgc_hs_index(lz, ly, lx);
+        int m = 0;
+#pragma unroll
+        for (int d = 0; d < 6; ++d) {
+            const int64_t c = (d >> 1) == 0 ? gx : ((d >> 1) == 1 ? gy : gz);
+            const int64_t lim = (d >> 1) == 0 ? L.dx : ((d >> 1) == 1 ? L.dy : L.dz);
+            const bool has = valid && ((d & 1) ? (c + 1 < lim) : (c > 0));
+            double w = 0.0;
+            if (has && A.term != MGC_TERM_NONE) {
+                /* evaluate with (lower voxel, upper voxel) operand order like the reference slices */
+                const double a = (d & 1) ? img[me] : img[me + mgc_hs_step(d)];
+                const double b = (d & 1) ? img[me + mgc_hs_step(d)] : img[me];
+                w = mgc_boundary_g(A.term, a, b, A.p0);
+                if (A.has_spacing) w = w / A.inv_axis[d >> 1]; /* energy_voxel.py:657-658 */
+            }
+            const int64_t o = ((int64_t)tile * 6 + d) * MGC_TV + t;
+            L.rcap[o] = w;
+            L.cap0[o] = w;
+            /* NaN weights (0/0 of the linear terms on a constant image) count as residual,
+             * like `if (a->r_cap)` in the reference (maxflow.cpp:510) */
+            if (w > 0.0) m |= 1 << d;
+        }
+        /* t-links: regional term, then fg marker, then bg marker (generate.py:159-172) */
+        double tr = 0.0, fc = 0.0;
+        if (valid) {
+            if (A.tr_in) tr = A.tr_in[id];
+            if (A.prob) {
+                double cs, ck;
+                if (A.prob_dtype == MGC_F32) {
+                    const float p = ((const float*)A.prob)[id], al = (float)A.alpha;
+                    cs = (double)(p * al);
+                    ck = (double)((1.0f - p) * al);
+                } else {
+                    const double p = ((const double*)A.prob)[id];
+                    cs = p * A.alpha;
+                    ck = (1.0 - p) * A.alpha;
+                }
+                mgc_add_tweights(tr, fc, cs, ck);
+            }
+            if (A.fg && A.fg[id]) mgc_add_tweights(tr, fc, MGC_MARKER_MAX, 0.0);
+            if (A.bg && A.bg[id]) mgc_add_tweights(tr, fc, 0.0, MGC_MARKER_MAX);
+        }
+        const int64_t v = (int64_t)tile * MGC_TV + t;
+        A.tr0[v] = tr;
+        L.excess[v] = tr > 0.0 ? tr : 0.0;
+        L.sink[v] = tr < 0.0 ? -tr : 0.0;
+        if (tr < 0.0) m |= MGC_MASK_SINK;
+        L.rmask[v] = (uint8_t)m;
+        L.height[v] = MGC_HINF;
+        if (t < 6 * MGC_TF / 8) { /* 48 lanes x 8 doubles clear the 6x64 outbox */
+#pragma unroll
+            for (int k = 0; k < 8; ++k) L.obox[(int64_t)tile * 6 * MGC_TF + t * 8 + k] = 0.0;
+        }
+        if (t == 0) {
+            L.oflags[tile] = 0;
+            L.stamp[tile] = 0;
+            L.rstamp[tile] = 0;
+            L.status[tile] = 0;
+        }
+        const double s = mgc_block_sum(fc, scratch);
+        if (t == 0) A.fpart[tile] = s;
+        __syncthreads();
+    }
+}
+
+/* min / max / max|.| of the image, one partial triple per block (deterministic), finished on the host */
+__global__ __launch_bounds__(256) void k_minmax(const void* image, int dtype, int64_t n, double* part)
+{
+    __shared__ double smin[256], smax[256], sabs[256];
+    double mn = INFINITY, mx = -INFINITY, ma = 0.0;
+    for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (int64_t)gridDim.x * 256) {
+        const double v = mgc_load_as_double(image, dtype, i, false);
+        mn = fmin(mn, v);
+        mx = fmax(mx, v);
+        ma = fmax(ma, fabs(v));
+    }
+    smin[threadIdx.x] = mn; smax[threadIdx.x] = mx; sabs[threadIdx.x] = ma;
+    __syncthreads();
+    for (int s = 128; s > 0; s >>= 1) {
+        if ((int)threadIdx.x < s) {
+            smin[threadIdx.x] = fmin(smin[threadIdx.x], smin[threadIdx.x + s]);
+            smax[threadIdx.x] = fmax(smax[threadIdx.x], smax[threadIdx.x + s]);
+            sabs[threadIdx.x] = fmax(sabs[threadIdx.x], sabs[threadIdx.x + s]);
+        }
+        __syncthreads();
+    }
+    if (threadIdx.x == 0) {
+        part[blockIdx.x * 3 + 0] = smin[0];
+        part[blockIdx.x * 3 + 1] = smax[0];
+        part[blockIdx.x * 3 + 2] = sabs[0];
+    }
+}
+
+/* plug-in path: accumulate explicit lattice edges like sum_edge (graph.h:457-480) */
+__global__ void k_add_edges(MgcLattice L, int64_t n, const int64_t* ei, const int64_t* ej, const double* cap,
+                            const double* rev, int* bad)
+{
+    for (int64_t k = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; k < n; k += (int64_t)gridDim.x * blockDim.x) {
+        const int64_t i = ei[k], j = ej[k];
+        if (i < 0 || j < 0 || i >= L.nvox || j >= L.nvox) { *bad = 1; continue; }
+        const int64_t diff = j - i;
+        int d = -1;
+        const int64_t xi = i % L.dx, yi = (i / L.dx) % L.dy;
+        if (diff == 1 && xi + 1 < L.dx) d = 1;
+        else if (diff == -1 && xi > 0) d = 0;
+        else if (diff == L.dx && yi + 1 < L.dy) d = 3;
+        else if (diff == -L.dx && yi > 0) d = 2;
+        else if (diff == L.dx * L.dy) d = 5;
+        else if (diff == -L.dx * L.dy) d = 4;
+        if (d < 0) { *bad = 1; continue; }
+        int ti, li, tj, lj;
+        mgc_node_to_tile(L, i, ti, li);
+        mgc_node_to_tile(L, j, tj, lj);
+        const int64_t oi = ((int64_t)ti * 6 + d) * MGC_TV + li, oj = ((int64_t)tj * 6 + (d ^ 1)) * MGC_TV + lj;
+        atomicAdd(&L.rcap[oi], cap[k]); atomicAdd(&L.cap0[oi], cap[k]);
+        atomicAdd(&L.rcap[oj], rev[k]); atomicAdd(&L.cap0[oj], rev[k]);
+    }
+}
+
+/* refresh rmask after explicit edges were added */
+__global__ __launch_bounds__(MGC_TV) void k_refresh_mask(MgcLattice L)
+{
+    for (int tile = blockIdx.x; tile < L.ntiles; tile += gridDim.x) {
+        const int t = threadIdx.x;
+        int m = L.sink[(int64_t)tile * MGC_TV + t] > 0.0 ? MGC_MASK_SINK : 0;
+#pragma unroll
+        for (int d = 0; d < 6; ++d) {
+            const double w = L.rcap[((int64_t)tile * 6 + d) * MGC_TV + t];
+            if (w > 0.0) m |= 1 << d;
+        }
+        L.rmask[(int64_t)tile * MGC_TV + t] = (uint8_t)m;
+    }
+}
+
+/* ======================================================================================
+ * read-out
+ * ==================================================================================== */
+__global__ void k_labels(MgcLattice L, uint8_t* out)
+{
+    for (int64_t id = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; id < L.nvox; id += (int64_t)gridDim.x * blockDim.x) {
+        int tile, loc;
+        mgc_node_to_tile(L, id, tile, loc);
+        out[id] = L.height[(int64_t)tile * MGC_TV + loc] < MGC_HINF ? 0 : 1;
+    }
+}
+
+/* capacity of the cut (S = label 1, T = label 0) from the capacities as built */
+__global__ __launch_bounds__(MGC_TV) void k_cut_value(MgcLattice L, const double* tr0, const uint8_t* labels, double* part)
+{
+    __shared__ double scratch[MGC_TV];
+    const int t = threadIdx.x;
+    for (int tile = blockIdx.x; tile < L.ntiles; tile += gridDim.x) {
+        int tz, ty, tx;
+        mgc_tile_coords(L, tile, tz, ty, tx);
+        const int lz = t >> 6, ly = (t >> 3) & 7, lx = t & 7;
+        const int64_t gz = (int64_t)tz * 8 + lz, gy = (int64_t)ty * 8 + ly, gx = (int64_t)tx * 8 + lx;
+        double s = 0.0;
+        if (gz < L.dz && gy < L.dy && gx < L.dx) {
+            const int64_t id = (gz * L.dy + gy) * L.dx + gx;
+            const double tr = tr0[(int64_t)tile * MGC_TV + t];
+            if (labels[id]) { /* source side: pays its sink link and every n-link into T */
+                if (tr < 0.0) s += -tr;
+                const int64_t step[6] = {-1, 1, -L.dx, L.dx, -L.dx * L.dy, L.dx * L.dy};
+#pragma unroll
+                for (int d = 0; d < 6; ++d) {
+                    const int64_t c = (d >> 1) == 0 ? gx : ((d >> 1) == 1 ? gy : gz);
+                    const int64_t lim = (d >> 1) == 0 ? L.dx : ((d >> 1) == 1 ? L.dy : L.dz);
+                    const bool has = (d & 1) ? (c + 1 < lim) : (c > 0);
+                    if (has && !labels[id + step[d]]) s += L.cap0[((int64_t)tile * 6 + d) * MGC_TV + t];
+                }
+            } else if (tr > 0.0) { /* sink side: pays its source link */
+                s += tr;
+            }
+        }
+        const double tot = mgc_block_sum(s, scratch);
+        if (t == 0) part[tile] = tot;
+        __syncthreads();
+    }
+}
+
+/* fixed-order sum of n partials by one block */
+__global__ __launch_bounds__(MGC_TV) void k_sum_partials(const double* part, int64_t n, double* out)
+{
+    __shared__ double scratch[MGC_TV];
+    double s = 0.0;
+    for (int64_t i = threadIdx.x; i < n; i += MGC_TV) s += part[i];
+    const double tot = mgc_block_sum(s, scratch);
+    if (threadIdx.x == 0) *out = tot;
+}
+
+__global__ void k_get_nweights(MgcLattice L, int axis /* array axis 0..2 */, double* out)
+{
+    const int64_t sh[3] = {L.dz, L.dy, L.dx};
+    int64_t osh[3] = {sh[0], sh[1], sh[2]};
+    osh[axis] -= 1;
+    const int64_t n = osh[0] * osh[1] * osh[2];
+    const int d = axis == 2 ? 1 : (axis == 1 ? 3 : 5); /* forward direction of that axis */
+    for (int64_t k = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; k < n; k += (int64_t)gridDim.x * blockDim.x) {
+        const int64_t x = k % osh[2], y = (k / osh[2]) % osh[1], z = k / (osh[2] * osh[1]);
+        int tile, loc;
+        mgc_node_to_tile(L, (z * L.dy + y) * L.dx + x, tile, loc);
+        out[k] = L.cap0[((int64_t)tile * 6 + d) * MGC_TV + loc];
+    }
+}
+
+__global__ void k_untile_f64(MgcLattice L, const double* tiled, double* out)
+{
+    for (int64_t id = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; id < L.nvox; id += (int64_t)gridDim.x * blockDim.x) {
+        int tile, loc;
+        mgc_node_to_tile(L, id, tile, loc);
+        out[id] = tiled[(int64_t)tile * MGC_TV + loc];
+    }
+}
+
+/* ======================================================================================
+ * host side: handle, device policy, C ABI
+ * ==================================================================================== */
+static std::string g_create_error;
+
+struct mgc_graph {
+    int device = 0;
+    int ndim = 0;
+    int64_t shape[3] = {1, 1, 1}; /* padded to 3-D with leading 1s */
+    int64_t nvox = 0;
+    hipStream_t stream = nullptr;
+    hipEvent_t ev[4] = {nullptr, nullptr, nullptr, nullptr};
+    MgcLattice L{};
+    /* inputs resident in HBM */
+    void* d_image = nullptr; int img_dtype = 0; int term = MGC_TERM_NONE; double sigma = 0; double spacing[3] = {1, 1, 1};
+    int has_spacing = 0;
+    void* d_prob = nullptr; int prob_dtype = 0; double alpha = 0;
+    uint8_t* d_fg = nullptr; uint8_t* d_bg = nullptr;
+    double* d_tr_in = nullptr; double flow_const_in = 0;
+    /* pending explicit edges (host copy kept until build) */
+    int64_t n_edges = 0; int64_t* d_ei = nullptr; int64_t* d_ej = nullptr; double* d_ecap = nullptr; double* d_erev = nullptr;
+    /* outputs / scratch */
+    double* d_tr0 = nullptr; double* d_part = nullptr; double* d_scalar = nullptr; uint8_t* d_labels = nullptr;
+    int32_t* h_count = nullptr; /* pinned */
+    double* h_scalar = nullptr; /* pinned */
+    uint8_t* h_labels = nullptr; bool labels_on_host = false;
+    bool built = false, solved = false;
+    double flow_const = 0.0, flow = 0.0;
+    MgcSolveParams params = mgc_default_params();
+    int grid_cap = 2048;
+    mgc_stats stats{};
+    int64_t device_bytes = 0;
+    std::string err;
+    bool timing = true;
+};
+
+static int mgc_fail(mgc_handle h, int code, const char* fmt, ...)
+{
+    char buf[512];
+    va_list ap;
+    va_start(ap, fmt);
+    vsnprintf(buf, sizeof(buf), fmt, ap);
+    va_end(ap);
+    if (h) h->err = buf;
+    else g_create_error = buf;
+    return code;
+}
+
+#define MGC_HIP(h, call)                                                                                       \
+    do {                                                                                                       \
+        hipError_t e_ = (call);                                                                                \
+        if (e_ != hipSuccess)                                                                                  \
+            return mgc_fail(h, e_ == hipErrorOutOfMemory ? MGC_ERR_OOM : MGC_ERR_HIP, "%s failed: %s (%s:%d)", \
+                            #call, hipGetErrorString(e_), __FILE__, __LINE__);                                 \
+    } while (0)
+
+template <class T>
+static int mgc_alloc(mgc_handle h, T** p, int64_t count)
+{
+    MGC_HIP(h, hipMalloc((void**)p, (size_t)count * sizeof(T)));
+    h->device_bytes += count * (int64_t)sizeof(T);
+    return MGC_OK;
+}
+
+static size_t mgc_dtype_size(int dt)
+{
+    switch (dt) {
+    case MGC_U8: case MGC_I8: return 1;
+    case MGC_U16: case MGC_I16: return 2;
+    case MGC_U32: case MGC_I32: case MGC_F32: return 4;
+    case MGC_U64: case MGC_I64: case MGC_F64: return 8;
+    default: return 0;
+    }
+}
+
+/* device policy for mgc_solve(): one kernel launch per call, in-order on the handle's stream */
+struct HipDev {
+    mgc_handle h;
+    hipError_t first_error = hipSuccess;
+    float discharge_ms = 0.f, relabel_ms = 0.f;
+    void check(hipError_t e) { if (e != hipSuccess && first_error == hipSuccess) first_error = e; }
+    int grid(int64_t n) const { return (int)(n < 1 ? 1 : (n < h->grid_cap ? n : h->grid_cap)); }
+    void fill_heights_inf() { check(hipMemsetAsync(h->L.height, 0x3f, (size_t)h->L.ntiles * MGC_TV * sizeof(int32_t), h->stream)); }
+    void zero_count(int i) { check(hipMemsetAsync(h->L.count + i, 0, sizeof(int32_t), h->stream)); }
+    void read_counts(int* out)
+    {
+        check(hipMemcpyAsync(h->h_count, h->L.count, 8 * sizeof(int32_t), hipMemcpyDeviceToHost, h->stream));
+        check(hipStreamSynchronize(h->stream));
+        memcpy(out, h->h_count, 8 * sizeof(int32_t));
+        last[0] = out[0]; last[1] = out[1]; last[2] = out[2]; last[3] = out[3]; last[4] = out[4]; last[5] = out[5];
+    }
+    int last[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+    void absorb_all() { hipLaunchKernelGGL(k_absorb, dim3(grid(h->L.ntiles)), dim3(MGC_TV), 0, h->stream, h->L); check(hipGetLastError()); }
+    void relabel_all(uint32_t epoch, int next)
+    {
+        time_begin();
+        hipLaunchKernelGGL(k_relabel_all, dim3(grid(h->L.ntiles)), dim3(MGC_TV), 0, h->stream, h->L, epoch, next);
+        check(hipGetLastError());
+        time_end(relabel_ms);
+        h->stats.relabel_launches++;
+    }
+    void relabel_list(int lst, uint32_t epoch, int next)
+    {
+        time_begin();
+        hipLaunchKernelGGL(k_relabel_list, dim3(grid(last[lst])), dim3(MGC_TV), 0, h->stream, h->L, lst, epoch, next);
+        check(hipGetLastError());
+        time_end(relabel_ms);
+        h->stats.relabel_launches++;
+    }
+    void activate_all(uint32_t phase)
+    {
+        hipLaunchKernelGGL(k_activate, dim3(grid(h->L.ntiles)), dim3(MGC_TV), 0, h->stream, h->L, phase);
+        check(hipGetLastError());
+    }
+    void discharge(int lst, uint32_t phase, int cycles, int sweeps)
+    {
+        if (last[lst] == 0) return;
+        time_begin();
+        hipLaunchKernelGGL(k_discharge, dim3(grid(last[lst])), dim3(MGC_TV), 0, h->stream, h->L, lst, phase, cycles, sweeps);
+        check(hipGetLastError());
+        time_end(discharge_ms);
+        h->stats.discharge_launches++;
+    }
+    /* HIP events on the launch stream: the numbers bench.py's roofline uses */
+    void time_begin() { if (h->timing) check(hipEventRecord(h->ev[2], h->stream)); }
+    void time_end(float& acc)
+    {
+        if (!h->timing) return;
+        check(hipEventRecord(h->ev[3], h->stream));
+        check(hipEventSynchronize(h->ev[3]));
+        float ms = 0.f;
+        check(hipEventElapsedTime(&ms, h->ev[2], h->ev[3]));
+        acc += ms;
+    }
+};
+
+extern "C" {
+
+int mgc_device_count(int* count)
+{
+    int n = 0;
+    hipError_t e = hipGetDeviceCount(&n);
+    if (e != hipSuccess) n = 0;
+    if (count) *count = n;
+    return MGC_OK;
+}
+
+const char* mgc_last_error(mgc_handle h) { return h ? h->err.c_str() : g_create_error.c_str(); }
+
+int mgc_create(int ndim, const int64_t* shape, int connectivity, int device, mgc_handle* out)
+{
+    if (!out) return mgc_fail(nullptr, MGC_ERR_INVALID, "mgc_create: out is NULL");
+    *out = nullptr;
+    if (ndim < 1 || ndim > 3 || !shape) return mgc_fail(nullptr, MGC_ERR_UNSUPPORTED, "mgc_create: ndim must be 1..3 (got %d)", ndim);
+    if (connectivity != 2 * ndim)
+        return mgc_fail(nullptr, MGC_ERR_UNSUPPORTED, "mgc_create: connectivity %d not implemented (reference supports 2*ndim = %d only)",
+                        connectivity, 2 * ndim);
+    int ndev = 0;
+    if (hipGetDeviceCount(&ndev) != hipSuccess || ndev <= 0)
+        return mgc_fail(nullptr, MGC_ERR_NO_DEVICE, "no HIP device: libmedpyhip has no CPU fallback");
+    if (device < 0 || device >= ndev) return mgc_fail(nullptr, MGC_ERR_INVALID, "device %d out of range (have %d)", device, ndev);
+    mgc_handle h = new (std::nothrow) mgc_graph();
+    if (!h) return mgc_fail(nullptr, MGC_ERR_OOM, "host allocation failed");
+    h->device = device;
+    h->ndim = ndim;
+    int64_t n = 1;
+    for (int k = 0; k < ndim; ++k) {
+        if (shape[k] < 1) { delete h; return mgc_fail(nullptr, MGC_ERR_INVALID, "shape[%d] = %lld", k, (long long)shape[k]); }
+        h->shape[3 - ndim + k] = shape[k];
+        n *= shape[k];
+    }
+    h->nvox = n;
+    MgcLattice& L = h->L;
+    L.dz = h->shape[0]; L.dy = h->shape[1]; L.dx = h->shape[2];
+    L.nvox = n;
+    const int64_t gz = (L.dz + 7) / 8, gy = (L.dy + 7) / 8, gx = (L.dx + 7) / 8;
+    if (gz * gy * gx > 0x3fffffff) { delete h; return mgc_fail(nullptr, MGC_ERR_UNSUPPORTED, "volume too large for 32-bit tile ids"); }
+    L.gz = (int)gz; L.gy = (int)gy; L.gx = (int)gx;
+    L.ntiles = (int)(gz * gy * gx);
+    *out = h; /* from here on errors are reported through the handle; caller destroys it */
+    MGC_HIP(h, hipSetDevice(device));
+    MGC_HIP(h, hipStreamCreateWithFlags(&h->stream, hipStreamNonBlocking));
+    for (int i = 0; i < 4; ++i) MGC_HIP(h, hipEventCreate(&h->ev[i]));
+    const int64_t nt = L.ntiles, nv = nt * MGC_TV;
+    int rc;
+    if ((rc = mgc_alloc(h, &L.rcap, nv * 6))) return rc;
+    if ((rc = mgc_alloc(h, &L.cap0, nv * 6))) return rc;
+    if ((rc = mgc_alloc(h, &L.excess, nv))) return rc;
+    if ((rc = mgc_alloc(h, &L.sink, nv))) return rc;
+    if ((rc = mgc_alloc(h, &L.height, nv))) return rc;
+    if ((rc = mgc_alloc(h, &L.rmask, nv))) return rc;
+    if ((rc = mgc_alloc(h, &L.obox, nt * 6 * MGC_TF))) return rc;
+    if ((rc = mgc_alloc(h, &L.oflags, nt))) return rc;
+    for (int i = 0; i < 6; ++i)
+        if ((rc = mgc_alloc(h, &L.list[i], nt))) return rc;
+    if ((rc = mgc_alloc(h, &L.count, (int64_t)8))) return rc;
+    if ((rc = mgc_alloc(h, &L.stamp, nt))) return rc;
+    if ((rc = mgc_alloc(h, &L.rstamp, nt))) return rc;
+    if ((rc = mgc_alloc(h, &L.status, nt))) return rc;
+    if ((rc = mgc_alloc(h, &h->d_tr0, nv))) return rc;
+    if ((rc = mgc_alloc(h, &h->d_part, nt > 4096 ? nt : (int64_t)4096))) return rc;
+    if ((rc = mgc_alloc(h, &h->d_scalar, (int64_t)8))) return rc;
+    if ((rc = mgc_alloc(h, &h->d_labels, n))) return rc;
+    MGC_HIP(h, hipHostMalloc((void**)&h->h_count, 8 * sizeof(int32_t), hipHostMallocDefault));
+    MGC_HIP(h, hipHostMalloc((void**)&h->h_scalar, 8 * sizeof(double), hipHostMallocDefault));
+    MGC_HIP(h, hipMemsetAsync(L.count, 0, 8 * sizeof(int32_t), h->stream));
+    MGC_HIP(h, hipStreamSynchronize(h->stream));
+    return MGC_OK;
+}
+
+int mgc_destroy(mgc_handle h)
+{
+    if (!h) return MGC_OK;
+    hipSetDevice(h->device);
+    if (h->stream) hipStreamSynchronize(h->stream);
+    MgcLattice& L = h->L;
+    void* ptrs[] = {L.rcap, L.cap0, L.excess, L.sink, L.height, L.rmask, L.obox, L.oflags, L.list[0], L.list[1], L.list[2],
+                    L.list[3], L.list[4], L.list[5], L.count, L.stamp, L.rstamp, L.status, h->d_tr0, h->d_part, h->d_scalar,
+                    h->d_labels, h->d_image, h->d_prob, h->d_fg, h->d_bg, h->d_tr_in, h->d_ei, h->d_ej, h->d_ecap, h->d_erev};
+    for (void* p : ptrs)
+        if (p) hipFree(p);
+    if (h->h_count) hipHostFree(h->h_count);
+    if (h->h_scalar) hipHostFree(h->h_scalar);
+    free(h->h_labels);
+    for (int i = 0; i < 4; ++i)
+        if (h->ev[i]) hipEventDestroy(h->ev[i]);
+    if (h->stream) hipStreamDestroy(h->stream);
+    delete h;
+    return MGC_OK;
+}
+
+static int mgc_upload(mgc_handle h, void** dst, const void* src, size_t bytes)
+{
+    if (!*dst) {
+        MGC_HIP(h, hipMalloc(dst, bytes));
+        h->device_bytes += (int64_t)bytes;
+    }
+    MGC_HIP(h, hipMemcpyAsync(*dst, src, bytes, hipMemcpyHostToDevice, h->stream));
+    MGC_HIP(h, hipStreamSynchronize(h->stream));
+    return MGC_OK;
+}
+
+int mgc_set_boundary(mgc_handle h, int term, const void* image, int dtype, double sigma, const double* spacing)
+{
+    if (!h) return MGC_ERR_INVALID;
+    if (term < MGC_TERM_NONE || term > MGC_TERM_MAXIMUM_POWER) return mgc_fail(h, MGC_ERR_INVALID, "unknown boundary term %d", term);
+    MGC_HIP(h, hipSetDevice(h->device));
+    h->term = term;
+    h->built = h->solved = false;
+    if (term == MGC_TERM_NONE) return MGC_OK;
+    const size_t es = mgc_dtype_size(dtype);
+    if (!image || !es) return mgc_fail(h, MGC_ERR_INVALID, "mgc_set_boundary: image NULL or bad dtype %d", dtype);
+    if (h->d_image && h->img_dtype != dtype) { hipFree(h->d_image); h->d_image = nullptr; }
+    h->img_dtype = dtype;
+    h->sigma = sigma;
+    h->has_spacing = spacing ? 1 : 0;
+    for (int k = 0; k < 3; ++k) h->spacing[k] = 1.0;
+    if (spacing)
+        for (int k = 0; k < h->ndim; ++k) h->spacing[3 - h->ndim + k] = spacing[k];
+    return mgc_upload(h, &h->d_image, image, (size_t)h->nvox * es);
+}
+
+int mgc_set_regional_probability(mgc_handle h, const void* pm, int dtype, double alpha)
+{
+    if (!h) return MGC_ERR_INVALID;
+    if (!pm || (dtype != MGC_F32 && dtype != MGC_F64)) return mgc_fail(h, MGC_ERR_INVALID, "probability map must be float32 or float64");
+    MGC_HIP(h, hipSetDevice(h->device));
+    if (h->d_prob && h->prob_dtype != dtype) { hipFree(h->d_prob); h->d_prob = nullptr; }
+    h->prob_dtype = dtype;
+    h->alpha = alpha;
+    h->built = h->solved = false;
+    return mgc_upload(h, &h->d_prob, pm, (size_t)h->nvox * mgc_dtype_size(dtype));
+}
+
+int mgc_set_markers(mgc_handle h, const uint8_t* fg, const uint8_t* bg)
+{
+    if (!h) return MGC_ERR_INVALID;
+    MGC_HIP(h, hipSetDevice(h->device));
+    h->built = h->solved = false;
+    int rc = MGC_OK;
+    if (fg) rc = mgc_upload(h, (void**)&h->d_fg, fg, (size_t)h->nvox);
+    else if (h->d_fg) { hipFree(h->d_fg); h->d_fg = nullptr; }
+    if (rc) return rc;
+    if (bg) rc = mgc_upload(h, (void**)&h->d_bg, bg, (size_t)h->nvox);
+    else if (h->d_bg) { hipFree(h->d_bg); h->d_bg = nullptr; }
+    return rc;
+}
+
+int mgc_set_tweights_merged(mgc_handle h, const double* tr, double flow_const)
+{
+    if (!h || !tr) return MGC_ERR_INVALID;
+    MGC_HIP(h, hipSetDevice(h->device));
+    h->flow_const_in = flow_const;
+    h->built = h->solved = false;
+    return mgc_upload(h, (void**)&h->d_tr_in, tr, (size_t)h->nvox * sizeof(double));
+}
+
+int mgc_add_edges(mgc_handle h, int64_t n, const int64_t* i, const int64_t* j, const double* cap, const double* rev)
+{
+    if (!h || n < 0 || (n && (!i || !j || !cap || !rev))) return MGC_ERR_INVALID;
+    if (h->n_edges) return mgc_fail(h, MGC_ERR_UNSUPPORTED, "mgc_add_edges: one batch per build (concatenate on the host)");
+    if (n == 0) return MGC_OK;
+    MGC_HIP(h, hipSetDevice(h->device));
+    int rc;
+    if ((rc = mgc_upload(h, (void**)&h->d_ei, i, (size_t)n * sizeof(int64_t)))) return rc;
+    if ((rc = mgc_upload(h, (void**)&h->d_ej, j, (size_t)n * sizeof(int64_t)))) return rc;
+    if ((rc = mgc_upload(h, (void**)&h->d_ecap, cap, (size_t)n * sizeof(double)))) return rc;
+    if ((rc = mgc_upload(h, (void**)&h->d_erev, rev, (size_t)n * sizeof(double)))) return rc;
+    h->n_edges = n;
+    h->built = h->solved = false;
+    return MGC_OK;
+}
+
+int mgc_build(mgc_handle h)
+{
+    if (!h) return MGC_ERR_INVALID;
+    MGC_HIP(h, hipSetDevice(h->device));
+    MgcLattice& L = h->L;
+    MgcBuildArgs A{};
+    A.image = h->d_image; A.img_dtype = h->img_dtype; A.term = h->d_image ? h->term : MGC_TERM_NONE;
+    MGC_HIP(h, hipEventRecord(h->ev[0], h->stream));
+    A.p0 = h->sigma;
+    if (A.term == MGC_TERM_DIFFERENCE_EXPONENTIAL || A.term == MGC_TERM_MAXIMUM_EXPONENTIAL) A.p0 = pow(h->sigma, 2); /* math.pow(sigma, 2) */
+    if (A.term == MGC_TERM_DIFFERENCE_LINEAR || A.term == MGC_TERM_MAXIMUM_LINEAR) {
+        const int nb = 1024;
+        hipLaunchKernelGGL(k_minmax, dim3(nb), dim3(256), 0, h->stream, (const void*)h->d_image, h->img_dtype, h->nvox, h->d_part);
+        MGC_HIP(h, hipGetLastError());
+        double* hp = (double*)malloc(nb * 3 * sizeof(double));
+        if (!hp) return mgc_fail(h, MGC_ERR_OOM, "host allocation failed");
+        hipError_t e = hipMemcpyAsync(hp, h->d_part, nb * 3 * sizeof(double), hipMemcpyDeviceToHost, h->stream);
+        if (e == hipSuccess) e = hipStreamSynchronize(h->stream);
+        double mn = INFINITY, mx = -INFINITY, ma = 0.0;
+        for (int b = 0; b < nb; ++b) { mn = fmin(mn, hp[3 * b]); mx = fmax(mx, hp[3 * b + 1]); ma = fmax(ma, hp[3 * b + 2]); }
+        free(hp);
+        MGC_HIP(h, e);
+        A.p0 = (A.term == MGC_TERM_MAXIMUM_LINEAR) ? ma : fabs(mx - mn); /* energy_voxel.py:101 / 174-176 */
+    }
+    A.has_spacing = h->has_spacing;
+    A.inv_axis[0] = h->spacing[2]; A.inv_axis[1] = h->spacing[1]; A.inv_axis[2] = h->spacing[0];
+    A.prob = h->d_prob; A.prob_dtype = h->prob_dtype; A.alpha = h->alpha;
+    A.fg = h->d_fg; A.bg = h->d_bg; A.tr_in = h->d_tr_in;
+    A.tr0 = h->d_tr0; A.fpart = h->d_part;
+    const int grid = L.ntiles < h->grid_cap * 4 ? L.ntiles : h->grid_cap * 4;
+    hipLaunchKernelGGL(k_build, dim3(grid), dim3(MGC_TV), 0, h->stream, L, A);
+    MGC_HIP(h, hipGetLastError());
+    hipLaunchKernelGGL(k_sum_partials, dim3(1), dim3(MGC_TV), 0, h->stream, (const double*)h->d_part, (int64_t)L.ntiles, h->d_scalar);
+    MGC_HIP(h, hipGetLastError());
+    if (h->n_edges) {
+        int* bad = (int*)(h->d_scalar + 4);
+        MGC_HIP(h, hipMemsetAsync(bad, 0, sizeof(int), h->stream));
+        hipLaunchKernelGGL(k_add_edges, dim3(1024), dim3(256), 0, h->stream, L, h->n_edges, (const int64_t*)h->d_ei,
+                           (const int64_t*)h->d_ej, (const double*)h->d_ecap, (const double*)h->d_erev, bad);
+        MGC_HIP(h, hipGetLastError());
+        hipLaunchKernelGGL(k_refresh_mask, dim3(grid), dim3(MGC_TV), 0, h->stream, L);
+        MGC_HIP(h, hipGetLastError());
+    }
+    MGC_HIP(h, hipMemsetAsync(L.count, 0, 8 * sizeof(int32_t), h->stream));
+    MGC_HIP(h, hipEventRecord(h->ev[1], h->stream));
+    MGC_HIP(h, hipMemcpyAsync(h->h_scalar, h->d_scalar, 8 * sizeof(double), hipMemcpyDeviceToHost, h->stream));
+    MGC_HIP(h, hipStreamSynchronize(h->stream));
+    float ms = 0.f;
+    MGC_HIP(h, hipEventElapsedTime(&ms, h->ev[0], h->ev[1]));
+    h->stats.build_ms = ms;
+    h->flow_const = h->h_scalar[0] + (h->d_tr_in ? h->flow_const_in : 0.0);
+    if (h->n_edges) {
+        int bad = 0;
+        memcpy(&bad, h->h_scalar + 4, sizeof(int));
+        h->n_edges = 0;
+        if (bad) return mgc_fail(h, MGC_ERR_UNSUPPORTED, "mgc_add_edges: an edge does not join lattice neighbours");
+    }
+    h->built = true;
+    h->solved = false;
+    h->labels_on_host = false;
+    return MGC_OK;
+}
+
+int mgc_maxflow(mgc_handle h, double* flow)
+{
+    if (!h) return MGC_ERR_INVALID;
+    if (!h->built) return mgc_fail(h, MGC_ERR_STATE, "mgc_maxflow before mgc_build");
+    MGC_HIP(h, hipSetDevice(h->device));
+    MgcLattice& L = h->L;
+    if (!h->solved) {
+        HipDev dev;
+        dev.h = h;
+        MgcSolveStats st;
+        h->stats.discharge_launches = h->stats.relabel_launches = 0;
+        MGC_HIP(h, hipEventRecord(h->ev[0], h->stream));
+        const int rc = mgc_solve(dev, L, h->params, st);
+        if (dev.first_error != hipSuccess)
+            return mgc_fail(h, MGC_ERR_HIP, "solver: HIP error %s", hipGetErrorString(dev.first_error));
+        if (rc) return mgc_fail(h, MGC_ERR_NOT_CONVERGED, "solver did not converge within %d global relabels", h->params.max_outer);
+        /* read-out: labels, then the capacity of the cut they define */
+        hipLaunchKernelGGL(k_labels, dim3(2048), dim3(256), 0, h->stream, L, h->d_labels);
+        MGC_HIP(h, hipGetLastError());
+        MGC_HIP(h, hipEventRecord(h->ev[1], h->stream));
+        const int grid = L.ntiles < h->grid_cap * 4 ? L.ntiles : h->grid_cap * 4;
+        hipLaunchKernelGGL(k_cut_value, dim3(grid), dim3(MGC_TV), 0, h->stream, L, (const double*)h->d_tr0,
+                           (const uint8_t*)h->d_labels, h->d_part);
+        MGC_HIP(h, hipGetLastError());
+        hipLaunchKernelGGL(k_sum_partials, dim3(1), dim3(MGC_TV), 0, h->stream, (const double*)h->d_part, (int64_t)L.ntiles,
+                           h->d_scalar + 1);
+        MGC_HIP(h, hipGetLastError());
+        MGC_HIP(h, hipMemcpyAsync(h->h_scalar, h->d_scalar, 8 * sizeof(double), hipMemcpyDeviceToHost, h->stream));
+        MGC_HIP(h, hipStreamSynchronize(h->stream));
+        float ms = 0.f;
+        MGC_HIP(h, hipEventElapsedTime(&ms, h->ev[0], h->ev[1]));
+        h->stats.solve_ms = ms;
+        h->stats.discharge_ms = dev.discharge_ms;
+        h->stats.relabel_ms = dev.relabel_ms;
+        h->stats.discharge_tiles = st.discharge_tiles;
+        h->stats.relabel_tiles = st.relabel_tiles;
+        h->stats.global_relabels = st.outer;
+        h->stats.phases = st.phases;
+        h->flow = h->flow_const + h->h_scalar[1];
+        h->solved = true;
+        h->labels_on_host = false;
+    }
+    if (flow) *flow = h->flow;
+    return MGC_OK;
+}
+
+int mgc_labels(mgc_handle h, uint8_t* out)
+{
+    if (!h || !out) return MGC_ERR_INVALID;
+    if (!h->solved) return mgc_fail(h, MGC_ERR_STATE, "mgc_labels before mgc_maxflow");
+    MGC_HIP(h, hipSetDevice(h->device));
+    MGC_HIP(h, hipMemcpyAsync(out, h->d_labels, (size_t)h->nvox, hipMemcpyDeviceToHost, h->stream));
+    MGC_HIP(h, hipStreamSynchronize(h->stream));
+    return MGC_OK;
+}
+
+int mgc_what_segment(mgc_handle h, int64_t i, int* segment)
+{
+    if (!h || !segment) return MGC_ERR_INVALID;
+    if (i < 0 || i >= h->nvox) return mgc_fail(h, MGC_ERR_INVALID, "node id %lld out of range", (long long)i);
+    if (!h->solved) { /* before maxflow() every node is free -> default segment SOURCE (graph.h:561-571) */
+        *segment = MGC_SOURCE;
+        return MGC_OK;
+    }
+    if (!h->labels_on_host) {
+        if (!h->h_labels) h->h_labels = (uint8_t*)malloc((size_t)h->nvox);
+        if (!h->h_labels) return mgc_fail(h, MGC_ERR_OOM, "host allocation failed");
+        const int rc = mgc_labels(h, h->h_labels);
+        if (rc) return rc;
+        h->labels_on_host = true;
+    }
+    *segment = h->h_labels[i] ? MGC_SOURCE : MGC_SINK;
+    return MGC_OK;
+}
+
+int mgc_get_nweights(mgc_handle h, int axis, double* out)
+{
+    if (!h || !out) return MGC_ERR_INVALID;
+    if (!h->built) return mgc_fail(h, MGC_ERR_STATE, "mgc_get_nweights before mgc_build");
+    if (axis < 0 || axis >= h->ndim) return mgc_fail(h, MGC_ERR_INVALID, "axis %d out of range", axis);
+    MGC_HIP(h, hipSetDevice(h->device));
+    const int a3 = 3 - h->ndim + axis;
+    int64_t osh[3] = {h->shape[0], h->shape[1], h->shape[2]};
+    osh[a3] -= 1;
+    const int64_t n = osh[0] * osh[1] * osh[2];
+    if (n <= 0) return MGC_OK;
+    double* d = nullptr;
+    MGC_HIP(h, hipMalloc((void**)&d, (size_t)n * sizeof(double)));
+    hipLaunchKernelGGL(k_get_nweights, dim3(1024), dim3(256), 0, h->stream, h->L, a3, d);
+    hipError_t e = hipGetLastError();
+    if (e == hipSuccess) e = hipMemcpyAsync(out, d, (size_t)n * sizeof(double), hipMemcpyDeviceToHost, h->stream);
+    if (e == hipSuccess) e = hipStreamSynchronize(h->stream);
+    hipFree(d);
+    MGC_HIP(h, e);
+    return MGC_OK;
+}
+
+int mgc_get_tweights(mgc_handle h, double* out)
+{
+    if (!h || !out) return MGC_ERR_INVALID;
+    if (!h->built) return mgc_fail(h, MGC_ERR_STATE, "mgc_get_tweights before mgc_build");
+    MGC_HIP(h, hipSetDevice(h->device));
+    double* d = nullptr;
+    MGC_HIP(h, hipMalloc((void**)&d, (size_t)h->nvox * sizeof(double)));
+    hipLaunchKernelGGL(k_untile_f64, dim3(1024), dim3(256), 0, h->stream, h->L, (const double*)h->d_tr0, d);
+    hipError_t e = hipGetLastError();
+    if (e == hipSuccess) e = hipMemcpyAsync(out, d, (size_t)h->nvox * sizeof(double), hipMemcpyDeviceToHost, h->stream);
+    if (e == hipSuccess) e = hipStreamSynchronize(h->stream);
+    hipFree(d);
+    MGC_HIP(h, e);
+    return MGC_OK;
+}
+
+int mgc_get_edge(mgc_handle h, int64_t i, int64_t j, double* out)
+{
+    if (!h || !out) return MGC_ERR_INVALID;
+    if (!h->built) return mgc_fail(h, MGC_ERR_STATE, "mgc_get_edge before mgc_build");
+    if (i < 0 || j < 0 || i >= h->nvox || j >= h->nvox || i == j) return mgc_fail(h, MGC_ERR_INVALID, "bad node pair");
+    MGC_HIP(h, hipSetDevice(h->device));
+    const MgcLattice& L = h->L;
+    const int64_t diff = j - i, xi = i % L.dx, yi = (i / L.dx) % L.dy;
+    int d = -1;
+    if (diff == 1 && xi + 1 < L.dx) d = 1;
+    else if (diff == -1 && xi > 0) d = 0;
+    else if (diff == L.dx && yi + 1 < L.dy) d = 3;
+    else if (diff == -L.dx && yi > 0) d = 2;
+    else if (diff == L.dx * L.dy) d = 5;
+    else if (diff == -L.dx * L.dy) d = 4;
+    *out = 0.0; /* no such arc: get_edge returns 0 (graph.h:497) */
+    if (d < 0) return MGC_OK;
+    int tile, loc;
+    mgc_node_to_tile(L, i, tile, loc);
+    const double* src = (h->solved ? L.rcap : L.cap0) + ((int64_t)tile * 6 + d) * MGC_TV + loc;
+    MGC_HIP(h, hipMemcpyAsync(h->h_scalar + 6, src, sizeof(double), hipMemcpyDeviceToHost, h->stream));
+    MGC_HIP(h, hipStreamSynchronize(h->stream));
+    *out = h->h_scalar[6];
+    return MGC_OK;
+}
+
+int mgc_get_node_num(mgc_handle h, int64_t* n)
+{
+    if (!h || !n) return MGC_ERR_INVALID;
+    *n = h->nvox;
+    return MGC_OK;
+}
+
+int mgc_set_param(mgc_handle h, const char* name, int64_t value)
+{
+    if (!h || !name) return MGC_ERR_INVALID;
+    if (!strcmp(name, "rounds_per_relabel") && value > 0) h->params.rounds_per_relabel = (int)value;
+    else if (!strcmp(name, "max_cycles") && value > 0) h->params.max_cycles = (int)value;
+    else if (!strcmp(name, "max_sweeps") && value > 0) h->params.max_sweeps = (int)value;
+    else if (!strcmp(name, "max_outer") && value > 0) h->params.max_outer = (int)value;
+    else if (!strcmp(name, "grid_cap") && value > 0) h->grid_cap = (int)value;
+    else if (!strcmp(name, "kernel_timing")) h->timing = value != 0;
+    else return mgc_fail(h, MGC_ERR_INVALID, "unknown or invalid parameter %s=%lld", name, (long long)value);
+    return MGC_OK;
+}
+
+int mgc_get_stats(mgc_handle h, mgc_stats* out)
+{
+    if (!h || !out) return MGC_ERR_INVALID;
+    h->stats.ntiles = h->L.ntiles;
+    h->stats.nvox = h->nvox;
+    h->stats.device_bytes = h->device_bytes;
+    *out = h->stats;
+    return MGC_OK;
+}
+
+} /* extern "C" */

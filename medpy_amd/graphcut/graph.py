@@ -1,0 +1,312 @@
+"""Graph facade of the voxel graph-cut path.
+
+Mirrors reference medpy/graphcut/graph.py:267-596 (``GCGraph``) and the object it wraps,
+``maxflow.GraphDouble`` (lib/maxflow/src/wrapper.cpp:59-89): same method names, argument
+meaning and ``ValueError`` contract -- but instead of inserting one edge per Python call into
+a CPU adjacency list, the facade records what the energy terms ask for and hands whole
+arrays to the HIP library, which builds the residual lattice in HBM and solves it there.
+"""
+import ctypes as C
+import enum
+
+import numpy
+
+from .. import _lib
+
+
+class termtype(enum.IntEnum):
+    """reference lib/maxflow/src/graph.h:57-61, exposed per class by wrapper.cpp:84-87."""
+    SOURCE = 0
+    SINK = 1
+
+
+class VoxelGraph(object):
+    """What ``graph_from_voxels`` returns: the stand-in for ``maxflow.GraphDouble``.
+
+    Supports what callers of the reference use on the returned object
+    (bin/medpy_graphcut_voxel.py:172-181, tests/graphcut_/energy_voxel.py:205-224):
+    ``maxflow()``, ``what_segment(i)``, ``termtype``, ``get_edge``, ``get_node_num``,
+    ``get_trcap`` -- plus bulk ``labels()`` so that nobody has to loop over voxels in Python.
+    """
+
+    termtype = termtype
+
+    def __init__(self, shape, device=0, connectivity=None):
+        lib = _lib.load()
+        if _lib.device_count() < 1:
+            raise _lib.MedpyHipError(_lib.ERR_NO_DEVICE, "no HIP device visible; medpy_amd has no CPU fallback")
+        self._shape = tuple(int(s) for s in shape)
+        nd = len(self._shape)
+        if nd < 1 or nd > 3:
+            raise NotImplementedError("medpy_amd: %d-D lattices are not implemented (1-D..3-D are)" % nd)
+        shp = (C.c_int64 * nd)(*self._shape)
+        h = C.c_void_p()
+        rc = lib.mgc_create(nd, shp, connectivity or 2 * nd, int(device), C.byref(h))
+        self._h = h if h.value else None
+        if rc != _lib.OK:
+            msg = (lib.mgc_last_error(self._h) or b"").decode()
+            self.close()
+            raise _lib.MedpyHipError(rc, msg)
+        self._nodes = int(numpy.prod(self._shape))
+        self._labels = None
+
+    # -- life cycle
+    def close(self):
+        if getattr(self, "_h", None):
+            _lib.load().mgc_destroy(self._h)
+            self._h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def _call(self, name, *args):
+        _lib.check(self._h, getattr(_lib.load(), name)(self._h, *args))
+
+    # -- inputs (called by GCGraph)
+    def _set_boundary(self, term, image, sigma, spacing):
+        image = numpy.ascontiguousarray(image)
+        if image.dtype == numpy.bool_:
+            image = image.astype(numpy.uint8)
+        if image.dtype == numpy.float16:
+            image = image.astype(numpy.float32)
+        if image.dtype not in _lib.DTYPE_IDS:
+            image = image.astype(numpy.float64)
+        sp = None
+        if spacing:
+            sp = (C.c_double * len(self._shape))(*[float(s) for s in spacing])
+        self._call("mgc_set_boundary", _lib.TERM_IDS[term], _lib.ptr(image), _lib.DTYPE_IDS[image.dtype],
+                   float(sigma) if sigma is not None else 0.0, sp)
+
+    def _set_regional(self, prob, alpha):
+        prob = numpy.asarray(prob)
+        if prob.dtype not in (numpy.float32, numpy.float64):
+            prob = prob.astype(numpy.float64)  # NumPy promotes (non-float array * python float) to float64
+        prob = numpy.ascontiguousarray(prob)
+        self._call("mgc_set_regional_probability", _lib.ptr(prob), _lib.DTYPE_IDS[prob.dtype], float(alpha))
+
+    def _set_markers(self, fg, bg):
+        fg8 = None if fg is None else numpy.ascontiguousarray(fg, dtype=numpy.uint8)
+        bg8 = None if bg is None else numpy.ascontiguousarray(bg, dtype=numpy.uint8)
+        self._call("mgc_set_markers", None if fg8 is None else _lib.ptr(fg8), None if bg8 is None else _lib.ptr(bg8))
+
+    def _add_edges(self, i, j, cap, rev):
+        i = numpy.ascontiguousarray(i, dtype=numpy.int64)
+        j = numpy.ascontiguousarray(j, dtype=numpy.int64)
+        cap = numpy.ascontiguousarray(cap, dtype=numpy.float64)
+        rev = numpy.ascontiguousarray(rev, dtype=numpy.float64)
+        self._call("mgc_add_edges", i.size, _lib.ptr(i), _lib.ptr(j), _lib.ptr(cap), _lib.ptr(rev))
+
+    def _set_tweights_merged(self, tr, flow_const):
+        tr = numpy.ascontiguousarray(tr, dtype=numpy.float64)
+        self._call("mgc_set_tweights_merged", _lib.ptr(tr), float(flow_const))
+
+    def _build(self):
+        self._call("mgc_build")
+        self._labels = None
+
+    def set_param(self, name, value):
+        self._call("mgc_set_param", name.encode(), int(value))
+
+    # -- GraphDouble surface
+    def maxflow(self):
+        """GraphDouble.maxflow(), reference maxflow.cpp:472-604."""
+        flow = C.c_double(0.0)
+        self._call("mgc_maxflow", C.byref(flow))
+        return flow.value
+
+    def labels(self):
+        """All voxels at once: bool array of the marker shape, False where what_segment == SINK
+        (the loop of bin/medpy_graphcut_voxel.py:177-182)."""
+        if self._labels is None:
+            out = numpy.empty(self._nodes, dtype=numpy.uint8)
+            self._call("mgc_labels", _lib.ptr(out))
+            self._labels = out.astype(numpy.bool_).reshape(self._shape)
+        return self._labels
+
+    def what_segment(self, i):
+        """Graph::what_segment, reference graph.h:561-571."""
+        seg = C.c_int(0)
+        self._call("mgc_what_segment", int(i), C.byref(seg))
+        return termtype(seg.value)
+
+    def get_edge(self, i, j):
+        out = C.c_double(0.0)
+        self._call("mgc_get_edge", int(i), int(j), C.byref(out))
+        return out.value
+
+    def get_node_num(self):
+        return self._nodes
+
+    def get_trcap(self, i):
+        return float(self.tweights().ravel()[int(i)])
+
+    # -- energy read-back (parity tests)
+    def nweights(self, axis):
+        shp = list(self._shape)
+        shp[axis] -= 1
+        out = numpy.empty(shp, dtype=numpy.float64)
+        if out.size:
+            self._call("mgc_get_nweights", int(axis), _lib.ptr(out))
+        return out
+
+    def tweights(self):
+        out = numpy.empty(self._shape, dtype=numpy.float64)
+        self._call("mgc_get_tweights", _lib.ptr(out))
+        return out
+
+    def stats(self):
+        st = _lib.Stats()
+        self._call("mgc_get_stats", C.byref(st))
+        return st.as_dict()
+
+
+class GCGraph(object):
+    """Validating facade handed to the energy terms; reference graph.py:267-596.
+
+    ``shape`` (not in the reference signature) tells the facade which voxel lattice the node
+    ids refer to; ``graph_from_voxels`` supplies it.  Built-in energy terms record themselves
+    (``record_boundary`` / ``record_regional``); foreign callables may still drive
+    ``set_nweight`` / ``set_tweight*`` -- those calls are validated exactly like the reference
+    does, accumulated, and uploaded in one batch.
+    """
+
+    __INT_16_BIT = 32767
+    __UINT_16_BIT = 65535
+    MAX = __UINT_16_BIT
+    """The maximum value a terminal weight can take."""
+
+    def __init__(self, nodes, edges, shape=None, device=0):
+        self.__nodes = int(nodes)
+        self.__edges = int(edges)
+        self.__shape = tuple(shape) if shape is not None else (int(nodes),)
+        if int(numpy.prod(self.__shape)) != self.__nodes:
+            raise ValueError("shape {} does not hold {} nodes".format(self.__shape, nodes))
+        self.__device = device
+        self.__boundary = None
+        self.__regional = None
+        self.__fg = None
+        self.__bg = None
+        self.__edge_i, self.__edge_j, self.__edge_w, self.__edge_r = [], [], [], []
+        self.__tr = None  # merged explicit t-links (graph.h:416-425 applied call by call)
+        self.__flow_const = 0.0
+        self.__graph = None
+
+    # -- fast path hooks used by medpy_amd.graphcut.energy_voxel
+    def record_boundary(self, term, image, sigma, spacing):
+        image = numpy.asarray(image)
+        if image.shape != self.__shape:
+            raise NotImplementedError(
+                "medpy_amd: boundary image shape {} differs from the marker shape {}; the reference numbers "
+                "nodes by the image shape in that case (energy_voxel.py:650-664), which is not a voxel lattice "
+                "of this graph".format(image.shape, self.__shape))
+        if self.__boundary is not None:
+            raise NotImplementedError("medpy_amd: only one built-in boundary term per graph")
+        self.__boundary = (term, image, sigma, spacing)
+
+    def record_regional(self, probability_map, alpha):
+        pm = numpy.asarray(probability_map)
+        if pm.size != self.__nodes:
+            raise ValueError("probability map holds {} values for {} nodes".format(pm.size, self.__nodes))
+        self.__regional = (pm.reshape(self.__shape), alpha)
+
+    # -- reference API
+    def set_source_nodes(self, source_nodes):
+        source_nodes = numpy.asarray(source_nodes)
+        if source_nodes.size == 0:
+            raise ValueError("max() arg is an empty sequence")  # the reference's max([]) (graph.py:334)
+        if source_nodes.max() >= self.__nodes or source_nodes.min() < 0:
+            raise ValueError("Invalid node id of {} or {}. Valid values are 0 to {}.".format(
+                source_nodes.max(), source_nodes.min(), self.__nodes - 1))
+        if self.__fg is None:
+            self.__fg = numpy.zeros(self.__nodes, dtype=numpy.uint8)
+        if numpy.unique(source_nodes).size != source_nodes.size or self.__fg[source_nodes].any():
+            for s in source_nodes:  # repeated ids accumulate in the reference; keep that via the explicit path
+                self.set_tweight(int(s), self.MAX, 0)
+            return
+        self.__fg[source_nodes] = 1
+
+    def set_sink_nodes(self, sink_nodes):
+        sink_nodes = numpy.asarray(sink_nodes)
+        if sink_nodes.size == 0:
+            raise ValueError("max() arg is an empty sequence")
+        if sink_nodes.max() >= self.__nodes or sink_nodes.min() < 0:
+            raise ValueError("Invalid node id of {} or {}. Valid values are 0 to {}.".format(
+                sink_nodes.max(), sink_nodes.min(), self.__nodes - 1))
+        if self.__bg is None:
+            self.__bg = numpy.zeros(self.__nodes, dtype=numpy.uint8)
+        if numpy.unique(sink_nodes).size != sink_nodes.size or self.__bg[sink_nodes].any():
+            for s in sink_nodes:
+                self.set_tweight(int(s), 0, self.MAX)
+            return
+        self.__bg[sink_nodes] = 1
+
+    def set_nweight(self, node_from, node_to, weight_there, weight_back):
+        if node_from >= self.__nodes or node_from < 0:
+            raise ValueError("Invalid node id (node_from) of {}. Valid values are 0 to {}.".format(node_from, self.__nodes - 1))
+        elif node_to >= self.__nodes or node_to < 0:
+            raise ValueError("Invalid node id (node_to) of {}. Valid values are 0 to {}.".format(node_to, self.__nodes - 1))
+        elif node_from == node_to:
+            raise ValueError("The node_from ({}) can not be equal to the node_to ({}) (self-connections are forbidden in graph cuts).".format(node_from, node_to))
+        elif weight_there <= 0 or weight_back <= 0:
+            raise ValueError("Negative or zero weights are not allowed.")
+        self.__edge_i.append(int(node_from))
+        self.__edge_j.append(int(node_to))
+        self.__edge_w.append(float(weight_there))
+        self.__edge_r.append(float(weight_back))
+
+    def set_nweights(self, nweights):
+        for edge, weight in list(nweights.items()):
+            self.set_nweight(edge[0], edge[1], weight[0], weight[1])
+
+    def set_tweight(self, node, weight_source, weight_sink):
+        if node >= self.__nodes or node < 0:
+            raise ValueError("Invalid node id of {}. Valid values are 0 to {}.".format(node, self.__nodes - 1))
+        if self.__tr is None:
+            self.__tr = numpy.zeros(self.__nodes, dtype=numpy.float64)
+        # Graph::add_tweights, graph.h:416-425, call by call
+        cs, ck = float(weight_source), float(weight_sink)
+        delta = self.__tr[node]
+        if delta > 0:
+            cs += delta
+        else:
+            ck -= delta
+        self.__flow_const += cs if cs < ck else ck
+        self.__tr[node] = cs - ck
+
+    def set_tweights(self, tweights):
+        for node, weight in list(tweights.items()):
+            self.set_tweight(node, weight[0], weight[1])
+
+    def set_tweights_all(self, tweights):
+        for node, (twsource, twsink) in enumerate(tweights):
+            self.set_tweight(node, twsource, twsink)
+
+    def get_graph(self):
+        """Builds the residual lattice in HBM (once) and returns the solver object."""
+        if self.__graph is None:
+            g = VoxelGraph(self.__shape, device=self.__device)
+            if self.__boundary is not None:
+                g._set_boundary(*self.__boundary)
+            if self.__regional is not None:
+                g._set_regional(*self.__regional)
+            if self.__tr is not None:
+                g._set_tweights_merged(self.__tr, self.__flow_const)
+            if self.__fg is not None or self.__bg is not None:
+                g._set_markers(None if self.__fg is None else self.__fg, None if self.__bg is None else self.__bg)
+            if self.__edge_i:
+                g._add_edges(self.__edge_i, self.__edge_j, self.__edge_w, self.__edge_r)
+            g._build()
+            self.__graph = g
+        return self.__graph
+
+    def get_node_count(self):
+        return self.__nodes
+
+    def get_nodes(self):
+        return list(range(0, self.__nodes))
+
+    def get_edge_count(self):
+        return self.__edges

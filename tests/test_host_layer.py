@@ -1,0 +1,113 @@
+"""CPU tier: host logic, C-ABI surface, hostsim (the solver's single-source tile ops run on the host)."""
+import ctypes
+import os
+import re
+import sys
+
+import numpy as np
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, os.path.join(ROOT, "tests", "hostsim"))
+
+
+def test_library_exports_every_declared_symbol():
+    import __graft_entry__ as ge
+    from medpy_amd import _lib, build
+    build.build_library()
+    header = open(os.path.join(ROOT, "include", "medpy_hip.h")).read()
+    declared = set(re.findall(r"\b(mgc_[a-z_]+)\s*\(", header))
+    assert declared == set(_lib.SIGNATURES), declared ^ set(_lib.SIGNATURES)
+    lib = ctypes.CDLL(_lib.LIB_PATH)
+    for name in declared:
+        assert hasattr(lib, name), name
+    assert callable(ge.build) and callable(ge.smoke)
+
+
+def test_fails_loudly_without_gpu():
+    from medpy_amd import _lib, graphcut
+    if _lib.device_count() > 0:
+        pytest.skip("a GPU is visible")
+    with pytest.raises(_lib.MedpyHipError) as ei:
+        graphcut.graph_from_voxels(np.zeros((4, 4), bool), np.zeros((4, 4), bool))
+    assert ei.value.code == _lib.ERR_NO_DEVICE
+
+
+def test_facade_validation_matches_reference_contract():
+    """reference tests/graphcut_/graph.py:28-84 (ValueError contract of GCGraph)."""
+    from medpy_amd.graphcut import GCGraph, graph_from_voxels
+    g = GCGraph(10, 20)
+    assert g.get_node_count() == 10 and g.get_edge_count() == 20 and g.get_nodes() == list(range(10))
+    for bad in ((-1, 1, 1, 1), (0, 10, 1, 1), (3, 3, 1, 1), (0, 1, 0, 1), (0, 1, 1, -1)):
+        with pytest.raises(ValueError):
+            g.set_nweight(*bad)
+    g.set_nweight(0, 1, float("nan"), 1.0)  # NaN passes `<= 0` exactly like the reference (graph.py:436)
+    with pytest.raises(ValueError):
+        g.set_tweight(10, 1, 1)
+    g.set_tweight(0, -3, 2)  # t-weights may be negative
+    with pytest.raises(ValueError):
+        g.set_source_nodes([10])
+    with pytest.raises(ValueError):
+        g.set_sink_nodes([-1])
+    with pytest.raises(AttributeError):
+        graph_from_voxels(np.zeros((2, 2)), np.zeros((2, 2)), regional_term=lambda a, b, c: None)
+    with pytest.raises(AttributeError):
+        graph_from_voxels(np.zeros((2, 2)), np.zeros((2, 2)), boundary_term=3)
+
+
+def test_split_marker():
+    from medpy_amd.graphcut import split_marker
+    fg, bg = split_marker(np.array([[0, 1, 2], [2, 1, 5]]))
+    assert fg.tolist() == [[False, True, False], [False, True, False]]
+    assert bg.tolist() == [[False, False, True], [True, False, False]]
+
+
+def _sim_case(gen, shape, **kw):
+    import sim
+    from medpy_amd import synthetic
+    from oracle import energy_numpy, pipeline
+    s = getattr(synthetic, gen)(shape)
+    term = kw.pop("term", s["term"])
+    w = energy_numpy.boundary_weights(term, s["image"], s["sigma"])
+    g = pipeline.build_graph(s["fg"], s["bg"], weights=w)
+    tr = np.array([g.get_trcap(i) for i in range(s["fg"].size)])
+    g.maxflow()
+    ref = g.labels().reshape(shape)
+    lab, st = sim.solve(shape, w, tr, **kw)
+    return lab, ref, st
+
+
+@pytest.mark.parametrize("gen,shape", [("sphere", (16, 16, 16)), ("sphere", (40, 40, 40)), ("hard", (32, 32, 32)),
+                                       ("sphere", (9, 21, 35)), ("sphere", (5, 8, 64))])
+def test_hostsim_solver_matches_bk(gen, shape):
+    """The solver's tile operations (same source as the HIP kernels) give the reference labels."""
+    lab, ref, st = _sim_case(gen, shape)
+    assert st["converged"] == 1
+    np.testing.assert_array_equal(lab, ref)
+
+
+def test_hostsim_schedule_independence():
+    """Any schedule (rounds between global relabels, cycle / sweep budgets) reaches the same cut."""
+    base = None
+    for kw in (dict(), dict(rounds=1, cycles=1, sweeps=1), dict(rounds=3, cycles=2, sweeps=4), dict(rounds=50, cycles=16, sweeps=64)):
+        lab, ref, st = _sim_case("sphere", (24, 24, 24), **kw)
+        assert st["converged"] == 1
+        np.testing.assert_array_equal(lab, ref)
+        base = lab if base is None else base
+        np.testing.assert_array_equal(lab, base)
+
+
+def test_hostsim_dyadic_ties_exact():
+    lab, ref, st = _sim_case("ties", (24, 24, 24), term="difference_division")  # sigma 1: weights 1, 1/2, 1/3, 1/4
+    # 1/3 is not dyadic; use linear below for the exact case
+    import sim
+    from medpy_amd import synthetic
+    from oracle import energy_numpy, pipeline
+    s = synthetic.ties((24, 24, 24))
+    img = s["image"].copy(); img.flat[0], img.flat[1] = 0.0, 4.0
+    w = energy_numpy.boundary_weights("difference_linear", img)
+    g = pipeline.build_graph(s["fg"], s["bg"], weights=w)
+    tr = np.array([g.get_trcap(i) for i in range(img.size)])
+    g.maxflow()
+    lab, st = sim.solve(img.shape, w, tr)
+    np.testing.assert_array_equal(lab, g.labels().reshape(img.shape))
