@@ -66,7 +66,7 @@ def main():
     ap.add_argument("--steps", type=int, default=3)
     ap.add_argument("--warmup", type=int, default=1)
     ap.add_argument("--size", type=int, default=512)
-    ap.add_argument("--cpu-sample", type=int, default=160)
+    ap.add_argument("--cpu-sample", type=int, default=320)
     ap.add_argument("--no-cpu", action="store_true")
     args = ap.parse_args()
 

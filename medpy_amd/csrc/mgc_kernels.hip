@@ -526,6 +526,19 @@ static size_t mgc_dtype_size(int dt)
     }
 }
 
+/* float(abs(image.max() - image.min())) evaluated in the image's own dtype, as NumPy scalars do
+ * (energy_voxel.py:174-176): float32 subtracts in float32, integers wrap at their width. */
+static double mgc_range_in_dtype(double mn, double mx, int dtype)
+{
+    switch (dtype) {
+    case MGC_F32: return (double)fabsf((float)mx - (float)mn);
+    case MGC_I8:  { int8_t d = (int8_t)((int64_t)mx - (int64_t)mn); d = (int8_t)(d < 0 ? -d : d); return (double)d; }
+    case MGC_I16: { int16_t d = (int16_t)((int64_t)mx - (int64_t)mn); d = (int16_t)(d < 0 ? -d : d); return (double)d; }
+    case MGC_I32: { int32_t d = (int32_t)((int64_t)mx - (int64_t)mn); d = (int32_t)(d < 0 ? -(int64_t)d : d); return (double)d; }
+    default: return fabs(mx - mn); /* unsigned: max >= min never wraps; f64; 64-bit ints via double */
+    }
+}
+
 /* device policy for mgc_solve(): one kernel launch per call, in-order on the handle's stream */
 struct HipDev {
     mgc_handle h;
@@ -664,20 +677,20 @@ int mgc_create(int ndim, const int64_t* shape, int connectivity, int device, mgc
 int mgc_destroy(mgc_handle h)
 {
     if (!h) return MGC_OK;
-    hipSetDevice(h->device);
-    if (h->stream) hipStreamSynchronize(h->stream);
+    (void)hipSetDevice(h->device);
+    if (h->stream) (void)hipStreamSynchronize(h->stream);
     MgcLattice& L = h->L;
     void* ptrs[] = {L.rcap, L.cap0, L.excess, L.sink, L.height, L.rmask, L.obox, L.oflags, L.list[0], L.list[1], L.list[2],
                     L.list[3], L.list[4], L.list[5], L.count, L.stamp, L.rstamp, L.status, h->d_tr0, h->d_part, h->d_scalar,
                     h->d_labels, h->d_image, h->d_prob, h->d_fg, h->d_bg, h->d_tr_in, h->d_ei, h->d_ej, h->d_ecap, h->d_erev};
     for (void* p : ptrs)
-        if (p) hipFree(p);
-    if (h->h_count) hipHostFree(h->h_count);
-    if (h->h_scalar) hipHostFree(h->h_scalar);
+        if (p) (void)hipFree(p);
+    if (h->h_count) (void)hipHostFree(h->h_count);
+    if (h->h_scalar) (void)hipHostFree(h->h_scalar);
     free(h->h_labels);
     for (int i = 0; i < 4; ++i)
-        if (h->ev[i]) hipEventDestroy(h->ev[i]);
-    if (h->stream) hipStreamDestroy(h->stream);
+        if (h->ev[i]) (void)hipEventDestroy(h->ev[i]);
+    if (h->stream) (void)hipStreamDestroy(h->stream);
     delete h;
     return MGC_OK;
 }
@@ -703,7 +716,7 @@ int mgc_set_boundary(mgc_handle h, int term, const void* image, int dtype, doubl
     if (term == MGC_TERM_NONE) return MGC_OK;
     const size_t es = mgc_dtype_size(dtype);
     if (!image || !es) return mgc_fail(h, MGC_ERR_INVALID, "mgc_set_boundary: image NULL or bad dtype %d", dtype);
-    if (h->d_image && h->img_dtype != dtype) { hipFree(h->d_image); h->d_image = nullptr; }
+    if (h->d_image && h->img_dtype != dtype) { (void)hipFree(h->d_image); h->d_image = nullptr; }
     h->img_dtype = dtype;
     h->sigma = sigma;
     h->has_spacing = spacing ? 1 : 0;
@@ -718,7 +731,7 @@ int mgc_set_regional_probability(mgc_handle h, const void* pm, int dtype, double
     if (!h) return MGC_ERR_INVALID;
     if (!pm || (dtype != MGC_F32 && dtype != MGC_F64)) return mgc_fail(h, MGC_ERR_INVALID, "probability map must be float32 or float64");
     MGC_HIP(h, hipSetDevice(h->device));
-    if (h->d_prob && h->prob_dtype != dtype) { hipFree(h->d_prob); h->d_prob = nullptr; }
+    if (h->d_prob && h->prob_dtype != dtype) { (void)hipFree(h->d_prob); h->d_prob = nullptr; }
     h->prob_dtype = dtype;
     h->alpha = alpha;
     h->built = h->solved = false;
@@ -732,10 +745,10 @@ int mgc_set_markers(mgc_handle h, const uint8_t* fg, const uint8_t* bg)
     h->built = h->solved = false;
     int rc = MGC_OK;
     if (fg) rc = mgc_upload(h, (void**)&h->d_fg, fg, (size_t)h->nvox);
-    else if (h->d_fg) { hipFree(h->d_fg); h->d_fg = nullptr; }
+    else if (h->d_fg) { (void)hipFree(h->d_fg); h->d_fg = nullptr; }
     if (rc) return rc;
     if (bg) rc = mgc_upload(h, (void**)&h->d_bg, bg, (size_t)h->nvox);
-    else if (h->d_bg) { hipFree(h->d_bg); h->d_bg = nullptr; }
+    else if (h->d_bg) { (void)hipFree(h->d_bg); h->d_bg = nullptr; }
     return rc;
 }
 
@@ -786,7 +799,7 @@ int mgc_build(mgc_handle h)
         for (int b = 0; b < nb; ++b) { mn = fmin(mn, hp[3 * b]); mx = fmax(mx, hp[3 * b + 1]); ma = fmax(ma, hp[3 * b + 2]); }
         free(hp);
         MGC_HIP(h, e);
-        A.p0 = (A.term == MGC_TERM_MAXIMUM_LINEAR) ? ma : fabs(mx - mn); /* energy_voxel.py:101 / 174-176 */
+        A.p0 = (A.term == MGC_TERM_MAXIMUM_LINEAR) ? ma : mgc_range_in_dtype(mn, mx, h->img_dtype); /* energy_voxel.py:101 / 174-176 */
     }
     A.has_spacing = h->has_spacing;
     A.inv_axis[0] = h->spacing[2]; A.inv_axis[1] = h->spacing[1]; A.inv_axis[2] = h->spacing[0];
@@ -919,7 +932,7 @@ int mgc_get_nweights(mgc_handle h, int axis, double* out)
     hipError_t e = hipGetLastError();
     if (e == hipSuccess) e = hipMemcpyAsync(out, d, (size_t)n * sizeof(double), hipMemcpyDeviceToHost, h->stream);
     if (e == hipSuccess) e = hipStreamSynchronize(h->stream);
-    hipFree(d);
+    (void)hipFree(d);
     MGC_HIP(h, e);
     return MGC_OK;
 }
@@ -935,7 +948,7 @@ int mgc_get_tweights(mgc_handle h, double* out)
     hipError_t e = hipGetLastError();
     if (e == hipSuccess) e = hipMemcpyAsync(out, d, (size_t)h->nvox * sizeof(double), hipMemcpyDeviceToHost, h->stream);
     if (e == hipSuccess) e = hipStreamSynchronize(h->stream);
-    hipFree(d);
+    (void)hipFree(d);
     MGC_HIP(h, e);
     return MGC_OK;
 }
