@@ -1,0 +1,29 @@
+"""Summarise a rocprofv3 (rocpd sqlite) result: per-kernel time stats and PMC counter sums.
+
+    python tools/rocpd_summary.py stats  <results.db>  > profiles/<round>_kernel_stats.csv
+    python tools/rocpd_summary.py pmc    <results.db>  > profiles/<round>_pmc_<counter>.csv
+"""
+import sqlite3
+import sys
+
+
+def main():
+    mode, path = sys.argv[1], sys.argv[2]
+    cur = sqlite3.connect(path).cursor()
+    if mode == "stats":
+        print("kernel,calls,total_us,avg_us,min_us,max_us,percent")
+        rows = cur.execute("select name, count(*), sum(duration), avg(duration), min(duration), max(duration) from kernels "
+                           "group by name order by sum(duration) desc").fetchall()
+        tot = sum(r[2] for r in rows) or 1
+        for n, c, s, a, mn, mx in rows:
+            print('"%s",%d,%.3f,%.3f,%.3f,%.3f,%.2f' % (n, c, s / 1e3, a / 1e3, mn / 1e3, mx / 1e3, 100.0 * s / tot))
+    else:
+        print("kernel,counter,dispatches,sum_value,avg_value_per_dispatch,avg_duration_us")
+        rows = cur.execute("select kernel_name, counter_name, count(*), sum(value), avg(value), avg(duration) from counters_collection "
+                           "group by kernel_name, counter_name order by sum(value) desc").fetchall()
+        for n, c, k, s, a, d in rows:
+            print('"%s",%s,%d,%.3f,%.3f,%.3f' % (n, c, k, s, a, d / 1e3))
+
+
+if __name__ == "__main__":
+    main()
