@@ -34,7 +34,9 @@ class Stats(C.Structure):
     ]
 
     def as_dict(self):
-        return {k: getattr(self, k) for k, _ in self._fields_ if k != "reserved"}
+        d = {k: getattr(self, k) for k, _ in self._fields_ if k != "reserved"}
+        d["readbacks"] = self.reserved[0]
+        return d
 
 
 # every symbol include/medpy_hip.h declares: (restype, argtypes)

@@ -33,6 +33,7 @@
 /* direction d: 0 = -x, 1 = +x, 2 = -y, 3 = +y, 4 = -z, 5 = +z ; opposite = d ^ 1 ; axis = d >> 1 */
 #define MGC_NDIR 6
 #define MGC_MASK_SINK 0x40      /* rmask bit 6: residual capacity to the sink > 0 */
+#define MGC_NCOUNT 16
 
 struct MgcLattice {
     /* logical volume */
@@ -53,10 +54,11 @@ struct MgcLattice {
     /* work lists: [0],[1] = discharge lists of colour 0 / 1 being consumed; [2],[3] = being produced;
        [4],[5] = relabel list consumed / produced */
     int32_t*  list[6];
-    int32_t*  count;          /* [8] list lengths (device resident)                 */
+    int32_t*  count;          /* [16] device resident: [0..5] list lengths, [6] active tiles found by the last
+                                 activation, [8]/[9] running totals of tiles discharged / relabelled            */
     uint32_t* stamp;          /* [ntiles] de-duplication stamp for list appends (discharge) */
     uint32_t* rstamp;         /* [ntiles] same for the relabel lists                */
-    uint32_t* status;         /* [ntiles] bit0: tile holds excess that can still reach the sink */
+    uint32_t* status;         /* [ntiles] bit1: the tile holds at least one residual arc to the sink */
 };
 
 MGC_HD int mgc_tile_id(const MgcLattice& L, int tz, int ty, int tx) { return (tz * L.gy + ty) * L.gx + tx; }

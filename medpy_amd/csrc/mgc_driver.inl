@@ -13,8 +13,12 @@
  *           face neighbours of a discharging tile are idle: region discharge is race-free and
  *           bit-reproducible without atomics on the flow data.
  *
+ * The work lists and their lengths live on the device; kernels read the length themselves, so the
+ * host launches passes / phases in batches and only reads the counter block back every
+ * `relabel_batch` passes / `check_rounds` rounds (a pass over an empty list is a no-op).
+ *
  * Dev concept (every call is asynchronous on the device's stream unless it returns a value):
- *   fill_heights_inf()  zero_count(i)  read_counts(int out[8])   absorb_all()
+ *   fill_heights_inf()  zero_count(i)  read_counts(int out[MGC_NCOUNT])   absorb_all()
  *   relabel_all(epoch, next_list)  relabel_list(list, epoch, next_list)
  *   activate_all(phase)  discharge(list, phase, max_cycles, max_sweeps)
  */
@@ -28,26 +32,31 @@ struct MgcSolveParams {
     int max_cycles;         /* label/push cycles per tile discharge                       */
     int max_sweeps;         /* push sweeps per cycle                                      */
     int max_outer;          /* safety cap on global relabels                              */
+    int relabel_batch;      /* BFS passes launched between two counter read-backs         */
+    int check_rounds;       /* colour rounds launched between two counter read-backs      */
 };
 
 struct MgcSolveStats {
     int64_t outer;            /* global relabels performed                                 */
-    int64_t relabel_passes;   /* tile-BFS passes over a work list                          */
+    int64_t relabel_passes;   /* tile-BFS passes launched                                  */
     int64_t relabel_tiles;    /* tiles visited by those passes                             */
     int64_t phases;           /* colour phases launched                                    */
     int64_t discharge_tiles;  /* tile discharges                                           */
     int64_t converged;        /* 1 when the preflow is maximum                             */
     int64_t last_active;      /* active tiles found by the last activation pass            */
-    int64_t reserved;
+    int64_t readbacks;        /* counter read-backs (host syncs)                           */
 };
 
 static inline MgcSolveParams mgc_default_params()
 {
     MgcSolveParams p;
-    p.rounds_per_relabel = 8;
-    p.max_cycles = 8;
-    p.max_sweeps = 32;
+    /* tuned on MI355X at 256^3 / 512^3 (tools/gpu_sweep.py; every schedule gives the same labels) */
+    p.rounds_per_relabel = 12;
+    p.max_cycles = 4;
+    p.max_sweeps = 8;
     p.max_outer = 100000;
+    p.relabel_batch = 8;
+    p.check_rounds = 4;
     return p;
 }
 
@@ -56,8 +65,10 @@ int mgc_solve(Dev& dev, const MgcLattice& L, const MgcSolveParams& P, MgcSolveSt
 {
     uint32_t phase = 4; /* stamps start at 0 */
     uint32_t rep = 2;   /* relabel epoch     */
-    int cnt[8];
+    int cnt[MGC_NCOUNT];
     st = MgcSolveStats();
+    dev.zero_count(8);
+    dev.zero_count(9);
 
     for (int outer = 0; outer < P.max_outer; ++outer) {
         /* ---- global relabel ---- */
@@ -67,16 +78,17 @@ int mgc_solve(Dev& dev, const MgcLattice& L, const MgcSolveParams& P, MgcSolveSt
         dev.zero_count(5);
         dev.relabel_all(rep + 1, 4 + (int)((rep + 1) & 1u));
         st.relabel_passes++;
-        st.relabel_tiles += L.ntiles;
         for (;;) {
-            rep++;
-            const int cur = 4 + (int)(rep & 1u), nxt = 4 + (int)((rep + 1) & 1u);
+            for (int b = 0; b < P.relabel_batch; ++b) {
+                rep++;
+                const int cur = 4 + (int)(rep & 1u), nxt = 4 + (int)((rep + 1) & 1u);
+                dev.zero_count(nxt);
+                dev.relabel_list(cur, rep + 1, nxt);
+                st.relabel_passes++;
+            }
             dev.read_counts(cnt);
-            if (cnt[cur] == 0) break;
-            dev.zero_count(nxt);
-            dev.relabel_list(cur, rep + 1, nxt);
-            st.relabel_passes++;
-            st.relabel_tiles += cnt[cur];
+            st.readbacks++;
+            if (cnt[4 + (int)((rep + 1) & 1u)] == 0) break; /* the last pass woke nobody: fixpoint */
         }
         st.outer++;
 
@@ -86,7 +98,10 @@ int mgc_solve(Dev& dev, const MgcLattice& L, const MgcSolveParams& P, MgcSolveSt
         dev.zero_count(6);
         dev.activate_all(phase);
         dev.read_counts(cnt);
+        st.readbacks++;
         st.last_active = cnt[6];
+        st.discharge_tiles = cnt[8];
+        st.relabel_tiles = cnt[9];
         if (cnt[6] == 0) {
             st.converged = 1;
             return 0;
@@ -96,14 +111,16 @@ int mgc_solve(Dev& dev, const MgcLattice& L, const MgcSolveParams& P, MgcSolveSt
         for (int r = 0; r < P.rounds_per_relabel; ++r) {
             for (int c = 0; c < 2; ++c) {
                 const int lst = (int)(phase & 3u);
-                st.discharge_tiles += cnt[lst];
                 dev.discharge(lst, phase, P.max_cycles, P.max_sweeps);
                 dev.zero_count(lst);
                 st.phases++;
                 phase++;
-                dev.read_counts(cnt);
             }
-            if (cnt[phase & 3u] == 0 && cnt[(phase + 1) & 3u] == 0) break;
+            if ((r + 1) % P.check_rounds == 0 && r + 1 < P.rounds_per_relabel) {
+                dev.read_counts(cnt);
+                st.readbacks++;
+                if (cnt[phase & 3u] == 0 && cnt[(phase + 1) & 3u] == 0) break;
+            }
         }
     }
     return 1; /* not converged within max_outer */

@@ -27,6 +27,7 @@
 #include <string.h>
 
 #include <string>
+#include <vector>
 
 #include "../../include/medpy_hip.h"
 #include "mgc_tile_ops.inl"
@@ -77,10 +78,13 @@ __global__ __launch_bounds__(MGC_TV) void k_relabel_all(MgcLattice L, uint32_t e
 {
     __shared__ MgcTileShared S;
     GpuBlock x(S);
+    int visited = 0;
     for (int tile = blockIdx.x; tile < L.ntiles; tile += gridDim.x) {
-        mgc_relabel_tile(x, L, tile, epoch, next_list);
+        visited += (L.status[tile] >> 1) & 1u;
+        mgc_relabel_tile(x, L, tile, epoch, next_list, true);
         __syncthreads();
     }
+    if (threadIdx.x == 0 && visited) atomicAdd(&L.count[9], visited);
 }
 
 __global__ __launch_bounds__(MGC_TV) void k_relabel_list(MgcLattice L, int lst, uint32_t epoch, int next_list)
@@ -88,8 +92,9 @@ __global__ __launch_bounds__(MGC_TV) void k_relabel_list(MgcLattice L, int lst, 
     __shared__ MgcTileShared S;
     GpuBlock x(S);
     const int n = L.count[lst];
+    if (blockIdx.x == 0 && threadIdx.x == 0 && n) atomicAdd(&L.count[9], n);
     for (int i = blockIdx.x; i < n; i += gridDim.x) {
-        mgc_relabel_tile(x, L, L.list[lst][i], epoch, next_list);
+        mgc_relabel_tile(x, L, L.list[lst][i], epoch, next_list, false);
         __syncthreads();
     }
 }
@@ -109,6 +114,7 @@ __global__ __launch_bounds__(MGC_TV) void k_discharge(MgcLattice L, int lst, uin
     __shared__ MgcTileShared S;
     GpuBlock x(S);
     const int n = L.count[lst];
+    if (blockIdx.x == 0 && threadIdx.x == 0 && n) atomicAdd(&L.count[8], n);
     for (int i = blockIdx.x; i < n; i += gridDim.x) {
         mgc_discharge_tile(x, L, L.list[lst][i], phase, cycles, sweeps);
         __syncthreads();
@@ -290,11 +296,12 @@ __global__ __launch_bounds__(MGC_TV) void k_build(MgcLattice L, MgcBuildArgs A)
 #pragma unroll
             for (int k = 0; k < 8; ++k) L.obox[(int64_t)tile * 6 * MGC_TF + t * 8 + k] = 0.0;
         }
+        const int any_sink = __syncthreads_or(tr < 0.0);
         if (t == 0) {
             L.oflags[tile] = 0;
             L.stamp[tile] = 0;
             L.rstamp[tile] = 0;
-            L.status[tile] = 0;
+            L.status[tile] = any_sink ? 2u : 0u;
         }
         const double s = mgc_block_sum(fc, scratch);
         if (t == 0) A.fpart[tile] = s;
@@ -463,6 +470,7 @@ struct mgc_graph {
     int64_t nvox = 0;
     hipStream_t stream = nullptr;
     hipEvent_t ev[4] = {nullptr, nullptr, nullptr, nullptr};
+    std::vector<hipEvent_t> ev_pool; /* per-launch timing */
     MgcLattice L{};
     /* inputs resident in HBM */
     void* d_image = nullptr; int img_dtype = 0; int term = MGC_TERM_NONE; double sigma = 0; double spacing[3] = {1, 1, 1};
@@ -480,7 +488,7 @@ struct mgc_graph {
     bool built = false, solved = false;
     double flow_const = 0.0, flow = 0.0;
     MgcSolveParams params = mgc_default_params();
-    int grid_cap = 2048;
+    int grid_cap = 4096;
     mgc_stats stats{};
     int64_t device_bytes = 0;
     std::string err;
@@ -539,39 +547,44 @@ static double mgc_range_in_dtype(double mn, double mx, int dtype)
     }
 }
 
-/* device policy for mgc_solve(): one kernel launch per call, in-order on the handle's stream */
+/* device policy for mgc_solve(): one kernel launch per call, in-order on the handle's stream.
+ * List lengths live on the device, so launches use a fixed persistent-style grid and never wait
+ * for the host; per-kernel time comes from HIP event pairs recorded on the launch stream and
+ * resolved after the solve (no synchronisation inside the timed region). */
 struct HipDev {
     mgc_handle h;
     hipError_t first_error = hipSuccess;
     float discharge_ms = 0.f, relabel_ms = 0.f;
+    int64_t discharge_launches = 0, relabel_launches = 0, readbacks = 0;
+    struct Span { int a, b, kind; };
+    std::vector<Span> spans;
     void check(hipError_t e) { if (e != hipSuccess && first_error == hipSuccess) first_error = e; }
     int grid(int64_t n) const { return (int)(n < 1 ? 1 : (n < h->grid_cap ? n : h->grid_cap)); }
     void fill_heights_inf() { check(hipMemsetAsync(h->L.height, 0x3f, (size_t)h->L.ntiles * MGC_TV * sizeof(int32_t), h->stream)); }
     void zero_count(int i) { check(hipMemsetAsync(h->L.count + i, 0, sizeof(int32_t), h->stream)); }
     void read_counts(int* out)
     {
-        check(hipMemcpyAsync(h->h_count, h->L.count, 8 * sizeof(int32_t), hipMemcpyDeviceToHost, h->stream));
+        check(hipMemcpyAsync(h->h_count, h->L.count, MGC_NCOUNT * sizeof(int32_t), hipMemcpyDeviceToHost, h->stream));
         check(hipStreamSynchronize(h->stream));
-        memcpy(out, h->h_count, 8 * sizeof(int32_t));
-        last[0] = out[0]; last[1] = out[1]; last[2] = out[2]; last[3] = out[3]; last[4] = out[4]; last[5] = out[5];
+        memcpy(out, h->h_count, MGC_NCOUNT * sizeof(int32_t));
+        readbacks++;
     }
-    int last[8] = {0, 0, 0, 0, 0, 0, 0, 0};
     void absorb_all() { hipLaunchKernelGGL(k_absorb, dim3(grid(h->L.ntiles)), dim3(MGC_TV), 0, h->stream, h->L); check(hipGetLastError()); }
     void relabel_all(uint32_t epoch, int next)
     {
-        time_begin();
+        const int id = time_begin(1);
         hipLaunchKernelGGL(k_relabel_all, dim3(grid(h->L.ntiles)), dim3(MGC_TV), 0, h->stream, h->L, epoch, next);
         check(hipGetLastError());
-        time_end(relabel_ms);
-        h->stats.relabel_launches++;
+        time_end(id);
+        relabel_launches++;
     }
     void relabel_list(int lst, uint32_t epoch, int next)
     {
-        time_begin();
-        hipLaunchKernelGGL(k_relabel_list, dim3(grid(last[lst])), dim3(MGC_TV), 0, h->stream, h->L, lst, epoch, next);
+        const int id = time_begin(1);
+        hipLaunchKernelGGL(k_relabel_list, dim3(grid(h->L.ntiles)), dim3(MGC_TV), 0, h->stream, h->L, lst, epoch, next);
         check(hipGetLastError());
-        time_end(relabel_ms);
-        h->stats.relabel_launches++;
+        time_end(id);
+        relabel_launches++;
     }
     void activate_all(uint32_t phase)
     {
@@ -580,23 +593,36 @@ struct HipDev {
     }
     void discharge(int lst, uint32_t phase, int cycles, int sweeps)
     {
-        if (last[lst] == 0) return;
-        time_begin();
-        hipLaunchKernelGGL(k_discharge, dim3(grid(last[lst])), dim3(MGC_TV), 0, h->stream, h->L, lst, phase, cycles, sweeps);
+        const int id = time_begin(0);
+        hipLaunchKernelGGL(k_discharge, dim3(grid(h->L.ntiles)), dim3(MGC_TV), 0, h->stream, h->L, lst, phase, cycles, sweeps);
         check(hipGetLastError());
-        time_end(discharge_ms);
-        h->stats.discharge_launches++;
+        time_end(id);
+        discharge_launches++;
     }
-    /* HIP events on the launch stream: the numbers bench.py's roofline uses */
-    void time_begin() { if (h->timing) check(hipEventRecord(h->ev[2], h->stream)); }
-    void time_end(float& acc)
+    int time_begin(int kind)
     {
-        if (!h->timing) return;
-        check(hipEventRecord(h->ev[3], h->stream));
-        check(hipEventSynchronize(h->ev[3]));
-        float ms = 0.f;
-        check(hipEventElapsedTime(&ms, h->ev[2], h->ev[3]));
-        acc += ms;
+        if (!h->timing) return -1;
+        const size_t need = 2 * spans.size() + 2;
+        while (h->ev_pool.size() < need) {
+            hipEvent_t e;
+            if (hipEventCreate(&e) != hipSuccess) return -1;
+            h->ev_pool.push_back(e);
+        }
+        Span sp{(int)(2 * spans.size()), (int)(2 * spans.size() + 1), kind};
+        check(hipEventRecord(h->ev_pool[sp.a], h->stream));
+        spans.push_back(sp);
+        return (int)spans.size() - 1;
+    }
+    void time_end(int id)
+    {
+        if (id >= 0) check(hipEventRecord(h->ev_pool[spans[id].b], h->stream));
+    }
+    void resolve_timing() /* after the stream has drained */
+    {
+        for (const Span& sp : spans) {
+            float ms = 0.f;
+            if (hipEventElapsedTime(&ms, h->ev_pool[sp.a], h->ev_pool[sp.b]) == hipSuccess) (sp.kind == 0 ? discharge_ms : relabel_ms) += ms;
+        }
     }
 };
 
@@ -659,7 +685,7 @@ int mgc_create(int ndim, const int64_t* shape, int connectivity, int device, mgc
     if ((rc = mgc_alloc(h, &L.oflags, nt))) return rc;
     for (int i = 0; i < 6; ++i)
         if ((rc = mgc_alloc(h, &L.list[i], nt))) return rc;
-    if ((rc = mgc_alloc(h, &L.count, (int64_t)8))) return rc;
+    if ((rc = mgc_alloc(h, &L.count, (int64_t)MGC_NCOUNT))) return rc;
     if ((rc = mgc_alloc(h, &L.stamp, nt))) return rc;
     if ((rc = mgc_alloc(h, &L.rstamp, nt))) return rc;
     if ((rc = mgc_alloc(h, &L.status, nt))) return rc;
@@ -667,9 +693,9 @@ int mgc_create(int ndim, const int64_t* shape, int connectivity, int device, mgc
     if ((rc = mgc_alloc(h, &h->d_part, nt > 4096 ? nt : (int64_t)4096))) return rc;
     if ((rc = mgc_alloc(h, &h->d_scalar, (int64_t)8))) return rc;
     if ((rc = mgc_alloc(h, &h->d_labels, n))) return rc;
-    MGC_HIP(h, hipHostMalloc((void**)&h->h_count, 8 * sizeof(int32_t), hipHostMallocDefault));
+    MGC_HIP(h, hipHostMalloc((void**)&h->h_count, MGC_NCOUNT * sizeof(int32_t), hipHostMallocDefault));
     MGC_HIP(h, hipHostMalloc((void**)&h->h_scalar, 8 * sizeof(double), hipHostMallocDefault));
-    MGC_HIP(h, hipMemsetAsync(L.count, 0, 8 * sizeof(int32_t), h->stream));
+    MGC_HIP(h, hipMemsetAsync(L.count, 0, MGC_NCOUNT * sizeof(int32_t), h->stream));
     MGC_HIP(h, hipStreamSynchronize(h->stream));
     return MGC_OK;
 }
@@ -690,6 +716,7 @@ int mgc_destroy(mgc_handle h)
     free(h->h_labels);
     for (int i = 0; i < 4; ++i)
         if (h->ev[i]) (void)hipEventDestroy(h->ev[i]);
+    for (hipEvent_t e : h->ev_pool) (void)hipEventDestroy(e);
     if (h->stream) (void)hipStreamDestroy(h->stream);
     delete h;
     return MGC_OK;
@@ -820,7 +847,7 @@ int mgc_build(mgc_handle h)
         hipLaunchKernelGGL(k_refresh_mask, dim3(grid), dim3(MGC_TV), 0, h->stream, L);
         MGC_HIP(h, hipGetLastError());
     }
-    MGC_HIP(h, hipMemsetAsync(L.count, 0, 8 * sizeof(int32_t), h->stream));
+    MGC_HIP(h, hipMemsetAsync(L.count, 0, MGC_NCOUNT * sizeof(int32_t), h->stream));
     MGC_HIP(h, hipEventRecord(h->ev[1], h->stream));
     MGC_HIP(h, hipMemcpyAsync(h->h_scalar, h->d_scalar, 8 * sizeof(double), hipMemcpyDeviceToHost, h->stream));
     MGC_HIP(h, hipStreamSynchronize(h->stream));
@@ -850,7 +877,6 @@ int mgc_maxflow(mgc_handle h, double* flow)
         HipDev dev;
         dev.h = h;
         MgcSolveStats st;
-        h->stats.discharge_launches = h->stats.relabel_launches = 0;
         MGC_HIP(h, hipEventRecord(h->ev[0], h->stream));
         const int rc = mgc_solve(dev, L, h->params, st);
         if (dev.first_error != hipSuccess)
@@ -872,8 +898,12 @@ int mgc_maxflow(mgc_handle h, double* flow)
         float ms = 0.f;
         MGC_HIP(h, hipEventElapsedTime(&ms, h->ev[0], h->ev[1]));
         h->stats.solve_ms = ms;
+        dev.resolve_timing();
         h->stats.discharge_ms = dev.discharge_ms;
         h->stats.relabel_ms = dev.relabel_ms;
+        h->stats.discharge_launches = dev.discharge_launches;
+        h->stats.relabel_launches = dev.relabel_launches;
+        h->stats.reserved[0] = dev.readbacks;
         h->stats.discharge_tiles = st.discharge_tiles;
         h->stats.relabel_tiles = st.relabel_tiles;
         h->stats.global_relabels = st.outer;
@@ -994,6 +1024,8 @@ int mgc_set_param(mgc_handle h, const char* name, int64_t value)
     else if (!strcmp(name, "max_sweeps") && value > 0) h->params.max_sweeps = (int)value;
     else if (!strcmp(name, "max_outer") && value > 0) h->params.max_outer = (int)value;
     else if (!strcmp(name, "grid_cap") && value > 0) h->grid_cap = (int)value;
+    else if (!strcmp(name, "relabel_batch") && value > 0) h->params.relabel_batch = (int)value;
+    else if (!strcmp(name, "check_rounds") && value > 0) h->params.check_rounds = (int)value;
     else if (!strcmp(name, "kernel_timing")) h->timing = value != 0;
     else return mgc_fail(h, MGC_ERR_INVALID, "unknown or invalid parameter %s=%lld", name, (long long)value);
     return MGC_OK;

@@ -163,8 +163,10 @@ MGC_HD void mgc_tile_bfs(X& x, MaskFn mask)
  * voxels that cannot reach it -- the set the reference reads out with what_segment().
  * ------------------------------------------------------------------------------------- */
 template <class X>
-MGC_HD void mgc_relabel_tile(X& x, const MgcLattice& L, int tile, uint32_t next_epoch, int next_list)
+MGC_HD void mgc_relabel_tile(X& x, const MgcLattice& L, int tile, uint32_t next_epoch, int next_list, bool first_pass)
 {
+    /* first pass of a global relabel: every label is INF, so only tiles holding a sink arc can seed anything */
+    if (first_pass && !(L.status[tile] & 2u)) return;
     typename X::template Reg<int> m, h0;
     const int64_t base = (int64_t)tile * MGC_TV;
     x.par([&](int t) { mgc_load_nbrs(x, L, tile, t); });
@@ -359,6 +361,7 @@ MGC_HD void mgc_discharge_tile(X& x, const MgcLattice& L, int tile, uint32_t pha
         /* cycle budget exhausted: is there still something to do with the current labels? */
         active = x.any([&](int t) -> bool { return e[t] > 0.0 && hme[t] < MGC_HINF; });
     }
+    const bool has_sink = x.any([&](int t) -> bool { return snk[t] > 0.0; });
 
     /* store */
     x.par([&](int t) {
@@ -389,6 +392,7 @@ MGC_HD void mgc_discharge_tile(X& x, const MgcLattice& L, int tile, uint32_t pha
             mgc_enqueue(x, L, (int)((phase + 1) & 3u), L.stamp, phase + 1, x.S.nbr[t]);
         }
         if (t == 6 && active) mgc_enqueue(x, L, (int)((phase + 2) & 3u), L.stamp, phase + 2, tile);
+        if (t == 7) L.status[tile] = (L.status[tile] & ~2u) | (has_sink ? 2u : 0u);
     });
 }
 

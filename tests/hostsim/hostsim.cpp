@@ -47,20 +47,29 @@ struct HostDev {
     MgcTileShared S;
     void fill_heights_inf() { for (int64_t i = 0; i < (int64_t)L.ntiles * MGC_TV; ++i) L.height[i] = MGC_HINF; }
     void zero_count(int i) { L.count[i] = 0; }
-    void read_counts(int* out) { memcpy(out, L.count, 8 * sizeof(int)); }
+    void read_counts(int* out) { memcpy(out, L.count, MGC_NCOUNT * sizeof(int)); }
     void absorb_all() { HostBlock x(S); for (int t = 0; t < L.ntiles; ++t) mgc_absorb_tile(x, L, t); }
-    void relabel_all(uint32_t epoch, int next) { HostBlock x(S); for (int t = 0; t < L.ntiles; ++t) mgc_relabel_tile(x, L, t, epoch, next); }
+    void relabel_all(uint32_t epoch, int next)
+    {
+        HostBlock x(S);
+        for (int t = 0; t < L.ntiles; ++t) {
+            if (L.status[t] & 2u) L.count[9]++;
+            mgc_relabel_tile(x, L, t, epoch, next, true);
+        }
+    }
     void relabel_list(int lst, uint32_t epoch, int next)
     {
         HostBlock x(S);
         const int n = L.count[lst];
-        for (int i = 0; i < n; ++i) mgc_relabel_tile(x, L, L.list[lst][i], epoch, next);
+        L.count[9] += n;
+        for (int i = 0; i < n; ++i) mgc_relabel_tile(x, L, L.list[lst][i], epoch, next, false);
     }
     void activate_all(uint32_t phase) { HostBlock x(S); for (int t = 0; t < L.ntiles; ++t) mgc_activate_tile(x, L, t, phase); }
     void discharge(int lst, uint32_t phase, int cycles, int sweeps)
     {
         HostBlock x(S);
         const int n = L.count[lst];
+        L.count[8] += n;
         for (int i = 0; i < n; ++i) mgc_discharge_tile(x, L, L.list[lst][i], phase, cycles, sweeps);
     }
 };
@@ -85,7 +94,7 @@ int hostsim_solve(const int64_t* shape, const double* w0, const double* w1, cons
     L.ntiles = L.gz * L.gy * L.gx;
     const int64_t nt = L.ntiles;
     std::vector<double> rcap(nt * 6 * MGC_TV, 0.0), excess(nt * MGC_TV, 0.0), sink(nt * MGC_TV, 0.0), obox(nt * 6 * MGC_TF, 0.0);
-    std::vector<int32_t> height(nt * MGC_TV, MGC_HINF), lists(6 * nt, 0), count(8, 0);
+    std::vector<int32_t> height(nt * MGC_TV, MGC_HINF), lists(6 * nt, 0), count(MGC_NCOUNT, 0);
     std::vector<uint8_t> rmask(nt * MGC_TV, 0);
     std::vector<uint32_t> oflags(nt, 0), stamp(nt, 0), rstamp(nt, 0), status(nt, 0);
     L.rcap = rcap.data(); L.cap0 = NULL; L.excess = excess.data(); L.sink = sink.data(); L.height = height.data();
@@ -115,7 +124,7 @@ int hostsim_solve(const int64_t* shape, const double* w0, const double* w1, cons
                 const double tr = trcap[id];
                 excess[(int64_t)tile * MGC_TV + loc] = tr > 0 ? tr : 0.0;
                 sink[(int64_t)tile * MGC_TV + loc] = tr < 0 ? -tr : 0.0;
-                if (tr < 0) m |= MGC_MASK_SINK;
+                if (tr < 0) { m |= MGC_MASK_SINK; status[tile] |= 2u; }
                 rmask[(int64_t)tile * MGC_TV + loc] = (uint8_t)m;
             }
 
