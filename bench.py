@@ -13,10 +13,11 @@ Prints ONE JSON line (rank 0) with `roofline` (dominant kernel, HIP-event timed 
 stream inside the library) and `cpu_baseline` (the reference's own BK solver, compiled in place
 as oracle/_ref, timed on a bounded sample on the host cores).
 
-N > 1: one process per GPU (torch.distributed launch contract), every rank cuts its own
-volume of the same size -- weak scaling over independent volumes; there is no data-path
-collective in that mode (the Z-slab split with RCCL halo exchange is not implemented yet, see
-DESIGN.md).
+N > 1: one process per GPU (torch.distributed launch contract, backend nccl = RCCL).  ONE volume of
+(size*N, size, size) voxels -- N sphere blocks stacked along axis 0 -- is cut as N exact Z-slabs, one
+per GPU (medpy_amd/slab.py): after every relabel pass / colour phase the packed slab borders
+(labels + outbox flow) travel to the neighbour ranks with RCCL send/recv over xGMI and tiny
+all-reduces decide termination.  Per-GPU work is fixed as N grows: weak scaling.
 """
 import argparse
 import json
@@ -73,10 +74,6 @@ def main():
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
-    dist = None
-    if world > 1:
-        import torch.distributed as dist  # plumbing only: rendezvous + barrier + max-reduce of the timing
-        dist.init_process_group("gloo", rank=rank, world_size=world)
 
     from medpy_amd import _lib, synthetic
     from medpy_amd.graphcut.graph import VoxelGraph
@@ -85,38 +82,85 @@ def main():
         raise SystemExit("bench.py: no MI355X visible (the HIP path has no CPU fallback)")
 
     n = args.size
-    shape = (n, n, n)
-    s = synthetic.sphere(shape, seed=rank)
-    g = VoxelGraph(shape, device=local_rank % max(_lib.device_count(), 1))
-    g._set_boundary("difference_exponential", s["image"], s["sigma"], False)  # H2D, outside the timed region
-    g._set_markers(s["fg"], s["bg"])
-
-    def step():
-        g._build()
-        return g.maxflow()
-
-    for _ in range(args.warmup):
-        step()
-    if dist:
-        dist.barrier()
-    t0 = time.perf_counter()
     acc = {"build_ms": 0.0, "solve_ms": 0.0, "discharge_ms": 0.0, "relabel_ms": 0.0, "discharge_launches": 0,
            "relabel_launches": 0, "discharge_tiles": 0, "relabel_tiles": 0, "global_relabels": 0, "phases": 0}
     flow = 0.0
-    for _ in range(args.steps):
-        flow = step()  # synchronous: returns after the stream drained
-        st = g.stats()
-        for k in acc:
-            acc[k] += st[k]
-    elapsed = time.perf_counter() - t0
-    if dist:
+    slab_stats = None
+    if world == 1:
+        shape = (n, n, n)
+        s = synthetic.sphere(shape, seed=0)
+        g = VoxelGraph(shape, device=0)
+        g._set_boundary("difference_exponential", s["image"], s["sigma"], False)  # H2D, outside the timed region
+        g._set_markers(s["fg"], s["bg"])
+
+        def step():
+            g._build()
+            return g.maxflow()
+
+        for _ in range(args.warmup):
+            step()
+        t0 = time.perf_counter()
+        for _ in range(args.steps):
+            flow = step()  # synchronous: returns after the stream drained
+            st = g.stats()
+            for k in acc:
+                acc[k] += st[k]
+        elapsed = time.perf_counter() - t0
+        fg_fraction = float(g.labels().mean())
+    else:
         import torch
-        t = torch.tensor([elapsed], dtype=torch.float64)
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        import torch.distributed as dist  # plumbing: rendezvous, RCCL send/recv of the packed borders, all-reduce
+        from medpy_amd.slab import DistExchange, HipSlab, solve_slabs
+        # MEDPY_DIST_BACKEND=gloo: development aid -- several ranks share the visible GPUs and the borders travel
+        # through host buffers (used to exercise this code path on a 1-GPU box); the default is RCCL.
+        backend = os.environ.get("MEDPY_DIST_BACKEND", "nccl")
+        dev_index = local_rank % _lib.device_count()
+        torch.cuda.set_device(dev_index)
+        if backend == "nccl":
+            dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", dev_index))
+        else:
+            dist.init_process_group(backend, rank=rank, world_size=world)
+        gshape = (n * world, n, n)
+        slab = HipSlab(gshape, rank, world, device=dev_index)
+        # the local planes of the global volume: sphere block `b` occupies planes [b*n, (b+1)*n)
+        b0, b1 = slab.plane0 // n, (slab.plane1 - 1) // n
+        imgs, fgs, bgs = [], [], []
+        for b in range(b0, b1 + 1):
+            blk = synthetic.sphere((n, n, n), seed=b)
+            bg = blk["bg"].copy()
+            if b > 0:
+                bg[0, 1:-1, 1:-1] = False  # interior block faces are not background: one connected medium
+            if b < world - 1:
+                bg[-1, 1:-1, 1:-1] = False
+            imgs.append(blk["image"]); fgs.append(blk["fg"]); bgs.append(bg)
+        sl = slice(slab.plane0 - b0 * n, slab.plane1 - b0 * n)
+        slab.set_boundary("difference_exponential", np.concatenate(imgs, axis=0)[sl], 15.0, False)
+        slab.set_markers(np.concatenate(fgs, axis=0)[sl], np.concatenate(bgs, axis=0)[sl])
+        del imgs, fgs, bgs
+        ex = DistExchange(slab)
+
+        def step():
+            slab.build()
+            st = solve_slabs([slab], ex)
+            return st, slab.finish_device()
+
+        for _ in range(args.warmup):
+            step()
+        torch.cuda.synchronize()
         dist.barrier()
+        t0 = time.perf_counter()
+        for _ in range(args.steps):
+            slab_stats, part = step()
+        torch.cuda.synchronize()
+        dist.barrier()
+        elapsed = time.perf_counter() - t0
+        t = torch.tensor([elapsed], dtype=torch.float64, device="cuda" if backend == "nccl" else "cpu")
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t[0])
-    labels = g.labels()
-    fg_fraction = float(labels.mean())
+        flow = float(ex.allreduce_sum([part]))
+        lab, _ = slab.finish()
+        fg_fraction = float(ex.allreduce_sum([float(lab.sum())])) / float(np.prod(gshape))
+        dist.barrier()
 
     if rank == 0:
         nvox = n ** 3
@@ -134,7 +178,8 @@ def main():
             "dtype": "f64", "data": "synthetic",
             "config": {"workload": "%d^3 sphere volume (float32), 6-conn, boundary_difference_exponential sigma=15, "
                                    "fg=inner ball, bg=6 faces" % n,
-                       "parallelism": "1 volume per GPU" if world > 1 else "single GPU",
+                       "parallelism": ("%d exact Z-slabs of one %dx%dx%d volume (%d stacked sphere blocks), RCCL halo exchange" %
+                                       (world, n * world, n, n, world)) if world > 1 else "single GPU",
                        "fg_fraction": round(fg_fraction, 5), "flow": flow},
             "phases_ms": {"build": round(acc["build_ms"] / args.steps, 3), "solve": round(acc["solve_ms"] / args.steps, 3),
                           "discharge_kernels": round(acc["discharge_ms"] / args.steps, 3),
@@ -147,12 +192,16 @@ def main():
                          "avg_launch_ms": round(avg_ms, 4), "launches_per_step": launches / args.steps,
                          "voxels_per_launch": round(vox_per_launch, 1), "bytes_per_voxel": B_ALG_6CONN},
         }
+        if slab_stats is not None:
+            out["slab_schedule"] = slab_stats
+            out["roofline"] = None  # per-kernel event timing is a single-GPU measurement (N=1 line)
         if not args.no_cpu and world == 1:
             out["cpu_baseline"] = cpu_baseline(args.cpu_sample)
         elif not args.no_cpu:
             out["cpu_baseline"] = None
         print(json.dumps(out))
-    if dist:
+    if world > 1:
+        import torch.distributed as dist
         dist.destroy_process_group()
 
 

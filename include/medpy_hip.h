@@ -130,6 +130,38 @@ int mgc_get_node_num(mgc_handle h, int64_t* n);
 int mgc_set_param(mgc_handle h, const char* name, int64_t value); /* solver schedule knobs, see DESIGN.md */
 int mgc_get_stats(mgc_handle h, mgc_stats* out);
 
+/* ------------------------------------------------------------------------------------------
+ * Z-slab decomposition across the GPUs of one node (no reference counterpart: the reference is
+ * single-process; its only splitter, wrapper.py:72-204, is approximate and label-based).
+ * One handle per slab.  The slab owns whole tile layers (8 voxel planes) of axis 0 and mirrors
+ * one ghost tile layer per neighbour; mgc_set_* take the LOCAL sub-arrays (planes
+ * info[0]..info[1] of the global arrays, ghost planes included).  The solve is driven from the
+ * host layer (medpy_amd/slab.py) through mgc_solver_op + mgc_halo_pack/unpack, exchanging the
+ * packed border (labels, outbox flow) with the neighbour rank after every pass / phase; the
+ * transport (RCCL over xGMI via torch.distributed, or an in-process loopback) is the caller's.
+ * ---------------------------------------------------------------------------------------- */
+enum {
+    MGC_OP_ABSORB_ALL = 0,   /* -                                          */
+    MGC_OP_FILL_INF = 1,     /* -                                          */
+    MGC_OP_ZERO_COUNT = 2,   /* a0 = counter index                          */
+    MGC_OP_RELABEL_ALL = 3,  /* a0 = next epoch, a1 = next list             */
+    MGC_OP_RELABEL_LIST = 4, /* a0 = list, a1 = next epoch, a2 = next list  */
+    MGC_OP_ACTIVATE = 5,     /* a0 = phase                                  */
+    MGC_OP_DISCHARGE = 6     /* a0 = list, a1 = phase, a2 = max cycles, a3 = max sweeps */
+};
+int mgc_create_slab(int ndim, const int64_t* global_shape, int connectivity, int device, int rank, int nranks, mgc_handle* out);
+/* info[0..1] = local plane range [first, last) in the global volume (ghost planes included), info[2..3] = owned
+ * plane range, info[4] / info[5] = has a lower / upper neighbour, info[6] = tiles per layer */
+int mgc_slab_info(mgc_handle h, int64_t* info8);
+int mgc_solver_op(mgc_handle h, int op, int64_t a0, int64_t a1, int64_t a2, int64_t a3);
+int mgc_read_counts(mgc_handle h, int32_t* out16);
+int mgc_halo_bytes(mgc_handle h, int kind, int64_t* bytes);
+/* side 0 = lower / 1 = upper slab boundary; kind 0 = labels (relabel pass), 1 = labels + outbox flow (phase) */
+int mgc_halo_pack(mgc_handle h, int side, int kind, void* buf, int buf_on_device);
+int mgc_halo_unpack(mgc_handle h, int side, int kind, const void* buf, int buf_on_device, uint32_t epoch, int list);
+/* after the slab driver has converged: labels of the local planes + this slab's part of the cut capacity */
+int mgc_finish(mgc_handle h, double* flow_partial);
+
 #ifdef __cplusplus
 }
 #endif

@@ -61,6 +61,15 @@ SIGNATURES = {
     "mgc_get_node_num": (_INT, [_VP, C.POINTER(_I64)]),
     "mgc_set_param": (_INT, [_VP, C.c_char_p, _I64]),
     "mgc_get_stats": (_INT, [_VP, C.POINTER(Stats)]),
+    # Z-slab decomposition (multi-GPU)
+    "mgc_create_slab": (_INT, [_INT, C.POINTER(_I64), _INT, _INT, _INT, _INT, C.POINTER(_VP)]),
+    "mgc_slab_info": (_INT, [_VP, C.POINTER(_I64)]),
+    "mgc_solver_op": (_INT, [_VP, _INT, _I64, _I64, _I64, _I64]),
+    "mgc_read_counts": (_INT, [_VP, _VP]),
+    "mgc_halo_bytes": (_INT, [_VP, _INT, C.POINTER(_I64)]),
+    "mgc_halo_pack": (_INT, [_VP, _INT, _INT, _VP, _INT]),
+    "mgc_halo_unpack": (_INT, [_VP, _INT, _INT, _VP, _INT, C.c_uint32, _INT]),
+    "mgc_finish": (_INT, [_VP, C.POINTER(_DBL)]),
 }
 
 _lib = None

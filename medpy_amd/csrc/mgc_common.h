@@ -42,6 +42,12 @@ struct MgcLattice {
     /* tile grid */
     int gz, gy, gx;           /* ceil(D / 8)                                        */
     int ntiles;
+    /* Z-slab decomposition (multi-GPU): this lattice is one slab of a taller volume.  Tile layers
+       [tz_own_lo, tz_own_hi) are owned; a layer below / above is a GHOST layer mirroring the
+       neighbour slab's border tiles (their labels and their outboxes towards us).  Single GPU:
+       tz_own_lo = 0, tz_own_hi = gz, tz_global0 = 0. */
+    int tz_own_lo, tz_own_hi;
+    int tz_global0;           /* global tile-layer index of local layer 0 (checkerboard colour) */
     /* per-tile state, tile-major */
     double*   rcap;           /* [ntiles][6][512] residual n-link capacities        */
     double*   cap0;           /* [ntiles][6][512] capacities as built (cut value, getters) */
@@ -84,7 +90,14 @@ MGC_HD int mgc_tile_nbr(const MgcLattice& L, int tz, int ty, int tx, int f)
     }
 }
 
-MGC_HD int mgc_tile_colour(int tz, int ty, int tx) { return (tz + ty + tx) & 1; }
+MGC_HD int mgc_tile_colour(const MgcLattice& L, int tz, int ty, int tx) { return (tz + L.tz_global0 + ty + tx) & 1; }
+
+/* is the tile owned by this slab (as opposed to a ghost mirror of the neighbour slab's tile)? */
+MGC_HD bool mgc_owned(const MgcLattice& L, int tile)
+{
+    const int tz = tile / (L.gy * L.gx);
+    return tz >= L.tz_own_lo && tz < L.tz_own_hi;
+}
 
 /* local voxel index inside a tile */
 MGC_HD int mgc_local(int z, int y, int x) { return (z * MGC_T + y) * MGC_T + x; }
@@ -111,6 +124,32 @@ MGC_HD void mgc_node_to_tile(const MgcLattice& L, int64_t id, int& tile, int& lo
     const int64_t z = r / L.dy;
     tile = mgc_tile_id(L, (int)(z >> 3), (int)(y >> 3), (int)(x >> 3));
     loc = mgc_local((int)(z & 7), (int)(y & 7), (int)(x & 7));
+}
+
+/* Z-slab split of a volume with D0 planes over `nranks` slabs at tile-layer granularity (shared by the
+ * HIP library and the host simulator so both cut the volume identically). */
+struct MgcSlabSpec {
+    int rank, nranks;
+    int own_lo, own_hi;     /* local tile layers owned: [own_lo, own_hi)            */
+    int tz_global0;         /* global tile-layer index of local layer 0             */
+    int64_t plane0, plane1; /* global plane range held locally (ghost planes incl.) */
+    int64_t own0, own1;     /* global plane range owned                             */
+};
+
+static inline int mgc_slab_spec(int64_t d0, int rank, int nranks, MgcSlabSpec* sp)
+{
+    const int64_t GZ = (d0 + 7) / 8;
+    if (nranks < 1 || rank < 0 || rank >= nranks || nranks > GZ) return 1;
+    const int64_t t0 = rank * GZ / nranks, t1 = (rank + 1) * GZ / nranks;
+    const int has_lo = rank > 0, has_hi = rank + 1 < nranks;
+    sp->rank = rank; sp->nranks = nranks;
+    sp->own_lo = has_lo; sp->own_hi = has_lo + (int)(t1 - t0);
+    sp->tz_global0 = (int)(t0 - has_lo);
+    sp->plane0 = (t0 - has_lo) * 8;
+    sp->plane1 = (t1 + has_hi) * 8 < d0 ? (t1 + has_hi) * 8 : d0;
+    sp->own0 = t0 * 8;
+    sp->own1 = t1 * 8 < d0 ? t1 * 8 : d0;
+    return 0;
 }
 
 #endif /* MGC_COMMON_H */

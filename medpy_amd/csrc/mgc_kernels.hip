@@ -121,6 +121,22 @@ __global__ __launch_bounds__(MGC_TV) void k_discharge(MgcLattice L, int lst, uin
     }
 }
 
+__global__ __launch_bounds__(MGC_TV) void k_halo_pack(MgcLattice L, int side, int kind, void* buf)
+{
+    __shared__ MgcTileShared S;
+    GpuBlock x(S);
+    const int T = L.gy * L.gx;
+    for (int i = blockIdx.x; i < T; i += gridDim.x) mgc_halo_pack_tile(x, L, side, kind, i, buf);
+}
+
+__global__ __launch_bounds__(MGC_TV) void k_halo_unpack(MgcLattice L, int side, int kind, const void* buf, uint32_t epoch, int list)
+{
+    __shared__ MgcTileShared S;
+    GpuBlock x(S);
+    const int T = L.gy * L.gx;
+    for (int i = blockIdx.x; i < T; i += gridDim.x) mgc_halo_unpack_tile(x, L, side, kind, i, buf, epoch, list);
+}
+
 /* ======================================================================================
  * graph construction
  * ==================================================================================== */
@@ -304,7 +320,7 @@ __global__ __launch_bounds__(MGC_TV) void k_build(MgcLattice L, MgcBuildArgs A)
             L.status[tile] = any_sink ? 2u : 0u;
         }
         const double s = mgc_block_sum(fc, scratch);
-        if (t == 0) A.fpart[tile] = s;
+        if (t == 0) A.fpart[tile] = mgc_owned(L, tile) ? s : 0.0;
         __syncthreads();
     }
 }
@@ -401,7 +417,7 @@ __global__ __launch_bounds__(MGC_TV) void k_cut_value(MgcLattice L, const double
         const int lz = t >> 6, ly = (t >> 3) & 7, lx = t & 7;
         const int64_t gz = (int64_t)tz * 8 + lz, gy = (int64_t)ty * 8 + ly, gx = (int64_t)tx * 8 + lx;
         double s = 0.0;
-        if (gz < L.dz && gy < L.dy && gx < L.dx) {
+        if (gz < L.dz && gy < L.dy && gx < L.dx && mgc_owned(L, tile)) {
             const int64_t id = (gz * L.dy + gy) * L.dx + gx;
             const double tr = tr0[(int64_t)tile * MGC_TV + t];
             if (labels[id]) { /* source side: pays its sink link and every n-link into T */
@@ -486,6 +502,9 @@ struct mgc_graph {
     double* h_scalar = nullptr; /* pinned */
     uint8_t* h_labels = nullptr; bool labels_on_host = false;
     bool built = false, solved = false;
+    int rank = 0, nranks = 1;
+    int64_t plane0 = 0, plane1 = 0, own0 = 0, own1 = 0; /* global plane ranges of a slab */
+    void* d_halo = nullptr; int64_t halo_cap = 0;
     double flow_const = 0.0, flow = 0.0;
     MgcSolveParams params = mgc_default_params();
     int grid_cap = 4096;
@@ -639,7 +658,7 @@ int mgc_device_count(int* count)
 
 const char* mgc_last_error(mgc_handle h) { return h ? h->err.c_str() : g_create_error.c_str(); }
 
-int mgc_create(int ndim, const int64_t* shape, int connectivity, int device, mgc_handle* out)
+static int mgc_create_impl(int ndim, const int64_t* shape, int connectivity, int device, const MgcSlabSpec* slab, mgc_handle* out)
 {
     if (!out) return mgc_fail(nullptr, MGC_ERR_INVALID, "mgc_create: out is NULL");
     *out = nullptr;
@@ -669,6 +688,14 @@ int mgc_create(int ndim, const int64_t* shape, int connectivity, int device, mgc
     if (gz * gy * gx > 0x3fffffff) { delete h; return mgc_fail(nullptr, MGC_ERR_UNSUPPORTED, "volume too large for 32-bit tile ids"); }
     L.gz = (int)gz; L.gy = (int)gy; L.gx = (int)gx;
     L.ntiles = (int)(gz * gy * gx);
+    L.tz_own_lo = 0; L.tz_own_hi = L.gz; L.tz_global0 = 0;
+    if (slab) {
+        L.tz_own_lo = slab->own_lo; L.tz_own_hi = slab->own_hi; L.tz_global0 = slab->tz_global0;
+        h->rank = slab->rank; h->nranks = slab->nranks;
+        h->plane0 = slab->plane0; h->plane1 = slab->plane1; h->own0 = slab->own0; h->own1 = slab->own1;
+    } else {
+        h->plane0 = h->own0 = 0; h->plane1 = h->own1 = L.dz;
+    }
     *out = h; /* from here on errors are reported through the handle; caller destroys it */
     MGC_HIP(h, hipSetDevice(device));
     MGC_HIP(h, hipStreamCreateWithFlags(&h->stream, hipStreamNonBlocking));
@@ -700,6 +727,128 @@ int mgc_create(int ndim, const int64_t* shape, int connectivity, int device, mgc
     return MGC_OK;
 }
 
+int mgc_create(int ndim, const int64_t* shape, int connectivity, int device, mgc_handle* out)
+{
+    return mgc_create_impl(ndim, shape, connectivity, device, nullptr, out);
+}
+
+int mgc_create_slab(int ndim, const int64_t* gshape, int connectivity, int device, int rank, int nranks, mgc_handle* out)
+{
+    if (!out) return mgc_fail(nullptr, MGC_ERR_INVALID, "mgc_create_slab: out is NULL");
+    *out = nullptr;
+    if (ndim != 3 || !gshape) return mgc_fail(nullptr, MGC_ERR_UNSUPPORTED, "mgc_create_slab: slabs need a 3-D volume");
+    if (nranks < 1 || rank < 0 || rank >= nranks) return mgc_fail(nullptr, MGC_ERR_INVALID, "bad rank %d of %d", rank, nranks);
+    MgcSlabSpec sp;
+    if (mgc_slab_spec(gshape[0], rank, nranks, &sp)) return mgc_fail(nullptr, MGC_ERR_INVALID, "cannot cut %lld planes into %d slabs", (long long)gshape[0], nranks);
+    const int64_t lshape[3] = {sp.plane1 - sp.plane0, gshape[1], gshape[2]};
+    return mgc_create_impl(3, lshape, connectivity, device, &sp, out);
+}
+
+int mgc_slab_info(mgc_handle h, int64_t* info)
+{
+    if (!h || !info) return MGC_ERR_INVALID;
+    info[0] = h->plane0; info[1] = h->plane1; info[2] = h->own0; info[3] = h->own1;
+    info[4] = h->L.tz_own_lo > 0; info[5] = h->L.tz_own_hi < h->L.gz; info[6] = (int64_t)h->L.gy * h->L.gx; info[7] = h->nranks;
+    return MGC_OK;
+}
+
+int mgc_solver_op(mgc_handle h, int op, int64_t a0, int64_t a1, int64_t a2, int64_t a3)
+{
+    if (!h) return MGC_ERR_INVALID;
+    if (!h->built) return mgc_fail(h, MGC_ERR_STATE, "mgc_solver_op before mgc_build");
+    MGC_HIP(h, hipSetDevice(h->device));
+    HipDev dev;
+    dev.h = h;
+    const bool timing = h->timing;
+    h->timing = false; /* per-launch events are resolved by mgc_maxflow only */
+    switch (op) {
+    case MGC_OP_ABSORB_ALL: dev.absorb_all(); break;
+    case MGC_OP_FILL_INF: dev.fill_heights_inf(); break;
+    case MGC_OP_ZERO_COUNT:
+        if (a0 < 0 || a0 >= MGC_NCOUNT) { h->timing = timing; return mgc_fail(h, MGC_ERR_INVALID, "counter index"); }
+        dev.zero_count((int)a0);
+        break;
+    case MGC_OP_RELABEL_ALL: dev.relabel_all((uint32_t)a0, (int)a1); break;
+    case MGC_OP_RELABEL_LIST: dev.relabel_list((int)a0, (uint32_t)a1, (int)a2); break;
+    case MGC_OP_ACTIVATE: dev.activate_all((uint32_t)a0); break;
+    case MGC_OP_DISCHARGE: dev.discharge((int)a0, (uint32_t)a1, (int)a2, (int)a3); break;
+    default: h->timing = timing; return mgc_fail(h, MGC_ERR_INVALID, "unknown solver op %d", op);
+    }
+    h->timing = timing;
+    h->solved = false;
+    if (dev.first_error != hipSuccess) return mgc_fail(h, MGC_ERR_HIP, "solver op %d: %s", op, hipGetErrorString(dev.first_error));
+    return MGC_OK;
+}
+
+int mgc_read_counts(mgc_handle h, int32_t* out)
+{
+    if (!h || !out) return MGC_ERR_INVALID;
+    MGC_HIP(h, hipSetDevice(h->device));
+    MGC_HIP(h, hipMemcpyAsync(h->h_count, h->L.count, MGC_NCOUNT * sizeof(int32_t), hipMemcpyDeviceToHost, h->stream));
+    MGC_HIP(h, hipStreamSynchronize(h->stream));
+    memcpy(out, h->h_count, MGC_NCOUNT * sizeof(int32_t));
+    return MGC_OK;
+}
+
+int mgc_halo_bytes(mgc_handle h, int kind, int64_t* bytes)
+{
+    if (!h || !bytes) return MGC_ERR_INVALID;
+    *bytes = mgc_halo_bytes(h->L, kind ? 1 : 0);
+    return MGC_OK;
+}
+
+static int mgc_halo_staging(mgc_handle h, int64_t bytes)
+{
+    if (h->halo_cap >= bytes) return MGC_OK;
+    if (h->d_halo) (void)hipFree(h->d_halo);
+    h->d_halo = nullptr;
+    MGC_HIP(h, hipMalloc(&h->d_halo, (size_t)bytes));
+    h->halo_cap = bytes;
+    return MGC_OK;
+}
+
+int mgc_halo_pack(mgc_handle h, int side, int kind, void* buf, int buf_on_device)
+{
+    if (!h || !buf || side < 0 || side > 1) return MGC_ERR_INVALID;
+    if (!h->built) return mgc_fail(h, MGC_ERR_STATE, "mgc_halo_pack before mgc_build");
+    if (side == 0 ? h->L.tz_own_lo == 0 : h->L.tz_own_hi == h->L.gz) return mgc_fail(h, MGC_ERR_INVALID, "no neighbour slab on side %d", side);
+    MGC_HIP(h, hipSetDevice(h->device));
+    const int64_t bytes = mgc_halo_bytes(h->L, kind ? 1 : 0);
+    void* dst = buf;
+    if (!buf_on_device) {
+        const int rc = mgc_halo_staging(h, bytes);
+        if (rc) return rc;
+        dst = h->d_halo;
+    }
+    const int T = h->L.gy * h->L.gx;
+    hipLaunchKernelGGL(k_halo_pack, dim3(T < 2048 ? T : 2048), dim3(MGC_TV), 0, h->stream, h->L, side, kind ? 1 : 0, dst);
+    MGC_HIP(h, hipGetLastError());
+    if (!buf_on_device) MGC_HIP(h, hipMemcpyAsync(buf, dst, (size_t)bytes, hipMemcpyDeviceToHost, h->stream));
+    MGC_HIP(h, hipStreamSynchronize(h->stream)); /* the transport runs on the caller's stream / thread */
+    return MGC_OK;
+}
+
+int mgc_halo_unpack(mgc_handle h, int side, int kind, const void* buf, int buf_on_device, uint32_t epoch, int list)
+{
+    if (!h || !buf || side < 0 || side > 1) return MGC_ERR_INVALID;
+    if (!h->built) return mgc_fail(h, MGC_ERR_STATE, "mgc_halo_unpack before mgc_build");
+    if (side == 0 ? h->L.tz_own_lo == 0 : h->L.tz_own_hi == h->L.gz) return mgc_fail(h, MGC_ERR_INVALID, "no neighbour slab on side %d", side);
+    MGC_HIP(h, hipSetDevice(h->device));
+    const int64_t bytes = mgc_halo_bytes(h->L, kind ? 1 : 0);
+    const void* src = buf;
+    if (!buf_on_device) {
+        const int rc = mgc_halo_staging(h, bytes);
+        if (rc) return rc;
+        MGC_HIP(h, hipMemcpyAsync(h->d_halo, buf, (size_t)bytes, hipMemcpyHostToDevice, h->stream));
+        src = h->d_halo;
+    }
+    const int T = h->L.gy * h->L.gx;
+    hipLaunchKernelGGL(k_halo_unpack, dim3(T < 2048 ? T : 2048), dim3(MGC_TV), 0, h->stream, h->L, side, kind ? 1 : 0, src, epoch, list);
+    MGC_HIP(h, hipGetLastError());
+    MGC_HIP(h, hipStreamSynchronize(h->stream));
+    return MGC_OK;
+}
+
 int mgc_destroy(mgc_handle h)
 {
     if (!h) return MGC_OK;
@@ -708,7 +857,7 @@ int mgc_destroy(mgc_handle h)
     MgcLattice& L = h->L;
     void* ptrs[] = {L.rcap, L.cap0, L.excess, L.sink, L.height, L.rmask, L.obox, L.oflags, L.list[0], L.list[1], L.list[2],
                     L.list[3], L.list[4], L.list[5], L.count, L.stamp, L.rstamp, L.status, h->d_tr0, h->d_part, h->d_scalar,
-                    h->d_labels, h->d_image, h->d_prob, h->d_fg, h->d_bg, h->d_tr_in, h->d_ei, h->d_ej, h->d_ecap, h->d_erev};
+                    h->d_labels, h->d_image, h->d_prob, h->d_fg, h->d_bg, h->d_tr_in, h->d_ei, h->d_ej, h->d_ecap, h->d_erev, h->d_halo};
     for (void* p : ptrs)
         if (p) (void)hipFree(p);
     if (h->h_count) (void)hipHostFree(h->h_count);
@@ -871,6 +1020,7 @@ int mgc_maxflow(mgc_handle h, double* flow)
 {
     if (!h) return MGC_ERR_INVALID;
     if (!h->built) return mgc_fail(h, MGC_ERR_STATE, "mgc_maxflow before mgc_build");
+    if (h->nranks > 1 && !h->solved) return mgc_fail(h, MGC_ERR_STATE, "a slab of a multi-GPU volume is solved by the slab driver (mgc_solver_op / mgc_finish)");
     MGC_HIP(h, hipSetDevice(h->device));
     MgcLattice& L = h->L;
     if (!h->solved) {
@@ -913,6 +1063,28 @@ int mgc_maxflow(mgc_handle h, double* flow)
         h->labels_on_host = false;
     }
     if (flow) *flow = h->flow;
+    return MGC_OK;
+}
+
+int mgc_finish(mgc_handle h, double* flow_partial)
+{
+    if (!h) return MGC_ERR_INVALID;
+    if (!h->built) return mgc_fail(h, MGC_ERR_STATE, "mgc_finish before mgc_build");
+    MGC_HIP(h, hipSetDevice(h->device));
+    MgcLattice& L = h->L;
+    hipLaunchKernelGGL(k_labels, dim3(2048), dim3(256), 0, h->stream, L, h->d_labels);
+    MGC_HIP(h, hipGetLastError());
+    const int grid = L.ntiles < h->grid_cap * 4 ? L.ntiles : h->grid_cap * 4;
+    hipLaunchKernelGGL(k_cut_value, dim3(grid), dim3(MGC_TV), 0, h->stream, L, (const double*)h->d_tr0, (const uint8_t*)h->d_labels, h->d_part);
+    MGC_HIP(h, hipGetLastError());
+    hipLaunchKernelGGL(k_sum_partials, dim3(1), dim3(MGC_TV), 0, h->stream, (const double*)h->d_part, (int64_t)L.ntiles, h->d_scalar + 1);
+    MGC_HIP(h, hipGetLastError());
+    MGC_HIP(h, hipMemcpyAsync(h->h_scalar, h->d_scalar, 8 * sizeof(double), hipMemcpyDeviceToHost, h->stream));
+    MGC_HIP(h, hipStreamSynchronize(h->stream));
+    h->flow = h->flow_const + h->h_scalar[1];
+    h->solved = true;
+    h->labels_on_host = false;
+    if (flow_partial) *flow_partial = h->flow;
     return MGC_OK;
 }
 

@@ -53,6 +53,7 @@ MGC_HD bool mgc_inside(int d, int z, int y, int x)
 template <class X>
 MGC_HD void mgc_enqueue(X& x, const MgcLattice& L, int listid, uint32_t* stamps, uint32_t epoch, int tile)
 {
+    if (!mgc_owned(L, tile)) return; /* ghost tiles are discharged / relabelled by the slab that owns them */
     if (x.atomic_exch(&stamps[tile], epoch) != epoch) {
         const int pos = x.atomic_add(&L.count[listid], 1);
         L.list[listid][pos] = tile;
@@ -166,7 +167,7 @@ template <class X>
 MGC_HD void mgc_relabel_tile(X& x, const MgcLattice& L, int tile, uint32_t next_epoch, int next_list, bool first_pass)
 {
     /* first pass of a global relabel: every label is INF, so only tiles holding a sink arc can seed anything */
-    if (first_pass && !(L.status[tile] & 2u)) return;
+    if (first_pass && (!(L.status[tile] & 2u) || !mgc_owned(L, tile))) return;
     typename X::template Reg<int> m, h0;
     const int64_t base = (int64_t)tile * MGC_TV;
     x.par([&](int t) { mgc_load_nbrs(x, L, tile, t); });
@@ -203,6 +204,7 @@ MGC_HD void mgc_relabel_tile(X& x, const MgcLattice& L, int tile, uint32_t next_
 template <class X>
 MGC_HD void mgc_absorb_tile(X& x, const MgcLattice& L, int tile)
 {
+    if (!mgc_owned(L, tile)) return;
     typename X::template Reg<double> e, r[6];
     const int64_t base = (int64_t)tile * MGC_TV;
     x.par([&](int t) { mgc_load_nbrs(x, L, tile, t); });
@@ -238,13 +240,14 @@ MGC_HD void mgc_absorb_tile(X& x, const MgcLattice& L, int tile)
 template <class X>
 MGC_HD void mgc_activate_tile(X& x, const MgcLattice& L, int tile, uint32_t phase)
 {
+    if (!mgc_owned(L, tile)) return;
     const int64_t base = (int64_t)tile * MGC_TV;
     const bool act = x.any([&](int t) -> bool { return L.excess[base + t] > 0.0 && L.height[base + t] < MGC_HINF; });
     x.par([&](int t) {
         if (t == 0 && act) {
             int tz, ty, tx;
             mgc_tile_coords(L, tile, tz, ty, tx);
-            const uint32_t target = phase + ((mgc_tile_colour(tz, ty, tx) ^ (int)(phase & 1u)) & 1);
+            const uint32_t target = phase + ((mgc_tile_colour(L, tz, ty, tx) ^ (int)(phase & 1u)) & 1);
             mgc_enqueue(x, L, (int)(target & 3u), L.stamp, target, tile);
             x.atomic_add(&L.count[6], 1);
         }
@@ -393,6 +396,90 @@ MGC_HD void mgc_discharge_tile(X& x, const MgcLattice& L, int tile, uint32_t pha
         }
         if (t == 6 && active) mgc_enqueue(x, L, (int)((phase + 2) & 3u), L.stamp, phase + 2, tile);
         if (t == 7) L.status[tile] = (L.status[tile] & ~2u) | (has_sink ? 2u : 0u);
+    });
+}
+
+/* ---------------------------------------------------------------------------------------
+ * Z-slab halo exchange (multi-GPU).  A slab boundary is an ordinary tile face whose
+ * neighbour lives on another GPU: the sender packs, per border tile, the labels of its 64 face
+ * voxels, its outbox across that face and the outbox flag; the receiver unpacks them into the
+ * GHOST tile that mirrors the sender's tile.  "side" 0 = lower slab boundary (face 4, -z),
+ * 1 = upper (face 5, +z).  Buffer layout for T = gy*gx tiles per layer:
+ *     double flow[T][64] ; int32 label[T][64] ; int32 flag[T]          (kind 1: discharge phases)
+ *     int32 label[T][64]                                              (kind 0: relabel passes)
+ * ------------------------------------------------------------------------------------- */
+MGC_HD int64_t mgc_halo_bytes(const MgcLattice& L, int kind)
+{
+    const int64_t T = (int64_t)L.gy * L.gx;
+    return kind ? T * (MGC_TF * 8 + MGC_TF * 4 + 4) : T * MGC_TF * 4;
+}
+
+/* i = tile index inside the layer; packs the OWNED border tile of `side` */
+template <class X>
+MGC_HD void mgc_halo_pack_tile(X& x, const MgcLattice& L, int side, int kind, int i, void* buf)
+{
+    const int64_t T = (int64_t)L.gy * L.gx;
+    const int layer = side ? L.tz_own_hi - 1 : L.tz_own_lo;
+    const int tile = layer * (int)T + i;
+    const int f = side ? 5 : 4;
+    double* flow = (double*)buf;
+    int32_t* lab = kind ? (int32_t*)((char*)buf + T * MGC_TF * 8) : (int32_t*)buf;
+    int32_t* flg = (int32_t*)((char*)buf + T * MGC_TF * 12);
+    x.par([&](int t) {
+        if (t < MGC_TF) {
+            lab[(int64_t)i * MGC_TF + t] = L.height[(int64_t)tile * MGC_TV + mgc_face_voxel(f, t)];
+            if (kind) {
+                double* slot = &L.obox[((int64_t)tile * 6 + f) * MGC_TF + t];
+                flow[(int64_t)i * MGC_TF + t] = *slot;
+                *slot = 0.0; /* the flow now travels in the message */
+            }
+        }
+        if (kind && t == MGC_TF) {
+            const uint32_t fl = (L.oflags[tile] >> f) & 1u;
+            flg[i] = (int32_t)fl;
+            if (fl) x.atomic_and(&L.oflags[tile], ~(1u << f));
+        }
+    });
+}
+
+/* unpacks into the GHOST tile beyond `side`; wakes the owned tile next to it.
+ * kind 1: `epoch` = the phase that just ran (the woken tile runs in phase + 1);
+ * kind 0: `epoch` / `list` = stamp and list of the next relabel pass. */
+template <class X>
+MGC_HD void mgc_halo_unpack_tile(X& x, const MgcLattice& L, int side, int kind, int i, const void* buf, uint32_t epoch, int list)
+{
+    const int64_t T = (int64_t)L.gy * L.gx;
+    const int ghost_layer = side ? L.tz_own_hi : L.tz_own_lo - 1;
+    const int own_layer = side ? L.tz_own_hi - 1 : L.tz_own_lo;
+    const int ghost = ghost_layer * (int)T + i, own = own_layer * (int)T + i;
+    const int f = side ? 4 : 5; /* the face of the SENDER's tile that touches us */
+    const double* flow = (const double*)buf;
+    const int32_t* lab = kind ? (const int32_t*)((const char*)buf + T * MGC_TF * 8) : (const int32_t*)buf;
+    const int32_t* flg = (const int32_t*)((const char*)buf + T * MGC_TF * 12);
+    const bool lowered = x.any([&](int t) -> bool {
+        bool low = false;
+        if (t < MGC_TF) {
+            int32_t* hp = &L.height[(int64_t)ghost * MGC_TV + mgc_face_voxel(f, t)];
+            const int32_t hn = lab[(int64_t)i * MGC_TF + t];
+            low = hn < *hp;
+            *hp = hn;
+            if (kind) {
+                const double d = flow[(int64_t)i * MGC_TF + t];
+                if (d != 0.0) L.obox[((int64_t)ghost * 6 + f) * MGC_TF + t] += d;
+            }
+        }
+        return low;
+    });
+    x.par([&](int t) {
+        if (t != 0) return;
+        if (kind) {
+            if (flg[i]) {
+                x.atomic_or(&L.oflags[ghost], 1u << f);
+                mgc_enqueue(x, L, (int)((epoch + 1) & 3u), L.stamp, epoch + 1, own);
+            }
+        } else if (lowered) {
+            mgc_enqueue(x, L, list, L.rstamp, epoch, own);
+        }
     });
 }
 

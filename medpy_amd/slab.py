@@ -1,0 +1,309 @@
+"""Exact Z-slab decomposition of one voxel graph cut over several GPUs.
+
+No reference counterpart: the reference is single-process, and its only splitter
+(``graphcut_split``, reference medpy/graphcut/wrapper.py:72-204) is approximate and
+label-based.  Here the split is exact: the volume is cut along axis 0 into slabs of whole
+8-plane tile layers, one slab per GPU; a slab boundary is an ordinary tile face whose neighbour
+lives on another GPU.  After every relabel pass / colour phase each slab packs the labels of
+its border voxels and the flow it pushed across the boundary (``mgc_halo_pack``), the packed
+border travels to the neighbour rank (RCCL send/recv over xGMI through ``torch.distributed``,
+or an in-process loopback), and is unpacked into the ghost tiles there (``mgc_halo_unpack``).
+Because region discharge only ever reads a neighbour tile's labels and outbox as of that
+tile's last discharge, the distributed run performs exactly the single-GPU computation:
+labels are bit-identical to the single-GPU (and hence the reference's) labels.
+
+This module holds the schedule (a mirror of ``medpy_amd/csrc/mgc_driver.inl`` with exchanges
+and all-reduces added) and the two transports.  It is backend-agnostic: the CPU test tier runs
+the same code over the host simulator with gloo (tests/test_slab_*.py).
+"""
+import numpy as np
+
+OP_ABSORB_ALL, OP_FILL_INF, OP_ZERO_COUNT, OP_RELABEL_ALL, OP_RELABEL_LIST, OP_ACTIVATE, OP_DISCHARGE = range(7)
+
+
+class LoopbackExchange(object):
+    """All slabs live in this process (one GPU time-multiplexed, or the host simulator)."""
+
+    def __init__(self, slabs, device_buffers=False):
+        """device_buffers: keep the packed borders in HBM (torch CUDA tensors), as the RCCL transport does."""
+        self.slabs = list(slabs)
+        self._bufs = {}
+        self.on_device = bool(device_buffers)
+        if self.on_device:
+            import torch
+            self.torch = torch
+
+    def _buf(self, key, nbytes):
+        b = self._bufs.get(key)
+        if b is None or (b.numel() if self.on_device else b.size) != nbytes:
+            b = self.torch.zeros(nbytes, dtype=self.torch.uint8, device="cuda") if self.on_device else np.zeros(nbytes, dtype=np.uint8)
+            self._bufs[key] = b
+        return b
+
+    def _raw(self, b):
+        return b.data_ptr() if self.on_device else b
+
+    def exchange(self, kind, epoch, lst):
+        packed = []
+        for i in range(len(self.slabs) - 1):
+            lo, hi = self.slabs[i], self.slabs[i + 1]
+            nb = lo.halo_bytes(kind)
+            up = self._buf((i, "up", kind), nb)
+            dn = self._buf((i, "dn", kind), nb)
+            lo.halo_pack(1, kind, self._raw(up), on_device=self.on_device)
+            hi.halo_pack(0, kind, self._raw(dn), on_device=self.on_device)
+            packed.append((up, dn))
+        for i, (up, dn) in enumerate(packed):
+            self.slabs[i + 1].halo_unpack(0, kind, self._raw(up), epoch, lst, on_device=self.on_device)
+            self.slabs[i].halo_unpack(1, kind, self._raw(dn), epoch, lst, on_device=self.on_device)
+
+    def allreduce_sum(self, values):
+        """values: one number (or vector) per local slab -> global sum"""
+        return np.sum(np.asarray(values, dtype=np.float64), axis=0)
+
+
+class DistExchange(object):
+    """One slab per process; neighbours are rank-1 / rank+1 of ``torch.distributed``.
+
+    backend "nccl" (= RCCL on ROCm): the packed borders stay in HBM (torch CUDA tensors own the
+    message buffers, the library packs/unpacks straight into them); "gloo": host buffers
+    (CPU test tier)."""
+
+    def __init__(self, slab, group=None):
+        import torch
+        import torch.distributed as dist
+        self.torch, self.dist = torch, dist
+        self.slabs = [slab]
+        self.rank, self.world = dist.get_rank(group), dist.get_world_size(group)
+        self.group = group
+        self.on_device = dist.get_backend(group) == "nccl"
+        self.dev = torch.device("cuda", torch.cuda.current_device()) if self.on_device else torch.device("cpu")
+        self._bufs = {}
+
+    def _buf(self, key, nbytes):
+        b = self._bufs.get(key)
+        if b is None or b.numel() != nbytes:
+            b = self.torch.zeros(nbytes, dtype=self.torch.uint8, device=self.dev)
+            self._bufs[key] = b
+        return b
+
+    def _raw(self, t):
+        return t.data_ptr() if self.on_device else t.numpy()
+
+    def exchange(self, kind, epoch, lst):
+        slab, dist = self.slabs[0], self.dist
+        nb = slab.halo_bytes(kind)
+        ops, recvs = [], []
+        for side, peer in ((0, self.rank - 1), (1, self.rank + 1)):
+            if peer < 0 or peer >= self.world:
+                continue
+            snd, rcv = self._buf((side, "s", kind), nb), self._buf((side, "r", kind), nb)
+            slab.halo_pack(side, kind, self._raw(snd), on_device=self.on_device)
+            ops.append(dist.P2POp(dist.isend, snd, peer, self.group))
+            ops.append(dist.P2POp(dist.irecv, rcv, peer, self.group))
+            recvs.append((side, rcv))
+        if ops:
+            for w in dist.batch_isend_irecv(ops):
+                w.wait()
+            if self.on_device:
+                self.torch.cuda.synchronize()
+        for side, rcv in recvs:
+            slab.halo_unpack(side, kind, self._raw(rcv), epoch, lst, on_device=self.on_device)
+
+    def allreduce_sum(self, values):
+        t = self.torch.as_tensor(np.sum(np.asarray(values, dtype=np.float64), axis=0), dtype=self.torch.float64).reshape(-1).to(self.dev)
+        self.dist.all_reduce(t, group=self.group)
+        out = t.cpu().numpy()
+        return out if out.size > 1 else float(out[0])
+
+
+def solve_slabs(slabs, ex, rounds_per_relabel=12, max_cycles=4, max_sweeps=8, max_outer=100000, check_rounds=1):
+    """Drives the local slabs to a maximum preflow.  Returns a stats dict (global numbers)."""
+    phase, rep = 4, 2
+    for s in slabs:
+        s.op(OP_ZERO_COUNT, 8)
+        s.op(OP_ZERO_COUNT, 9)
+    st = {"outer": 0, "relabel_passes": 0, "phases": 0, "exchanges": 0, "converged": 0}
+    for _ in range(max_outer):
+        # ---- global relabel: tile BFS passes + border label exchange, to a global fixpoint
+        for s in slabs:
+            s.op(OP_ABSORB_ALL)
+            s.op(OP_FILL_INF)
+            s.op(OP_ZERO_COUNT, 4)
+            s.op(OP_ZERO_COUNT, 5)
+        nxt = 4 + ((rep + 1) & 1)
+        for s in slabs:
+            s.op(OP_RELABEL_ALL, rep + 1, nxt)
+        ex.exchange(0, rep + 1, nxt)
+        st["relabel_passes"] += 1
+        st["exchanges"] += 1
+        while True:
+            rep += 1
+            cur, nxt = 4 + (rep & 1), 4 + ((rep + 1) & 1)
+            if ex.allreduce_sum([float(s.read_counts()[cur]) for s in slabs]) == 0:
+                break
+            for s in slabs:
+                s.op(OP_ZERO_COUNT, nxt)
+                s.op(OP_RELABEL_LIST, cur, rep + 1, nxt)
+            ex.exchange(0, rep + 1, nxt)
+            st["relabel_passes"] += 1
+            st["exchanges"] += 1
+        st["outer"] += 1
+
+        # ---- who can still push towards the sink?
+        phase += 4
+        for s in slabs:
+            for i in (0, 1, 2, 3, 6):
+                s.op(OP_ZERO_COUNT, i)
+            s.op(OP_ACTIVATE, phase)
+        if ex.allreduce_sum([float(s.read_counts()[6]) for s in slabs]) == 0:
+            st["converged"] = 1
+            break
+
+        # ---- colour phases, border (labels + outbox flow) exchanged after each
+        for r in range(rounds_per_relabel):
+            for _c in range(2):
+                lst = phase & 3
+                for s in slabs:
+                    s.op(OP_DISCHARGE, lst, phase, max_cycles, max_sweeps)
+                    s.op(OP_ZERO_COUNT, lst)
+                ex.exchange(1, phase, 0)
+                st["phases"] += 1
+                st["exchanges"] += 1
+                phase += 1
+            if (r + 1) % check_rounds == 0 and r + 1 < rounds_per_relabel:
+                pend = [float(c[phase & 3] + c[(phase + 1) & 3]) for c in (s.read_counts() for s in slabs)]
+                if ex.allreduce_sum(pend) == 0:
+                    break
+    tot = ex.allreduce_sum([[float(c[8]), float(c[9])] for c in (s.read_counts() for s in slabs)])
+    st["discharge_tiles"], st["relabel_tiles"] = int(tot[0]), int(tot[1])
+    return st
+
+
+class HipSlab(object):
+    """One Z-slab of a volume on one MI355X (C ABI: mgc_create_slab ... mgc_finish)."""
+
+    def __init__(self, global_shape, rank, nranks, device=0):
+        import ctypes as C
+        from . import _lib
+        self._C, self._lib = C, _lib
+        lib = _lib.load()
+        if _lib.device_count() < 1:
+            raise _lib.MedpyHipError(_lib.ERR_NO_DEVICE, "no HIP device visible; medpy_amd has no CPU fallback")
+        shp = (C.c_int64 * 3)(*[int(v) for v in global_shape])
+        h = C.c_void_p()
+        rc = lib.mgc_create_slab(3, shp, 6, int(device), int(rank), int(nranks), C.byref(h))
+        self._h = h if h.value else None
+        if rc != _lib.OK:
+            msg = (lib.mgc_last_error(self._h) or b"").decode()
+            self.close()
+            raise _lib.MedpyHipError(rc, msg)
+        info = (C.c_int64 * 8)()
+        self._call("mgc_slab_info", info)
+        self.plane0, self.plane1, self.own0, self.own1 = int(info[0]), int(info[1]), int(info[2]), int(info[3])
+        self.has_lo, self.has_hi = bool(info[4]), bool(info[5])
+        self.local_shape = (self.plane1 - self.plane0, int(global_shape[1]), int(global_shape[2]))
+        self.rank, self.nranks = rank, nranks
+
+    def close(self):
+        if getattr(self, "_h", None):
+            self._lib.load().mgc_destroy(self._h)
+            self._h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def _call(self, name, *args):
+        self._lib.check(self._h, getattr(self._lib.load(), name)(self._h, *args))
+
+    # -- inputs: LOCAL planes [plane0, plane1) of the global arrays
+    def set_boundary(self, term, image_local, sigma, spacing=False):
+        C, _lib = self._C, self._lib
+        image = np.ascontiguousarray(image_local)
+        assert image.shape == self.local_shape, (image.shape, self.local_shape)
+        if image.dtype not in _lib.DTYPE_IDS:
+            image = image.astype(np.float64)
+        sp = (C.c_double * 3)(*[float(v) for v in spacing]) if spacing else None
+        self._call("mgc_set_boundary", _lib.TERM_IDS[term], _lib.ptr(image), _lib.DTYPE_IDS[image.dtype],
+                   float(sigma) if sigma is not None else 0.0, sp)
+
+    def set_markers(self, fg_local, bg_local):
+        fg = np.ascontiguousarray(fg_local, dtype=np.uint8)
+        bg = np.ascontiguousarray(bg_local, dtype=np.uint8)
+        self._call("mgc_set_markers", self._lib.ptr(fg), self._lib.ptr(bg))
+
+    def set_regional(self, prob_local, alpha):
+        prob = np.ascontiguousarray(prob_local)
+        if prob.dtype not in (np.float32, np.float64):
+            prob = prob.astype(np.float64)
+        self._call("mgc_set_regional_probability", self._lib.ptr(prob), self._lib.DTYPE_IDS[prob.dtype], float(alpha))
+
+    def build(self):
+        self._call("mgc_build")
+
+    # -- the stepwise solver surface used by solve_slabs()
+    def op(self, op, a0=0, a1=0, a2=0, a3=0):
+        self._call("mgc_solver_op", int(op), int(a0), int(a1), int(a2), int(a3))
+
+    def read_counts(self):
+        out = np.zeros(16, dtype=np.int32)
+        self._call("mgc_read_counts", self._lib.ptr(out))
+        return out
+
+    def halo_bytes(self, kind):
+        n = self._C.c_int64(0)
+        self._call("mgc_halo_bytes", int(kind), self._C.byref(n))
+        return n.value
+
+    def _ptr(self, buf, on_device):
+        return self._C.c_void_p(int(buf)) if on_device else self._lib.ptr(buf)
+
+    def halo_pack(self, side, kind, buf, on_device=False):
+        self._call("mgc_halo_pack", int(side), int(kind), self._ptr(buf, on_device), int(bool(on_device)))
+
+    def halo_unpack(self, side, kind, buf, epoch, lst, on_device=False):
+        self._call("mgc_halo_unpack", int(side), int(kind), self._ptr(buf, on_device), int(bool(on_device)), int(epoch), int(lst))
+
+    def finish_device(self):
+        """labels (left in HBM) + this slab's part of the cut value"""
+        f = self._C.c_double(0.0)
+        self._call("mgc_finish", self._C.byref(f))
+        return f.value
+
+    def finish(self):
+        """labels of the OWNED planes (bool, False where what_segment == SINK) and this slab's part of the cut value"""
+        f = self._C.c_double(self.finish_device())
+        out = np.empty(int(np.prod(self.local_shape)), dtype=np.uint8)
+        self._call("mgc_labels", self._lib.ptr(out))
+        lab = out.reshape(self.local_shape)[self.own0 - self.plane0:self.own1 - self.plane0].astype(np.bool_)
+        return lab, f.value
+
+    def stats(self):
+        st = self._lib.Stats()
+        self._call("mgc_get_stats", self._C.byref(st))
+        return st.as_dict()
+
+
+def graphcut_voxel_slabs(image, fg, bg, term="difference_exponential", sigma=None, spacing=False, nslabs=2, device=0,
+                         device_buffers=False, **schedule):
+    """Cut one volume as ``nslabs`` Z-slabs time-multiplexed on ONE GPU with the loopback transport.
+
+    Exercises exactly the code path of the multi-GPU run (ghost layers, halo pack/unpack, the
+    distributed schedule) where only one MI355X is available.  Returns (labels, flow, stats)."""
+    image, fg, bg = np.asarray(image), np.asarray(fg), np.asarray(bg)
+    slabs = [HipSlab(image.shape, r, nslabs, device=device) for r in range(nslabs)]
+    for s in slabs:
+        sl = slice(s.plane0, s.plane1)
+        s.set_boundary(term, image[sl], sigma, spacing)
+        s.set_markers(fg[sl], bg[sl])
+        s.build()
+    st = solve_slabs(slabs, LoopbackExchange(slabs, device_buffers=device_buffers), **schedule)
+    parts = [s.finish() for s in slabs]
+    labels = np.concatenate([p[0] for p in parts], axis=0)
+    flow = float(sum(p[1] for p in parts))
+    for s in slabs:
+        s.close()
+    return labels, flow, st

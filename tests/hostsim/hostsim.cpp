@@ -3,9 +3,15 @@
  *
  * Executes the solver's single-source tile operations (medpy_amd/csrc/mgc_tile_ops.inl) and
  * schedule (mgc_driver.inl) on the host: a "block" is a loop over its 512 lanes, a kernel
- * launch is a loop over tiles.  This lets the algorithm be parity-tested against the BK
- * oracle without a GPU.  It is NOT a fallback: the product library (libmedpyhip.so) is built
- * from mgc_kernels.hip only, contains none of this, and fails loudly without a GPU.
+ * launch is a loop over tiles.  This lets the algorithm -- including the multi-GPU Z-slab
+ * protocol, with slabs living in different processes talking over gloo -- be parity-tested
+ * against the BK oracle without a GPU.  It is NOT a fallback: the product library
+ * (libmedpyhip.so) is built from mgc_kernels.hip only, contains none of this, and fails loudly
+ * without a GPU.
+ *
+ * The handle API mirrors the slab part of include/medpy_hip.h (mgc_create_slab, mgc_slab_info,
+ * mgc_solver_op, mgc_read_counts, mgc_halo_*, mgc_finish) so that medpy_amd/slab.py drives
+ * either backend with the same code.
  */
 #include <stdint.h>
 #include <stdlib.h>
@@ -45,6 +51,12 @@ struct HostBlock {
 struct HostDev {
     MgcLattice L;
     MgcTileShared S;
+    MgcSlabSpec spec;
+    std::vector<double> rcap, excess, sink, obox;
+    std::vector<int32_t> height, lists, count;
+    std::vector<uint8_t> rmask;
+    std::vector<uint32_t> oflags, stamp, rstamp, status;
+
     void fill_heights_inf() { for (int64_t i = 0; i < (int64_t)L.ntiles * MGC_TV; ++i) L.height[i] = MGC_HINF; }
     void zero_count(int i) { L.count[i] = 0; }
     void read_counts(int* out) { memcpy(out, L.count, MGC_NCOUNT * sizeof(int)); }
@@ -72,75 +84,160 @@ struct HostDev {
         L.count[8] += n;
         for (int i = 0; i < n; ++i) mgc_discharge_tile(x, L, L.list[lst][i], phase, cycles, sweeps);
     }
+
+    void init(int64_t d0, int64_t d1, int64_t d2, const MgcSlabSpec* sp)
+    {
+        memset(&L, 0, sizeof(L));
+        L.dz = d0; L.dy = d1; L.dx = d2;
+        L.nvox = d0 * d1 * d2;
+        L.gz = (int)((d0 + 7) / 8); L.gy = (int)((d1 + 7) / 8); L.gx = (int)((d2 + 7) / 8);
+        L.ntiles = L.gz * L.gy * L.gx;
+        L.tz_own_lo = 0; L.tz_own_hi = L.gz; L.tz_global0 = 0;
+        if (sp) { spec = *sp; L.tz_own_lo = sp->own_lo; L.tz_own_hi = sp->own_hi; L.tz_global0 = sp->tz_global0; }
+        else { memset(&spec, 0, sizeof(spec)); spec.nranks = 1; spec.own_hi = L.gz; spec.plane1 = spec.own1 = d0; }
+        const int64_t nt = L.ntiles;
+        rcap.assign(nt * 6 * MGC_TV, 0.0); excess.assign(nt * MGC_TV, 0.0); sink.assign(nt * MGC_TV, 0.0);
+        obox.assign(nt * 6 * MGC_TF, 0.0); height.assign(nt * MGC_TV, MGC_HINF); lists.assign(6 * nt, 0);
+        count.assign(MGC_NCOUNT, 0); rmask.assign(nt * MGC_TV, 0);
+        oflags.assign(nt, 0); stamp.assign(nt, 0); rstamp.assign(nt, 0); status.assign(nt, 0);
+        L.rcap = rcap.data(); L.cap0 = NULL; L.excess = excess.data(); L.sink = sink.data(); L.height = height.data();
+        L.rmask = rmask.data(); L.obox = obox.data(); L.oflags = oflags.data();
+        for (int i = 0; i < 6; ++i) L.list[i] = lists.data() + i * nt;
+        L.count = count.data(); L.stamp = stamp.data(); L.rstamp = rstamp.data(); L.status = status.data();
+    }
+
+    /* w[a] = forward n-link capacities along array axis a of the LOCAL volume in the oracle's per-axis layout
+     * (oracle/energy_numpy.py:boundary_weights); trcap = merged t-link residual per local voxel */
+    void load(const double* w0, const double* w1, const double* w2, const double* trcap)
+    {
+        const int64_t D0 = L.dz, D1 = L.dy, D2 = L.dx;
+        for (int64_t z = 0; z < D0; ++z)
+            for (int64_t y = 0; y < D1; ++y)
+                for (int64_t x = 0; x < D2; ++x) {
+                    int tile, loc;
+                    const int64_t id = (z * D1 + y) * D2 + x;
+                    mgc_node_to_tile(L, id, tile, loc);
+                    double r[6] = {0, 0, 0, 0, 0, 0};
+                    if (x > 0) r[0] = w2[(z * D1 + y) * (D2 - 1) + (x - 1)];
+                    if (x < D2 - 1) r[1] = w2[(z * D1 + y) * (D2 - 1) + x];
+                    if (y > 0) r[2] = w1[(z * (D1 - 1) + (y - 1)) * D2 + x];
+                    if (y < D1 - 1) r[3] = w1[(z * (D1 - 1) + y) * D2 + x];
+                    if (z > 0) r[4] = w0[((z - 1) * D1 + y) * D2 + x];
+                    if (z < D0 - 1) r[5] = w0[(z * D1 + y) * D2 + x];
+                    int m = 0;
+                    for (int d = 0; d < 6; ++d) {
+                        rcap[((int64_t)tile * 6 + d) * MGC_TV + loc] = r[d];
+                        if (r[d] > 0.0) m |= 1 << d;
+                    }
+                    const double tr = trcap[id];
+                    excess[(int64_t)tile * MGC_TV + loc] = tr > 0 ? tr : 0.0;
+                    sink[(int64_t)tile * MGC_TV + loc] = tr < 0 ? -tr : 0.0;
+                    if (tr < 0) { m |= MGC_MASK_SINK; status[tile] |= 2u; }
+                    rmask[(int64_t)tile * MGC_TV + loc] = (uint8_t)m;
+                }
+    }
+
+    void labels(uint8_t* out)
+    {
+        for (int64_t id = 0; id < L.nvox; ++id) {
+            int tile, loc;
+            mgc_node_to_tile(L, id, tile, loc);
+            out[id] = height[(int64_t)tile * MGC_TV + loc] < MGC_HINF ? 0 : 1;
+        }
+    }
 };
 
 extern "C" {
 
-/*
- * shape[3] = (D0, D1, D2); w[a] = forward n-link capacities along array axis a in the oracle's
- * per-axis layout (oracle/energy_numpy.py:boundary_weights, i.e. energy_voxel.py:644-658);
- * trcap[N] = merged t-link residual (graph.h:416-425).  labels_out[N]: 0 = sink side, 1 otherwise.
- * stats_out[8] = MgcSolveStats.  Returns 0 when converged.
- */
+/* ---- handle API (mirrors the slab part of include/medpy_hip.h) ---- */
+void* hostsim_create(const int64_t* gshape, int rank, int nranks)
+{
+    HostDev* d = new HostDev();
+    if (nranks <= 1) {
+        d->init(gshape[0], gshape[1], gshape[2], NULL);
+    } else {
+        MgcSlabSpec sp;
+        if (mgc_slab_spec(gshape[0], rank, nranks, &sp)) { delete d; return NULL; }
+        d->init(sp.plane1 - sp.plane0, gshape[1], gshape[2], &sp);
+    }
+    return d;
+}
+
+void hostsim_destroy(void* h) { delete (HostDev*)h; }
+
+int hostsim_slab_info(void* h, int64_t* info)
+{
+    HostDev* d = (HostDev*)h;
+    info[0] = d->spec.plane0; info[1] = d->spec.plane1; info[2] = d->spec.own0; info[3] = d->spec.own1;
+    info[4] = d->L.tz_own_lo > 0; info[5] = d->L.tz_own_hi < d->L.gz; info[6] = (int64_t)d->L.gy * d->L.gx; info[7] = d->spec.nranks;
+    return 0;
+}
+
+int hostsim_load(void* h, const double* w0, const double* w1, const double* w2, const double* trcap)
+{
+    ((HostDev*)h)->load(w0, w1, w2, trcap);
+    return 0;
+}
+
+int hostsim_solver_op(void* h, int op, int64_t a0, int64_t a1, int64_t a2, int64_t a3)
+{
+    HostDev* d = (HostDev*)h;
+    switch (op) {
+    case 0: d->absorb_all(); break;
+    case 1: d->fill_heights_inf(); break;
+    case 2: d->zero_count((int)a0); break;
+    case 3: d->relabel_all((uint32_t)a0, (int)a1); break;
+    case 4: d->relabel_list((int)a0, (uint32_t)a1, (int)a2); break;
+    case 5: d->activate_all((uint32_t)a0); break;
+    case 6: d->discharge((int)a0, (uint32_t)a1, (int)a2, (int)a3); break;
+    default: return 1;
+    }
+    return 0;
+}
+
+int hostsim_read_counts(void* h, int32_t* out) { ((HostDev*)h)->read_counts(out); return 0; }
+
+int hostsim_halo_bytes(void* h, int kind, int64_t* bytes) { *bytes = mgc_halo_bytes(((HostDev*)h)->L, kind ? 1 : 0); return 0; }
+
+int hostsim_halo_pack(void* h, int side, int kind, void* buf, int on_device)
+{
+    (void)on_device;
+    HostDev* d = (HostDev*)h;
+    HostBlock x(d->S);
+    const int T = d->L.gy * d->L.gx;
+    for (int i = 0; i < T; ++i) mgc_halo_pack_tile(x, d->L, side, kind ? 1 : 0, i, buf);
+    return 0;
+}
+
+int hostsim_halo_unpack(void* h, int side, int kind, const void* buf, int on_device, uint32_t epoch, int list)
+{
+    (void)on_device;
+    HostDev* d = (HostDev*)h;
+    HostBlock x(d->S);
+    const int T = d->L.gy * d->L.gx;
+    for (int i = 0; i < T; ++i) mgc_halo_unpack_tile(x, d->L, side, kind ? 1 : 0, i, buf, epoch, list);
+    return 0;
+}
+
+/* labels of the LOCAL planes (ghost planes included; the caller slices the owned range) */
+int hostsim_labels(void* h, uint8_t* out) { ((HostDev*)h)->labels(out); return 0; }
+
+/* ---- one-call convenience: single slab, the C++ schedule of mgc_driver.inl ---- */
 int hostsim_solve(const int64_t* shape, const double* w0, const double* w1, const double* w2, const double* trcap,
                   int rounds, int cycles, int sweeps, int max_outer, uint8_t* labels_out, int64_t* stats_out)
 {
-    HostDev dev;
-    MgcLattice& L = dev.L;
-    memset(&L, 0, sizeof(L));
-    L.dz = shape[0]; L.dy = shape[1]; L.dx = shape[2];
-    L.nvox = L.dz * L.dy * L.dx;
-    L.gz = (int)((L.dz + 7) / 8); L.gy = (int)((L.dy + 7) / 8); L.gx = (int)((L.dx + 7) / 8);
-    L.ntiles = L.gz * L.gy * L.gx;
-    const int64_t nt = L.ntiles;
-    std::vector<double> rcap(nt * 6 * MGC_TV, 0.0), excess(nt * MGC_TV, 0.0), sink(nt * MGC_TV, 0.0), obox(nt * 6 * MGC_TF, 0.0);
-    std::vector<int32_t> height(nt * MGC_TV, MGC_HINF), lists(6 * nt, 0), count(MGC_NCOUNT, 0);
-    std::vector<uint8_t> rmask(nt * MGC_TV, 0);
-    std::vector<uint32_t> oflags(nt, 0), stamp(nt, 0), rstamp(nt, 0), status(nt, 0);
-    L.rcap = rcap.data(); L.cap0 = NULL; L.excess = excess.data(); L.sink = sink.data(); L.height = height.data();
-    L.rmask = rmask.data(); L.obox = obox.data(); L.oflags = oflags.data();
-    for (int i = 0; i < 6; ++i) L.list[i] = lists.data() + i * nt;
-    L.count = count.data(); L.stamp = stamp.data(); L.rstamp = rstamp.data(); L.status = status.data();
-
-    const int64_t D0 = L.dz, D1 = L.dy, D2 = L.dx;
-    for (int64_t z = 0; z < D0; ++z)
-        for (int64_t y = 0; y < D1; ++y)
-            for (int64_t x = 0; x < D2; ++x) {
-                int tile, loc;
-                const int64_t id = (z * D1 + y) * D2 + x;
-                mgc_node_to_tile(L, id, tile, loc);
-                double r[6] = {0, 0, 0, 0, 0, 0};
-                if (x > 0) r[0] = w2[(z * D1 + y) * (D2 - 1) + (x - 1)];
-                if (x < D2 - 1) r[1] = w2[(z * D1 + y) * (D2 - 1) + x];
-                if (y > 0) r[2] = w1[(z * (D1 - 1) + (y - 1)) * D2 + x];
-                if (y < D1 - 1) r[3] = w1[(z * (D1 - 1) + y) * D2 + x];
-                if (z > 0) r[4] = w0[((z - 1) * D1 + y) * D2 + x];
-                if (z < D0 - 1) r[5] = w0[(z * D1 + y) * D2 + x];
-                int m = 0;
-                for (int d = 0; d < 6; ++d) {
-                    rcap[((int64_t)tile * 6 + d) * MGC_TV + loc] = r[d];
-                    if (r[d] > 0.0) m |= 1 << d;
-                }
-                const double tr = trcap[id];
-                excess[(int64_t)tile * MGC_TV + loc] = tr > 0 ? tr : 0.0;
-                sink[(int64_t)tile * MGC_TV + loc] = tr < 0 ? -tr : 0.0;
-                if (tr < 0) { m |= MGC_MASK_SINK; status[tile] |= 2u; }
-                rmask[(int64_t)tile * MGC_TV + loc] = (uint8_t)m;
-            }
-
+    HostDev* d = (HostDev*)hostsim_create(shape, 0, 1);
+    d->load(w0, w1, w2, trcap);
     MgcSolveParams P = mgc_default_params();
     if (rounds > 0) P.rounds_per_relabel = rounds;
     if (cycles > 0) P.max_cycles = cycles;
     if (sweeps > 0) P.max_sweeps = sweeps;
     if (max_outer > 0) P.max_outer = max_outer;
     MgcSolveStats st;
-    const int rc = mgc_solve(dev, L, P, st);
+    const int rc = mgc_solve(*d, d->L, P, st);
     memcpy(stats_out, &st, sizeof(st));
-    for (int64_t id = 0; id < L.nvox; ++id) {
-        int tile, loc;
-        mgc_node_to_tile(L, id, tile, loc);
-        labels_out[id] = height[(int64_t)tile * MGC_TV + loc] < MGC_HINF ? 0 : 1;
-    }
+    d->labels(labels_out);
+    delete d;
     return rc;
 }
 

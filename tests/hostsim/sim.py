@@ -47,3 +47,76 @@ def solve(shape, weights, trcap, rounds=0, cycles=0, sweeps=0, max_outer=0):
     st = dict(zip(STAT_NAMES, stats.tolist()))
     st["rc"] = rc
     return labels.reshape(tuple(shape)), st
+
+
+# ------------------------------------------------------------------------------------------
+# Slab handle over the host simulator: same surface as medpy_amd.slab.HipSlab, so the
+# distributed schedule (medpy_amd/slab.py:solve_slabs) and the transports are tested on CPU.
+# ------------------------------------------------------------------------------------------
+class SimSlab(object):
+    def __init__(self, global_shape, rank, nranks):
+        L = lib()
+        vp, i64 = C.c_void_p, C.c_int64
+        L.hostsim_create.restype = vp
+        L.hostsim_create.argtypes = [np.ctypeslib.ndpointer(np.int64), C.c_int, C.c_int]
+        L.hostsim_destroy.argtypes = [vp]
+        L.hostsim_slab_info.argtypes = [vp, np.ctypeslib.ndpointer(np.int64)]
+        pf = np.ctypeslib.ndpointer(np.float64, flags="C_CONTIGUOUS")
+        L.hostsim_load.argtypes = [vp, pf, pf, pf, pf]
+        L.hostsim_solver_op.argtypes = [vp, C.c_int, i64, i64, i64, i64]
+        L.hostsim_read_counts.argtypes = [vp, np.ctypeslib.ndpointer(np.int32)]
+        L.hostsim_halo_bytes.argtypes = [vp, C.c_int, C.POINTER(i64)]
+        L.hostsim_halo_pack.argtypes = [vp, C.c_int, C.c_int, vp, C.c_int]
+        L.hostsim_halo_unpack.argtypes = [vp, C.c_int, C.c_int, vp, C.c_int, C.c_uint32, C.c_int]
+        L.hostsim_labels.argtypes = [vp, np.ctypeslib.ndpointer(np.uint8)]
+        self._L = L
+        self._h = L.hostsim_create(np.asarray(global_shape, dtype=np.int64), rank, nranks)
+        assert self._h, "cannot cut the volume into that many slabs"
+        info = np.zeros(8, np.int64)
+        L.hostsim_slab_info(self._h, info)
+        self.plane0, self.plane1, self.own0, self.own1 = (int(v) for v in info[:4])
+        self.has_lo, self.has_hi = bool(info[4]), bool(info[5])
+        self.local_shape = (self.plane1 - self.plane0, int(global_shape[1]), int(global_shape[2]))
+        self.rank, self.nranks = rank, nranks
+
+    def close(self):
+        if self._h:
+            self._L.hostsim_destroy(self._h)
+            self._h = None
+
+    def __del__(self):
+        self.close()
+
+    def load(self, weights_global, trcap_global):
+        """slice the LOCAL planes out of the global per-axis weights / t-links and load them"""
+        a, b = self.plane0, self.plane1
+        w0 = np.ascontiguousarray(weights_global[0][a:b - 1], dtype=np.float64).ravel()
+        w1 = np.ascontiguousarray(weights_global[1][a:b], dtype=np.float64).ravel()
+        w2 = np.ascontiguousarray(weights_global[2][a:b], dtype=np.float64).ravel()
+        tr = np.ascontiguousarray(np.asarray(trcap_global).reshape((-1,) + self.local_shape[1:])[a:b], dtype=np.float64).ravel()
+        pad = lambda w: w if w.size else np.zeros(1)
+        self._L.hostsim_load(self._h, pad(w0), pad(w1), pad(w2), tr)
+
+    def op(self, op, a0=0, a1=0, a2=0, a3=0):
+        assert self._L.hostsim_solver_op(self._h, int(op), int(a0), int(a1), int(a2), int(a3)) == 0
+
+    def read_counts(self):
+        out = np.zeros(16, np.int32)
+        self._L.hostsim_read_counts(self._h, out)
+        return out
+
+    def halo_bytes(self, kind):
+        n = C.c_int64(0)
+        self._L.hostsim_halo_bytes(self._h, int(kind), C.byref(n))
+        return n.value
+
+    def halo_pack(self, side, kind, buf, on_device=False):
+        self._L.hostsim_halo_pack(self._h, int(side), int(kind), C.c_void_p(buf.ctypes.data), 0)
+
+    def halo_unpack(self, side, kind, buf, epoch, lst, on_device=False):
+        self._L.hostsim_halo_unpack(self._h, int(side), int(kind), C.c_void_p(buf.ctypes.data), 0, int(epoch), int(lst))
+
+    def finish(self):
+        out = np.empty(int(np.prod(self.local_shape)), np.uint8)
+        self._L.hostsim_labels(self._h, out)
+        return out.reshape(self.local_shape)[self.own0 - self.plane0:self.own1 - self.plane0].astype(np.bool_), 0.0

@@ -1,0 +1,103 @@
+"""CPU tier: the multi-GPU Z-slab protocol (medpy_amd/slab.py: schedule + transports) executed over
+the host simulator.  Loopback (all slabs in-process) and a real 2-process gloo run must both give
+exactly the labels of the BK oracle (= the single-slab labels)."""
+import os
+import subprocess
+import sys
+
+import numpy as np
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, os.path.join(ROOT, "tests", "hostsim"))
+
+
+def _problem(gen, shape):
+    from medpy_amd import synthetic
+    from oracle import energy_numpy, pipeline
+    s = getattr(synthetic, gen)(shape)
+    w = energy_numpy.boundary_weights(s["term"], s["image"], s["sigma"])
+    g = pipeline.build_graph(s["fg"], s["bg"], weights=w)
+    tr = np.array([g.get_trcap(i) for i in range(s["fg"].size)])
+    g.maxflow()
+    return w, tr, g.labels().reshape(shape).astype(bool)
+
+
+@pytest.mark.parametrize("gen,shape,nslabs", [("sphere", (32, 24, 24), 2), ("sphere", (40, 24, 16), 3), ("hard", (32, 32, 32), 4),
+                                              ("sphere", (21, 16, 24), 2), ("sphere", (64, 16, 16), 8)])
+def test_loopback_slabs_match_oracle(gen, shape, nslabs):
+    import sim
+    from medpy_amd.slab import LoopbackExchange, solve_slabs
+    w, tr, ref = _problem(gen, shape)
+    slabs = [sim.SimSlab(shape, r, nslabs) for r in range(nslabs)]
+    for s in slabs:
+        s.load(w, tr)
+    st = solve_slabs(slabs, LoopbackExchange(slabs))
+    assert st["converged"] == 1
+    labels = np.concatenate([s.finish()[0] for s in slabs], axis=0)
+    np.testing.assert_array_equal(labels, ref)
+    # slab boundaries fall on tile layers and partition the planes
+    assert slabs[0].own0 == 0 and slabs[-1].own1 == shape[0]
+    assert all(a.own1 == b.own0 for a, b in zip(slabs, slabs[1:]))
+
+
+def test_schedule_independent_of_slab_count():
+    import sim
+    from medpy_amd.slab import LoopbackExchange, solve_slabs
+    shape = (48, 16, 24)
+    w, tr, ref = _problem("sphere", shape)
+    for nslabs in (1, 2, 3, 6):
+        slabs = [sim.SimSlab(shape, r, nslabs) for r in range(nslabs)]
+        for s in slabs:
+            s.load(w, tr)
+        st = solve_slabs(slabs, LoopbackExchange(slabs), rounds_per_relabel=3, max_cycles=2, max_sweeps=4)
+        assert st["converged"] == 1
+        np.testing.assert_array_equal(np.concatenate([s.finish()[0] for s in slabs], axis=0), ref)
+
+
+WORKER = r'''
+import os, sys
+import numpy as np
+ROOT = sys.argv[1]; out = sys.argv[2]
+sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, "tests", "hostsim"))
+import torch.distributed as dist
+dist.init_process_group("gloo")
+rank, world = dist.get_rank(), dist.get_world_size()
+import sim
+from medpy_amd import synthetic
+from medpy_amd.slab import DistExchange, solve_slabs
+from oracle import energy_numpy, pipeline
+shape = (40, 24, 24)
+s = synthetic.sphere(shape)
+w = energy_numpy.boundary_weights(s["term"], s["image"], s["sigma"])
+g = pipeline.build_graph(s["fg"], s["bg"], weights=w)
+tr = np.array([g.get_trcap(i) for i in range(s["fg"].size)])
+slab = sim.SimSlab(shape, rank, world)
+slab.load(w, tr)
+st = solve_slabs([slab], DistExchange(slab))
+lab, _ = slab.finish()
+np.save(os.path.join(out, "labels_%d.npy" % rank), lab)
+np.save(os.path.join(out, "range_%d.npy" % rank), np.array([slab.own0, slab.own1, st["converged"], st["exchanges"]]))
+dist.barrier()
+dist.destroy_process_group()
+'''
+
+
+@pytest.mark.timeout(300)
+def test_two_process_gloo_slabs(tmp_path):
+    """world_size 2, gloo, one slab per process: the N>1 path of bench.py / the multi-GPU run."""
+    script = tmp_path / "worker.py"
+    script.write_text(WORKER)
+    env = dict(os.environ, MASTER_ADDR="127.0.0.1", OMP_NUM_THREADS="1")
+    port = 29500 + (os.getpid() % 2000)
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node=2", "--master-addr", "127.0.0.1",
+           "--master-port", str(port), str(script), ROOT, str(tmp_path)]
+    res = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=280)
+    assert res.returncode == 0, res.stderr[-3000:]
+    _, _, ref = _problem("sphere", (40, 24, 24))
+    parts, ranges = [], []
+    for r in range(2):
+        parts.append(np.load(tmp_path / ("labels_%d.npy" % r)))
+        ranges.append(np.load(tmp_path / ("range_%d.npy" % r)))
+    assert ranges[0][1] == ranges[1][0] and ranges[0][2] == 1 and ranges[1][2] == 1 and ranges[0][3] > 0
+    np.testing.assert_array_equal(np.concatenate(parts, axis=0), ref)
