@@ -108,18 +108,13 @@ def main():
         elapsed = time.perf_counter() - t0
         fg_fraction = float(g.labels().mean())
     else:
-        import torch
-        import torch.distributed as dist  # plumbing: rendezvous, RCCL send/recv of the packed borders, all-reduce
-        from medpy_amd.slab import DistExchange, HipSlab, solve_slabs
-        # MEDPY_DIST_BACKEND=gloo: development aid -- several ranks share the visible GPUs and the borders travel
-        # through host buffers (used to exercise this code path on a 1-GPU box); the default is RCCL.
+        import torch.distributed as dist  # out-of-band channel only (gloo): RCCL id broadcast, barriers, host scalars
+        from medpy_amd.slab import DistExchange, HipSlab, RcclExchange, solve_slabs
+        # MEDPY_DIST_BACKEND=gloo: development aid -- the borders travel through host buffers and the ranks may share
+        # a GPU (exercises this code path on a 1-GPU box).  Default: RCCL over xGMI, driven by the library itself.
         backend = os.environ.get("MEDPY_DIST_BACKEND", "nccl")
         dev_index = local_rank % _lib.device_count()
-        torch.cuda.set_device(dev_index)
-        if backend == "nccl":
-            dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", dev_index))
-        else:
-            dist.init_process_group(backend, rank=rank, world_size=world)
+        dist.init_process_group("gloo", rank=rank, world_size=world)
         gshape = (n * world, n, n)
         slab = HipSlab(gshape, rank, world, device=dev_index)
         # the local planes of the global volume: sphere block `b` occupies planes [b*n, (b+1)*n)
@@ -137,7 +132,7 @@ def main():
         slab.set_boundary("difference_exponential", np.concatenate(imgs, axis=0)[sl], 15.0, False)
         slab.set_markers(np.concatenate(fgs, axis=0)[sl], np.concatenate(bgs, axis=0)[sl])
         del imgs, fgs, bgs
-        ex = DistExchange(slab)
+        ex = RcclExchange(slab) if backend == "nccl" else DistExchange(slab)
 
         def step():
             slab.build()
@@ -146,15 +141,14 @@ def main():
 
         for _ in range(args.warmup):
             step()
-        torch.cuda.synchronize()
-        dist.barrier()
+        dist.barrier()  # every library call above returned after its stream drained (device synchronised)
         t0 = time.perf_counter()
         for _ in range(args.steps):
-            slab_stats, part = step()
-        torch.cuda.synchronize()
+            slab_stats, part = step()  # finish_device() synchronises the stream
         dist.barrier()
         elapsed = time.perf_counter() - t0
-        t = torch.tensor([elapsed], dtype=torch.float64, device="cuda" if backend == "nccl" else "cpu")
+        import torch
+        t = torch.tensor([elapsed], dtype=torch.float64)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t[0])
         flow = float(ex.allreduce_sum([part]))

@@ -162,6 +162,17 @@ int mgc_halo_unpack(mgc_handle h, int side, int kind, const void* buf, int buf_o
 /* after the slab driver has converged: labels of the local planes + this slab's part of the cut capacity */
 int mgc_finish(mgc_handle h, double* flow_partial);
 
+/* Native transport: RCCL over xGMI (librccl is dlopen()ed on first use, single-GPU users never need it).
+ * Rank 0 obtains a 128-byte id (mgc_comm_unique_id) that the launcher broadcasts out of band (bench.py uses the
+ * gloo store of torch.distributed); every rank then calls mgc_comm_init on its slab handle.  mgc_halo_exchange =
+ * pack both borders -> grouped ncclSend/ncclRecv with rank-1 / rank+1 -> unpack, all ordered on the handle's
+ * stream (no host synchronisation).  mgc_allreduce_counts sums the 16 solver counters over all ranks
+ * (ncclAllReduce) and returns them: the termination / fixpoint tests of the distributed schedule. */
+int mgc_comm_unique_id(uint8_t* id128);
+int mgc_comm_init(mgc_handle h, const uint8_t* id128);
+int mgc_halo_exchange(mgc_handle h, int kind, uint32_t epoch, int list);
+int mgc_allreduce_counts(mgc_handle h, int64_t* out16);
+
 #ifdef __cplusplus
 }
 #endif

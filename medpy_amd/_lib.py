@@ -70,6 +70,10 @@ SIGNATURES = {
     "mgc_halo_pack": (_INT, [_VP, _INT, _INT, _VP, _INT]),
     "mgc_halo_unpack": (_INT, [_VP, _INT, _INT, _VP, _INT, C.c_uint32, _INT]),
     "mgc_finish": (_INT, [_VP, C.POINTER(_DBL)]),
+    "mgc_comm_unique_id": (_INT, [_VP]),
+    "mgc_comm_init": (_INT, [_VP, _VP]),
+    "mgc_halo_exchange": (_INT, [_VP, _INT, C.c_uint32, _INT]),
+    "mgc_allreduce_counts": (_INT, [_VP, _VP]),
 }
 
 _lib = None
@@ -90,7 +94,9 @@ def load():
         raise ImportError(
             "medpy_amd: %s not found. Build it with `python -c 'import __graft_entry__ as g; g.build()'` "
             "(hipcc --offload-arch=gfx950). There is no CPU fallback." % LIB_PATH)
-    lib = C.CDLL(LIB_PATH)
+    # RTLD_DEEPBIND: bind to the HIP runtime the library was linked against (system ROCm) even when the host
+    # application (e.g. a PyTorch wheel, which bundles its own libamdhip64) already exported HIP symbols globally.
+    lib = C.CDLL(LIB_PATH, mode=os.RTLD_NOW | os.RTLD_LOCAL | os.RTLD_DEEPBIND)
     for name, (res, args) in SIGNATURES.items():
         f = getattr(lib, name)
         f.restype, f.argtypes = res, args

@@ -7,7 +7,7 @@ CSRC = os.path.join(HERE, "csrc")
 LIB = os.path.join(HERE, "libmedpyhip.so")
 SOURCES = ["mgc_kernels.hip"]
 DEPS = ["mgc_kernels.hip", "mgc_tile_ops.inl", "mgc_driver.inl", "mgc_common.h", os.path.join("..", "..", "include", "medpy_hip.h")]
-FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-ffp-contract=off", "-fPIC", "-shared"]
+FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-ffp-contract=off", "-fPIC", "-shared", "-ldl"]
 
 
 def hipcc():

@@ -19,6 +19,9 @@
  *   k_get_*         energy read-back for the parity tests
  */
 #include <hip/hip_runtime.h>
+#include <rccl/rccl.h> /* types only: the library itself is dlopen()ed on first use */
+
+#include <dlfcn.h>
 
 #include <math.h>
 #include <stdarg.h>
@@ -505,6 +508,8 @@ struct mgc_graph {
     int rank = 0, nranks = 1;
     int64_t plane0 = 0, plane1 = 0, own0 = 0, own1 = 0; /* global plane ranges of a slab */
     void* d_halo = nullptr; int64_t halo_cap = 0;
+    ncclComm_t comm = nullptr; void* d_xchg[4] = {nullptr, nullptr, nullptr, nullptr}; int64_t xchg_cap = 0; /* send lo, recv lo, send hi, recv hi */
+    int64_t* d_cnt64 = nullptr;
     double flow_const = 0.0, flow = 0.0;
     MgcSolveParams params = mgc_default_params();
     int grid_cap = 4096;
@@ -849,15 +854,145 @@ int mgc_halo_unpack(mgc_handle h, int side, int kind, const void* buf, int buf_o
     return MGC_OK;
 }
 
+/* ---- RCCL, resolved lazily from the system ROCm (same HIP runtime this library is linked to) ---- */
+struct MgcRccl {
+    void* dl = nullptr;
+    ncclResult_t (*GetUniqueId)(ncclUniqueId*) = nullptr;
+    ncclResult_t (*CommInitRank)(ncclComm_t*, int, ncclUniqueId, int) = nullptr;
+    ncclResult_t (*CommDestroy)(ncclComm_t) = nullptr;
+    ncclResult_t (*Send)(const void*, size_t, ncclDataType_t, int, ncclComm_t, hipStream_t) = nullptr;
+    ncclResult_t (*Recv)(void*, size_t, ncclDataType_t, int, ncclComm_t, hipStream_t) = nullptr;
+    ncclResult_t (*AllReduce)(const void*, void*, size_t, ncclDataType_t, ncclRedOp_t, ncclComm_t, hipStream_t) = nullptr;
+    ncclResult_t (*GroupStart)() = nullptr;
+    ncclResult_t (*GroupEnd)() = nullptr;
+    const char* (*GetErrorString)(ncclResult_t) = nullptr;
+    std::string err;
+    bool load()
+    {
+        if (dl) return true;
+        /* the RCCL that belongs to the HIP runtime this library is linked against comes first: it sits next to
+         * libamdhip64 (a bare "librccl.so" could resolve to a copy some host application already loaded) */
+        std::string sibling;
+        Dl_info info;
+        if (dladdr((void*)&hipGetDeviceCount, &info) && info.dli_fname) {
+            sibling = info.dli_fname;
+            const size_t slash = sibling.rfind('/');
+            sibling = (slash == std::string::npos ? std::string() : sibling.substr(0, slash + 1)) + "librccl.so.1";
+        }
+        const char* names[] = {sibling.c_str(), "/opt/rocm/lib/librccl.so.1", "librccl.so.1", "librccl.so"};
+        for (const char* n : names)
+            /* DEEPBIND: librccl must bind to the HIP runtime it is linked against (the system one this library
+             * uses too), not to another copy a host application may have put in the global scope (PyTorch wheels
+             * bundle their own libamdhip64) */
+            if (*n && (dl = dlopen(n, RTLD_NOW | RTLD_LOCAL | RTLD_DEEPBIND))) break;
+        if (!dl) { err = std::string("cannot dlopen librccl: ") + dlerror(); return false; }
+#define MGC_SYM(field, name) do { *(void**)(&field) = dlsym(dl, name); if (!field) { err = std::string("librccl lacks ") + name; dl = nullptr; return false; } } while (0)
+        MGC_SYM(GetUniqueId, "ncclGetUniqueId"); MGC_SYM(CommInitRank, "ncclCommInitRank"); MGC_SYM(CommDestroy, "ncclCommDestroy");
+        MGC_SYM(Send, "ncclSend"); MGC_SYM(Recv, "ncclRecv"); MGC_SYM(AllReduce, "ncclAllReduce");
+        MGC_SYM(GroupStart, "ncclGroupStart"); MGC_SYM(GroupEnd, "ncclGroupEnd"); MGC_SYM(GetErrorString, "ncclGetErrorString");
+#undef MGC_SYM
+        return true;
+    }
+};
+static MgcRccl g_rccl;
+
+#define MGC_NCCL(h, call)                                                                                          \
+    do {                                                                                                           \
+        ncclResult_t r_ = (call);                                                                                  \
+        if (r_ != ncclSuccess) return mgc_fail(h, MGC_ERR_HIP, "%s failed: %s", #call, g_rccl.GetErrorString(r_)); \
+    } while (0)
+
+int mgc_comm_unique_id(uint8_t* id128)
+{
+    if (!id128) return MGC_ERR_INVALID;
+    if (!g_rccl.load()) return mgc_fail(nullptr, MGC_ERR_UNSUPPORTED, "%s", g_rccl.err.c_str());
+    ncclUniqueId id;
+    MGC_NCCL(nullptr, g_rccl.GetUniqueId(&id));
+    static_assert(sizeof(id) == NCCL_UNIQUE_ID_BYTES, "ncclUniqueId size");
+    memcpy(id128, &id, NCCL_UNIQUE_ID_BYTES);
+    return MGC_OK;
+}
+
+int mgc_comm_init(mgc_handle h, const uint8_t* id128)
+{
+    if (!h || !id128) return MGC_ERR_INVALID;
+    if (!g_rccl.load()) return mgc_fail(h, MGC_ERR_UNSUPPORTED, "%s", g_rccl.err.c_str());
+    MGC_HIP(h, hipSetDevice(h->device));
+    ncclUniqueId id;
+    memcpy(&id, id128, NCCL_UNIQUE_ID_BYTES);
+    MGC_NCCL(h, g_rccl.CommInitRank(&h->comm, h->nranks, id, h->rank));
+    if (!h->d_cnt64) MGC_HIP(h, hipMalloc((void**)&h->d_cnt64, 2 * MGC_NCOUNT * sizeof(int64_t)));
+    return MGC_OK;
+}
+
+__global__ void k_widen_counts(const int32_t* c, int64_t* out)
+{
+    if (threadIdx.x < MGC_NCOUNT) out[threadIdx.x] = c[threadIdx.x];
+}
+
+int mgc_allreduce_counts(mgc_handle h, int64_t* out)
+{
+    if (!h || !out) return MGC_ERR_INVALID;
+    if (!h->comm) return mgc_fail(h, MGC_ERR_STATE, "mgc_allreduce_counts before mgc_comm_init");
+    MGC_HIP(h, hipSetDevice(h->device));
+    hipLaunchKernelGGL(k_widen_counts, dim3(1), dim3(64), 0, h->stream, (const int32_t*)h->L.count, h->d_cnt64);
+    MGC_HIP(h, hipGetLastError());
+    MGC_NCCL(h, g_rccl.AllReduce(h->d_cnt64, h->d_cnt64 + MGC_NCOUNT, MGC_NCOUNT, ncclInt64, ncclSum, h->comm, h->stream));
+    MGC_HIP(h, hipMemcpyAsync(out, h->d_cnt64 + MGC_NCOUNT, MGC_NCOUNT * sizeof(int64_t), hipMemcpyDeviceToHost, h->stream));
+    MGC_HIP(h, hipStreamSynchronize(h->stream));
+    return MGC_OK;
+}
+
+int mgc_halo_exchange(mgc_handle h, int kind, uint32_t epoch, int list)
+{
+    if (!h) return MGC_ERR_INVALID;
+    if (!h->built) return mgc_fail(h, MGC_ERR_STATE, "mgc_halo_exchange before mgc_build");
+    if (!h->comm) return mgc_fail(h, MGC_ERR_STATE, "mgc_halo_exchange before mgc_comm_init");
+    MGC_HIP(h, hipSetDevice(h->device));
+    kind = kind ? 1 : 0;
+    const int64_t bytes = mgc_halo_bytes(h->L, 1); /* size for the larger kind; reused for both */
+    if (h->xchg_cap < bytes) {
+        for (int i = 0; i < 4; ++i) {
+            if (h->d_xchg[i]) (void)hipFree(h->d_xchg[i]);
+            h->d_xchg[i] = nullptr;
+            MGC_HIP(h, hipMalloc(&h->d_xchg[i], (size_t)bytes));
+        }
+        h->xchg_cap = bytes;
+    }
+    const int64_t nb = mgc_halo_bytes(h->L, kind);
+    const bool has[2] = {h->L.tz_own_lo > 0, h->L.tz_own_hi < h->L.gz};
+    const int peer[2] = {h->rank - 1, h->rank + 1};
+    const int T = h->L.gy * h->L.gx, grid = T < 2048 ? T : 2048;
+    for (int side = 0; side < 2; ++side)
+        if (has[side]) {
+            hipLaunchKernelGGL(k_halo_pack, dim3(grid), dim3(MGC_TV), 0, h->stream, h->L, side, kind, h->d_xchg[2 * side]);
+            MGC_HIP(h, hipGetLastError());
+        }
+    MGC_NCCL(h, g_rccl.GroupStart());
+    for (int side = 0; side < 2; ++side)
+        if (has[side]) {
+            MGC_NCCL(h, g_rccl.Send(h->d_xchg[2 * side], (size_t)nb, ncclUint8, peer[side], h->comm, h->stream));
+            MGC_NCCL(h, g_rccl.Recv(h->d_xchg[2 * side + 1], (size_t)nb, ncclUint8, peer[side], h->comm, h->stream));
+        }
+    MGC_NCCL(h, g_rccl.GroupEnd());
+    for (int side = 0; side < 2; ++side)
+        if (has[side]) {
+            hipLaunchKernelGGL(k_halo_unpack, dim3(grid), dim3(MGC_TV), 0, h->stream, h->L, side, kind, (const void*)h->d_xchg[2 * side + 1], epoch, list);
+            MGC_HIP(h, hipGetLastError());
+        }
+    return MGC_OK;
+}
+
 int mgc_destroy(mgc_handle h)
 {
     if (!h) return MGC_OK;
     (void)hipSetDevice(h->device);
     if (h->stream) (void)hipStreamSynchronize(h->stream);
+    if (h->comm && g_rccl.CommDestroy) (void)g_rccl.CommDestroy(h->comm);
     MgcLattice& L = h->L;
     void* ptrs[] = {L.rcap, L.cap0, L.excess, L.sink, L.height, L.rmask, L.obox, L.oflags, L.list[0], L.list[1], L.list[2],
                     L.list[3], L.list[4], L.list[5], L.count, L.stamp, L.rstamp, L.status, h->d_tr0, h->d_part, h->d_scalar,
-                    h->d_labels, h->d_image, h->d_prob, h->d_fg, h->d_bg, h->d_tr_in, h->d_ei, h->d_ej, h->d_ecap, h->d_erev, h->d_halo};
+                    h->d_labels, h->d_image, h->d_prob, h->d_fg, h->d_bg, h->d_tr_in, h->d_ei, h->d_ej, h->d_ecap, h->d_erev, h->d_halo, h->d_xchg[0], h->d_xchg[1], h->d_xchg[2], h->d_xchg[3], h->d_cnt64};
     for (void* p : ptrs)
         if (p) (void)hipFree(p);
     if (h->h_count) (void)hipHostFree(h->h_count);

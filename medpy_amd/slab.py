@@ -24,24 +24,20 @@ OP_ABSORB_ALL, OP_FILL_INF, OP_ZERO_COUNT, OP_RELABEL_ALL, OP_RELABEL_LIST, OP_A
 class LoopbackExchange(object):
     """All slabs live in this process (one GPU time-multiplexed, or the host simulator)."""
 
-    def __init__(self, slabs, device_buffers=False):
-        """device_buffers: keep the packed borders in HBM (torch CUDA tensors), as the RCCL transport does."""
+    def __init__(self, slabs):
         self.slabs = list(slabs)
         self._bufs = {}
-        self.on_device = bool(device_buffers)
-        if self.on_device:
-            import torch
-            self.torch = torch
+        self.on_device = False
 
     def _buf(self, key, nbytes):
         b = self._bufs.get(key)
-        if b is None or (b.numel() if self.on_device else b.size) != nbytes:
-            b = self.torch.zeros(nbytes, dtype=self.torch.uint8, device="cuda") if self.on_device else np.zeros(nbytes, dtype=np.uint8)
+        if b is None or b.size != nbytes:
+            b = np.zeros(nbytes, dtype=np.uint8)
             self._bufs[key] = b
         return b
 
     def _raw(self, b):
-        return b.data_ptr() if self.on_device else b
+        return b
 
     def exchange(self, kind, epoch, lst):
         packed = []
@@ -61,13 +57,17 @@ class LoopbackExchange(object):
         """values: one number (or vector) per local slab -> global sum"""
         return np.sum(np.asarray(values, dtype=np.float64), axis=0)
 
+    def global_counts(self):
+        """the 16 solver counters summed over every slab of the volume"""
+        return np.sum([s.read_counts().astype(np.int64) for s in self.slabs], axis=0)
+
 
 class DistExchange(object):
-    """One slab per process; neighbours are rank-1 / rank+1 of ``torch.distributed``.
-
-    backend "nccl" (= RCCL on ROCm): the packed borders stay in HBM (torch CUDA tensors own the
-    message buffers, the library packs/unpacks straight into them); "gloo": host buffers
-    (CPU test tier)."""
+    """One slab per process; neighbours are rank-1 / rank+1 of ``torch.distributed``; the packed borders
+    travel as torch tensors.  Used with "gloo" (host buffers): the CPU test tier over the host simulator,
+    and a development mode of bench.py.  The production transport is RcclExchange below -- PyTorch's ROCm
+    wheel bundles its own HIP runtime, which cannot share a process with the system runtime this library
+    is linked against, so torch.cuda tensors are deliberately not used here."""
 
     def __init__(self, slab, group=None):
         import torch
@@ -116,6 +116,38 @@ class DistExchange(object):
         out = t.cpu().numpy()
         return out if out.size > 1 else float(out[0])
 
+    def global_counts(self):
+        return self.allreduce_sum([self.slabs[0].read_counts().astype(np.float64)]).astype(np.int64)
+
+
+class RcclExchange(object):
+    """One slab per process, borders moved by the library itself: pack -> grouped ncclSend/ncclRecv with
+    rank-1 / rank+1 -> unpack, stream-ordered in HBM (``mgc_halo_exchange``); counters summed with
+    ncclAllReduce (``mgc_allreduce_counts``).  ``torch.distributed`` (gloo, CPU) is only the out-of-band
+    channel that hands rank 0's RCCL id to the other ranks and sums a few host scalars at the end."""
+
+    def __init__(self, slab, group=None):
+        import torch
+        import torch.distributed as dist
+        self.torch, self.dist, self.group = torch, dist, group
+        self.slabs = [slab]
+        self.rank, self.world = dist.get_rank(group), dist.get_world_size(group)
+        box = [slab.comm_unique_id() if self.rank == 0 else None]
+        dist.broadcast_object_list(box, src=0, group=group)
+        slab.comm_init(box[0])
+
+    def exchange(self, kind, epoch, lst):
+        self.slabs[0].exchange(kind, epoch, lst)
+
+    def global_counts(self):
+        return self.slabs[0].allreduce_counts()
+
+    def allreduce_sum(self, values):
+        t = self.torch.as_tensor(np.sum(np.asarray(values, dtype=np.float64), axis=0), dtype=self.torch.float64).reshape(-1)
+        self.dist.all_reduce(t, group=self.group)
+        out = t.numpy()
+        return out if out.size > 1 else float(out[0])
+
 
 def solve_slabs(slabs, ex, rounds_per_relabel=12, max_cycles=4, max_sweeps=8, max_outer=100000, check_rounds=1):
     """Drives the local slabs to a maximum preflow.  Returns a stats dict (global numbers)."""
@@ -140,7 +172,7 @@ def solve_slabs(slabs, ex, rounds_per_relabel=12, max_cycles=4, max_sweeps=8, ma
         while True:
             rep += 1
             cur, nxt = 4 + (rep & 1), 4 + ((rep + 1) & 1)
-            if ex.allreduce_sum([float(s.read_counts()[cur]) for s in slabs]) == 0:
+            if ex.global_counts()[cur] == 0:
                 break
             for s in slabs:
                 s.op(OP_ZERO_COUNT, nxt)
@@ -156,7 +188,7 @@ def solve_slabs(slabs, ex, rounds_per_relabel=12, max_cycles=4, max_sweeps=8, ma
             for i in (0, 1, 2, 3, 6):
                 s.op(OP_ZERO_COUNT, i)
             s.op(OP_ACTIVATE, phase)
-        if ex.allreduce_sum([float(s.read_counts()[6]) for s in slabs]) == 0:
+        if ex.global_counts()[6] == 0:
             st["converged"] = 1
             break
 
@@ -172,11 +204,11 @@ def solve_slabs(slabs, ex, rounds_per_relabel=12, max_cycles=4, max_sweeps=8, ma
                 st["exchanges"] += 1
                 phase += 1
             if (r + 1) % check_rounds == 0 and r + 1 < rounds_per_relabel:
-                pend = [float(c[phase & 3] + c[(phase + 1) & 3]) for c in (s.read_counts() for s in slabs)]
-                if ex.allreduce_sum(pend) == 0:
+                c = ex.global_counts()
+                if c[phase & 3] + c[(phase + 1) & 3] == 0:
                     break
-    tot = ex.allreduce_sum([[float(c[8]), float(c[9])] for c in (s.read_counts() for s in slabs)])
-    st["discharge_tiles"], st["relabel_tiles"] = int(tot[0]), int(tot[1])
+    c = ex.global_counts()
+    st["discharge_tiles"], st["relabel_tiles"] = int(c[8]), int(c[9])
     return st
 
 
@@ -267,6 +299,25 @@ class HipSlab(object):
     def halo_unpack(self, side, kind, buf, epoch, lst, on_device=False):
         self._call("mgc_halo_unpack", int(side), int(kind), self._ptr(buf, on_device), int(bool(on_device)), int(epoch), int(lst))
 
+    # -- native transport (RCCL): see RcclExchange
+    def comm_unique_id(self):
+        buf = np.zeros(128, dtype=np.uint8)
+        rc = self._lib.load().mgc_comm_unique_id(self._lib.ptr(buf))
+        self._lib.check(None, rc)
+        return buf.tobytes()
+
+    def comm_init(self, id_bytes):
+        buf = np.frombuffer(id_bytes, dtype=np.uint8).copy()
+        self._call("mgc_comm_init", self._lib.ptr(buf))
+
+    def exchange(self, kind, epoch, lst):
+        self._call("mgc_halo_exchange", int(kind), int(epoch), int(lst))
+
+    def allreduce_counts(self):
+        out = np.zeros(16, dtype=np.int64)
+        self._call("mgc_allreduce_counts", self._lib.ptr(out))
+        return out
+
     def finish_device(self):
         """labels (left in HBM) + this slab's part of the cut value"""
         f = self._C.c_double(0.0)
@@ -288,7 +339,7 @@ class HipSlab(object):
 
 
 def graphcut_voxel_slabs(image, fg, bg, term="difference_exponential", sigma=None, spacing=False, nslabs=2, device=0,
-                         device_buffers=False, **schedule):
+                         **schedule):
     """Cut one volume as ``nslabs`` Z-slabs time-multiplexed on ONE GPU with the loopback transport.
 
     Exercises exactly the code path of the multi-GPU run (ghost layers, halo pack/unpack, the
@@ -300,7 +351,7 @@ def graphcut_voxel_slabs(image, fg, bg, term="difference_exponential", sigma=Non
         s.set_boundary(term, image[sl], sigma, spacing)
         s.set_markers(fg[sl], bg[sl])
         s.build()
-    st = solve_slabs(slabs, LoopbackExchange(slabs, device_buffers=device_buffers), **schedule)
+    st = solve_slabs(slabs, LoopbackExchange(slabs), **schedule)
     parts = [s.finish() for s in slabs]
     labels = np.concatenate([p[0] for p in parts], axis=0)
     flow = float(sum(p[1] for p in parts))

@@ -17,14 +17,13 @@ def _single(s):
     return g.labels(), flow
 
 
-@pytest.mark.parametrize("gen,shape,nslabs,devbuf", [("sphere", (64, 48, 40), 2, False), ("sphere", (64, 48, 40), 4, True),
-                                                     ("hard", (48, 48, 48), 3, False), ("sphere", (37, 40, 24), 2, True),
-                                                     ("sphere", (128, 64, 64), 8, True)])
-def test_slabs_equal_single_and_oracle(gen, shape, nslabs, devbuf):
+@pytest.mark.parametrize("gen,shape,nslabs", [("sphere", (64, 48, 40), 2), ("sphere", (64, 48, 40), 4), ("hard", (48, 48, 48), 3),
+                                              ("sphere", (37, 40, 24), 2), ("sphere", (128, 64, 64), 8)])
+def test_slabs_equal_single_and_oracle(gen, shape, nslabs):
     from medpy_amd import synthetic
     from medpy_amd.slab import graphcut_voxel_slabs
     s = getattr(synthetic, gen)(shape)
-    labels, flow, st = graphcut_voxel_slabs(s["image"], s["fg"], s["bg"], s["term"], s["sigma"], nslabs=nslabs, device_buffers=devbuf)
+    labels, flow, st = graphcut_voxel_slabs(s["image"], s["fg"], s["bg"], s["term"], s["sigma"], nslabs=nslabs)
     assert st["converged"] == 1
     single, sflow = _single(s)
     np.testing.assert_array_equal(labels, single)
@@ -45,3 +44,34 @@ def test_slab_handle_refuses_single_gpu_entry_points():
     with pytest.raises(_lib.MedpyHipError):
         s._call("mgc_maxflow", C.byref(C.c_double()))
     s.close()
+
+
+def test_rccl_transport_single_rank_and_torch_coexistence():
+    """What can be checked of the native RCCL transport on a 1-GPU box: librccl is dlopen()ed, a 1-rank
+    communicator initialises on the handle's device, ncclAllReduce of the counters round-trips, the exchange
+    is a no-op without neighbours -- all in a process that has torch (gloo) imported, as bench.py does."""
+    import torch.distributed as dist
+    from medpy_amd import synthetic
+    from medpy_amd.slab import HipSlab, RcclExchange, solve_slabs
+    import os
+    os.environ.setdefault("MASTER_ADDR", "127.0.0.1"); os.environ.setdefault("MASTER_PORT", "29677")
+    os.environ.setdefault("NCCL_DEBUG", "WARN")
+    dist.init_process_group("gloo", rank=0, world_size=1)
+    try:
+        shape = (40, 32, 32)
+        s = synthetic.sphere(shape)
+        slab = HipSlab(shape, 0, 1)
+        slab.set_boundary(s["term"], s["image"], s["sigma"])
+        slab.set_markers(s["fg"], s["bg"])
+        slab.build()
+        ex = RcclExchange(slab)
+        st = solve_slabs([slab], ex)
+        assert st["converged"] == 1
+        labels, flow = slab.finish()
+        single, sflow = _single(s)
+        np.testing.assert_array_equal(labels, single)
+        assert flow == pytest.approx(sflow, rel=1e-12)
+        assert (slab.allreduce_counts() == slab.read_counts()).all()
+        slab.close()
+    finally:
+        dist.destroy_process_group()
