@@ -79,8 +79,9 @@ typedef struct mgc_stats {
 int mgc_device_count(int* count);
 
 /* Replaces GCGraph.__init__ -> GraphDouble(nodes, edges) + add_node (graph.py:294-308,
- * graph.cpp:12-31).  ndim 1..3; connectivity must be 2*ndim (the only neighbourhood the
- * reference supports, generate.py:44-49). */
+ * graph.cpp:12-31).  ndim 1..3; connectivity = 2*ndim (the only neighbourhood the reference supports,
+ * generate.py:44-49) or 3^ndim - 1 (full neighbourhood: 8 in 2-D, 26 in 3-D -- an extension named by
+ * BASELINE.json configs 3 and 5, weights = the same g(.) on every offset, spacing = Euclidean offset length). */
 int mgc_create(int ndim, const int64_t* shape, int connectivity, int device, mgc_handle* out);
 int mgc_destroy(mgc_handle h);
 const char* mgc_last_error(mgc_handle h); /* h may be NULL: error of the last failed mgc_create */
@@ -115,6 +116,9 @@ int mgc_build(mgc_handle h);
  * `neighbourhood_intensity_term` (energy_voxel.py:644-658); tr_cap per node (Graph::get_trcap). */
 int mgc_get_nweights(mgc_handle h, int axis, double* out);
 int mgc_get_tweights(mgc_handle h, double* out);
+/* weight of the arc (p, p + offset) for every voxel p (handle shape), NaN where p + offset is outside; offset has
+ * ndim components in {-1,0,1}.  The read-back used for the full (8 / 26) neighbourhood. */
+int mgc_get_nweights_offset(mgc_handle h, const int* offset, double* out);
 int mgc_get_edge(mgc_handle h, int64_t i, int64_t j, double* out); /* Graph::get_edge, graph.h:482-498 */
 
 /* Replaces GraphDouble.maxflow() (maxflow.cpp:472-604).  flow = capacity of the minimum cut
@@ -154,7 +158,7 @@ int mgc_create_slab(int ndim, const int64_t* global_shape, int connectivity, int
  * plane range, info[4] / info[5] = has a lower / upper neighbour, info[6] = tiles per layer */
 int mgc_slab_info(mgc_handle h, int64_t* info8);
 int mgc_solver_op(mgc_handle h, int op, int64_t a0, int64_t a1, int64_t a2, int64_t a3);
-int mgc_read_counts(mgc_handle h, int32_t* out16);
+int mgc_read_counts(mgc_handle h, int32_t* out32); /* 32 counters */
 int mgc_halo_bytes(mgc_handle h, int kind, int64_t* bytes);
 /* side 0 = lower / 1 = upper slab boundary; kind 0 = labels (relabel pass), 1 = labels + outbox flow (phase) */
 int mgc_halo_pack(mgc_handle h, int side, int kind, void* buf, int buf_on_device);
@@ -166,12 +170,12 @@ int mgc_finish(mgc_handle h, double* flow_partial);
  * Rank 0 obtains a 128-byte id (mgc_comm_unique_id) that the launcher broadcasts out of band (bench.py uses the
  * gloo store of torch.distributed); every rank then calls mgc_comm_init on its slab handle.  mgc_halo_exchange =
  * pack both borders -> grouped ncclSend/ncclRecv with rank-1 / rank+1 -> unpack, all ordered on the handle's
- * stream (no host synchronisation).  mgc_allreduce_counts sums the 16 solver counters over all ranks
+ * stream (no host synchronisation).  mgc_allreduce_counts sums the 32 solver counters over all ranks
  * (ncclAllReduce) and returns them: the termination / fixpoint tests of the distributed schedule. */
 int mgc_comm_unique_id(uint8_t* id128);
 int mgc_comm_init(mgc_handle h, const uint8_t* id128);
 int mgc_halo_exchange(mgc_handle h, int kind, uint32_t epoch, int list);
-int mgc_allreduce_counts(mgc_handle h, int64_t* out16);
+int mgc_allreduce_counts(mgc_handle h, int64_t* out32);
 
 #ifdef __cplusplus
 }

@@ -54,6 +54,7 @@ SIGNATURES = {
     "mgc_build": (_INT, [_VP]),
     "mgc_get_nweights": (_INT, [_VP, _INT, _VP]),
     "mgc_get_tweights": (_INT, [_VP, _VP]),
+    "mgc_get_nweights_offset": (_INT, [_VP, C.POINTER(_INT), _VP]),
     "mgc_get_edge": (_INT, [_VP, _I64, _I64, C.POINTER(_DBL)]),
     "mgc_maxflow": (_INT, [_VP, C.POINTER(_DBL)]),
     "mgc_labels": (_INT, [_VP, _VP]),

@@ -33,7 +33,7 @@
 /* direction d: 0 = -x, 1 = +x, 2 = -y, 3 = +y, 4 = -z, 5 = +z ; opposite = d ^ 1 ; axis = d >> 1 */
 #define MGC_NDIR 6
 #define MGC_MASK_SINK 0x40      /* rmask bit 6: residual capacity to the sink > 0 */
-#define MGC_NCOUNT 16
+#define MGC_NCOUNT 32
 
 struct MgcLattice {
     /* logical volume */
@@ -55,12 +55,14 @@ struct MgcLattice {
     double*   sink;           /* [ntiles][512] residual capacity voxel -> sink      */
     int32_t*  height;         /* [ntiles][512] distance label, MGC_HINF = unreachable */
     uint8_t*  rmask;          /* [ntiles][512] bit d: rcap[d] > 0 ; bit 6: sink > 0 */
+    uint32_t* rmask32;        /* 26-neighbourhood: [ntiles][512] bit d (0..25): rcap[d] > 0 ; bit 26: sink > 0 */
+    int       ndir;           /* 6 or 26: rcap / cap0 hold ndir planes per tile      */
     double*   obox;           /* [ntiles][6][64] flow pushed across face f, not yet absorbed by the neighbour */
     uint32_t* oflags;         /* [ntiles] bit f: obox[f] holds something            */
     /* work lists: [0],[1] = discharge lists of colour 0 / 1 being consumed; [2],[3] = being produced;
        [4],[5] = relabel list consumed / produced */
-    int32_t*  list[6];
-    int32_t*  count;          /* [16] device resident: [0..5] list lengths, [6] active tiles found by the last
+    int32_t*  list[18];       /* 26-neighbourhood: [0..15] discharge lists (target phase & 15), [16],[17] relabel */
+    int32_t*  count;          /* [MGC_NCOUNT] device resident: [0..5] list lengths, [6] active tiles found by the last
                                  activation, [8]/[9] running totals of tiles discharged / relabelled            */
     uint32_t* stamp;          /* [ntiles] de-duplication stamp for list appends (discharge) */
     uint32_t* rstamp;         /* [ntiles] same for the relabel lists                */

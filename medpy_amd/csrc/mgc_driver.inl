@@ -47,6 +47,18 @@ struct MgcSolveStats {
     int64_t readbacks;        /* counter read-backs (host syncs)                           */
 };
 
+/* where a solver variant keeps its lists and counters (6-neighbourhood: 2 colours, lists 0..3 + 4,5;
+ * 26-neighbourhood: 8 colours, lists 0..15 + 16,17) */
+struct MgcLayout {
+    int ncolours;   /* colour phases per round                   */
+    int list_mask;  /* discharge list of phase p = p & list_mask */
+    int rl_base;    /* relabel lists rl_base, rl_base + 1        */
+    int cnt_active, cnt_dis, cnt_rel;
+};
+
+static inline MgcLayout mgc_layout6() { MgcLayout l = {2, 3, 4, 6, 8, 9}; return l; }
+static inline MgcLayout mgc_layout26() { MgcLayout l = {8, 15, 16, 18, 19, 20}; return l; }
+
 static inline MgcSolveParams mgc_default_params()
 {
     MgcSolveParams p;
@@ -61,56 +73,56 @@ static inline MgcSolveParams mgc_default_params()
 }
 
 template <class Dev>
-int mgc_solve(Dev& dev, const MgcLattice& L, const MgcSolveParams& P, MgcSolveStats& st)
+int mgc_solve(Dev& dev, const MgcLattice& L, const MgcSolveParams& P, MgcSolveStats& st, const MgcLayout lay = mgc_layout6())
 {
     uint32_t phase = 4; /* stamps start at 0 */
     uint32_t rep = 2;   /* relabel epoch     */
     int cnt[MGC_NCOUNT];
     st = MgcSolveStats();
-    dev.zero_count(8);
-    dev.zero_count(9);
+    dev.zero_count(lay.cnt_dis);
+    dev.zero_count(lay.cnt_rel);
 
     for (int outer = 0; outer < P.max_outer; ++outer) {
         /* ---- global relabel ---- */
         dev.absorb_all();
         dev.fill_heights_inf();
-        dev.zero_count(4);
-        dev.zero_count(5);
-        dev.relabel_all(rep + 1, 4 + (int)((rep + 1) & 1u));
+        dev.zero_count(lay.rl_base);
+        dev.zero_count(lay.rl_base + 1);
+        dev.relabel_all(rep + 1, lay.rl_base + (int)((rep + 1) & 1u));
         st.relabel_passes++;
         for (;;) {
             for (int b = 0; b < P.relabel_batch; ++b) {
                 rep++;
-                const int cur = 4 + (int)(rep & 1u), nxt = 4 + (int)((rep + 1) & 1u);
+                const int cur = lay.rl_base + (int)(rep & 1u), nxt = lay.rl_base + (int)((rep + 1) & 1u);
                 dev.zero_count(nxt);
                 dev.relabel_list(cur, rep + 1, nxt);
                 st.relabel_passes++;
             }
             dev.read_counts(cnt);
             st.readbacks++;
-            if (cnt[4 + (int)((rep + 1) & 1u)] == 0) break; /* the last pass woke nobody: fixpoint */
+            if (cnt[lay.rl_base + (int)((rep + 1) & 1u)] == 0) break; /* the last pass woke nobody: fixpoint */
         }
         st.outer++;
 
         /* ---- who can still push towards the sink? ---- */
-        phase += 4; /* fresh stamps: anything queued before the relabel is void */
-        for (int i = 0; i < 4; ++i) dev.zero_count(i);
-        dev.zero_count(6);
+        phase += 2 * (uint32_t)(lay.list_mask + 1); /* fresh stamps: anything queued before the relabel is void */
+        for (int i = 0; i <= lay.list_mask; ++i) dev.zero_count(i);
+        dev.zero_count(lay.cnt_active);
         dev.activate_all(phase);
         dev.read_counts(cnt);
         st.readbacks++;
-        st.last_active = cnt[6];
-        st.discharge_tiles = cnt[8];
-        st.relabel_tiles = cnt[9];
-        if (cnt[6] == 0) {
+        st.last_active = cnt[lay.cnt_active];
+        st.discharge_tiles = cnt[lay.cnt_dis];
+        st.relabel_tiles = cnt[lay.cnt_rel];
+        if (cnt[lay.cnt_active] == 0) {
             st.converged = 1;
             return 0;
         }
 
         /* ---- colour phases ---- */
         for (int r = 0; r < P.rounds_per_relabel; ++r) {
-            for (int c = 0; c < 2; ++c) {
-                const int lst = (int)(phase & 3u);
+            for (int c = 0; c < lay.ncolours; ++c) {
+                const int lst = (int)(phase & (uint32_t)lay.list_mask);
                 dev.discharge(lst, phase, P.max_cycles, P.max_sweeps);
                 dev.zero_count(lst);
                 st.phases++;
@@ -119,7 +131,9 @@ int mgc_solve(Dev& dev, const MgcLattice& L, const MgcSolveParams& P, MgcSolveSt
             if ((r + 1) % P.check_rounds == 0 && r + 1 < P.rounds_per_relabel) {
                 dev.read_counts(cnt);
                 st.readbacks++;
-                if (cnt[phase & 3u] == 0 && cnt[(phase + 1) & 3u] == 0) break;
+                int pending = 0;
+                for (int i = 0; i <= lay.list_mask; ++i) pending += cnt[i];
+                if (pending == 0) break;
             }
         }
     }

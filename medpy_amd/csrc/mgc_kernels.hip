@@ -34,6 +34,7 @@
 
 #include "../../include/medpy_hip.h"
 #include "mgc_tile_ops.inl"
+#include "mgc_tile_ops26.inl"
 #include "mgc_driver.inl"
 
 #define MGC_DBL_MIN 2.2250738585072014e-308 /* sys.float_info.min, energy_voxel.py:113,...,513 */
@@ -42,14 +43,15 @@
 /* ======================================================================================
  * block executor for the single-source tile operations
  * ==================================================================================== */
-struct GpuBlock {
+template <class SH>
+struct GpuBlockT {
     template <class T>
     struct Reg {
         T v;
         __device__ __forceinline__ T& operator[](int) { return v; }
     };
-    MgcTileShared& S;
-    __device__ __forceinline__ explicit GpuBlock(MgcTileShared& s) : S(s) {}
+    SH& S;
+    __device__ __forceinline__ explicit GpuBlockT(SH& s) : S(s) {}
     template <class F>
     __device__ __forceinline__ void par(F f)
     {
@@ -66,6 +68,56 @@ struct GpuBlock {
     __device__ __forceinline__ void atomic_or(uint32_t* p, uint32_t v) { atomicOr(p, v); }
     __device__ __forceinline__ void atomic_and(uint32_t* p, uint32_t v) { atomicAnd(p, v); }
 };
+typedef GpuBlockT<MgcTileShared> GpuBlock;
+typedef GpuBlockT<MgcTileShared26> GpuBlock26;
+
+/* ---- 26-neighbourhood solver kernels (bodies: mgc_tile_ops26.inl) ---- */
+__global__ __launch_bounds__(MGC_TV) void k26_relabel_all(MgcLattice L, uint32_t epoch, int next_list)
+{
+    __shared__ MgcTileShared26 S;
+    GpuBlock26 x(S);
+    int visited = 0;
+    for (int tile = blockIdx.x; tile < L.ntiles; tile += gridDim.x) {
+        visited += (L.status[tile] >> 1) & 1u;
+        mgc26_relabel_tile(x, L, tile, epoch, next_list, true);
+        __syncthreads();
+    }
+    if (threadIdx.x == 0 && visited) atomicAdd(&L.count[MGC26_CNT_REL], visited);
+}
+
+__global__ __launch_bounds__(MGC_TV) void k26_relabel_list(MgcLattice L, int lst, uint32_t epoch, int next_list)
+{
+    __shared__ MgcTileShared26 S;
+    GpuBlock26 x(S);
+    const int n = L.count[lst];
+    if (blockIdx.x == 0 && threadIdx.x == 0 && n) atomicAdd(&L.count[MGC26_CNT_REL], n);
+    for (int i = blockIdx.x; i < n; i += gridDim.x) {
+        mgc26_relabel_tile(x, L, L.list[lst][i], epoch, next_list, false);
+        __syncthreads();
+    }
+}
+
+__global__ __launch_bounds__(MGC_TV) void k26_activate(MgcLattice L, uint32_t phase)
+{
+    __shared__ MgcTileShared26 S;
+    GpuBlock26 x(S);
+    for (int tile = blockIdx.x; tile < L.ntiles; tile += gridDim.x) {
+        mgc26_activate_tile(x, L, tile, phase);
+        __syncthreads();
+    }
+}
+
+__global__ __launch_bounds__(MGC_TV) void k26_discharge(MgcLattice L, int lst, uint32_t phase, int cycles, int sweeps)
+{
+    __shared__ MgcTileShared26 S;
+    GpuBlock26 x(S);
+    const int n = L.count[lst];
+    if (blockIdx.x == 0 && threadIdx.x == 0 && n) atomicAdd(&L.count[MGC26_CNT_DIS], n);
+    for (int i = blockIdx.x; i < n; i += gridDim.x) {
+        mgc26_discharge_tile(x, L, L.list[lst][i], phase, cycles, sweeps);
+        __syncthreads();
+    }
+}
 
 __global__ __launch_bounds__(MGC_TV) void k_absorb(MgcLattice L)
 {
@@ -149,6 +201,7 @@ struct MgcBuildArgs {
     int term;
     double p0;           /* linear: M ; exponential: sigma^2 ; division / power: sigma */
     double inv_axis[3];  /* divisor per axis x,y,z (spacing) -- only used when has_spacing */
+    double div26[26];    /* 26-neighbourhood: Euclidean length of (offset * spacing) per direction */
     int has_spacing;
     const void* prob;    /* regional probability map or NULL */
     int prob_dtype;
@@ -237,6 +290,7 @@ __device__ __forceinline__ double mgc_block_sum(double v, double* scratch)
     return scratch[0];
 }
 
+template <bool FULL> /* FULL: 26-neighbourhood */
 __global__ __launch_bounds__(MGC_TV) void k_build(MgcLattice L, MgcBuildArgs A)
 {
     __shared__ double img[1000]; /* 10x10x10: tile + one-voxel halo, already |.|'d for the maximum terms */
@@ -263,26 +317,46 @@ __global__ __launch_bounds__(MGC_TV) void k_build(MgcLattice L, MgcBuildArgs A)
         const bool valid = gz < L.dz && gy < L.dy && gx < L.dx;
         const int64_t id = (gz * L.dy + gy) * L.dx + gx;
         const int me = mgc_hs_index(lz, ly, lx);
-        int m = 0;
+        uint32_t m = 0;
+        if constexpr (!FULL) {
 #pragma unroll
-        for (int d = 0; d < 6; ++d) {
-            const int64_t c = (d >> 1) == 0 ? gx : ((d >> 1) == 1 ? gy : gz);
-            const int64_t lim = (d >> 1) == 0 ? L.dx : ((d >> 1) == 1 ? L.dy : L.dz);
-            const bool has = valid && ((d & 1) ? (c + 1 < lim) : (c > 0));
-            double w = 0.0;
-            if (has && A.term != MGC_TERM_NONE) {
-                /* evaluate with (lower voxel, upper voxel) operand order like the reference slices */
-                const double a = (d & 1) ? img[me] : img[me + mgc_hs_step(d)];
-                const double b = (d & 1) ? img[me + mgc_hs_step(d)] : img[me];
-                w = mgc_boundary_g(A.term, a, b, A.p0);
-                if (A.has_spacing) w = w / A.inv_axis[d >> 1]; /* energy_voxel.py:657-658 */
+            for (int d = 0; d < 6; ++d) {
+                const int64_t c = (d >> 1) == 0 ? gx : ((d >> 1) == 1 ? gy : gz);
+                const int64_t lim = (d >> 1) == 0 ? L.dx : ((d >> 1) == 1 ? L.dy : L.dz);
+                const bool has = valid && ((d & 1) ? (c + 1 < lim) : (c > 0));
+                double w = 0.0;
+                if (has && A.term != MGC_TERM_NONE) {
+                    /* evaluate with (lower voxel, upper voxel) operand order like the reference slices */
+                    const double a = (d & 1) ? img[me] : img[me + mgc_hs_step(d)];
+                    const double b = (d & 1) ? img[me + mgc_hs_step(d)] : img[me];
+                    w = mgc_boundary_g(A.term, a, b, A.p0);
+                    if (A.has_spacing) w = w / A.inv_axis[d >> 1]; /* energy_voxel.py:657-658 */
+                }
+                const int64_t o = ((int64_t)tile * 6 + d) * MGC_TV + t;
+                L.rcap[o] = w;
+                L.cap0[o] = w;
+                if (w > 0.0) m |= 1u << d; /* NaN (0/0 of the linear terms on a constant image) is not residual */
             }
-            const int64_t o = ((int64_t)tile * 6 + d) * MGC_TV + t;
-            L.rcap[o] = w;
-            L.cap0[o] = w;
-            /* NaN weights (0/0 of the linear terms on a constant image) count as residual,
-             * like `if (a->r_cap)` in the reference (maxflow.cpp:510) */
-            if (w > 0.0) m |= 1 << d;
+        } else {
+            /* full neighbourhood: same g(.) on all 26 offsets (oracle/energy_numpy.py:boundary_weights_offsets) */
+            for (int d = 0; d < MGC26_NDIR; ++d) {
+                int dz, dy, dx;
+                mgc26_offset(d, dz, dy, dx);
+                const int64_t nz = gz + dz, ny = gy + dy, nx = gx + dx;
+                const bool has = valid && nz >= 0 && nz < L.dz && ny >= 0 && ny < L.dy && nx >= 0 && nx < L.dx;
+                double w = 0.0;
+                if (has && A.term != MGC_TERM_NONE) {
+                    const bool fwd = d >= 13;
+                    const double a = fwd ? img[me] : img[me + mgc26_hs_step(d)];
+                    const double b = fwd ? img[me + mgc26_hs_step(d)] : img[me];
+                    w = mgc_boundary_g(A.term, a, b, A.p0);
+                    if (A.has_spacing) w = w / A.div26[d];
+                }
+                const int64_t o = ((int64_t)tile * MGC26_NDIR + d) * MGC_TV + t;
+                L.rcap[o] = w;
+                L.cap0[o] = w;
+                if (w > 0.0) m |= 1u << d;
+            }
         }
         /* t-links: regional term, then fg marker, then bg marker (generate.py:159-172) */
         double tr = 0.0, fc = 0.0;
@@ -308,10 +382,15 @@ __global__ __launch_bounds__(MGC_TV) void k_build(MgcLattice L, MgcBuildArgs A)
         A.tr0[v] = tr;
         L.excess[v] = tr > 0.0 ? tr : 0.0;
         L.sink[v] = tr < 0.0 ? -tr : 0.0;
-        if (tr < 0.0) m |= MGC_MASK_SINK;
-        L.rmask[v] = (uint8_t)m;
+        if constexpr (!FULL) {
+            if (tr < 0.0) m |= MGC_MASK_SINK;
+            L.rmask[v] = (uint8_t)m;
+        } else {
+            if (tr < 0.0) m |= MGC26_MASK_SINK;
+            L.rmask32[v] = m;
+        }
         L.height[v] = MGC_HINF;
-        if (t < 6 * MGC_TF / 8) { /* 48 lanes x 8 doubles clear the 6x64 outbox */
+        if (!FULL && t < 6 * MGC_TF / 8) { /* 48 lanes x 8 doubles clear the 6x64 outbox */
 #pragma unroll
             for (int k = 0; k < 8; ++k) L.obox[(int64_t)tile * 6 * MGC_TF + t * 8 + k] = 0.0;
         }
@@ -356,6 +435,21 @@ __global__ __launch_bounds__(256) void k_minmax(const void* image, int dtype, in
     }
 }
 
+/* direction index of the arc i -> j (node ids) in a lattice with `ndir` neighbours, or -1 */
+MGC_HD int mgc_arc_direction(const MgcLattice& L, int64_t i, int64_t j)
+{
+    const int64_t xi = i % L.dx, yi = (i / L.dx) % L.dy, zi = i / (L.dx * L.dy);
+    const int64_t xj = j % L.dx, yj = (j / L.dx) % L.dy, zj = j / (L.dx * L.dy);
+    const int64_t dz = zj - zi, dy = yj - yi, dx = xj - xi;
+    if (dz < -1 || dz > 1 || dy < -1 || dy > 1 || dx < -1 || dx > 1 || (!dz && !dy && !dx)) return -1;
+    if (L.ndir == 6) {
+        if ((dz != 0) + (dy != 0) + (dx != 0) != 1) return -1;
+        return dx ? (dx > 0 ? 1 : 0) : (dy ? (dy > 0 ? 3 : 2) : (dz > 0 ? 5 : 4));
+    }
+    const int c = (int)((dz + 1) * 9 + (dy + 1) * 3 + (dx + 1));
+    return c < 13 ? c : c - 1;
+}
+
 /* plug-in path: accumulate explicit lattice edges like sum_edge (graph.h:457-480) */
 __global__ void k_add_edges(MgcLattice L, int64_t n, const int64_t* ei, const int64_t* ej, const double* cap,
                             const double* rev, int* bad)
@@ -363,20 +457,13 @@ __global__ void k_add_edges(MgcLattice L, int64_t n, const int64_t* ei, const in
     for (int64_t k = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; k < n; k += (int64_t)gridDim.x * blockDim.x) {
         const int64_t i = ei[k], j = ej[k];
         if (i < 0 || j < 0 || i >= L.nvox || j >= L.nvox) { *bad = 1; continue; }
-        const int64_t diff = j - i;
-        int d = -1;
-        const int64_t xi = i % L.dx, yi = (i / L.dx) % L.dy;
-        if (diff == 1 && xi + 1 < L.dx) d = 1;
-        else if (diff == -1 && xi > 0) d = 0;
-        else if (diff == L.dx && yi + 1 < L.dy) d = 3;
-        else if (diff == -L.dx && yi > 0) d = 2;
-        else if (diff == L.dx * L.dy) d = 5;
-        else if (diff == -L.dx * L.dy) d = 4;
+        const int d = mgc_arc_direction(L, i, j);
         if (d < 0) { *bad = 1; continue; }
+        const int dr = L.ndir == 6 ? (d ^ 1) : (25 - d);
         int ti, li, tj, lj;
         mgc_node_to_tile(L, i, ti, li);
         mgc_node_to_tile(L, j, tj, lj);
-        const int64_t oi = ((int64_t)ti * 6 + d) * MGC_TV + li, oj = ((int64_t)tj * 6 + (d ^ 1)) * MGC_TV + lj;
+        const int64_t oi = ((int64_t)ti * L.ndir + d) * MGC_TV + li, oj = ((int64_t)tj * L.ndir + dr) * MGC_TV + lj;
         atomicAdd(&L.rcap[oi], cap[k]); atomicAdd(&L.cap0[oi], cap[k]);
         atomicAdd(&L.rcap[oj], rev[k]); atomicAdd(&L.cap0[oj], rev[k]);
     }
@@ -387,13 +474,12 @@ __global__ __launch_bounds__(MGC_TV) void k_refresh_mask(MgcLattice L)
 {
     for (int tile = blockIdx.x; tile < L.ntiles; tile += gridDim.x) {
         const int t = threadIdx.x;
-        int m = L.sink[(int64_t)tile * MGC_TV + t] > 0.0 ? MGC_MASK_SINK : 0;
-#pragma unroll
-        for (int d = 0; d < 6; ++d) {
-            const double w = L.rcap[((int64_t)tile * 6 + d) * MGC_TV + t];
-            if (w > 0.0) m |= 1 << d;
-        }
-        L.rmask[(int64_t)tile * MGC_TV + t] = (uint8_t)m;
+        const bool snk = L.sink[(int64_t)tile * MGC_TV + t] > 0.0;
+        uint32_t m = 0;
+        for (int d = 0; d < L.ndir; ++d)
+            if (L.rcap[((int64_t)tile * L.ndir + d) * MGC_TV + t] > 0.0) m |= 1u << d;
+        if (L.ndir == 6) L.rmask[(int64_t)tile * MGC_TV + t] = (uint8_t)(m | (snk ? MGC_MASK_SINK : 0));
+        else L.rmask32[(int64_t)tile * MGC_TV + t] = m | (snk ? MGC26_MASK_SINK : 0u);
     }
 }
 
@@ -425,13 +511,23 @@ __global__ __launch_bounds__(MGC_TV) void k_cut_value(MgcLattice L, const double
             const double tr = tr0[(int64_t)tile * MGC_TV + t];
             if (labels[id]) { /* source side: pays its sink link and every n-link into T */
                 if (tr < 0.0) s += -tr;
-                const int64_t step[6] = {-1, 1, -L.dx, L.dx, -L.dx * L.dy, L.dx * L.dy};
+                if (L.ndir == 6) {
+                    const int64_t step[6] = {-1, 1, -L.dx, L.dx, -L.dx * L.dy, L.dx * L.dy};
 #pragma unroll
-                for (int d = 0; d < 6; ++d) {
-                    const int64_t c = (d >> 1) == 0 ? gx : ((d >> 1) == 1 ? gy : gz);
-                    const int64_t lim = (d >> 1) == 0 ? L.dx : ((d >> 1) == 1 ? L.dy : L.dz);
-                    const bool has = (d & 1) ? (c + 1 < lim) : (c > 0);
-                    if (has && !labels[id + step[d]]) s += L.cap0[((int64_t)tile * 6 + d) * MGC_TV + t];
+                    for (int d = 0; d < 6; ++d) {
+                        const int64_t c = (d >> 1) == 0 ? gx : ((d >> 1) == 1 ? gy : gz);
+                        const int64_t lim = (d >> 1) == 0 ? L.dx : ((d >> 1) == 1 ? L.dy : L.dz);
+                        const bool has = (d & 1) ? (c + 1 < lim) : (c > 0);
+                        if (has && !labels[id + step[d]]) s += L.cap0[((int64_t)tile * 6 + d) * MGC_TV + t];
+                    }
+                } else {
+                    for (int d = 0; d < MGC26_NDIR; ++d) {
+                        int dz, dy, dx;
+                        mgc26_offset(d, dz, dy, dx);
+                        const int64_t nz = gz + dz, ny = gy + dy, nx = gx + dx;
+                        if (nz >= 0 && nz < L.dz && ny >= 0 && ny < L.dy && nx >= 0 && nx < L.dx && !labels[(nz * L.dy + ny) * L.dx + nx])
+                            s += L.cap0[((int64_t)tile * MGC26_NDIR + d) * MGC_TV + t];
+                    }
                 }
             } else if (tr > 0.0) { /* sink side: pays its source link */
                 s += tr;
@@ -459,12 +555,31 @@ __global__ void k_get_nweights(MgcLattice L, int axis /* array axis 0..2 */, dou
     int64_t osh[3] = {sh[0], sh[1], sh[2]};
     osh[axis] -= 1;
     const int64_t n = osh[0] * osh[1] * osh[2];
-    const int d = axis == 2 ? 1 : (axis == 1 ? 3 : 5); /* forward direction of that axis */
+    const int d = L.ndir == 6 ? (axis == 2 ? 1 : (axis == 1 ? 3 : 5)) : (axis == 2 ? 13 : (axis == 1 ? 15 : 21)); /* forward direction of that axis */
     for (int64_t k = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; k < n; k += (int64_t)gridDim.x * blockDim.x) {
         const int64_t x = k % osh[2], y = (k / osh[2]) % osh[1], z = k / (osh[2] * osh[1]);
         int tile, loc;
         mgc_node_to_tile(L, (z * L.dy + y) * L.dx + x, tile, loc);
-        out[k] = L.cap0[((int64_t)tile * 6 + d) * MGC_TV + loc];
+        out[k] = L.cap0[((int64_t)tile * L.ndir + d) * MGC_TV + loc];
+    }
+}
+
+/* weight of the arc (p, p + offset) for every voxel p, NaN where p + offset is outside (parity read-back) */
+__global__ void k_get_nweights_offset(MgcLattice L, int dz, int dy, int dx, double* out)
+{
+    int d;
+    if (L.ndir == 6) d = dx ? (dx > 0 ? 1 : 0) : (dy ? (dy > 0 ? 3 : 2) : (dz > 0 ? 5 : 4));
+    else { const int c = (dz + 1) * 9 + (dy + 1) * 3 + (dx + 1); d = c < 13 ? c : c - 1; }
+    for (int64_t id = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; id < L.nvox; id += (int64_t)gridDim.x * blockDim.x) {
+        const int64_t x = id % L.dx, y = (id / L.dx) % L.dy, z = id / (L.dx * L.dy);
+        const int64_t nz = z + dz, ny = y + dy, nx = x + dx;
+        double w = NAN;
+        if (nz >= 0 && nz < L.dz && ny >= 0 && ny < L.dy && nx >= 0 && nx < L.dx) {
+            int tile, loc;
+            mgc_node_to_tile(L, id, tile, loc);
+            w = L.cap0[((int64_t)tile * L.ndir + d) * MGC_TV + loc];
+        }
+        out[id] = w;
     }
 }
 
@@ -575,7 +690,8 @@ static double mgc_range_in_dtype(double mn, double mx, int dtype)
  * List lengths live on the device, so launches use a fixed persistent-style grid and never wait
  * for the host; per-kernel time comes from HIP event pairs recorded on the launch stream and
  * resolved after the solve (no synchronisation inside the timed region). */
-struct HipDev {
+template <bool FULL> /* FULL: 26-neighbourhood kernels */
+struct HipDevT {
     mgc_handle h;
     hipError_t first_error = hipSuccess;
     float discharge_ms = 0.f, relabel_ms = 0.f;
@@ -593,11 +709,16 @@ struct HipDev {
         memcpy(out, h->h_count, MGC_NCOUNT * sizeof(int32_t));
         readbacks++;
     }
-    void absorb_all() { hipLaunchKernelGGL(k_absorb, dim3(grid(h->L.ntiles)), dim3(MGC_TV), 0, h->stream, h->L); check(hipGetLastError()); }
+    void absorb_all()
+    {
+        if constexpr (FULL) return; /* no outboxes: neighbours are updated in place */
+        else { hipLaunchKernelGGL(k_absorb, dim3(grid(h->L.ntiles)), dim3(MGC_TV), 0, h->stream, h->L); check(hipGetLastError()); }
+    }
     void relabel_all(uint32_t epoch, int next)
     {
         const int id = time_begin(1);
-        hipLaunchKernelGGL(k_relabel_all, dim3(grid(h->L.ntiles)), dim3(MGC_TV), 0, h->stream, h->L, epoch, next);
+        if constexpr (FULL) hipLaunchKernelGGL(k26_relabel_all, dim3(grid(h->L.ntiles)), dim3(MGC_TV), 0, h->stream, h->L, epoch, next);
+        else hipLaunchKernelGGL(k_relabel_all, dim3(grid(h->L.ntiles)), dim3(MGC_TV), 0, h->stream, h->L, epoch, next);
         check(hipGetLastError());
         time_end(id);
         relabel_launches++;
@@ -605,20 +726,23 @@ struct HipDev {
     void relabel_list(int lst, uint32_t epoch, int next)
     {
         const int id = time_begin(1);
-        hipLaunchKernelGGL(k_relabel_list, dim3(grid(h->L.ntiles)), dim3(MGC_TV), 0, h->stream, h->L, lst, epoch, next);
+        if constexpr (FULL) hipLaunchKernelGGL(k26_relabel_list, dim3(grid(h->L.ntiles)), dim3(MGC_TV), 0, h->stream, h->L, lst, epoch, next);
+        else hipLaunchKernelGGL(k_relabel_list, dim3(grid(h->L.ntiles)), dim3(MGC_TV), 0, h->stream, h->L, lst, epoch, next);
         check(hipGetLastError());
         time_end(id);
         relabel_launches++;
     }
     void activate_all(uint32_t phase)
     {
-        hipLaunchKernelGGL(k_activate, dim3(grid(h->L.ntiles)), dim3(MGC_TV), 0, h->stream, h->L, phase);
+        if constexpr (FULL) hipLaunchKernelGGL(k26_activate, dim3(grid(h->L.ntiles)), dim3(MGC_TV), 0, h->stream, h->L, phase);
+        else hipLaunchKernelGGL(k_activate, dim3(grid(h->L.ntiles)), dim3(MGC_TV), 0, h->stream, h->L, phase);
         check(hipGetLastError());
     }
     void discharge(int lst, uint32_t phase, int cycles, int sweeps)
     {
         const int id = time_begin(0);
-        hipLaunchKernelGGL(k_discharge, dim3(grid(h->L.ntiles)), dim3(MGC_TV), 0, h->stream, h->L, lst, phase, cycles, sweeps);
+        if constexpr (FULL) hipLaunchKernelGGL(k26_discharge, dim3(grid(h->L.ntiles)), dim3(MGC_TV), 0, h->stream, h->L, lst, phase, cycles, sweeps);
+        else hipLaunchKernelGGL(k_discharge, dim3(grid(h->L.ntiles)), dim3(MGC_TV), 0, h->stream, h->L, lst, phase, cycles, sweeps);
         check(hipGetLastError());
         time_end(id);
         discharge_launches++;
@@ -649,6 +773,8 @@ struct HipDev {
         }
     }
 };
+typedef HipDevT<false> HipDev;
+typedef HipDevT<true> HipDev26;
 
 extern "C" {
 
@@ -668,9 +794,13 @@ static int mgc_create_impl(int ndim, const int64_t* shape, int connectivity, int
     if (!out) return mgc_fail(nullptr, MGC_ERR_INVALID, "mgc_create: out is NULL");
     *out = nullptr;
     if (ndim < 1 || ndim > 3 || !shape) return mgc_fail(nullptr, MGC_ERR_UNSUPPORTED, "mgc_create: ndim must be 1..3 (got %d)", ndim);
-    if (connectivity != 2 * ndim)
-        return mgc_fail(nullptr, MGC_ERR_UNSUPPORTED, "mgc_create: connectivity %d not implemented (reference supports 2*ndim = %d only)",
-                        connectivity, 2 * ndim);
+    int full = 1;
+    for (int k = 0; k < ndim; ++k) full *= 3;
+    full -= 1; /* 2, 8, 26 */
+    if (connectivity != 2 * ndim && connectivity != full)
+        return mgc_fail(nullptr, MGC_ERR_UNSUPPORTED, "mgc_create: connectivity %d not implemented (2*ndim = %d is the reference's, %d the full neighbourhood)",
+                        connectivity, 2 * ndim, full);
+    if (slab && connectivity != 2 * ndim) return mgc_fail(nullptr, MGC_ERR_UNSUPPORTED, "Z-slabs are implemented for the 2*ndim neighbourhood only");
     int ndev = 0;
     if (hipGetDeviceCount(&ndev) != hipSuccess || ndev <= 0)
         return mgc_fail(nullptr, MGC_ERR_NO_DEVICE, "no HIP device: libmedpyhip has no CPU fallback");
@@ -694,6 +824,7 @@ static int mgc_create_impl(int ndim, const int64_t* shape, int connectivity, int
     L.gz = (int)gz; L.gy = (int)gy; L.gx = (int)gx;
     L.ntiles = (int)(gz * gy * gx);
     L.tz_own_lo = 0; L.tz_own_hi = L.gz; L.tz_global0 = 0;
+    L.ndir = (connectivity == 2 * ndim) ? 6 : 26;
     if (slab) {
         L.tz_own_lo = slab->own_lo; L.tz_own_hi = slab->own_hi; L.tz_global0 = slab->tz_global0;
         h->rank = slab->rank; h->nranks = slab->nranks;
@@ -707,15 +838,19 @@ static int mgc_create_impl(int ndim, const int64_t* shape, int connectivity, int
     for (int i = 0; i < 4; ++i) MGC_HIP(h, hipEventCreate(&h->ev[i]));
     const int64_t nt = L.ntiles, nv = nt * MGC_TV;
     int rc;
-    if ((rc = mgc_alloc(h, &L.rcap, nv * 6))) return rc;
-    if ((rc = mgc_alloc(h, &L.cap0, nv * 6))) return rc;
+    if ((rc = mgc_alloc(h, &L.rcap, nv * L.ndir))) return rc;
+    if ((rc = mgc_alloc(h, &L.cap0, nv * L.ndir))) return rc;
     if ((rc = mgc_alloc(h, &L.excess, nv))) return rc;
     if ((rc = mgc_alloc(h, &L.sink, nv))) return rc;
     if ((rc = mgc_alloc(h, &L.height, nv))) return rc;
-    if ((rc = mgc_alloc(h, &L.rmask, nv))) return rc;
-    if ((rc = mgc_alloc(h, &L.obox, nt * 6 * MGC_TF))) return rc;
+    if (L.ndir == 6) {
+        if ((rc = mgc_alloc(h, &L.rmask, nv))) return rc;
+        if ((rc = mgc_alloc(h, &L.obox, nt * 6 * MGC_TF))) return rc;
+    } else {
+        if ((rc = mgc_alloc(h, &L.rmask32, nv))) return rc;
+    }
     if ((rc = mgc_alloc(h, &L.oflags, nt))) return rc;
-    for (int i = 0; i < 6; ++i)
+    for (int i = 0; i < (L.ndir == 6 ? 6 : 18); ++i)
         if ((rc = mgc_alloc(h, &L.list[i], nt))) return rc;
     if ((rc = mgc_alloc(h, &L.count, (int64_t)MGC_NCOUNT))) return rc;
     if ((rc = mgc_alloc(h, &L.stamp, nt))) return rc;
@@ -761,6 +896,7 @@ int mgc_solver_op(mgc_handle h, int op, int64_t a0, int64_t a1, int64_t a2, int6
 {
     if (!h) return MGC_ERR_INVALID;
     if (!h->built) return mgc_fail(h, MGC_ERR_STATE, "mgc_solver_op before mgc_build");
+    if (h->L.ndir != 6) return mgc_fail(h, MGC_ERR_UNSUPPORTED, "the stepwise (slab) driver covers the 2*ndim neighbourhood only");
     MGC_HIP(h, hipSetDevice(h->device));
     HipDev dev;
     dev.h = h;
@@ -990,8 +1126,9 @@ int mgc_destroy(mgc_handle h)
     if (h->stream) (void)hipStreamSynchronize(h->stream);
     if (h->comm && g_rccl.CommDestroy) (void)g_rccl.CommDestroy(h->comm);
     MgcLattice& L = h->L;
-    void* ptrs[] = {L.rcap, L.cap0, L.excess, L.sink, L.height, L.rmask, L.obox, L.oflags, L.list[0], L.list[1], L.list[2],
-                    L.list[3], L.list[4], L.list[5], L.count, L.stamp, L.rstamp, L.status, h->d_tr0, h->d_part, h->d_scalar,
+    void* ptrs[] = {L.rcap, L.cap0, L.excess, L.sink, L.height, L.rmask, L.rmask32, L.obox, L.oflags, L.list[0], L.list[1], L.list[2],
+                    L.list[3], L.list[4], L.list[5], L.list[6], L.list[7], L.list[8], L.list[9], L.list[10], L.list[11], L.list[12],
+                    L.list[13], L.list[14], L.list[15], L.list[16], L.list[17], L.count, L.stamp, L.rstamp, L.status, h->d_tr0, h->d_part, h->d_scalar,
                     h->d_labels, h->d_image, h->d_prob, h->d_fg, h->d_bg, h->d_tr_in, h->d_ei, h->d_ej, h->d_ecap, h->d_erev, h->d_halo, h->d_xchg[0], h->d_xchg[1], h->d_xchg[2], h->d_xchg[3], h->d_cnt64};
     for (void* p : ptrs)
         if (p) (void)hipFree(p);
@@ -1114,11 +1251,21 @@ int mgc_build(mgc_handle h)
     }
     A.has_spacing = h->has_spacing;
     A.inv_axis[0] = h->spacing[2]; A.inv_axis[1] = h->spacing[1]; A.inv_axis[2] = h->spacing[0];
+    for (int d = 0; d < 26; ++d) {
+        int dz, dy, dx;
+        mgc26_offset(d, dz, dy, dx);
+        /* math.sqrt(sum((o_k * s_k) ** 2)) in array-axis order, as oracle/energy_numpy.py:boundary_weights_offsets */
+        double acc = 0.0;
+        const int off[3] = {dz, dy, dx};
+        for (int k = 3 - h->ndim; k < 3; ++k) acc += (off[k] * h->spacing[k]) * (off[k] * h->spacing[k]);
+        A.div26[d] = sqrt(acc);
+    }
     A.prob = h->d_prob; A.prob_dtype = h->prob_dtype; A.alpha = h->alpha;
     A.fg = h->d_fg; A.bg = h->d_bg; A.tr_in = h->d_tr_in;
     A.tr0 = h->d_tr0; A.fpart = h->d_part;
     const int grid = L.ntiles < h->grid_cap * 4 ? L.ntiles : h->grid_cap * 4;
-    hipLaunchKernelGGL(k_build, dim3(grid), dim3(MGC_TV), 0, h->stream, L, A);
+    if (L.ndir == 6) hipLaunchKernelGGL(k_build<false>, dim3(grid), dim3(MGC_TV), 0, h->stream, L, A);
+    else hipLaunchKernelGGL(k_build<true>, dim3(grid), dim3(MGC_TV), 0, h->stream, L, A);
     MGC_HIP(h, hipGetLastError());
     hipLaunchKernelGGL(k_sum_partials, dim3(1), dim3(MGC_TV), 0, h->stream, (const double*)h->d_part, (int64_t)L.ntiles, h->d_scalar);
     MGC_HIP(h, hipGetLastError());
@@ -1159,11 +1306,21 @@ int mgc_maxflow(mgc_handle h, double* flow)
     MGC_HIP(h, hipSetDevice(h->device));
     MgcLattice& L = h->L;
     if (!h->solved) {
-        HipDev dev;
-        dev.h = h;
         MgcSolveStats st;
         MGC_HIP(h, hipEventRecord(h->ev[0], h->stream));
-        const int rc = mgc_solve(dev, L, h->params, st);
+        HipDev dev;
+        HipDev26 dev26;
+        dev.h = dev26.h = h;
+        int rc;
+        if (L.ndir == 6) {
+            rc = mgc_solve(dev, L, h->params, st);
+        } else {
+            rc = mgc_solve(dev26, L, h->params, st, mgc_layout26());
+            dev.first_error = dev26.first_error;
+            dev.spans.clear();
+            for (const auto& sp : dev26.spans) dev.spans.push_back({sp.a, sp.b, sp.kind});
+            dev.discharge_launches = dev26.discharge_launches; dev.relabel_launches = dev26.relabel_launches; dev.readbacks = dev26.readbacks;
+        }
         if (dev.first_error != hipSuccess)
             return mgc_fail(h, MGC_ERR_HIP, "solver: HIP error %s", hipGetErrorString(dev.first_error));
         if (rc) return mgc_fail(h, MGC_ERR_NOT_CONVERGED, "solver did not converge within %d global relabels", h->params.max_outer);
@@ -1274,6 +1431,28 @@ int mgc_get_nweights(mgc_handle h, int axis, double* out)
     return MGC_OK;
 }
 
+int mgc_get_nweights_offset(mgc_handle h, const int* offset, double* out)
+{
+    if (!h || !out || !offset) return MGC_ERR_INVALID;
+    if (!h->built) return mgc_fail(h, MGC_ERR_STATE, "mgc_get_nweights_offset before mgc_build");
+    int o[3] = {0, 0, 0};
+    for (int k = 0; k < h->ndim; ++k) o[3 - h->ndim + k] = offset[k];
+    const int nz = (o[0] != 0) + (o[1] != 0) + (o[2] != 0);
+    for (int k = 0; k < 3; ++k)
+        if (o[k] < -1 || o[k] > 1) return mgc_fail(h, MGC_ERR_INVALID, "offset components must be -1, 0 or 1");
+    if (nz == 0 || (h->L.ndir == 6 && nz != 1)) return mgc_fail(h, MGC_ERR_INVALID, "offset is not a neighbour of this lattice");
+    MGC_HIP(h, hipSetDevice(h->device));
+    double* d = nullptr;
+    MGC_HIP(h, hipMalloc((void**)&d, (size_t)h->nvox * sizeof(double)));
+    hipLaunchKernelGGL(k_get_nweights_offset, dim3(1024), dim3(256), 0, h->stream, h->L, o[0], o[1], o[2], d);
+    hipError_t e = hipGetLastError();
+    if (e == hipSuccess) e = hipMemcpyAsync(out, d, (size_t)h->nvox * sizeof(double), hipMemcpyDeviceToHost, h->stream);
+    if (e == hipSuccess) e = hipStreamSynchronize(h->stream);
+    (void)hipFree(d);
+    MGC_HIP(h, e);
+    return MGC_OK;
+}
+
 int mgc_get_tweights(mgc_handle h, double* out)
 {
     if (!h || !out) return MGC_ERR_INVALID;
@@ -1297,19 +1476,12 @@ int mgc_get_edge(mgc_handle h, int64_t i, int64_t j, double* out)
     if (i < 0 || j < 0 || i >= h->nvox || j >= h->nvox || i == j) return mgc_fail(h, MGC_ERR_INVALID, "bad node pair");
     MGC_HIP(h, hipSetDevice(h->device));
     const MgcLattice& L = h->L;
-    const int64_t diff = j - i, xi = i % L.dx, yi = (i / L.dx) % L.dy;
-    int d = -1;
-    if (diff == 1 && xi + 1 < L.dx) d = 1;
-    else if (diff == -1 && xi > 0) d = 0;
-    else if (diff == L.dx && yi + 1 < L.dy) d = 3;
-    else if (diff == -L.dx && yi > 0) d = 2;
-    else if (diff == L.dx * L.dy) d = 5;
-    else if (diff == -L.dx * L.dy) d = 4;
+    const int d = mgc_arc_direction(L, i, j);
     *out = 0.0; /* no such arc: get_edge returns 0 (graph.h:497) */
     if (d < 0) return MGC_OK;
     int tile, loc;
     mgc_node_to_tile(L, i, tile, loc);
-    const double* src = (h->solved ? L.rcap : L.cap0) + ((int64_t)tile * 6 + d) * MGC_TV + loc;
+    const double* src = (h->solved ? L.rcap : L.cap0) + ((int64_t)tile * L.ndir + d) * MGC_TV + loc;
     MGC_HIP(h, hipMemcpyAsync(h->h_scalar + 6, src, sizeof(double), hipMemcpyDeviceToHost, h->stream));
     MGC_HIP(h, hipStreamSynchronize(h->stream));
     *out = h->h_scalar[6];

@@ -1,0 +1,297 @@
+/*
+ * mgc_tile_ops26.inl -- tile operations of the lattice max-flow solver for the FULL neighbourhood
+ * (26 neighbours in 3-D, 8 in 2-D).  Same executor concept and same algorithm as mgc_tile_ops.inl
+ * (region discharge with exact in-tile labels + global relabel), single source for the HIP kernels and
+ * the host simulator.
+ *
+ * No reference counterpart: MedPy's voxel graph supports only the 2*ndim neighbourhood
+ * (reference medpy/graphcut/generate.py:44-49, energy_voxel.py:583).  The 26-neighbourhood is named by
+ * BASELINE.json configs 3 and 5; its oracle is the reference BK core fed the edge list of
+ * oracle/energy_numpy.py:boundary_weights_offsets.
+ *
+ * Differences from the 6-neighbourhood ops:
+ *   - direction index d = 0..25 enumerates offsets (dz,dy,dx) in lexicographic order without the centre;
+ *     opposite(d) = 25 - d;
+ *   - tiles are coloured with EIGHT colours (parity of tz,ty,tx), so no two tiles that share a face, an
+ *     edge or a corner run in the same phase.  A voxel of an idle tile is then adjacent to at most one
+ *     running tile, so a push over a tile boundary updates the neighbour tile's excess / reverse residual
+ *     directly in HBM -- direction by direction, one writer per target voxel per step, no atomics, fixed
+ *     floating point order -- and there is no outbox;
+ *   - rmask is 32 bits per voxel (26 arc bits + sink bit 26); discharge lists rotate over 16 slots.
+ */
+#ifndef MGC_TILE_OPS26_INL
+#define MGC_TILE_OPS26_INL
+
+#include "mgc_tile_ops.inl"
+
+#define MGC26_NDIR 26
+#define MGC26_MASK_SINK (1u << 26)
+/* counter / list layout of the 26-neighbourhood solver */
+#define MGC26_NLIST 16        /* discharge lists 0..15 (target phase & 15)   */
+#define MGC26_RL 16           /* relabel lists 16, 17                         */
+#define MGC26_CNT_ACTIVE 18
+#define MGC26_CNT_DIS 19
+#define MGC26_CNT_REL 20
+
+struct MgcTileShared26 {
+    int32_t hs[1000];
+    double  out[2][MGC_TV];
+    int32_t nbr[27];      /* neighbour tile ids, index = (dz+1)*9 + (dy+1)*3 + (dx+1); 13 = self */
+    int32_t nbrflag[27];
+    int32_t flag[2];
+};
+
+MGC_HD void mgc26_offset(int d, int& dz, int& dy, int& dx)
+{
+    const int c = d < 13 ? d : d + 1;
+    dz = c / 9 - 1;
+    dy = (c / 3) % 3 - 1;
+    dx = c % 3 - 1;
+}
+
+MGC_HD int mgc26_hs_step(int d)
+{
+    int dz, dy, dx;
+    mgc26_offset(d, dz, dy, dx);
+    return dz * 100 + dy * 10 + dx;
+}
+
+MGC_HD int mgc26_colour(const MgcLattice& L, int tz, int ty, int tx) { return (((tz + L.tz_global0) & 1) << 2) | ((ty & 1) << 1) | (tx & 1); }
+
+/* every lane: 27 neighbour tile ids into LDS, flags cleared.  Needs a barrier afterwards. */
+template <class X>
+MGC_HD void mgc26_load_nbrs(X& x, const MgcLattice& L, int tile, int t)
+{
+    if (t < 27) {
+        int tz, ty, tx;
+        mgc_tile_coords(L, tile, tz, ty, tx);
+        const int nz = tz + t / 9 - 1, ny = ty + (t / 3) % 3 - 1, nx = tx + t % 3 - 1;
+        x.S.nbr[t] = (nz >= 0 && nz < L.gz && ny >= 0 && ny < L.gy && nx >= 0 && nx < L.gx) ? mgc_tile_id(L, nz, ny, nx) : -1;
+        x.S.nbrflag[t] = 0;
+    }
+    if (t < 2) x.S.flag[t] = 0;
+}
+
+/* the 488 halo cells of the 10x10x10 label block come from up to 26 neighbour tiles */
+template <class X>
+MGC_HD void mgc26_load_halo(X& x, const MgcLattice& L, int t)
+{
+    for (int k = t; k < 1000; k += MGC_TV) {
+        const int z = k / 100 - 1, y = (k / 10) % 10 - 1, xx = k % 10 - 1;
+        const int oz = z < 0 ? -1 : (z > 7 ? 1 : 0), oy = y < 0 ? -1 : (y > 7 ? 1 : 0), ox = xx < 0 ? -1 : (xx > 7 ? 1 : 0);
+        if (oz == 0 && oy == 0 && ox == 0) continue;
+        const int nt = x.S.nbr[(oz + 1) * 9 + (oy + 1) * 3 + (ox + 1)];
+        x.S.hs[k] = nt < 0 ? MGC_HINF : L.height[(int64_t)nt * MGC_TV + mgc_local(z & 7, y & 7, xx & 7)];
+    }
+}
+
+template <class X, class MaskFn>
+MGC_HD void mgc26_tile_bfs(X& x, MaskFn mask)
+{
+    for (;;) {
+        const bool changed = x.any([&](int t) -> bool {
+            const uint32_t m = mask(t);
+            if (!m) return false;
+            const int me = mgc_hs_index(t >> 6, (t >> 3) & 7, t & 7);
+            int cand = (m & MGC26_MASK_SINK) ? 1 : MGC_HINF;
+#pragma unroll
+            for (int d = 0; d < MGC26_NDIR; ++d)
+                if ((m >> d) & 1u) {
+                    const int hv = x.S.hs[me + mgc26_hs_step(d)] + 1;
+                    cand = hv < cand ? hv : cand;
+                }
+            if (cand < x.S.hs[me]) {
+                x.S.hs[me] = cand;
+                return true;
+            }
+            return false;
+        });
+        if (!changed) break;
+    }
+}
+
+/* global relabel, one tile of one pass (see mgc_relabel_tile) */
+template <class X>
+MGC_HD void mgc26_relabel_tile(X& x, const MgcLattice& L, int tile, uint32_t next_epoch, int next_list, bool first_pass)
+{
+    if (first_pass && !(L.status[tile] & 2u)) return;
+    typename X::template Reg<uint32_t> m;
+    typename X::template Reg<int> h0;
+    const int64_t base = (int64_t)tile * MGC_TV;
+    x.par([&](int t) { mgc26_load_nbrs(x, L, tile, t); });
+    x.par([&](int t) {
+        m[t] = L.rmask32[base + t];
+        h0[t] = L.height[base + t];
+        x.S.hs[mgc_hs_index(t >> 6, (t >> 3) & 7, t & 7)] = h0[t];
+        mgc26_load_halo(x, L, t);
+    });
+    mgc26_tile_bfs(x, [&](int t) { return m[t]; });
+    x.par([&](int t) {
+        const int z = t >> 6, y = (t >> 3) & 7, xx = t & 7;
+        const int h = x.S.hs[mgc_hs_index(z, y, xx)];
+        if (h < h0[t]) {
+            L.height[base + t] = h;
+            /* wake every neighbour tile this voxel touches (face, edge and corner neighbours) */
+            const int bz = z == 0 ? -1 : (z == 7 ? 1 : 0), by = y == 0 ? -1 : (y == 7 ? 1 : 0), bx = xx == 0 ? -1 : (xx == 7 ? 1 : 0);
+            for (int a = 0; a < 2; ++a)
+                for (int b = 0; b < 2; ++b)
+                    for (int c = 0; c < 2; ++c) {
+                        const int oz = a ? bz : 0, oy = b ? by : 0, ox = c ? bx : 0;
+                        if (oz || oy || ox) x.S.nbrflag[(oz + 1) * 9 + (oy + 1) * 3 + (ox + 1)] = 1;
+                    }
+        }
+    });
+    x.par([&](int t) {
+        if (t < 27 && t != 13 && x.S.nbrflag[t] && x.S.nbr[t] >= 0) mgc_enqueue(x, L, next_list, L.rstamp, next_epoch, x.S.nbr[t]);
+    });
+}
+
+template <class X>
+MGC_HD void mgc26_activate_tile(X& x, const MgcLattice& L, int tile, uint32_t phase)
+{
+    const int64_t base = (int64_t)tile * MGC_TV;
+    const bool act = x.any([&](int t) -> bool { return L.excess[base + t] > 0.0 && L.height[base + t] < MGC_HINF; });
+    x.par([&](int t) {
+        if (t == 0 && act) {
+            int tz, ty, tx;
+            mgc_tile_coords(L, tile, tz, ty, tx);
+            const uint32_t target = phase + (((uint32_t)mgc26_colour(L, tz, ty, tx) - phase) & 7u);
+            mgc_enqueue(x, L, (int)(target & 15u), L.stamp, target, tile);
+            x.atomic_add(&L.count[MGC26_CNT_ACTIVE], 1);
+        }
+    });
+}
+
+/* region discharge of one tile in colour phase `phase` (all 26 neighbour tiles are idle) */
+template <class X>
+MGC_HD void mgc26_discharge_tile(X& x, const MgcLattice& L, int tile, uint32_t phase, int max_cycles, int max_sweeps)
+{
+    typename X::template Reg<double> e, snk, r[MGC26_NDIR];
+    typename X::template Reg<int> hme;
+    const int64_t base = (int64_t)tile * MGC_TV;
+
+    x.par([&](int t) { mgc26_load_nbrs(x, L, tile, t); });
+    x.par([&](int t) {
+        e[t] = L.excess[base + t];
+        snk[t] = L.sink[base + t];
+#pragma unroll
+        for (int d = 0; d < MGC26_NDIR; ++d) r[d][t] = L.rcap[((int64_t)tile * MGC26_NDIR + d) * MGC_TV + t];
+        mgc26_load_halo(x, L, t);
+    });
+
+    bool active = false;
+    int sweep_id = 0;
+    for (int cyc = 0; cyc < max_cycles; ++cyc) {
+        x.par([&](int t) { x.S.hs[mgc_hs_index(t >> 6, (t >> 3) & 7, t & 7)] = MGC_HINF; });
+        mgc26_tile_bfs(x, [&](int t) {
+            uint32_t m = snk[t] > 0.0 ? MGC26_MASK_SINK : 0u;
+#pragma unroll
+            for (int d = 0; d < MGC26_NDIR; ++d) m |= (r[d][t] > 0.0) ? (1u << d) : 0u;
+            return m;
+        });
+        active = x.any([&](int t) -> bool {
+            hme[t] = x.S.hs[mgc_hs_index(t >> 6, (t >> 3) & 7, t & 7)];
+            return e[t] > 0.0 && hme[t] < MGC_HINF;
+        });
+        if (!active) break;
+
+        for (int sw = 0; sw < max_sweeps; ++sw, ++sweep_id) {
+            const int fl = sweep_id & 1;
+            /* 27 steps: step s pushes along direction s (s < 26) after receiving direction s-1 */
+            auto step = [&](auto sc) {
+                constexpr int s = decltype(sc)::value;
+                x.par([&](int t) {
+                    const int z = t >> 6, y = (t >> 3) & 7, xx = t & 7;
+                    if (s == 0) {
+                        if (e[t] > 0.0 && snk[t] > 0.0) {
+                            const double delta = e[t] < snk[t] ? e[t] : snk[t];
+                            e[t] -= delta;
+                            snk[t] -= delta;
+                            x.S.flag[fl] = 1;
+                        }
+                    } else {
+                        if (s == 1 && t == 0) x.S.flag[fl ^ 1] = 0;
+                        constexpr int dp = s > 0 ? s - 1 : 0;
+                        int dz, dy, dx;
+                        mgc26_offset(dp, dz, dy, dx);
+                        const int sz = z - dz, sy = y - dy, sx = xx - dx; /* the voxel that pushed towards me */
+                        if (sz >= 0 && sz < 8 && sy >= 0 && sy < 8 && sx >= 0 && sx < 8) {
+                            const double din = x.S.out[dp & 1][mgc_local(sz, sy, sx)];
+                            if (din != 0.0) {
+                                e[t] += din;
+                                r[25 - dp][t] += din;
+                            }
+                        }
+                    }
+                    if (s < MGC26_NDIR) {
+                        constexpr int d = s < MGC26_NDIR ? s : 0;
+                        int dz, dy, dx;
+                        mgc26_offset(d, dz, dy, dx);
+                        const int vz = z + dz, vy = y + dy, vx = xx + dx;
+                        const bool inside = vz >= 0 && vz < 8 && vy >= 0 && vy < 8 && vx >= 0 && vx < 8;
+                        double delta = 0.0;
+                        if (e[t] > 0.0 && r[d][t] > 0.0 && hme[t] < MGC_HINF) {
+                            const int hv = x.S.hs[mgc_hs_index(z, y, xx) + mgc26_hs_step(d)];
+                            if (hv == hme[t] - 1) {
+                                delta = e[t] < r[d][t] ? e[t] : r[d][t];
+                                e[t] -= delta;
+                                r[d][t] -= delta;
+                                x.S.flag[fl] = 1;
+                            }
+                        }
+                        if (inside) {
+                            x.S.out[d & 1][t] = delta;
+                        } else if (delta != 0.0) {
+                            /* the target voxel lives in an idle neighbour tile and nobody else writes it in
+                             * this step: update its excess and reverse residual in place */
+                            const int ni = ((vz < 0 ? -1 : (vz > 7 ? 1 : 0)) + 1) * 9 + ((vy < 0 ? -1 : (vy > 7 ? 1 : 0)) + 1) * 3 +
+                                           ((vx < 0 ? -1 : (vx > 7 ? 1 : 0)) + 1);
+                            const int nt = x.S.nbr[ni];
+                            const int lv = mgc_local(vz & 7, vy & 7, vx & 7);
+                            L.excess[(int64_t)nt * MGC_TV + lv] += delta;
+                            L.rcap[((int64_t)nt * MGC26_NDIR + (25 - d)) * MGC_TV + lv] += delta;
+                            L.rmask32[(int64_t)nt * MGC_TV + lv] |= 1u << (25 - d);
+                            x.S.nbrflag[ni] = 1;
+                        }
+                    }
+                });
+            };
+#define MGC26_STEP(n) step(std::integral_constant<int, n>{});
+            MGC26_STEP(0) MGC26_STEP(1) MGC26_STEP(2) MGC26_STEP(3) MGC26_STEP(4) MGC26_STEP(5) MGC26_STEP(6) MGC26_STEP(7) MGC26_STEP(8)
+            MGC26_STEP(9) MGC26_STEP(10) MGC26_STEP(11) MGC26_STEP(12) MGC26_STEP(13) MGC26_STEP(14) MGC26_STEP(15) MGC26_STEP(16)
+            MGC26_STEP(17) MGC26_STEP(18) MGC26_STEP(19) MGC26_STEP(20) MGC26_STEP(21) MGC26_STEP(22) MGC26_STEP(23) MGC26_STEP(24)
+            MGC26_STEP(25) MGC26_STEP(26)
+#undef MGC26_STEP
+            if (!x.S.flag[fl]) break;
+        }
+    }
+    if (active) active = x.any([&](int t) -> bool { return e[t] > 0.0 && hme[t] < MGC_HINF; });
+    const bool has_sink = x.any([&](int t) -> bool { return snk[t] > 0.0; });
+
+    x.par([&](int t) {
+        L.excess[base + t] = e[t];
+        L.sink[base + t] = snk[t];
+        uint32_t m = snk[t] > 0.0 ? MGC26_MASK_SINK : 0u;
+#pragma unroll
+        for (int d = 0; d < MGC26_NDIR; ++d) {
+            L.rcap[((int64_t)tile * MGC26_NDIR + d) * MGC_TV + t] = r[d][t];
+            m |= (r[d][t] > 0.0) ? (1u << d) : 0u;
+        }
+        L.rmask32[base + t] = m;
+        L.height[base + t] = x.S.hs[mgc_hs_index(t >> 6, (t >> 3) & 7, t & 7)];
+    });
+    x.par([&](int t) {
+        if (t < 27 && t != 13 && x.S.nbrflag[t] && x.S.nbr[t] >= 0) {
+            int tz, ty, tx;
+            mgc_tile_coords(L, tile, tz, ty, tx);
+            const int mine = mgc26_colour(L, tz, ty, tx);
+            const int theirs = mgc26_colour(L, tz + t / 9 - 1, ty + (t / 3) % 3 - 1, tx + t % 3 - 1);
+            const uint32_t target = phase + (uint32_t)((theirs - mine) & 7);
+            mgc_enqueue(x, L, (int)(target & 15u), L.stamp, target, x.S.nbr[t]);
+        }
+        if (t == 27 && active) mgc_enqueue(x, L, (int)((phase + 8) & 15u), L.stamp, phase + 8, tile);
+        if (t == 28) L.status[tile] = (L.status[tile] & ~2u) | (has_sink ? 2u : 0u);
+    });
+}
+
+#endif /* MGC_TILE_OPS26_INL */

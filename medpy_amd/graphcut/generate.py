@@ -18,6 +18,7 @@ def graph_from_voxels(
     boundary_term=False,
     regional_term_args=False,
     boundary_term_args=False,
+    connectivity=None,
 ):
     """Create a graph-cut ready graph to segment an nD image using the voxel neighbourhood.
 
@@ -32,12 +33,16 @@ def graph_from_voxels(
 
     Raises ``AttributeError`` when a term is not a callable of exactly two parameters
     (generate.py:135-146).
+
+    ``connectivity`` (extension, not in the reference): ``None`` / ``2*ndim`` = the reference's
+    neighbourhood; ``3**ndim - 1`` (8 in 2-D, 26 in 3-D) = full neighbourhood, the built-in boundary
+    terms then apply the same g(.) to every neighbour offset (spacing: Euclidean offset length).
     """
     fg_markers = numpy.asarray(fg_markers)
     bg_markers = numpy.asarray(bg_markers)
     logger.debug("Assuming %d nodes and %d edges for image of shape %s", fg_markers.size,
                  __voxel_4conectedness(fg_markers.shape), fg_markers.shape)
-    graph = GCGraph(fg_markers.size, __voxel_4conectedness(fg_markers.shape), shape=fg_markers.shape)
+    graph = GCGraph(fg_markers.size, __voxel_4conectedness(fg_markers.shape), shape=fg_markers.shape, connectivity=connectivity)
 
     logger.info("Performing attribute tests...")
     fg_markers = numpy.asarray(fg_markers, dtype=numpy.bool_)

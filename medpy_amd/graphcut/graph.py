@@ -144,6 +144,13 @@ class VoxelGraph(object):
         return float(self.tweights().ravel()[int(i)])
 
     # -- energy read-back (parity tests)
+    def nweights_offset(self, offset):
+        """weights of the arcs (p, p + offset), NaN where p + offset is outside the volume"""
+        off = (C.c_int * len(self._shape))(*[int(v) for v in offset])
+        out = numpy.empty(self._shape, dtype=numpy.float64)
+        self._call("mgc_get_nweights_offset", off, _lib.ptr(out))
+        return out
+
     def nweights(self, axis):
         shp = list(self._shape)
         shp[axis] -= 1
@@ -178,7 +185,8 @@ class GCGraph(object):
     MAX = __UINT_16_BIT
     """The maximum value a terminal weight can take."""
 
-    def __init__(self, nodes, edges, shape=None, device=0):
+    def __init__(self, nodes, edges, shape=None, device=0, connectivity=None):
+        self.__connectivity = connectivity
         self.__nodes = int(nodes)
         self.__edges = int(edges)
         self.__shape = tuple(shape) if shape is not None else (int(nodes),)
@@ -287,7 +295,7 @@ class GCGraph(object):
     def get_graph(self):
         """Builds the residual lattice in HBM (once) and returns the solver object."""
         if self.__graph is None:
-            g = VoxelGraph(self.__shape, device=self.__device)
+            g = VoxelGraph(self.__shape, device=self.__device, connectivity=self.__connectivity)
             if self.__boundary is not None:
                 g._set_boundary(*self.__boundary)
             if self.__regional is not None:

@@ -281,7 +281,7 @@ class HipSlab(object):
         self._call("mgc_solver_op", int(op), int(a0), int(a1), int(a2), int(a3))
 
     def read_counts(self):
-        out = np.zeros(16, dtype=np.int32)
+        out = np.zeros(32, dtype=np.int32)
         self._call("mgc_read_counts", self._lib.ptr(out))
         return out
 
@@ -314,7 +314,7 @@ class HipSlab(object):
         self._call("mgc_halo_exchange", int(kind), int(epoch), int(lst))
 
     def allreduce_counts(self):
-        out = np.zeros(16, dtype=np.int64)
+        out = np.zeros(32, dtype=np.int64)
         self._call("mgc_allreduce_counts", self._lib.ptr(out))
         return out
 

@@ -20,16 +20,18 @@
 #include <vector>
 
 #include "../../medpy_amd/csrc/mgc_tile_ops.inl"
+#include "../../medpy_amd/csrc/mgc_tile_ops26.inl"
 #include "../../medpy_amd/csrc/mgc_driver.inl"
 
-struct HostBlock {
+template <class SH>
+struct HostBlockT {
     template <class T>
     struct Reg {
         T v[MGC_TV];
         T& operator[](int t) { return v[t]; }
     };
-    MgcTileShared& S;
-    explicit HostBlock(MgcTileShared& s) : S(s) {}
+    SH& S;
+    explicit HostBlockT(SH& s) : S(s) {}
     template <class F>
     void par(F f)
     {
@@ -47,6 +49,8 @@ struct HostBlock {
     void atomic_or(uint32_t* p, uint32_t v) { *p |= v; }
     void atomic_and(uint32_t* p, uint32_t v) { *p &= v; }
 };
+typedef HostBlockT<MgcTileShared> HostBlock;
+typedef HostBlockT<MgcTileShared26> HostBlock26;
 
 struct HostDev {
     MgcLattice L;
@@ -237,6 +241,101 @@ int hostsim_solve(const int64_t* shape, const double* w0, const double* w1, cons
     const int rc = mgc_solve(*d, d->L, P, st);
     memcpy(stats_out, &st, sizeof(st));
     d->labels(labels_out);
+    delete d;
+    return rc;
+}
+
+} /* extern "C" */
+
+/* ------------------------------------------------------------------------------------------
+ * 26-neighbourhood (mgc_tile_ops26.inl): one-call solve for the CPU tests
+ * ---------------------------------------------------------------------------------------- */
+struct HostDev26 {
+    MgcLattice L;
+    MgcTileShared26 S;
+    std::vector<double> rcap, excess, sink;
+    std::vector<int32_t> height, lists, count;
+    std::vector<uint32_t> rmask32, stamp, rstamp, status;
+    void fill_heights_inf() { for (int64_t i = 0; i < (int64_t)L.ntiles * MGC_TV; ++i) L.height[i] = MGC_HINF; }
+    void zero_count(int i) { L.count[i] = 0; }
+    void read_counts(int* out) { memcpy(out, L.count, MGC_NCOUNT * sizeof(int)); }
+    void absorb_all() {}
+    void relabel_all(uint32_t epoch, int next)
+    {
+        HostBlock26 x(S);
+        for (int t = 0; t < L.ntiles; ++t) {
+            if (L.status[t] & 2u) L.count[MGC26_CNT_REL]++;
+            mgc26_relabel_tile(x, L, t, epoch, next, true);
+        }
+    }
+    void relabel_list(int lst, uint32_t epoch, int next)
+    {
+        HostBlock26 x(S);
+        const int n = L.count[lst];
+        L.count[MGC26_CNT_REL] += n;
+        for (int i = 0; i < n; ++i) mgc26_relabel_tile(x, L, L.list[lst][i], epoch, next, false);
+    }
+    void activate_all(uint32_t phase) { HostBlock26 x(S); for (int t = 0; t < L.ntiles; ++t) mgc26_activate_tile(x, L, t, phase); }
+    void discharge(int lst, uint32_t phase, int cycles, int sweeps)
+    {
+        HostBlock26 x(S);
+        const int n = L.count[lst];
+        L.count[MGC26_CNT_DIS] += n;
+        for (int i = 0; i < n; ++i) mgc26_discharge_tile(x, L, L.list[lst][i], phase, cycles, sweeps);
+    }
+};
+
+extern "C" {
+
+/* w[d*N + id] = capacity of the arc from voxel id in direction d (0..25, mgc26_offset order), 0 where there is
+ * no neighbour; trcap[N].  labels_out: 0 = sink side.  stats_out[8] = MgcSolveStats. */
+int hostsim_solve26(const int64_t* shape, const double* w, const double* trcap, int rounds, int cycles, int sweeps, int max_outer,
+                    uint8_t* labels_out, int64_t* stats_out)
+{
+    HostDev26* d = new HostDev26();
+    MgcLattice& L = d->L;
+    memset(&L, 0, sizeof(L));
+    L.dz = shape[0]; L.dy = shape[1]; L.dx = shape[2];
+    L.nvox = L.dz * L.dy * L.dx;
+    L.gz = (int)((L.dz + 7) / 8); L.gy = (int)((L.dy + 7) / 8); L.gx = (int)((L.dx + 7) / 8);
+    L.ntiles = L.gz * L.gy * L.gx;
+    L.tz_own_lo = 0; L.tz_own_hi = L.gz; L.tz_global0 = 0; L.ndir = 26;
+    const int64_t nt = L.ntiles, N = L.nvox;
+    d->rcap.assign(nt * 26 * MGC_TV, 0.0); d->excess.assign(nt * MGC_TV, 0.0); d->sink.assign(nt * MGC_TV, 0.0);
+    d->height.assign(nt * MGC_TV, MGC_HINF); d->lists.assign(18 * nt, 0); d->count.assign(MGC_NCOUNT, 0);
+    d->rmask32.assign(nt * MGC_TV, 0); d->stamp.assign(nt, 0); d->rstamp.assign(nt, 0); d->status.assign(nt, 0);
+    L.rcap = d->rcap.data(); L.excess = d->excess.data(); L.sink = d->sink.data(); L.height = d->height.data();
+    L.rmask32 = d->rmask32.data();
+    for (int i = 0; i < 18; ++i) L.list[i] = d->lists.data() + i * nt;
+    L.count = d->count.data(); L.stamp = d->stamp.data(); L.rstamp = d->rstamp.data(); L.status = d->status.data();
+    for (int64_t id = 0; id < N; ++id) {
+        int tile, loc;
+        mgc_node_to_tile(L, id, tile, loc);
+        uint32_t m = 0;
+        for (int dir = 0; dir < 26; ++dir) {
+            const double c = w[(int64_t)dir * N + id];
+            d->rcap[((int64_t)tile * 26 + dir) * MGC_TV + loc] = c;
+            if (c > 0.0) m |= 1u << dir;
+        }
+        const double tr = trcap[id];
+        d->excess[(int64_t)tile * MGC_TV + loc] = tr > 0 ? tr : 0.0;
+        d->sink[(int64_t)tile * MGC_TV + loc] = tr < 0 ? -tr : 0.0;
+        if (tr < 0) { m |= MGC26_MASK_SINK; d->status[tile] |= 2u; }
+        d->rmask32[(int64_t)tile * MGC_TV + loc] = m;
+    }
+    MgcSolveParams P = mgc_default_params();
+    if (rounds > 0) P.rounds_per_relabel = rounds;
+    if (cycles > 0) P.max_cycles = cycles;
+    if (sweeps > 0) P.max_sweeps = sweeps;
+    if (max_outer > 0) P.max_outer = max_outer;
+    MgcSolveStats st;
+    const int rc = mgc_solve(*d, L, P, st, mgc_layout26());
+    memcpy(stats_out, &st, sizeof(st));
+    for (int64_t id = 0; id < N; ++id) {
+        int tile, loc;
+        mgc_node_to_tile(L, id, tile, loc);
+        labels_out[id] = d->height[(int64_t)tile * MGC_TV + loc] < MGC_HINF ? 0 : 1;
+    }
     delete d;
     return rc;
 }

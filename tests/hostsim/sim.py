@@ -13,7 +13,7 @@ _lib = None
 def build():
     src = os.path.join(_HERE, "hostsim.cpp")
     deps = [src] + [os.path.join(_HERE, "..", "..", "medpy_amd", "csrc", f) for f in
-                    ("mgc_tile_ops.inl", "mgc_driver.inl", "mgc_common.h")]
+                    ("mgc_tile_ops.inl", "mgc_tile_ops26.inl", "mgc_driver.inl", "mgc_common.h")]
     if os.path.exists(_SO) and all(os.path.getmtime(_SO) >= os.path.getmtime(d) for d in deps):
         return
     subprocess.check_call(["g++", "-O2", "-std=c++17", "-Wno-unknown-pragmas", "-fPIC", "-shared", "-o", _SO, src])
@@ -101,7 +101,7 @@ class SimSlab(object):
         assert self._L.hostsim_solver_op(self._h, int(op), int(a0), int(a1), int(a2), int(a3)) == 0
 
     def read_counts(self):
-        out = np.zeros(16, np.int32)
+        out = np.zeros(32, np.int32)
         self._L.hostsim_read_counts(self._h, out)
         return out
 
@@ -120,3 +120,32 @@ class SimSlab(object):
         out = np.empty(int(np.prod(self.local_shape)), np.uint8)
         self._L.hostsim_labels(self._h, out)
         return out.reshape(self.local_shape)[self.own0 - self.plane0:self.own1 - self.plane0].astype(np.bool_), 0.0
+
+
+def solve26(shape, weights_by_offset, trcap, rounds=0, cycles=0, sweeps=0, max_outer=0):
+    """26-neighbourhood: weights_by_offset = {offset: array (NaN where no neighbour)} for the 13 forward offsets
+    (oracle/energy_numpy.py:boundary_weights_offsets).  Returns (labels, stats)."""
+    L = lib()
+    pf = np.ctypeslib.ndpointer(np.float64, flags="C_CONTIGUOUS")
+    L.hostsim_solve26.restype = C.c_int
+    L.hostsim_solve26.argtypes = [np.ctypeslib.ndpointer(np.int64), pf, pf, C.c_int, C.c_int, C.c_int, C.c_int,
+                                  np.ctypeslib.ndpointer(np.uint8), np.ctypeslib.ndpointer(np.int64)]
+    shape = tuple(int(v) for v in shape)
+    n = int(np.prod(shape))
+    w = np.zeros((26,) + shape)
+    for o, arr in weights_by_offset.items():
+        code = (o[0] + 1) * 9 + (o[1] + 1) * 3 + (o[2] + 1)
+        d = code if code < 13 else code - 1
+        fwd = np.nan_to_num(np.asarray(arr, dtype=np.float64), nan=0.0)
+        w[d] = fwd
+        # the reverse arc of (p, p+o) leaves p+o in direction -o with the same (symmetric) capacity
+        src = tuple(slice(max(0, -k), shape[a] - max(0, k)) for a, k in enumerate(o))
+        dst = tuple(slice(max(0, k), shape[a] - max(0, -k)) for a, k in enumerate(o))
+        w[25 - d][dst] = fwd[src]
+    labels = np.empty(n, np.uint8)
+    stats = np.zeros(8, np.int64)
+    rc = L.hostsim_solve26(np.asarray(shape, np.int64), np.ascontiguousarray(w).ravel(), np.ascontiguousarray(trcap, dtype=np.float64).ravel(),
+                           rounds, cycles, sweeps, max_outer, labels, stats)
+    st = dict(zip(STAT_NAMES, stats.tolist()))
+    st["rc"] = rc
+    return labels.reshape(shape), st

@@ -111,3 +111,21 @@ def test_hostsim_dyadic_ties_exact():
     g.maxflow()
     lab, st = sim.solve(img.shape, w, tr)
     np.testing.assert_array_equal(lab, g.labels().reshape(img.shape))
+
+
+@pytest.mark.parametrize("gen,shape", [("sphere", (16, 16, 16)), ("hard", (24, 24, 24)), ("sphere", (9, 21, 30)), ("sphere", (1, 24, 40))])
+def test_hostsim_full_neighbourhood_matches_bk(gen, shape):
+    """26-neighbourhood tile ops (mgc_tile_ops26.inl, same source as the k26_* kernels) vs the BK oracle fed the
+    26-neighbour edge list."""
+    import sim
+    from medpy_amd import synthetic
+    from oracle import energy_numpy, pipeline
+    s = getattr(synthetic, gen)(shape)
+    offs = energy_numpy.forward_offsets(3, 26)
+    w = energy_numpy.boundary_weights_offsets(s["term"], s["image"], offs, s["sigma"])
+    g = pipeline.build_graph(s["fg"], s["bg"], weights=w, connectivity=26)
+    tr = np.array([g.get_trcap(i) for i in range(s["fg"].size)])
+    g.maxflow()
+    lab, st = sim.solve26(shape, w, tr)
+    assert st["converged"] == 1
+    np.testing.assert_array_equal(lab, g.labels().reshape(shape))
