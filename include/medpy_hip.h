@@ -133,6 +133,9 @@ int mgc_what_segment(mgc_handle h, int64_t i, int* segment); /* Graph::what_segm
 int mgc_get_node_num(mgc_handle h, int64_t* n);
 int mgc_set_param(mgc_handle h, const char* name, int64_t value); /* solver schedule knobs, see DESIGN.md */
 int mgc_get_stats(mgc_handle h, mgc_stats* out);
+/* development aid (mgc_set_param "profile_sections" 1): out16[0..3] = shader cycles of workgroup lane 0 spent in
+ * load+absorb / in-tile labels / push sweeps / store of k_discharge, out16[8..11] = how many such sections */
+int mgc_get_profile(mgc_handle h, uint64_t* out16);
 
 /* ------------------------------------------------------------------------------------------
  * Z-slab decomposition across the GPUs of one node (no reference counterpart: the reference is

@@ -8,7 +8,7 @@ import os
 import numpy as np
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "libmedpyhip.so")
+LIB_PATH = os.environ.get("MEDPY_HIP_LIB") or os.path.join(_HERE, "libmedpyhip.so")  # override: development builds
 
 OK, ERR_INVALID, ERR_NO_DEVICE, ERR_HIP, ERR_OOM, ERR_STATE, ERR_UNSUPPORTED, ERR_NOT_CONVERGED = range(8)
 
@@ -62,6 +62,7 @@ SIGNATURES = {
     "mgc_get_node_num": (_INT, [_VP, C.POINTER(_I64)]),
     "mgc_set_param": (_INT, [_VP, C.c_char_p, _I64]),
     "mgc_get_stats": (_INT, [_VP, C.POINTER(Stats)]),
+    "mgc_get_profile": (_INT, [_VP, _VP]),
     # Z-slab decomposition (multi-GPU)
     "mgc_create_slab": (_INT, [_INT, C.POINTER(_I64), _INT, _INT, _INT, _INT, C.POINTER(_VP)]),
     "mgc_slab_info": (_INT, [_VP, C.POINTER(_I64)]),

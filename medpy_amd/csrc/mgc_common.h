@@ -34,6 +34,11 @@
 #define MGC_NDIR 6
 #define MGC_MASK_SINK 0x40      /* rmask bit 6: residual capacity to the sink > 0 */
 #define MGC_NCOUNT 32
+#define MGC_ST_SINK 2u
+#define MGC_ST_DIRTY 4u
+#define MGC_ST_SUSPECT 8u
+#define MGC_ST_DEP_SHIFT 8
+#define MGC_CNT_CHANGED 10     /* counter slot: suspect-closure pass changed something */
 
 struct MgcLattice {
     /* logical volume */
@@ -66,7 +71,10 @@ struct MgcLattice {
                                  activation, [8]/[9] running totals of tiles discharged / relabelled            */
     uint32_t* stamp;          /* [ntiles] de-duplication stamp for list appends (discharge) */
     uint32_t* rstamp;         /* [ntiles] same for the relabel lists                */
-    uint32_t* status;         /* [ntiles] bit1: the tile holds at least one residual arc to the sink */
+    uint32_t* status;         /* [ntiles] bit1 (2): the tile holds a residual arc to the sink; bit2 (4): DIRTY = discharged
+                                 since the last global relabel; bit3 (8): SUSPECT (labels must be recomputed);
+                                 bits 8..13: faces through which the tile's labels are supported by a neighbour */
+    unsigned long long* prof; /* optional [16] cycle accumulators of the discharge sections (development aid) or NULL */
 };
 
 MGC_HD int mgc_tile_id(const MgcLattice& L, int tz, int ty, int tx) { return (tz * L.gy + ty) * L.gx + tx; }

@@ -34,6 +34,7 @@ struct MgcSolveParams {
     int max_outer;          /* safety cap on global relabels                              */
     int relabel_batch;      /* BFS passes launched between two counter read-backs         */
     int check_rounds;       /* colour rounds launched between two counter read-backs      */
+    int incremental_relabel;/* 1: later global relabels touch suspect tiles only          */
 };
 
 struct MgcSolveStats {
@@ -54,10 +55,11 @@ struct MgcLayout {
     int list_mask;  /* discharge list of phase p = p & list_mask */
     int rl_base;    /* relabel lists rl_base, rl_base + 1        */
     int cnt_active, cnt_dis, cnt_rel;
+    int incremental; /* global relabels after the first recompute only suspect tiles (Dev: suspect_pass, reset_suspect) */
 };
 
-static inline MgcLayout mgc_layout6() { MgcLayout l = {2, 3, 4, 6, 8, 9}; return l; }
-static inline MgcLayout mgc_layout26() { MgcLayout l = {8, 15, 16, 18, 19, 20}; return l; }
+static inline MgcLayout mgc_layout6() { MgcLayout l = {2, 3, 4, 6, 8, 9, 1}; return l; }
+static inline MgcLayout mgc_layout26() { MgcLayout l = {8, 15, 16, 18, 19, 20, 0}; return l; }
 
 static inline MgcSolveParams mgc_default_params()
 {
@@ -69,6 +71,7 @@ static inline MgcSolveParams mgc_default_params()
     p.max_outer = 100000;
     p.relabel_batch = 8;
     p.check_rounds = 4;
+    p.incremental_relabel = 1;
     return p;
 }
 
@@ -85,10 +88,22 @@ int mgc_solve(Dev& dev, const MgcLattice& L, const MgcSolveParams& P, MgcSolveSt
     for (int outer = 0; outer < P.max_outer; ++outer) {
         /* ---- global relabel ---- */
         dev.absorb_all();
-        dev.fill_heights_inf();
         dev.zero_count(lay.rl_base);
         dev.zero_count(lay.rl_base + 1);
-        dev.relabel_all(rep + 1, lay.rl_base + (int)((rep + 1) & 1u));
+        if (outer == 0 || !lay.incremental || !P.incremental_relabel) {
+            dev.fill_heights_inf();
+            dev.relabel_all(rep + 1, lay.rl_base + (int)((rep + 1) & 1u));
+        } else {
+            /* which tiles could have lost the support of their labels? (tile-level closure, cheap passes) */
+            for (;;) {
+                dev.zero_count(MGC_CNT_CHANGED);
+                for (int b = 0; b < 8; ++b) dev.suspect_pass();
+                dev.read_counts(cnt);
+                st.readbacks++;
+                if (cnt[MGC_CNT_CHANGED] == 0) break;
+            }
+            dev.reset_suspect(rep + 1, lay.rl_base + (int)((rep + 1) & 1u));
+        }
         st.relabel_passes++;
         for (;;) {
             for (int b = 0; b < P.relabel_batch; ++b) {

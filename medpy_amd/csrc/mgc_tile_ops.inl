@@ -32,9 +32,14 @@
 struct MgcTileShared {
     int32_t hs[1000];          /* 10x10x10 distance labels: the tile plus a one-voxel halo */
     double  out[2][MGC_TV];    /* per-direction push hand-off, double buffered             */
+    double  r[6][MGC_TV];      /* residual n-link capacities of the tile being discharged  */
     int32_t nbr[8];            /* neighbour tile ids                                       */
+    int32_t inflag[8];         /* neighbour f has flow for us in its outbox                */
+    double  inbox[6][MGC_TF];  /* that flow, staged by the loading lanes                   */
     int32_t faceflag[8];
+    int32_t depflag[8];        /* relabel: face f supports some label of the tile           */
     int32_t flag[2];
+    int32_t satflag;           /* discharge: some arc (or sink link) of the tile was saturated */
 };
 
 MGC_HD int mgc_hs_index(int z, int y, int x) { return (z + 1) * 100 + (y + 1) * 10 + (x + 1); }
@@ -67,10 +72,14 @@ MGC_HD void mgc_load_nbrs(X& x, const MgcLattice& L, int tile, int t)
     if (t < 6) {
         int tz, ty, tx;
         mgc_tile_coords(L, tile, tz, ty, tx);
-        x.S.nbr[t] = mgc_tile_nbr(L, tz, ty, tx, t);
+        const int nt = mgc_tile_nbr(L, tz, ty, tx, t);
+        x.S.nbr[t] = nt;
+        x.S.inflag[t] = (nt >= 0 && L.obox) ? (int32_t)((L.oflags[nt] >> (t ^ 1)) & 1u) : 0;
         x.S.faceflag[t] = 0;
+        x.S.depflag[t] = 0;
     }
     if (t < 2) x.S.flag[t] = 0;
+    if (t == 2) x.S.satflag = 0;
 }
 
 /* halo labels: 6 faces x 64 voxels, read from the neighbour tiles' label arrays */
@@ -88,25 +97,52 @@ MGC_HD void mgc_load_halo(X& x, const MgcLattice& L, int t)
     }
 }
 
+/* ONE trip to HBM for everything a tile needs from its six neighbours: lane k < 384 fetches the label of the
+ * voxel its face cell touches AND the outbox slot the neighbour may have filled for it (slots nobody filled
+ * hold 0.0, so they are fetched unconditionally instead of waiting for the flag word first).  Results go to
+ * LDS (hs halo, inbox); filled slots are emptied.  Must run in the same par() as mgc_load_nbrs -- it computes
+ * the neighbour ids itself. */
+template <class X>
+MGC_HD void mgc_load_halo_inbox(X& x, const MgcLattice& L, int tile, int t)
+{
+    if (t < 6 * MGC_TF) {
+        const int f = t >> 6, k = t & 63;
+        int tz, ty, tx;
+        mgc_tile_coords(L, tile, tz, ty, tx);
+        const int nt = mgc_tile_nbr(L, tz, ty, tx, f);
+        const int mine = mgc_face_voxel(f, k);
+        const int z = mine >> 6, y = (mine >> 3) & 7, xx = mine & 7;
+        int32_t h = MGC_HINF;
+        double din = 0.0;
+        if (nt >= 0) {
+            h = L.height[(int64_t)nt * MGC_TV + mgc_face_voxel(f ^ 1, k)];
+            double* slot = &L.obox[((int64_t)nt * 6 + (f ^ 1)) * MGC_TF + k];
+            din = *slot;
+            if (din != 0.0) *slot = 0.0;
+        }
+        x.S.hs[mgc_hs_index(z, y, xx) + mgc_hs_step(f)] = h;
+        x.S.inbox[f][k] = din;
+    }
+}
+
 /* one lane absorbs what the neighbour tiles pushed across its (up to three) faces:
  * e += delta, reverse residual += delta (the receiving half of a push, maxflow.cpp:268-271 analogue) */
-template <class X, class RegD>
-MGC_HD bool mgc_absorb_lane(X& x, const MgcLattice& L, int t, RegD& e, RegD (&r)[6])
+template <class X, class RegD, class RAdd>
+MGC_HD bool mgc_absorb_lane(X& x, const MgcLattice& L, int t, RegD& e, RAdd radd)
 {
     const int z = t >> 6, y = (t >> 3) & 7, xx = t & 7;
     bool got = false;
 #pragma unroll
     for (int d = 0; d < 6; ++d) {
         if (mgc_inside(d, z, y, xx)) continue;
+        if (!x.S.inflag[d]) continue;
         const int nt = x.S.nbr[d];
-        if (nt < 0) continue;
-        if (!((L.oflags[nt] >> (d ^ 1)) & 1u)) continue;
         const int k = mgc_face_index(d >> 1, z, y, xx);
         double* slot = &L.obox[((int64_t)nt * 6 + (d ^ 1)) * MGC_TF + k];
         const double delta = *slot;
         if (delta != 0.0) {
             e[t] += delta;
-            r[d][t] += delta;
+            radd(d, delta);
             *slot = 0.0;
             got = true;
         }
@@ -118,10 +154,7 @@ MGC_HD bool mgc_absorb_lane(X& x, const MgcLattice& L, int t, RegD& e, RegD (&r)
 template <class X>
 MGC_HD void mgc_clear_inbox_flags(X& x, const MgcLattice& L, int t)
 {
-    if (t < 6) {
-        const int nt = x.S.nbr[t];
-        if (nt >= 0 && ((L.oflags[nt] >> (t ^ 1)) & 1u)) x.atomic_and(&L.oflags[nt], ~(1u << (t ^ 1)));
-    }
+    if (t < 6 && x.S.inflag[t]) x.atomic_and(&L.oflags[x.S.nbr[t]], ~(1u << (t ^ 1)));
 }
 
 /* ---------------------------------------------------------------------------------------
@@ -135,7 +168,7 @@ template <class X, class MaskFn>
 MGC_HD void mgc_tile_bfs(X& x, MaskFn mask)
 {
     for (;;) {
-        const bool changed = x.any([&](int t) -> bool {
+        auto relax = [&](int t) -> bool {
             const int m = mask(t);
             if (!m) return false;
             const int z = t >> 6, y = (t >> 3) & 7, xx = t & 7;
@@ -152,8 +185,11 @@ MGC_HD void mgc_tile_bfs(X& x, MaskFn mask)
                 return true;
             }
             return false;
-        });
-        if (!changed) break;
+        };
+        /* two plain relaxation rounds per convergence test: the OR-reduction costs more than a round */
+        x.par([&](int t) { (void)relax(t); });
+        x.par([&](int t) { (void)relax(t); });
+        if (!x.any(relax)) break;
     }
 }
 
@@ -170,20 +206,32 @@ MGC_HD void mgc_relabel_tile(X& x, const MgcLattice& L, int tile, uint32_t next_
     if (first_pass && (!(L.status[tile] & 2u) || !mgc_owned(L, tile))) return;
     typename X::template Reg<int> m, h0;
     const int64_t base = (int64_t)tile * MGC_TV;
-    x.par([&](int t) { mgc_load_nbrs(x, L, tile, t); });
-    x.par([&](int t) {
+    x.par([&](int t) { /* one trip to HBM: masks, own labels, label halo */
         const int z = t >> 6, y = (t >> 3) & 7, xx = t & 7;
+        mgc_load_nbrs(x, L, tile, t);
         m[t] = L.rmask[base + t];
         h0[t] = L.height[base + t];
         x.S.hs[mgc_hs_index(z, y, xx)] = h0[t];
-        mgc_load_halo(x, L, t);
+        if (t < 6 * MGC_TF) {
+            const int f = t >> 6, k = t & 63;
+            int tz, ty, tx;
+            mgc_tile_coords(L, tile, tz, ty, tx);
+            const int nt = mgc_tile_nbr(L, tz, ty, tx, f);
+            const int mine = mgc_face_voxel(f, k);
+            x.S.hs[mgc_hs_index(mine >> 6, (mine >> 3) & 7, mine & 7) + mgc_hs_step(f)] =
+                nt < 0 ? MGC_HINF : L.height[(int64_t)nt * MGC_TV + mgc_face_voxel(f ^ 1, k)];
+        }
     });
     mgc_tile_bfs(x, [&](int t) { return m[t]; });
-    x.par([&](int t) {
+    x.par([&](int t) { /* LDS only: which faces saw a label drop; which faces support a label (incremental relabel) */
         const int z = t >> 6, y = (t >> 3) & 7, xx = t & 7;
-        const int h = x.S.hs[mgc_hs_index(z, y, xx)];
-        if (h < h0[t]) {
-            L.height[base + t] = h;
+        const int me = mgc_hs_index(z, y, xx);
+        const int hm = x.S.hs[me];
+        if (hm < MGC_HINF) {
+            for (int d = 0; d < 6; ++d)
+                if (((m[t] >> d) & 1) && !mgc_inside(d, z, y, xx) && x.S.hs[me + mgc_hs_step(d)] + 1 == hm) x.S.depflag[d] = 1;
+        }
+        if (x.S.hs[mgc_hs_index(z, y, xx)] < h0[t]) {
             if (xx == 0) x.S.faceflag[0] = 1;
             if (xx == MGC_T - 1) x.S.faceflag[1] = 1;
             if (y == 0) x.S.faceflag[2] = 1;
@@ -192,8 +240,15 @@ MGC_HD void mgc_relabel_tile(X& x, const MgcLattice& L, int tile, uint32_t next_
             if (z == MGC_T - 1) x.S.faceflag[5] = 1;
         }
     });
-    x.par([&](int t) {
+    x.par([&](int t) { /* one block of global traffic: labels + wake-ups */
+        const int h = x.S.hs[mgc_hs_index(t >> 6, (t >> 3) & 7, t & 7)];
+        if (h < h0[t]) L.height[base + t] = h;
         if (t < 6 && x.S.faceflag[t] && x.S.nbr[t] >= 0) mgc_enqueue(x, L, next_list, L.rstamp, next_epoch, x.S.nbr[t]);
+        if (t == 6) {
+            uint32_t dep = 0;
+            for (int f = 0; f < 6; ++f) dep |= x.S.depflag[f] ? (1u << f) : 0u;
+            L.status[tile] = (L.status[tile] & ~(63u << MGC_ST_DEP_SHIFT)) | (dep << MGC_ST_DEP_SHIFT);
+        }
     });
 }
 
@@ -208,11 +263,7 @@ MGC_HD void mgc_absorb_tile(X& x, const MgcLattice& L, int tile)
     typename X::template Reg<double> e, r[6];
     const int64_t base = (int64_t)tile * MGC_TV;
     x.par([&](int t) { mgc_load_nbrs(x, L, tile, t); });
-    const bool pending = x.any([&](int t) -> bool {
-        if (t >= 6) return false;
-        const int nt = x.S.nbr[t];
-        return nt >= 0 && ((L.oflags[nt] >> (t ^ 1)) & 1u);
-    });
+    const bool pending = x.any([&](int t) -> bool { return t < 6 && x.S.inflag[t]; });
     if (!pending) return;
     x.par([&](int t) {
         const int z = t >> 6, y = (t >> 3) & 7, xx = t & 7;
@@ -220,7 +271,7 @@ MGC_HD void mgc_absorb_tile(X& x, const MgcLattice& L, int tile)
         e[t] = L.excess[base + t];
 #pragma unroll
         for (int d = 0; d < 6; ++d) r[d][t] = L.rcap[((int64_t)tile * 6 + d) * MGC_TV + t];
-        if (mgc_absorb_lane(x, L, t, e, r)) {
+        if (mgc_absorb_lane(x, L, t, e, [&](int d, double delta) { r[d][t] += delta; })) {
             L.excess[base + t] = e[t];
             int m = L.rmask[base + t];
 #pragma unroll
@@ -270,44 +321,65 @@ MGC_HD void mgc_activate_tile(X& x, const MgcLattice& L, int tile, uint32_t phas
 template <class X>
 MGC_HD void mgc_discharge_tile(X& x, const MgcLattice& L, int tile, uint32_t phase, int max_cycles, int max_sweeps)
 {
-    typename X::template Reg<double> e, snk, r[6], ob[3];
-    typename X::template Reg<int> hme;
-    const int64_t base = (int64_t)tile * MGC_TV;
+    /* per lane: excess, sink residual, outbox accumulators, label, residual mask.  The six n-link residuals live
+     * in LDS (x.S.r): that keeps the kernel under 64 VGPRs, i.e. 4 workgroups (32 waves) per CU, which is what
+     * hides the HBM latency of the load / store phases of the neighbouring workgroups. */
+    typename X::template Reg<double> e, snk, ob0, ob1, ob2;
+    typename X::template Reg<int> hme, msk;
+    /* per-tile (wave-uniform) base pointers + 32-bit lane offsets: SGPR-base addressing, fewer VGPRs */
+    double* const t_excess = L.excess + (int64_t)tile * MGC_TV;
+    double* const t_sink = L.sink + (int64_t)tile * MGC_TV;
+    double* const t_rcap = L.rcap + (int64_t)tile * 6 * MGC_TV;
+    double* const t_obox = L.obox + (int64_t)tile * 6 * MGC_TF;
+    uint8_t* const t_rmask = L.rmask + (int64_t)tile * MGC_TV;
+    int32_t* const t_height = L.height + (int64_t)tile * MGC_TV;
 
-    x.par([&](int t) { mgc_load_nbrs(x, L, tile, t); });
+    /* was two dependent trips to HBM: (1) neighbour outbox flags + the tile's own state, issued together;
+     * kept for reference: everything is fetched in ONE trip now */
     x.par([&](int t) {
-        e[t] = L.excess[base + t];
-        snk[t] = L.sink[base + t];
-#pragma unroll
-        for (int d = 0; d < 6; ++d) r[d][t] = L.rcap[((int64_t)tile * 6 + d) * MGC_TV + t];
-        ob[0][t] = ob[1][t] = ob[2][t] = 0.0;
-        mgc_load_halo(x, L, t);
-        mgc_absorb_lane(x, L, t, e, r);
+        mgc_load_nbrs(x, L, tile, t);
+        mgc_load_halo_inbox(x, L, tile, t);
+        e[t] = t_excess[(unsigned)t];
+        snk[t] = t_sink[(unsigned)t];
+        for (int d = 0; d < 6; ++d) x.S.r[d][t] = t_rcap[(unsigned)(d * MGC_TV + t)];
+        ob0[t] = ob1[t] = ob2[t] = 0.0;
     });
-    x.par([&](int t) { mgc_clear_inbox_flags(x, L, t); });
+    x.par([&](int t) { /* absorb the staged inbox (LDS only): e += delta, reverse residual += delta, fixed face order */
+        const int z = t >> 6, y = (t >> 3) & 7, xx = t & 7;
+        for (int d = 0; d < 6; ++d) {
+            if (mgc_inside(d, z, y, xx)) continue;
+            const double delta = x.S.inbox[d][mgc_face_index(d >> 1, z, y, xx)];
+            if (delta != 0.0) {
+                e[t] += delta;
+                x.S.r[d][t] += delta;
+            }
+        }
+        mgc_clear_inbox_flags(x, L, t);
+    });
+    x.mark(L, 0); /* load + absorb */
 
     bool active = false;
     int sweep_id = 0;
     for (int cyc = 0; cyc < max_cycles; ++cyc) {
         /* exact labels given the frozen halo */
-        x.par([&](int t) { x.S.hs[mgc_hs_index(t >> 6, (t >> 3) & 7, t & 7)] = MGC_HINF; });
-        mgc_tile_bfs(x, [&](int t) {
+        x.par([&](int t) {
+            x.S.hs[mgc_hs_index(t >> 6, (t >> 3) & 7, t & 7)] = MGC_HINF;
             int m = snk[t] > 0.0 ? MGC_MASK_SINK : 0;
-#pragma unroll
-            for (int d = 0; d < 6; ++d) m |= (r[d][t] > 0.0) ? (1 << d) : 0;
-            return m;
+            for (int d = 0; d < 6; ++d) m |= (x.S.r[d][t] > 0.0) ? (1 << d) : 0;
+            msk[t] = m;
         });
+        mgc_tile_bfs(x, [&](int t) { return msk[t]; });
         active = x.any([&](int t) -> bool {
             hme[t] = x.S.hs[mgc_hs_index(t >> 6, (t >> 3) & 7, t & 7)];
             return e[t] > 0.0 && hme[t] < MGC_HINF;
         });
+        x.mark(L, 1); /* in-tile labels */
         if (!active) break;
 
         for (int sw = 0; sw < max_sweeps; ++sw, ++sweep_id) {
             const int fl = sweep_id & 1;
             /* 7 steps: step s pushes along direction s (s < 6) after receiving direction s-1 */
-            auto step = [&](auto sc) {
-                constexpr int s = decltype(sc)::value;
+            for (int s = 0; s <= 6; ++s) {
                 x.par([&](int t) {
                     const int z = t >> 6, y = (t >> 3) & 7, xx = t & 7;
                     if (s == 0) {
@@ -317,46 +389,44 @@ MGC_HD void mgc_discharge_tile(X& x, const MgcLattice& L, int tile, uint32_t pha
                             e[t] -= delta;
                             snk[t] -= delta;
                             x.S.flag[fl] = 1;
+                            if (snk[t] == 0.0) x.S.satflag = 1;
                         }
                     } else {
                         if (s == 1 && t == 0) x.S.flag[fl ^ 1] = 0; /* everybody has read it by now */
                         /* receive what the neighbour pushed in direction s-1 */
-                        constexpr int dp = s > 0 ? s - 1 : 0;
+                        const int dp = s - 1;
                         if (mgc_inside(dp ^ 1, z, y, xx)) {
                             const double din = x.S.out[dp & 1][t - mgc_loc_step(dp)];
                             if (din != 0.0) {
                                 e[t] += din;
-                                r[dp ^ 1][t] += din;
+                                x.S.r[dp ^ 1][t] += din;
                             }
                         }
                     }
                     if (s < 6) {
-                        constexpr int d = s < 6 ? s : 0;
+                        const int d = s;
                         double delta = 0.0;
-                        if (e[t] > 0.0 && r[d][t] > 0.0 && hme[t] < MGC_HINF) {
-                            const int hv = x.S.hs[mgc_hs_index(z, y, xx) + mgc_hs_step(d)];
-                            if (hv == hme[t] - 1) {
-                                delta = e[t] < r[d][t] ? e[t] : r[d][t];
+                        if (e[t] > 0.0 && hme[t] < MGC_HINF) {
+                            const double rd = x.S.r[d][t];
+                            if (rd > 0.0 && x.S.hs[mgc_hs_index(z, y, xx) + mgc_hs_step(d)] == hme[t] - 1) {
+                                delta = e[t] < rd ? e[t] : rd;
                                 e[t] -= delta;
-                                r[d][t] -= delta;
+                                x.S.r[d][t] = rd - delta; /* saturating push: rd - rd == 0.0 exactly */
                                 x.S.flag[fl] = 1;
+                                if (delta == rd) x.S.satflag = 1;
                             }
                         }
                         if (mgc_inside(d, z, y, xx)) {
                             x.S.out[d & 1][t] = delta;
                         } else if (delta != 0.0) {
-                            ob[d >> 1][t] += delta;
+                            if ((d >> 1) == 0) ob0[t] += delta;
+                            else if ((d >> 1) == 1) ob1[t] += delta;
+                            else ob2[t] += delta;
                         }
                     }
                 });
-            };
-            step(std::integral_constant<int, 0>{});
-            step(std::integral_constant<int, 1>{});
-            step(std::integral_constant<int, 2>{});
-            step(std::integral_constant<int, 3>{});
-            step(std::integral_constant<int, 4>{});
-            step(std::integral_constant<int, 5>{});
-            step(std::integral_constant<int, 6>{});
+            }
+            x.mark(L, 2); /* one push sweep */
             if (!x.S.flag[fl]) break; /* uniform: written before the last barrier */
         }
     }
@@ -365,38 +435,87 @@ MGC_HD void mgc_discharge_tile(X& x, const MgcLattice& L, int tile, uint32_t pha
         active = x.any([&](int t) -> bool { return e[t] > 0.0 && hme[t] < MGC_HINF; });
     }
     const bool has_sink = x.any([&](int t) -> bool { return snk[t] > 0.0; });
+    x.mark(L, 4); /* tail votes */
 
-    /* store */
+    /* which faces carry flow out of the tile (LDS only) ... */
     x.par([&](int t) {
         const int z = t >> 6, y = (t >> 3) & 7, xx = t & 7;
-        L.excess[base + t] = e[t];
-        L.sink[base + t] = snk[t];
-        int m = snk[t] > 0.0 ? MGC_MASK_SINK : 0;
-#pragma unroll
-        for (int d = 0; d < 6; ++d) {
-            L.rcap[((int64_t)tile * 6 + d) * MGC_TV + t] = r[d][t];
-            m |= (r[d][t] > 0.0) ? (1 << d) : 0;
-        }
-        L.rmask[base + t] = (uint8_t)m;
-        L.height[base + t] = x.S.hs[mgc_hs_index(z, y, xx)];
-#pragma unroll
-        for (int a = 0; a < 3; ++a) {
-            if (ob[a][t] != 0.0) {
-                const int c = a == 0 ? xx : (a == 1 ? y : z);
-                const int f = 2 * a + (c == 0 ? 0 : 1);
-                L.obox[((int64_t)tile * 6 + f) * MGC_TF + mgc_face_index(a, z, y, xx)] += ob[a][t];
-                x.S.faceflag[f] = 1;
-            }
-        }
+        if (ob0[t] != 0.0) x.S.faceflag[xx == 0 ? 0 : 1] = 1;
+        if (ob1[t] != 0.0) x.S.faceflag[y == 0 ? 2 : 3] = 1;
+        if (ob2[t] != 0.0) x.S.faceflag[z == 0 ? 4 : 5] = 1;
     });
+    x.mark(L, 5); /* face flags */
+    /* ... then ONE block of global stores: state, masks, labels, outbox, wake-ups */
     x.par([&](int t) {
+        const int z = t >> 6, y = (t >> 3) & 7, xx = t & 7;
+        t_excess[(unsigned)t] = e[t];
+        t_sink[(unsigned)t] = snk[t];
+        int m = snk[t] > 0.0 ? MGC_MASK_SINK : 0;
+        for (int d = 0; d < 6; ++d) {
+            const double rd = x.S.r[d][t];
+            t_rcap[(unsigned)(d * MGC_TV + t)] = rd;
+            m |= (rd > 0.0) ? (1 << d) : 0;
+        }
+        t_rmask[(unsigned)t] = (uint8_t)m;
+        t_height[(unsigned)t] = x.S.hs[mgc_hs_index(z, y, xx)];
+        /* plain stores: the neighbour emptied these slots when it last absorbed, and it always runs (or absorb_all
+         * does) between two of our discharges */
+        if (ob0[t] != 0.0) t_obox[(unsigned)((xx == 0 ? 0 : 1) * MGC_TF + mgc_face_index(0, z, y, xx))] = ob0[t];
+        if (ob1[t] != 0.0) t_obox[(unsigned)((y == 0 ? 2 : 3) * MGC_TF + mgc_face_index(1, z, y, xx))] = ob1[t];
+        if (ob2[t] != 0.0) t_obox[(unsigned)((z == 0 ? 4 : 5) * MGC_TF + mgc_face_index(2, z, y, xx))] = ob2[t];
         if (t < 6 && x.S.faceflag[t]) {
             x.atomic_or(&L.oflags[tile], 1u << t);
             mgc_enqueue(x, L, (int)((phase + 1) & 3u), L.stamp, phase + 1, x.S.nbr[t]);
         }
         if (t == 6 && active) mgc_enqueue(x, L, (int)((phase + 2) & 3u), L.stamp, phase + 2, tile);
-        if (t == 7) L.status[tile] = (L.status[tile] & ~2u) | (has_sink ? 2u : 0u);
+        /* DIRTY only if a residual arc disappeared: otherwise no distance in the tile (or through it) can have changed */
+        if (t == 7) L.status[tile] = (L.status[tile] & ~MGC_ST_SINK) | (has_sink ? MGC_ST_SINK : 0u) | (x.S.satflag ? MGC_ST_DIRTY : 0u);
     });
+    x.mark(L, 3); /* store */
+}
+
+/* ---------------------------------------------------------------------------------------
+ * Incremental global relabel.  Distances to the sink never decrease, and a tile's exact labels stay exact as
+ * long as a supporting path survives.  A tile is SUSPECT when it was discharged since the last global relabel
+ * (arcs may have saturated) or when one of the faces that support its labels leads into a suspect tile
+ * (transitive closure, tile-level, one thread per tile per pass).  Only suspect tiles are reset to INF and
+ * recomputed; everything else (typically the whole sink side of the cut) keeps its labels.
+ * ------------------------------------------------------------------------------------- */
+MGC_HD bool mgc_suspect_tile(const MgcLattice& L, int tile)
+{
+    const uint32_t st = L.status[tile];
+    if (st & MGC_ST_SUSPECT) return false;
+    bool sus = (st & MGC_ST_DIRTY) != 0;
+    if (!sus) {
+        const uint32_t dep = (st >> MGC_ST_DEP_SHIFT) & 63u;
+        if (dep) {
+            int tz, ty, tx;
+            mgc_tile_coords(L, tile, tz, ty, tx);
+            for (int f = 0; f < 6 && !sus; ++f)
+                if ((dep >> f) & 1u) {
+                    const int nt = mgc_tile_nbr(L, tz, ty, tx, f);
+                    sus = nt >= 0 && (L.status[nt] & MGC_ST_SUSPECT);
+                }
+        }
+    }
+    if (sus) L.status[tile] = st | MGC_ST_SUSPECT;
+    return sus;
+}
+
+/* suspect tiles: labels := INF, queued for the first relabel pass; flags retired */
+template <class X>
+MGC_HD void mgc_reset_suspect_tile(X& x, const MgcLattice& L, int tile, uint32_t epoch, int list)
+{
+    const uint32_t st = L.status[tile];
+    if (st & MGC_ST_SUSPECT) {
+        x.par([&](int t) {
+            L.height[(int64_t)tile * MGC_TV + t] = MGC_HINF;
+            if (t == 0) {
+                L.status[tile] = st & ~(MGC_ST_SUSPECT | MGC_ST_DIRTY | (63u << MGC_ST_DEP_SHIFT));
+                mgc_enqueue(x, L, list, L.rstamp, epoch, tile);
+            }
+        });
+    }
 }
 
 /* ---------------------------------------------------------------------------------------

@@ -164,6 +164,12 @@ class VoxelGraph(object):
         self._call("mgc_get_tweights", _lib.ptr(out))
         return out
 
+    def profile(self):
+        out = numpy.zeros(16, dtype=numpy.uint64)
+        self._call("mgc_get_profile", _lib.ptr(out))
+        names = ("load", "labels", "sweep", "store", "votes", "faceflags")
+        return {n: {"cycles": int(out[i]), "count": int(out[i + 8])} for i, n in enumerate(names)}
+
     def stats(self):
         st = _lib.Stats()
         self._call("mgc_get_stats", C.byref(st))

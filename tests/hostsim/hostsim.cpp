@@ -48,6 +48,7 @@ struct HostBlockT {
     uint32_t atomic_exch(uint32_t* p, uint32_t v) { uint32_t o = *p; *p = v; return o; }
     void atomic_or(uint32_t* p, uint32_t v) { *p |= v; }
     void atomic_and(uint32_t* p, uint32_t v) { *p &= v; }
+    void mark(const MgcLattice&, int) {}
 };
 typedef HostBlockT<MgcTileShared> HostBlock;
 typedef HostBlockT<MgcTileShared26> HostBlock26;
@@ -81,6 +82,16 @@ struct HostDev {
         for (int i = 0; i < n; ++i) mgc_relabel_tile(x, L, L.list[lst][i], epoch, next, false);
     }
     void activate_all(uint32_t phase) { HostBlock x(S); for (int t = 0; t < L.ntiles; ++t) mgc_activate_tile(x, L, t, phase); }
+    void suspect_pass()
+    {
+        for (int t = 0; t < L.ntiles; ++t)
+            if (mgc_suspect_tile(L, t)) L.count[MGC_CNT_CHANGED] = 1;
+    }
+    void reset_suspect(uint32_t epoch, int list)
+    {
+        HostBlock x(S);
+        for (int t = 0; t < L.ntiles; ++t) mgc_reset_suspect_tile(x, L, t, epoch, list);
+    }
     void discharge(int lst, uint32_t phase, int cycles, int sweeps)
     {
         HostBlock x(S);
@@ -230,6 +241,8 @@ int hostsim_labels(void* h, uint8_t* out) { ((HostDev*)h)->labels(out); return 0
 int hostsim_solve(const int64_t* shape, const double* w0, const double* w1, const double* w2, const double* trcap,
                   int rounds, int cycles, int sweeps, int max_outer, uint8_t* labels_out, int64_t* stats_out)
 {
+    const int incremental = max_outer >= 0;
+    if (max_outer < 0) max_outer = -max_outer - 1; /* negative: from-scratch relabels only (A/B tests) */
     HostDev* d = (HostDev*)hostsim_create(shape, 0, 1);
     d->load(w0, w1, w2, trcap);
     MgcSolveParams P = mgc_default_params();
@@ -237,6 +250,7 @@ int hostsim_solve(const int64_t* shape, const double* w0, const double* w1, cons
     if (cycles > 0) P.max_cycles = cycles;
     if (sweeps > 0) P.max_sweeps = sweeps;
     if (max_outer > 0) P.max_outer = max_outer;
+    P.incremental_relabel = incremental;
     MgcSolveStats st;
     const int rc = mgc_solve(*d, d->L, P, st);
     memcpy(stats_out, &st, sizeof(st));
@@ -260,6 +274,8 @@ struct HostDev26 {
     void zero_count(int i) { L.count[i] = 0; }
     void read_counts(int* out) { memcpy(out, L.count, MGC_NCOUNT * sizeof(int)); }
     void absorb_all() {}
+    void suspect_pass() {}
+    void reset_suspect(uint32_t, int) {}
     void relabel_all(uint32_t epoch, int next)
     {
         HostBlock26 x(S);
