@@ -34,6 +34,17 @@ B_ALG_6CONN = 71.0  # algorithmic bytes per voxel, SURVEY.md 8(d): 4 + 2 + 2*(3*
 HBM_PEAK_GBS = 8000.0  # /opt/skills/guides/MI355X_MICROARCH.md
 
 
+def pmc_traffic_per_launch():
+    """HBM bytes per k_discharge launch from the committed rocprofv3 PMC passes (profiles/pmc_discharge.json, written by
+    tools/rocpd_summary.py from `rocprofv3 --pmc FETCH_SIZE` / `--pmc WRITE_SIZE` runs of this very command).
+    FETCH_SIZE is doubled as MI355X_MICROARCH.md (HBM section) prescribes for wide coalesced reads on gfx950."""
+    path = os.path.join(ROOT, "profiles", "pmc_discharge.json")
+    if not os.path.exists(path):
+        return None
+    d = json.load(open(path))
+    return int((2.0 * d["fetch_kib_per_launch"] + d["write_kib_per_launch"]) * 1024)
+
+
 def cpu_baseline(sample_n):
     """Reference BK (oracle/_ref, or the C restatement when it did not travel) on a bounded sample."""
     from medpy_amd import synthetic
@@ -182,7 +193,7 @@ def main():
                           "tile_discharges": acc["discharge_tiles"] / args.steps, "tile_relabels": acc["relabel_tiles"] / args.steps},
             "job_roofline_frac": round(value * 1e6 / world * B_ALG_6CONN / (HBM_PEAK_GBS * 1e9), 6),
             "roofline": {"bound": "hbm", "kernel": "k_discharge", "achieved": round(achieved, 2), "peak": HBM_PEAK_GBS,
-                         "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBS, 5), "traffic": None,
+                         "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBS, 5), "traffic": pmc_traffic_per_launch(),
                          "avg_launch_ms": round(avg_ms, 4), "launches_per_step": launches / args.steps,
                          "voxels_per_launch": round(vox_per_launch, 1), "bytes_per_voxel": B_ALG_6CONN},
         }

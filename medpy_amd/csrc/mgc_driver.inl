@@ -65,9 +65,9 @@ static inline MgcSolveParams mgc_default_params()
 {
     MgcSolveParams p;
     /* tuned on MI355X at 256^3 / 512^3 (tools/gpu_sweep.py; every schedule gives the same labels) */
-    p.rounds_per_relabel = 12;
-    p.max_cycles = 4;
-    p.max_sweeps = 8;
+    p.rounds_per_relabel = 8;
+    p.max_cycles = 3;
+    p.max_sweeps = 4;
     p.max_outer = 100000;
     p.relabel_batch = 8;
     p.check_rounds = 4;

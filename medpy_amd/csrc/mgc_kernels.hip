@@ -67,6 +67,8 @@ struct GpuBlockT {
     __device__ __forceinline__ uint32_t atomic_exch(uint32_t* p, uint32_t v) { return atomicExch(p, v); }
     __device__ __forceinline__ void atomic_or(uint32_t* p, uint32_t v) { atomicOr(p, v); }
     __device__ __forceinline__ void atomic_and(uint32_t* p, uint32_t v) { atomicAnd(p, v); }
+    /* order this wave's LDS accesses (lockstep execution makes them visible to its own lanes) */
+    __device__ __forceinline__ void wave_fence() { __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront"); __builtin_amdgcn_wave_barrier(); }
     /* development aid: cycles spent since the previous mark go to section `id` (count in id + 8).  Accumulated in
      * lane 0's registers and flushed once per workgroup (flush_marks), so the probe does not perturb the kernel. */
     unsigned long long last = 0;

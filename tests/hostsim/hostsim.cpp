@@ -49,6 +49,7 @@ struct HostBlockT {
     void atomic_or(uint32_t* p, uint32_t v) { *p |= v; }
     void atomic_and(uint32_t* p, uint32_t v) { *p &= v; }
     void mark(const MgcLattice&, int) {}
+    void wave_fence() {}
 };
 typedef HostBlockT<MgcTileShared> HostBlock;
 typedef HostBlockT<MgcTileShared26> HostBlock26;

@@ -9,6 +9,8 @@ g = VoxelGraph((n, n, n))
 g._set_boundary("difference_exponential", s["image"], s["sigma"], False)
 g._set_markers(s["fg"], s["bg"])
 g._build(); g.maxflow()
+if len(sys.argv) > 2:
+    g.set_param("grid_cap", int(sys.argv[2]))
 g.set_param("profile_sections", 1)
 g._build(); t0 = time.perf_counter(); g.maxflow(); dt = time.perf_counter() - t0
 st = g.stats(); pr = g.profile()

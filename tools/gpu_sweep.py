@@ -10,13 +10,14 @@ s = getattr(synthetic, gen)((n, n, n))
 g = VoxelGraph((n, n, n))
 g._set_boundary("difference_exponential", s["image"], s["sigma"], False)
 g._set_markers(s["fg"], s["bg"])
-base = dict(rounds_per_relabel=8, max_cycles=8, max_sweeps=32, relabel_batch=4, check_rounds=2, grid_cap=2048)
+base = dict(rounds_per_relabel=12, max_cycles=4, max_sweeps=8, relabel_batch=8, check_rounds=4, grid_cap=4096)
 grid = [dict()]
-for k, vals in dict(rounds_per_relabel=[2, 4, 16, 32, 64], max_cycles=[1, 2, 4, 16], max_sweeps=[4, 8, 16, 64],
-                    relabel_batch=[1, 2, 8, 16], check_rounds=[1, 4, 8], grid_cap=[512, 1024, 4096]).items():
+for k, vals in dict(rounds_per_relabel=[2, 3, 4, 6, 8, 16], max_cycles=[1, 2, 3, 6, 8], max_sweeps=[2, 4, 6, 12, 16],
+                    check_rounds=[1, 2, 8], grid_cap=[1024, 2048, 8192]).items():
     grid += [{k: v} for v in vals]
-grid += [dict(rounds_per_relabel=16, max_cycles=4), dict(rounds_per_relabel=16, max_cycles=2, max_sweeps=16),
-         dict(rounds_per_relabel=32, max_cycles=4, relabel_batch=8), dict(rounds_per_relabel=16, relabel_batch=8, check_rounds=4)]
+grid += [dict(rounds_per_relabel=4, max_cycles=2), dict(rounds_per_relabel=4, max_cycles=2, max_sweeps=4), dict(rounds_per_relabel=6, max_cycles=2, max_sweeps=6),
+         dict(rounds_per_relabel=3, max_cycles=2, max_sweeps=4, check_rounds=1), dict(rounds_per_relabel=6, max_cycles=3, max_sweeps=4),
+         dict(rounds_per_relabel=8, max_cycles=2, max_sweeps=4), dict(rounds_per_relabel=4, max_cycles=3, max_sweeps=6, check_rounds=2)]
 g.set_param("kernel_timing", 0)
 ref = None
 for over in grid:

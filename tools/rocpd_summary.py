@@ -17,6 +17,16 @@ def main():
         tot = sum(r[2] for r in rows) or 1
         for n, c, s, a, mn, mx in rows:
             print('"%s",%d,%.3f,%.3f,%.3f,%.3f,%.2f' % (n, c, s / 1e3, a / 1e3, mn / 1e3, mx / 1e3, 100.0 * s / tot))
+    elif mode == "json":
+        # python tools/rocpd_summary.py json <fetch.db> <write.db> > profiles/pmc_discharge.json
+        import json
+        out = {}
+        for key, db in (("fetch_kib_per_launch", sys.argv[2]), ("write_kib_per_launch", sys.argv[3])):
+            c = sqlite3.connect(db).cursor()
+            n, v = c.execute("select count(*), avg(value) from counters_collection where kernel_name like 'k_discharge%'").fetchone()
+            out[key] = v
+            out[key.replace("kib_per_launch", "launches")] = n
+        print(json.dumps(out))
     else:
         print("kernel,counter,dispatches,sum_value,avg_value_per_dispatch,avg_duration_us")
         rows = cur.execute("select kernel_name, counter_name, count(*), sum(value), avg(value), avg(duration) from counters_collection "
