@@ -29,7 +29,7 @@
 
 #include "mgc_common.h"
 
-struct MgcTileShared {
+struct alignas(16) MgcTileShared {
     int32_t hs[1000];          /* 10x10x10 distance labels: the tile plus a one-voxel halo */
     double  out[2][MGC_TV];    /* per-direction push hand-off, double buffered             */
     double  r[6][MGC_TV];      /* residual n-link capacities of the tile being discharged  */
@@ -339,18 +339,17 @@ MGC_HD void mgc_discharge_tile(X& x, const MgcLattice& L, int tile, uint32_t pha
     /* was two dependent trips to HBM: (1) neighbour outbox flags + the tile's own state, issued together;
      * kept for reference: everything is fetched in ONE trip now */
     x.par([&](int t) {
-        /* issue the eight state loads FIRST: the halo / inbox code below branches on loaded values, and loads placed
+        /* issue the state loads FIRST: the halo / inbox code below branches on loaded values, and loads placed
          * after such a branch would only be issued once the first batch has returned (a second trip to HBM) */
-        double rr[6];
+        /* the 24 KiB of residuals go HBM -> LDS directly (global_load_lds DMA on gfx950): no VGPR round trip, which
+         * is what used to spill in this phase */
+        x.async_to_lds(t, &x.S.r[0][0], t_rcap, 6 * MGC_TV * (int)sizeof(double));
         e[t] = t_excess[(unsigned)t];
         snk[t] = t_sink[(unsigned)t];
-#pragma unroll
-        for (int d = 0; d < 6; ++d) rr[d] = t_rcap[(unsigned)(d * MGC_TV + t)];
         mgc_load_nbrs(x, L, tile, t);
         mgc_load_halo_inbox(x, L, tile, t);
-#pragma unroll
-        for (int d = 0; d < 6; ++d) x.S.r[d][t] = rr[d];
         ob0[t] = ob1[t] = ob2[t] = 0.0;
+        x.async_wait(); /* the DMA must have landed before the barrier that ends this step */
     });
     x.par([&](int t) { /* absorb the staged inbox (LDS only): e += delta, reverse residual += delta, fixed face order */
         const int z = t >> 6, y = (t >> 3) & 7, xx = t & 7;
@@ -387,6 +386,13 @@ MGC_HD void mgc_discharge_tile(X& x, const MgcLattice& L, int tile, uint32_t pha
         for (int sw = 0; sw < max_sweeps; ++sw, ++sweep_id) {
             const int fl = sweep_id & 1;
             /* 7 steps: step s pushes along direction s (s < 6) after receiving direction s-1 */
+            /* unrolled: with a run-time direction the seven steps cost 2.7x more (measured: 10.8k vs 4.0k cycles per
+             * sweep); the price is ~30 hoisted LDS addresses, i.e. some scratch spills at the 64-VGPR budget */
+#if defined(MGC_NOUNROLL_STEPS)
+#pragma nounroll
+#else
+#pragma unroll
+#endif
             for (int s = 0; s <= 6; ++s) {
                 x.par([&](int t) {
                     const int z = t >> 6, y = (t >> 3) & 7, xx = t & 7;

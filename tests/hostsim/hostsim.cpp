@@ -50,6 +50,8 @@ struct HostBlockT {
     void atomic_and(uint32_t* p, uint32_t v) { *p &= v; }
     void mark(const MgcLattice&, int) {}
     void wave_fence() {}
+    void async_to_lds(int t, void* dst, const void* src, int bytes) { if (t == 0) memcpy(dst, src, (size_t)bytes); }
+    void async_wait() {}
 };
 typedef HostBlockT<MgcTileShared> HostBlock;
 typedef HostBlockT<MgcTileShared26> HostBlock26;
