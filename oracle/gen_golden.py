@@ -158,5 +158,29 @@ def main():
         print(f, os.path.getsize(os.path.join(OUT, f)))
 
 
+def main_b0():
+    """Real 2-D data: the reference's notebook fixture (notebooks/scripts/resources/b0.nii.gz + b0markers.nii.gz,
+    1024x1024 uint16) through the reference pipeline; loaded the way medpy.io.load would hand it over ((x, y) view)."""
+    from medpy_amd import io
+    gc = import_reference_graphcut()
+    res = os.path.join(os.environ.get("MEDPY_REFERENCE", "/root/reference"), "notebooks", "scripts", "resources")
+    img, _ = io.load(os.path.join(res, "b0.nii.gz"))
+    markers, _ = io.load(os.path.join(res, "b0markers.nii.gz"))
+    fg, bg = (markers == 1), (markers == 2)
+    store = {"image": np.ascontiguousarray(img).astype(np.uint8) if img.max() < 256 else np.ascontiguousarray(img),
+             "image_dtype": np.asarray(str(img.dtype)), "markers": np.ascontiguousarray(markers).astype(np.uint8)}
+    for term, sigma in (("difference_exponential", 10.0), ("difference_division", 10.0)):
+        r = run_reference(gc, fg, bg, term, img, sigma)
+        store[term + "/labels"] = np.packbits(r["labels"])
+        store[term + "/flow"] = r["flow"]
+        store[term + "/sigma"] = np.float64(sigma)
+        print(term, "flow", r["flow"], "fg fraction", r["labels"].mean())
+    np.savez_compressed(os.path.join(OUT, "reference_b0.npz"), **store)
+    print("reference_b0.npz", os.path.getsize(os.path.join(OUT, "reference_b0.npz")))
+
+
 if __name__ == "__main__":
-    main()
+    if len(sys.argv) > 1 and sys.argv[1] == "b0":
+        main_b0()
+    else:
+        main()

@@ -1,0 +1,90 @@
+"""CLI edge: medpy_amd.io layout contract and the command line that mirrors
+reference bin/medpy_graphcut_voxel.py.  CPU part here; the end-to-end runs need a GPU (marked)."""
+import os
+
+import numpy as np
+import pytest
+
+from oracle import pipeline
+
+
+def _b0(golden_dir):
+    z = np.load(os.path.join(golden_dir, "reference_b0.npz"))
+    img = z["image"].astype(np.dtype(str(z["image_dtype"])))
+    return z, img, z["markers"]
+
+
+def test_io_roundtrip_and_layout(tmp_path):
+    from medpy_amd import io
+    rng = np.random.default_rng(0)
+    vol = rng.integers(0, 4000, (5, 7, 9)).astype(np.uint16)  # indexed (x, y, z)
+    hdr = io.Header((0.5, 1.25, 3.0))
+    for name in ("a.nii", "a.nii.gz", "a.npy"):
+        p = str(tmp_path / name)
+        io.save(vol, p, hdr, force=True)
+        back, h = io.load(p)
+        np.testing.assert_array_equal(back, vol)
+        if name != "a.npy":
+            assert io.get_pixel_spacing(h) == (0.5, 1.25, 3.0)
+            assert back.flags["F_CONTIGUOUS"]  # transposed view, as reference io/load.py:127 returns it
+    with pytest.raises(IOError):
+        io.save(vol, str(tmp_path / "a.nii"), hdr, force=False)  # exists, no force (save.py:75-78)
+    io.save(vol > 100, str(tmp_path / "m.nii.gz"), hdr, force=True)
+    assert io.load(str(tmp_path / "m.nii.gz"))[0].dtype == np.uint8  # bool -> uint8, save.py:104-106
+
+
+def test_oracle_matches_reference_on_real_data():
+    """the reference's notebook fixture b0 (1024x1024 uint16): oracle pipeline == reference pipeline (bitwise flow, labels)"""
+    from conftest import GOLDEN
+    z, img, markers = _b0(GOLDEN)
+    fg, bg = markers == 1, markers == 2
+    for term in ("difference_exponential", "difference_division"):
+        cut = pipeline.graphcut_voxel(fg, bg, kind="port", term=term, image=img, sigma=float(z[term + "/sigma"]))
+        ref = np.unpackbits(z[term + "/labels"])[: img.size].reshape(img.shape).astype(bool)
+        np.testing.assert_array_equal(cut.labels, ref)
+        assert cut.flow == float(z[term + "/flow"])
+
+
+def test_cli_parser_matches_reference_surface():
+    from medpy_amd.cli.graphcut_voxel import BOUNDARY_TERMS, getParser
+    a = getParser().parse_args(["15", "img.nii", "markers.nii", "out.nii", "--boundary", "max_div", "-s", "-f", "-v"])
+    assert (a.sigma, a.badditional, a.markers, a.output, a.boundary, a.spacing, a.force, a.verbose, a.debug) == (
+        15.0, "img.nii", "markers.nii", "out.nii", "max_div", True, True, True, False)
+    assert getParser().parse_args(["1", "a", "b", "c"]).boundary == "diff_exp"  # reference default (:218)
+    assert list(BOUNDARY_TERMS) == ["diff_linear", "diff_exp", "diff_div", "diff_pow", "max_linear", "max_exp", "max_div", "max_pow"]
+
+
+@pytest.mark.gpu
+def test_cli_end_to_end_real_data(tmp_path):
+    """`medpy_amd_graphcut_voxel.py sigma b0 markers out` == the reference's output on its own notebook fixture"""
+    from conftest import GOLDEN
+    from medpy_amd import io
+    from medpy_amd.cli.graphcut_voxel import main
+    z, img, markers = _b0(GOLDEN)
+    hdr = io.Header((1.0, 1.0))
+    io.save(img, str(tmp_path / "b0.nii.gz"), hdr, True)
+    io.save(markers, str(tmp_path / "b0markers.nii.gz"), hdr, True)
+    for term, flag in (("difference_division", "diff_div"), ("difference_exponential", "diff_exp")):
+        out = str(tmp_path / ("seg_%s.nii.gz" % flag))
+        assert main([str(float(z[term + "/sigma"])), str(tmp_path / "b0.nii.gz"), str(tmp_path / "b0markers.nii.gz"), out,
+                     "--boundary", flag, "-f"]) == 0
+        seg, _ = io.load(out)
+        ref = np.unpackbits(z[term + "/labels"])[: img.size].reshape(img.shape)
+        nbad = int((seg != ref).sum())
+        print(term, "voxels differing from the reference:", nbad)
+        # uint8-valued image: weights repeat everywhere -> exact ties between cuts (DESIGN.md "Parity limits")
+        assert nbad <= 64
+    assert main(["10", str(tmp_path / "b0.nii.gz"), str(tmp_path / "b0markers.nii.gz"), out]) == -1  # exists, no -f
+
+
+@pytest.mark.gpu
+def test_cli_npy_3d_with_spacing(tmp_path):
+    from medpy_amd import io, synthetic
+    from medpy_amd.cli.graphcut_voxel import main
+    s = synthetic.sphere((24, 32, 20))
+    np.save(tmp_path / "img.npy", s["image"])
+    np.save(tmp_path / "markers.npy", s["fg"].astype(np.uint8) + 2 * s["bg"].astype(np.uint8))
+    out = str(tmp_path / "seg.npy")
+    assert main(["15", str(tmp_path / "img.npy"), str(tmp_path / "markers.npy"), out, "-s"]) == 0
+    ref = pipeline.graphcut_voxel(s["fg"], s["bg"], term="difference_exponential", image=s["image"], sigma=15.0, spacing=(1.0, 1.0, 1.0))
+    np.testing.assert_array_equal(np.load(out).astype(bool), ref.labels)
