@@ -37,6 +37,7 @@
 #define MGC_ST_SINK 2u
 #define MGC_ST_DIRTY 4u
 #define MGC_ST_SUSPECT 8u
+#define MGC_ST_EXCESS 16u      /* some voxel of the tile holds excess (maintained by build / absorb / discharge) */
 #define MGC_ST_DEP_SHIFT 8
 #define MGC_CNT_CHANGED 10     /* counter slot: suspect-closure pass changed something */
 
@@ -66,7 +67,7 @@ struct MgcLattice {
     uint32_t* oflags;         /* [ntiles] bit f: obox[f] holds something            */
     /* work lists: [0],[1] = discharge lists of colour 0 / 1 being consumed; [2],[3] = being produced;
        [4],[5] = relabel list consumed / produced */
-    int32_t*  list[18];       /* 26-neighbourhood: [0..15] discharge lists (target phase & 15), [16],[17] relabel */
+    int32_t*  list[20];       /* 26-neighbourhood: [0..15] discharge lists (target phase & 15), [16],[17] relabel */
     int32_t*  count;          /* [MGC_NCOUNT] device resident: [0..5] list lengths, [6] active tiles found by the last
                                  activation, [8]/[9] running totals of tiles discharged / relabelled            */
     uint32_t* stamp;          /* [ntiles] de-duplication stamp for list appends (discharge) */

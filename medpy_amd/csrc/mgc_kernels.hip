@@ -232,6 +232,80 @@ __global__ __launch_bounds__(MGC_TV) void k_reset_suspect(MgcLattice L, uint32_t
     }
 }
 
+/* Tile-level filters: ONE THREAD PER TILE decides whether the tile needs the 512-lane operation at all and, if so,
+ * appends it to a scratch list (one atomic per wave).  mode 0: a neighbour left flow in its outbox for this tile;
+ * mode 1: the tile holds excess (status bit); mode 2: the tile is suspect. */
+__global__ void k_filter(MgcLattice L, int mode, int list, int cnt)
+{
+    for (int base = blockIdx.x * blockDim.x; base < L.ntiles; base += gridDim.x * blockDim.x) { /* uniform per block */
+        const int tile = base + (int)threadIdx.x;
+        bool take = false;
+        if (tile < L.ntiles && mgc_owned(L, tile)) {
+            if (mode == 0) {
+                int tz, ty, tx;
+                mgc_tile_coords(L, tile, tz, ty, tx);
+                for (int f = 0; f < 6 && !take; ++f) {
+                    const int nt = mgc_tile_nbr(L, tz, ty, tx, f);
+                    take = nt >= 0 && ((L.oflags[nt] >> (f ^ 1)) & 1u);
+                }
+            } else if (mode == 1) {
+                take = (L.status[tile] & MGC_ST_EXCESS) != 0;
+            } else {
+                take = (L.status[tile] & MGC_ST_SUSPECT) != 0;
+            }
+        }
+        const unsigned long long m = __ballot(take);
+        if (m) {
+            int pos = 0;
+            if ((threadIdx.x & 63) == 0) pos = atomicAdd(&L.count[cnt], __popcll(m));
+            pos = __shfl(pos, 0);
+            if (take) L.list[list][pos + __popcll(m & ((1ull << (threadIdx.x & 63)) - 1ull))] = tile;
+        }
+    }
+}
+
+__global__ void k_count_status(MgcLattice L, uint32_t bit, int cnt)
+{
+    for (int tile = blockIdx.x * blockDim.x + threadIdx.x; tile < L.ntiles; tile += gridDim.x * blockDim.x)
+        if (L.status[tile] & bit) atomicAdd(&L.count[cnt], 1);
+}
+
+__global__ __launch_bounds__(MGC_TV) void k_absorb_list(MgcLattice L, int list, int cnt)
+{
+    __shared__ MgcTileShared S;
+    GpuBlock x(S);
+    const int n = L.count[cnt];
+    for (int i = blockIdx.x; i < n; i += gridDim.x) {
+        x.new_tile();
+        mgc_absorb_tile(x, L, L.list[list][i]);
+        __syncthreads();
+    }
+}
+
+__global__ __launch_bounds__(MGC_TV) void k_activate_list(MgcLattice L, int list, int cnt, uint32_t phase)
+{
+    __shared__ MgcTileShared S;
+    GpuBlock x(S);
+    const int n = L.count[cnt];
+    for (int i = blockIdx.x; i < n; i += gridDim.x) {
+        x.new_tile();
+        mgc_activate_tile(x, L, L.list[list][i], phase);
+        __syncthreads();
+    }
+}
+
+__global__ __launch_bounds__(MGC_TV) void k_reset_suspect_list(MgcLattice L, int list, int cnt, uint32_t epoch, int out_list)
+{
+    __shared__ MgcTileShared S;
+    GpuBlock x(S);
+    const int n = L.count[cnt];
+    for (int i = blockIdx.x; i < n; i += gridDim.x) {
+        x.new_tile();
+        mgc_reset_suspect_tile(x, L, L.list[list][i], epoch, out_list);
+        __syncthreads();
+    }
+}
+
 __global__ __launch_bounds__(MGC_TV) void k_activate(MgcLattice L, uint32_t phase)
 {
     __shared__ MgcTileShared S;
@@ -481,11 +555,12 @@ __global__ __launch_bounds__(MGC_TV) void k_build(MgcLattice L, MgcBuildArgs A)
             for (int k = 0; k < 8; ++k) L.obox[(int64_t)tile * 6 * MGC_TF + t * 8 + k] = 0.0;
         }
         const int any_sink = __syncthreads_or(tr < 0.0);
+        const int any_exc = __syncthreads_or(tr > 0.0);
         if (t == 0) {
             L.oflags[tile] = 0;
             L.stamp[tile] = 0;
             L.rstamp[tile] = 0;
-            L.status[tile] = any_sink ? 2u : 0u;
+            L.status[tile] = (any_sink ? MGC_ST_SINK : 0u) | (any_exc ? MGC_ST_EXCESS : 0u);
         }
         const double s = mgc_block_sum(fc, scratch);
         if (t == 0) A.fpart[tile] = mgc_owned(L, tile) ? s : 0.0;
@@ -714,6 +789,8 @@ struct mgc_graph {
     double flow_const = 0.0, flow = 0.0;
     MgcSolveParams params = mgc_default_params();
     int grid_cap = 4096;
+    int use_filters = 3; /* bit0 absorb, bit1 activate, bit2 reset-suspect go through the tile-level filter.  Bit2 is off:
+                            measured on MI355X it doubles the number of global relabels (cause not understood yet) */
     mgc_stats stats{};
     int64_t device_bytes = 0;
     std::string err;
@@ -795,10 +872,18 @@ struct HipDevT {
         memcpy(out, h->h_count, MGC_NCOUNT * sizeof(int32_t));
         readbacks++;
     }
+    int filter_grid() const { const int g = (h->L.ntiles + 255) / 256; return g < 1024 ? g : 1024; }
     void absorb_all()
     {
         if constexpr (FULL) return; /* no outboxes: neighbours are updated in place */
-        else { hipLaunchKernelGGL(k_absorb, dim3(grid(h->L.ntiles)), dim3(MGC_TV), 0, h->stream, h->L); check(hipGetLastError()); }
+        else if (!(h->use_filters & 1)) { hipLaunchKernelGGL(k_absorb, dim3(grid(h->L.ntiles)), dim3(MGC_TV), 0, h->stream, h->L); check(hipGetLastError()); }
+        else {
+            /* one thread per tile finds the tiles with a pending inbox; only those get a workgroup */
+            zero_count(11);
+            hipLaunchKernelGGL(k_filter, dim3(filter_grid()), dim3(256), 0, h->stream, h->L, 0, 6, 11);
+            hipLaunchKernelGGL(k_absorb_list, dim3(grid(h->L.ntiles)), dim3(MGC_TV), 0, h->stream, h->L, 6, 11);
+            check(hipGetLastError());
+        }
     }
     void relabel_all(uint32_t epoch, int next)
     {
@@ -829,7 +914,14 @@ struct HipDevT {
     {
         if constexpr (!FULL) {
             const int id = time_begin(1);
-            hipLaunchKernelGGL(k_reset_suspect, dim3(grid(h->L.ntiles)), dim3(MGC_TV), 0, h->stream, h->L, epoch, list);
+            if (!(h->use_filters & 4)) hipLaunchKernelGGL(k_reset_suspect, dim3(grid(h->L.ntiles)), dim3(MGC_TV), 0, h->stream, h->L, epoch, list);
+            else {
+            zero_count(11);
+            if (getenv("MGC_DEBUG_SUSPECT")) { hipLaunchKernelGGL(k_count_status, dim3(256), dim3(256), 0, h->stream, h->L, (uint32_t)MGC_ST_SUSPECT, 13); }
+            hipLaunchKernelGGL(k_filter, dim3(filter_grid()), dim3(256), 0, h->stream, h->L, 2, 6, 11);
+            hipLaunchKernelGGL(k_reset_suspect_list, dim3(grid(h->L.ntiles)), dim3(MGC_TV), 0, h->stream, h->L, 6, 11, epoch, list);
+            if (getenv("MGC_DEBUG_SUSPECT")) { hipLaunchKernelGGL(k_count_status, dim3(256), dim3(256), 0, h->stream, h->L, (uint32_t)MGC_ST_SUSPECT, 14); }
+            }
             check(hipGetLastError());
             time_end(id);
             relabel_launches++;
@@ -838,7 +930,13 @@ struct HipDevT {
     void activate_all(uint32_t phase)
     {
         if constexpr (FULL) hipLaunchKernelGGL(k26_activate, dim3(grid(h->L.ntiles)), dim3(MGC_TV), 0, h->stream, h->L, phase);
-        else hipLaunchKernelGGL(k_activate, dim3(grid(h->L.ntiles)), dim3(MGC_TV), 0, h->stream, h->L, phase);
+        else if (!(h->use_filters & 2)) hipLaunchKernelGGL(k_activate, dim3(grid(h->L.ntiles)), dim3(MGC_TV), 0, h->stream, h->L, phase);
+        else {
+            /* only tiles whose status says "holds excess" are examined voxel by voxel */
+            zero_count(12);
+            hipLaunchKernelGGL(k_filter, dim3(filter_grid()), dim3(256), 0, h->stream, h->L, 1, 7, 12);
+            hipLaunchKernelGGL(k_activate_list, dim3(grid(h->L.ntiles)), dim3(MGC_TV), 0, h->stream, h->L, 7, 12, phase);
+        }
         check(hipGetLastError());
     }
     void discharge(int lst, uint32_t phase, int cycles, int sweeps)
@@ -953,7 +1051,7 @@ static int mgc_create_impl(int ndim, const int64_t* shape, int connectivity, int
         if ((rc = mgc_alloc(h, &L.rmask32, nv))) return rc;
     }
     if ((rc = mgc_alloc(h, &L.oflags, nt))) return rc;
-    for (int i = 0; i < (L.ndir == 6 ? 6 : 18); ++i)
+    for (int i = 0; i < (L.ndir == 6 ? 8 : 18); ++i)
         if ((rc = mgc_alloc(h, &L.list[i], nt))) return rc;
     if ((rc = mgc_alloc(h, &L.count, (int64_t)MGC_NCOUNT))) return rc;
     if ((rc = mgc_alloc(h, &L.stamp, nt))) return rc;
@@ -1609,6 +1707,7 @@ int mgc_set_param(mgc_handle h, const char* name, int64_t value)
     else if (!strcmp(name, "relabel_batch") && value > 0) h->params.relabel_batch = (int)value;
     else if (!strcmp(name, "check_rounds") && value > 0) h->params.check_rounds = (int)value;
     else if (!strcmp(name, "incremental_relabel")) h->params.incremental_relabel = value != 0;
+    else if (!strcmp(name, "use_filters")) h->use_filters = (int)value;
     else if (!strcmp(name, "kernel_timing")) h->timing = value != 0;
     else if (!strcmp(name, "profile_sections")) {
         if (value && !h->L.prof) {

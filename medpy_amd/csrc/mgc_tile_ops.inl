@@ -40,6 +40,7 @@ struct alignas(16) MgcTileShared {
     int32_t depflag[8];        /* relabel: face f supports some label of the tile           */
     int32_t flag[2];
     int32_t satflag;           /* discharge: some arc (or sink link) of the tile was saturated */
+    int32_t excflag;           /* discharge: some voxel still holds excess at store time      */
 };
 
 MGC_HD int mgc_hs_index(int z, int y, int x) { return (z + 1) * 100 + (y + 1) * 10 + (x + 1); }
@@ -80,6 +81,7 @@ MGC_HD void mgc_load_nbrs(X& x, const MgcLattice& L, int tile, int t)
     }
     if (t < 2) x.S.flag[t] = 0;
     if (t == 2) x.S.satflag = 0;
+    if (t == 3) x.S.excflag = 0;
 }
 
 /* halo labels: 6 faces x 64 voxels, read from the neighbour tiles' label arrays */
@@ -284,7 +286,10 @@ MGC_HD void mgc_absorb_tile(X& x, const MgcLattice& L, int tile)
             L.rmask[base + t] = (uint8_t)m;
         }
     });
-    x.par([&](int t) { mgc_clear_inbox_flags(x, L, t); });
+    x.par([&](int t) {
+        mgc_clear_inbox_flags(x, L, t);
+        if (t == 6) L.status[tile] |= MGC_ST_EXCESS; /* flow arrived: the tile may hold excess now */
+    });
 }
 
 /* ---------------------------------------------------------------------------------------
@@ -457,6 +462,7 @@ MGC_HD void mgc_discharge_tile(X& x, const MgcLattice& L, int tile, uint32_t pha
         if (ob0[t] != 0.0) x.S.faceflag[xx == 0 ? 0 : 1] = 1;
         if (ob1[t] != 0.0) x.S.faceflag[y == 0 ? 2 : 3] = 1;
         if (ob2[t] != 0.0) x.S.faceflag[z == 0 ? 4 : 5] = 1;
+        if (e[t] > 0.0) x.S.excflag = 1;
     });
     x.mark(L, 5); /* face flags */
     /* ... then ONE block of global stores: state, masks, labels, outbox, wake-ups */
@@ -483,7 +489,7 @@ MGC_HD void mgc_discharge_tile(X& x, const MgcLattice& L, int tile, uint32_t pha
         }
         if (t == 6 && active) mgc_enqueue(x, L, (int)((phase + 2) & 3u), L.stamp, phase + 2, tile);
         /* DIRTY only if a residual arc disappeared: otherwise no distance in the tile (or through it) can have changed */
-        if (t == 7) L.status[tile] = (L.status[tile] & ~MGC_ST_SINK) | (has_sink ? MGC_ST_SINK : 0u) | (x.S.satflag ? MGC_ST_DIRTY : 0u);
+        if (t == 7) L.status[tile] = (L.status[tile] & ~(MGC_ST_SINK | MGC_ST_EXCESS)) | (has_sink ? MGC_ST_SINK : 0u) | (x.S.satflag ? MGC_ST_DIRTY : 0u) | (x.S.excflag ? MGC_ST_EXCESS : 0u);
     });
     x.mark(L, 3); /* store */
 }

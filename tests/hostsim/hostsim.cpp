@@ -149,6 +149,7 @@ struct HostDev {
                     }
                     const double tr = trcap[id];
                     excess[(int64_t)tile * MGC_TV + loc] = tr > 0 ? tr : 0.0;
+                    if (tr > 0) status[tile] |= MGC_ST_EXCESS;
                     sink[(int64_t)tile * MGC_TV + loc] = tr < 0 ? -tr : 0.0;
                     if (tr < 0) { m |= MGC_MASK_SINK; status[tile] |= 2u; }
                     rmask[(int64_t)tile * MGC_TV + loc] = (uint8_t)m;
