@@ -86,6 +86,24 @@ struct GpuBlockT {
     __device__ __forceinline__ uint32_t atomic_exch(uint32_t* p, uint32_t v) { return atomicExch(p, v); }
     __device__ __forceinline__ void atomic_or(uint32_t* p, uint32_t v) { atomicOr(p, v); }
     __device__ __forceinline__ void atomic_and(uint32_t* p, uint32_t v) { atomicAnd(p, v); }
+    /* ---- exact in-tile labels (executor primitive, see mgc_tile_ops.inl) ----
+     * Chaotic relaxation in LDS (mgc_tile_bfs).  A bit-parallel level-synchronous BFS (lane = (y,x) column, bit z of
+     * a byte = voxel, four ds_bpermute + two shifts per level) was implemented and verified label-for-label against
+     * this form on MI355X, but measured SLOWER: 18.3k cycles per BFS when every wave ran it redundantly, 20.9k with
+     * one wave per tile, vs 15.2k for the relaxation -- ~40 dependent levels x (bpermute latency + a lone wave's
+     * issue rate) cost more than ~24 barrier rounds.  Removed again; the numbers are kept in profiles/README.md. */
+    template <class MaskFn, class RegI>
+    __device__ __forceinline__ void tile_labels(MaskFn mask, RegI& out)
+    {
+        int m = 0; /* the residual mask is evaluated once, not once per relaxation round */
+        par([&](int t) {
+            S.hs[mgc_hs_index(t >> 6, (t >> 3) & 7, t & 7)] = MGC_HINF;
+            m = mask(t);
+        });
+        mgc_tile_bfs(*this, [&](int) { return m; });
+        const int t = lane(); /* own cell, last written by this lane before the barrier that ended the relaxation */
+        out[t] = S.hs[mgc_hs_index(t >> 6, (t >> 3) & 7, t & 7)];
+    }
     /* HBM -> LDS copy without a VGPR round trip: every wave moves 1 KiB chunks (64 lanes x 16 B) with
      * global_load_lds_dwordx4; `bytes` must be a multiple of 1024 and both pointers 16-byte aligned.  Tracked by
      * vmcnt: async_wait() before the barrier that publishes the data. */

@@ -21,6 +21,10 @@
  *   x.any(f)             barrier-OR of f(lane) over all lanes
  *   x.S                  MgcTileShared& (LDS)
  *   x.atomic_add/or/and/exch   device-scope atomics on global words
+ *   x.tile_labels(mask, out)   exact in-tile distance labels from scratch given the halo in x.S.hs: out[lane] and the
+ *                              tile's own cells of x.S.hs.  The fixpoint is unique, so executors may compute it their own
+ *                              way: the host executor relaxes (mgc_tile_bfs below), the GPU executor runs a bit-parallel
+ *                              level-synchronous BFS in every wave (mgc_kernels.hip: GpuBlockT::tile_labels)
  */
 #ifndef MGC_TILE_OPS_INL
 #define MGC_TILE_OPS_INL
@@ -226,7 +230,11 @@ MGC_HD void mgc_relabel_tile(X& x, const MgcLattice& L, int tile, uint32_t next_
                 nt < 0 ? MGC_HINF : L.height[(int64_t)nt * MGC_TV + mgc_face_voxel(f ^ 1, k)];
         }
     });
-    mgc_tile_bfs(x, [&](int t) { return m[t]; });
+    typename X::template Reg<int> hn;
+    x.tile_labels([&](int t) { return m[t]; }, hn);
+    x.par([&](int t) { /* labels never go up within a relabel: keep the better of the old and the recomputed one */
+        if (h0[t] < hn[t]) x.S.hs[mgc_hs_index(t >> 6, (t >> 3) & 7, t & 7)] = h0[t];
+    });
     x.par([&](int t) { /* LDS only: which faces saw a label drop; which faces support a label (incremental relabel) */
         const int z = t >> 6, y = (t >> 3) & 7, xx = t & 7;
         const int me = mgc_hs_index(z, y, xx);
@@ -374,17 +382,13 @@ MGC_HD void mgc_discharge_tile(X& x, const MgcLattice& L, int tile, uint32_t pha
     int sweep_id = 0;
     for (int cyc = 0; cyc < max_cycles; ++cyc) {
         /* exact labels given the frozen halo */
-        x.par([&](int t) {
-            x.S.hs[mgc_hs_index(t >> 6, (t >> 3) & 7, t & 7)] = MGC_HINF;
+        x.tile_labels([&](int t) {
             int m = snk[t] > 0.0 ? MGC_MASK_SINK : 0;
             for (int d = 0; d < 6; ++d) m |= (x.S.r[d][t] > 0.0) ? (1 << d) : 0;
             msk[t] = m;
-        });
-        mgc_tile_bfs(x, [&](int t) { return msk[t]; });
-        active = x.any([&](int t) -> bool {
-            hme[t] = x.S.hs[mgc_hs_index(t >> 6, (t >> 3) & 7, t & 7)];
-            return e[t] > 0.0 && hme[t] < MGC_HINF;
-        });
+            return m;
+        }, hme);
+        active = x.any([&](int t) -> bool { return e[t] > 0.0 && hme[t] < MGC_HINF; });
         x.mark(L, 1); /* in-tile labels */
         if (!active) break;
 

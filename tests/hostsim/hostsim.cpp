@@ -50,6 +50,18 @@ struct HostBlockT {
     void atomic_and(uint32_t* p, uint32_t v) { *p &= v; }
     void mark(const MgcLattice&, int) {}
     void wave_fence() {}
+    /* exact in-tile labels: reference implementation = chaotic relaxation from scratch (mgc_tile_bfs) */
+    template <class MaskFn, class RegI>
+    void tile_labels(MaskFn mask, RegI& out)
+    {
+        int m[MGC_TV];
+        for (int t = 0; t < MGC_TV; ++t) {
+            S.hs[mgc_hs_index(t >> 6, (t >> 3) & 7, t & 7)] = MGC_HINF;
+            m[t] = mask(t);
+        }
+        mgc_tile_bfs(*this, [&](int t) { return m[t]; });
+        for (int t = 0; t < MGC_TV; ++t) out[t] = S.hs[mgc_hs_index(t >> 6, (t >> 3) & 7, t & 7)];
+    }
     void async_to_lds(int t, void* dst, const void* src, int bytes) { if (t == 0) memcpy(dst, src, (size_t)bytes); }
     void async_wait() {}
 };
