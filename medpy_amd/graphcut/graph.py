@@ -176,6 +176,50 @@ class VoxelGraph(object):
         return st.as_dict()
 
 
+class EmbeddedLatticeGraph(object):
+    """`nodes` graph nodes of which the first prod(lattice_shape) form a voxel lattice (the boundary image had another
+    shape than the markers, see GCGraph.record_boundary); the other nodes carry only their marker t-links.  Same surface
+    as VoxelGraph; the lattice part is solved on the GPU, the isolated nodes are read out by the sign of their t-link
+    exactly as BK would (tr_cap < 0: sink tree root -> SINK; otherwise SOURCE, graph.h:561-571)."""
+
+    termtype = termtype
+
+    def __init__(self, nodes, lattice_shape, boundary, fg, bg, device=0, connectivity=None):
+        self._nodes = int(nodes)
+        n = int(numpy.prod(lattice_shape))
+        fg = numpy.zeros(self._nodes, numpy.uint8) if fg is None else numpy.asarray(fg, dtype=numpy.uint8).ravel()
+        bg = numpy.zeros(self._nodes, numpy.uint8) if bg is None else numpy.asarray(bg, dtype=numpy.uint8).ravel()
+        self._inner = VoxelGraph(lattice_shape, device=device, connectivity=connectivity)
+        self._inner._set_boundary(*boundary)
+        self._inner._set_markers(fg[:n].reshape(lattice_shape), bg[:n].reshape(lattice_shape))
+        self._inner._build()
+        tr = fg[n:].astype(numpy.float64) * GCGraph.MAX - bg[n:].astype(numpy.float64) * GCGraph.MAX
+        self._tail_labels = ~(tr < 0)
+        self._tail_flow = float(numpy.sum(numpy.minimum(fg[n:], bg[n:]).astype(numpy.float64)) * GCGraph.MAX)  # graph.h:423
+        self._n = n
+
+    def maxflow(self):
+        return self._inner.maxflow() + self._tail_flow
+
+    def labels(self):
+        return numpy.concatenate([self._inner.labels().ravel(), self._tail_labels])
+
+    def what_segment(self, i):
+        i = int(i)
+        if i < self._n:
+            return self._inner.what_segment(i)
+        return termtype.SOURCE if self._tail_labels[i - self._n] else termtype.SINK
+
+    def get_node_num(self):
+        return self._nodes
+
+    def get_edge(self, i, j):
+        return self._inner.get_edge(i, j) if (i < self._n and j < self._n) else 0.0
+
+    def stats(self):
+        return self._inner.stats()
+
+
 class GCGraph(object):
     """Validating facade handed to the energy terms; reference graph.py:267-596.
 
@@ -207,15 +251,21 @@ class GCGraph(object):
         self.__tr = None  # merged explicit t-links (graph.h:416-425 applied call by call)
         self.__flow_const = 0.0
         self.__graph = None
+        self.__lattice_shape = None  # set when the boundary image has another shape than the markers
 
     # -- fast path hooks used by medpy_amd.graphcut.energy_voxel
     def record_boundary(self, term, image, sigma, spacing):
         image = numpy.asarray(image)
         if image.shape != self.__shape:
-            raise NotImplementedError(
-                "medpy_amd: boundary image shape {} differs from the marker shape {}; the reference numbers "
-                "nodes by the image shape in that case (energy_voxel.py:650-664), which is not a voxel lattice "
-                "of this graph".format(image.shape, self.__shape))
+            # The reference numbers the n-link endpoints by the IMAGE shape (energy_voxel.py:650-664), whatever the
+            # marker shape is (its own tests do that: tests/graphcut_/energy_voxel.py:162-179, 4x4 markers, 3x3 image).
+            # The edges then form a lattice of the image shape over node ids 0..image.size-1; the remaining nodes are
+            # isolated.  Too many ids -> the same ValueError GCGraph.set_nweight raises (graph.py:418-425).
+            if image.size > self.__nodes:
+                raise ValueError("Invalid node id (node_to) of {}. Valid values are 0 to {}.".format(image.size - 1, self.__nodes - 1))
+            if self.__regional is not None or self.__tr is not None or self.__edge_i:
+                raise NotImplementedError("medpy_amd: a boundary image of another shape cannot be combined with other terms")
+            self.__lattice_shape = image.shape
         if self.__boundary is not None:
             raise NotImplementedError("medpy_amd: only one built-in boundary term per graph")
         self.__boundary = (term, image, sigma, spacing)
@@ -300,6 +350,9 @@ class GCGraph(object):
 
     def get_graph(self):
         """Builds the residual lattice in HBM (once) and returns the solver object."""
+        if self.__graph is None and self.__lattice_shape is not None:
+            self.__graph = EmbeddedLatticeGraph(self.__nodes, self.__lattice_shape, self.__boundary, self.__fg, self.__bg,
+                                                device=self.__device, connectivity=self.__connectivity)
         if self.__graph is None:
             g = VoxelGraph(self.__shape, device=self.__device, connectivity=self.__connectivity)
             if self.__boundary is not None:

@@ -149,13 +149,17 @@ class RcclExchange(object):
         return out if out.size > 1 else float(out[0])
 
 
-def solve_slabs(slabs, ex, rounds_per_relabel=12, max_cycles=4, max_sweeps=8, max_outer=100000, check_rounds=1):
-    """Drives the local slabs to a maximum preflow.  Returns a stats dict (global numbers)."""
+def solve_slabs(slabs, ex, rounds_per_relabel=8, max_cycles=3, max_sweeps=4, max_outer=100000, check_rounds=4, relabel_batch=8):
+    """Drives the local slabs to a maximum preflow.  Returns a stats dict (global numbers).
+
+    Every loop decision is taken on globally summed counters, so all ranks run the same control flow.  The counters
+    are only summed every ``relabel_batch`` relabel passes / ``check_rounds`` colour rounds (a pass over an empty list
+    is a no-op), the borders are exchanged after every pass / phase."""
     phase, rep = 4, 2
     for s in slabs:
         s.op(OP_ZERO_COUNT, 8)
         s.op(OP_ZERO_COUNT, 9)
-    st = {"outer": 0, "relabel_passes": 0, "phases": 0, "exchanges": 0, "converged": 0}
+    st = {"outer": 0, "relabel_passes": 0, "phases": 0, "exchanges": 0, "reductions": 0, "converged": 0}
     for _ in range(max_outer):
         # ---- global relabel: tile BFS passes + border label exchange, to a global fixpoint
         for s in slabs:
@@ -170,24 +174,27 @@ def solve_slabs(slabs, ex, rounds_per_relabel=12, max_cycles=4, max_sweeps=8, ma
         st["relabel_passes"] += 1
         st["exchanges"] += 1
         while True:
-            rep += 1
-            cur, nxt = 4 + (rep & 1), 4 + ((rep + 1) & 1)
-            if ex.global_counts()[cur] == 0:
+            for _b in range(relabel_batch):
+                rep += 1
+                cur, nxt = 4 + (rep & 1), 4 + ((rep + 1) & 1)
+                for s in slabs:
+                    s.op(OP_ZERO_COUNT, nxt)
+                    s.op(OP_RELABEL_LIST, cur, rep + 1, nxt)
+                ex.exchange(0, rep + 1, nxt)
+                st["relabel_passes"] += 1
+                st["exchanges"] += 1
+            st["reductions"] += 1
+            if ex.global_counts()[4 + ((rep + 1) & 1)] == 0:  # the last pass (and its exchange) woke nobody anywhere
                 break
-            for s in slabs:
-                s.op(OP_ZERO_COUNT, nxt)
-                s.op(OP_RELABEL_LIST, cur, rep + 1, nxt)
-            ex.exchange(0, rep + 1, nxt)
-            st["relabel_passes"] += 1
-            st["exchanges"] += 1
         st["outer"] += 1
 
         # ---- who can still push towards the sink?
-        phase += 4
+        phase += 8
         for s in slabs:
             for i in (0, 1, 2, 3, 6):
                 s.op(OP_ZERO_COUNT, i)
             s.op(OP_ACTIVATE, phase)
+        st["reductions"] += 1
         if ex.global_counts()[6] == 0:
             st["converged"] = 1
             break
@@ -204,8 +211,9 @@ def solve_slabs(slabs, ex, rounds_per_relabel=12, max_cycles=4, max_sweeps=8, ma
                 st["exchanges"] += 1
                 phase += 1
             if (r + 1) % check_rounds == 0 and r + 1 < rounds_per_relabel:
+                st["reductions"] += 1
                 c = ex.global_counts()
-                if c[phase & 3] + c[(phase + 1) & 3] == 0:
+                if c[0] + c[1] + c[2] + c[3] == 0:
                     break
     c = ex.global_counts()
     st["discharge_tiles"], st["relabel_tiles"] = int(c[8]), int(c[9])

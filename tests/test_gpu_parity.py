@@ -288,3 +288,30 @@ def test_api_contract():
     np.testing.assert_array_equal(vg.labels().ravel().astype(np.uint8), o.labels())
     with pytest.raises(AttributeError):
         gc.graph_from_voxels(np.zeros((2, 2)), np.zeros((2, 2)), boundary_term=lambda a: None)
+
+
+def test_boundary_image_of_another_shape_like_the_reference_tests():
+    """reference tests/graphcut_/energy_voxel.py:152-179 (__test_all_on_image): 4x4 markers with a 3x3 image, all eight
+    terms must run; the reference numbers the edges by the image shape (energy_voxel.py:650-664).  Labels are compared
+    with the oracle built the same way (lattice of the image shape over ids 0..8, ids 9..15 isolated)."""
+    gc = _gc()
+    from oracle import bk
+    fgm = np.zeros((4, 4), bool); fgm[3, 3] = True
+    bgm = np.zeros((4, 4), bool); bgm[0, 0] = True
+    for image in (np.asarray([[-1, 1, -4], [2, -7, 3], [-2.3, 3, -7]], dtype=float), np.zeros((3, 3))):
+        for term in TERMS:
+            g = gc.graph_from_voxels(fgm, bgm, boundary_term=_term_fn(term), boundary_term_args=_term_args(term, image, 1.0, False))
+            g.maxflow()
+            res = np.array([0 if g.termtype.SINK == g.what_segment(i) else 1 for i in range(16)])
+            assert res.shape == (16,)
+            with np.errstate(all="ignore"):
+                w = energy_numpy.boundary_weights(term, image, 1.0)
+            if not np.isnan(np.concatenate([x.ravel() for x in w])).any():
+                o = bk.BKGraph(16, 24)
+                o.sum_lattice((3, 3), w)
+                o.add_tweights([15], [65535.0], [0.0]); o.add_tweights([0], [0.0], [65535.0])
+                o.maxflow()
+                np.testing.assert_array_equal(res, o.labels())
+    with pytest.raises(ValueError):
+        gc.graph_from_voxels(np.zeros((2, 2)), np.zeros((2, 2)), boundary_term=_term_fn("difference_linear"),
+                             boundary_term_args=(np.zeros((3, 3)), False))
