@@ -154,7 +154,9 @@ enum {
     MGC_OP_RELABEL_ALL = 3,  /* a0 = next epoch, a1 = next list             */
     MGC_OP_RELABEL_LIST = 4, /* a0 = list, a1 = next epoch, a2 = next list  */
     MGC_OP_ACTIVATE = 5,     /* a0 = phase                                  */
-    MGC_OP_DISCHARGE = 6     /* a0 = list, a1 = phase, a2 = max cycles, a3 = max sweeps */
+    MGC_OP_DISCHARGE = 6,    /* a0 = list, a1 = phase, a2 = max cycles, a3 = max sweeps */
+    MGC_OP_SUSPECT_PASS = 7, /* one pass of the tile-level suspect closure (sets counter 10 when something changed) */
+    MGC_OP_RESET_SUSPECT = 8 /* a0 = next epoch, a1 = next list: suspect tiles -> labels INF, queued for relabelling */
 };
 int mgc_create_slab(int ndim, const int64_t* global_shape, int connectivity, int device, int rank, int nranks, mgc_handle* out);
 /* info[0..1] = local plane range [first, last) in the global volume (ghost planes included), info[2..3] = owned
@@ -163,7 +165,8 @@ int mgc_slab_info(mgc_handle h, int64_t* info8);
 int mgc_solver_op(mgc_handle h, int op, int64_t a0, int64_t a1, int64_t a2, int64_t a3);
 int mgc_read_counts(mgc_handle h, int32_t* out32); /* 32 counters */
 int mgc_halo_bytes(mgc_handle h, int kind, int64_t* bytes);
-/* side 0 = lower / 1 = upper slab boundary; kind 0 = labels (relabel pass), 1 = labels + outbox flow (phase) */
+/* side 0 = lower / 1 = upper slab boundary; kind 0 = labels (relabel pass), 1 = labels + outbox flow (phase),
+   2 = DIRTY / SUSPECT flags of the border tiles (suspect closure of an incremental relabel) */
 int mgc_halo_pack(mgc_handle h, int side, int kind, void* buf, int buf_on_device);
 int mgc_halo_unpack(mgc_handle h, int side, int kind, const void* buf, int buf_on_device, uint32_t epoch, int list);
 /* after the slab driver has converged: labels of the local planes + this slab's part of the cut capacity */

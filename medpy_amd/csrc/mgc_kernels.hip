@@ -1132,6 +1132,8 @@ int mgc_solver_op(mgc_handle h, int op, int64_t a0, int64_t a1, int64_t a2, int6
     case MGC_OP_RELABEL_LIST: dev.relabel_list((int)a0, (uint32_t)a1, (int)a2); break;
     case MGC_OP_ACTIVATE: dev.activate_all((uint32_t)a0); break;
     case MGC_OP_DISCHARGE: dev.discharge((int)a0, (uint32_t)a1, (int)a2, (int)a3); break;
+    case MGC_OP_SUSPECT_PASS: dev.suspect_pass(); break;
+    case MGC_OP_RESET_SUSPECT: dev.reset_suspect((uint32_t)a0, (int)a1); break;
     default: h->timing = timing; return mgc_fail(h, MGC_ERR_INVALID, "unknown solver op %d", op);
     }
     h->timing = timing;
@@ -1153,7 +1155,7 @@ int mgc_read_counts(mgc_handle h, int32_t* out)
 int mgc_halo_bytes(mgc_handle h, int kind, int64_t* bytes)
 {
     if (!h || !bytes) return MGC_ERR_INVALID;
-    *bytes = mgc_halo_bytes(h->L, kind ? 1 : 0);
+    *bytes = mgc_halo_bytes(h->L, kind);
     return MGC_OK;
 }
 
@@ -1173,7 +1175,7 @@ int mgc_halo_pack(mgc_handle h, int side, int kind, void* buf, int buf_on_device
     if (!h->built) return mgc_fail(h, MGC_ERR_STATE, "mgc_halo_pack before mgc_build");
     if (side == 0 ? h->L.tz_own_lo == 0 : h->L.tz_own_hi == h->L.gz) return mgc_fail(h, MGC_ERR_INVALID, "no neighbour slab on side %d", side);
     MGC_HIP(h, hipSetDevice(h->device));
-    const int64_t bytes = mgc_halo_bytes(h->L, kind ? 1 : 0);
+    const int64_t bytes = mgc_halo_bytes(h->L, kind);
     void* dst = buf;
     if (!buf_on_device) {
         const int rc = mgc_halo_staging(h, bytes);
@@ -1181,7 +1183,7 @@ int mgc_halo_pack(mgc_handle h, int side, int kind, void* buf, int buf_on_device
         dst = h->d_halo;
     }
     const int T = h->L.gy * h->L.gx;
-    hipLaunchKernelGGL(k_halo_pack, dim3(T < 2048 ? T : 2048), dim3(MGC_TV), 0, h->stream, h->L, side, kind ? 1 : 0, dst);
+    hipLaunchKernelGGL(k_halo_pack, dim3(T < 2048 ? T : 2048), dim3(MGC_TV), 0, h->stream, h->L, side, kind, dst);
     MGC_HIP(h, hipGetLastError());
     if (!buf_on_device) MGC_HIP(h, hipMemcpyAsync(buf, dst, (size_t)bytes, hipMemcpyDeviceToHost, h->stream));
     MGC_HIP(h, hipStreamSynchronize(h->stream)); /* the transport runs on the caller's stream / thread */
@@ -1194,7 +1196,7 @@ int mgc_halo_unpack(mgc_handle h, int side, int kind, const void* buf, int buf_o
     if (!h->built) return mgc_fail(h, MGC_ERR_STATE, "mgc_halo_unpack before mgc_build");
     if (side == 0 ? h->L.tz_own_lo == 0 : h->L.tz_own_hi == h->L.gz) return mgc_fail(h, MGC_ERR_INVALID, "no neighbour slab on side %d", side);
     MGC_HIP(h, hipSetDevice(h->device));
-    const int64_t bytes = mgc_halo_bytes(h->L, kind ? 1 : 0);
+    const int64_t bytes = mgc_halo_bytes(h->L, kind);
     const void* src = buf;
     if (!buf_on_device) {
         const int rc = mgc_halo_staging(h, bytes);
@@ -1203,7 +1205,7 @@ int mgc_halo_unpack(mgc_handle h, int side, int kind, const void* buf, int buf_o
         src = h->d_halo;
     }
     const int T = h->L.gy * h->L.gx;
-    hipLaunchKernelGGL(k_halo_unpack, dim3(T < 2048 ? T : 2048), dim3(MGC_TV), 0, h->stream, h->L, side, kind ? 1 : 0, src, epoch, list);
+    hipLaunchKernelGGL(k_halo_unpack, dim3(T < 2048 ? T : 2048), dim3(MGC_TV), 0, h->stream, h->L, side, kind, src, epoch, list);
     MGC_HIP(h, hipGetLastError());
     MGC_HIP(h, hipStreamSynchronize(h->stream));
     return MGC_OK;
@@ -1304,7 +1306,7 @@ int mgc_halo_exchange(mgc_handle h, int kind, uint32_t epoch, int list)
     if (!h->built) return mgc_fail(h, MGC_ERR_STATE, "mgc_halo_exchange before mgc_build");
     if (!h->comm) return mgc_fail(h, MGC_ERR_STATE, "mgc_halo_exchange before mgc_comm_init");
     MGC_HIP(h, hipSetDevice(h->device));
-    kind = kind ? 1 : 0;
+    if (kind < 0 || kind > 2) return mgc_fail(h, MGC_ERR_INVALID, "mgc_halo_exchange: kind must be 0, 1 or 2");
     const int64_t bytes = mgc_halo_bytes(h->L, 1); /* size for the larger kind; reused for both */
     if (h->xchg_cap < bytes) {
         for (int i = 0; i < 4; ++i) {

@@ -550,11 +550,12 @@ MGC_HD void mgc_reset_suspect_tile(X& x, const MgcLattice& L, int tile, uint32_t
  * 1 = upper (face 5, +z).  Buffer layout for T = gy*gx tiles per layer:
  *     double flow[T][64] ; int32 label[T][64] ; int32 flag[T]          (kind 1: discharge phases)
  *     int32 label[T][64]                                              (kind 0: relabel passes)
+ *     int32 status[T]  (DIRTY | SUSPECT bits of the border tile)      (kind 2: suspect closure of an incremental relabel)
  * ------------------------------------------------------------------------------------- */
 MGC_HD int64_t mgc_halo_bytes(const MgcLattice& L, int kind)
 {
     const int64_t T = (int64_t)L.gy * L.gx;
-    return kind ? T * (MGC_TF * 8 + MGC_TF * 4 + 4) : T * MGC_TF * 4;
+    return kind == 2 ? T * 4 : (kind ? T * (MGC_TF * 8 + MGC_TF * 4 + 4) : T * MGC_TF * 4);
 }
 
 /* i = tile index inside the layer; packs the OWNED border tile of `side` */
@@ -568,6 +569,12 @@ MGC_HD void mgc_halo_pack_tile(X& x, const MgcLattice& L, int side, int kind, in
     double* flow = (double*)buf;
     int32_t* lab = kind ? (int32_t*)((char*)buf + T * MGC_TF * 8) : (int32_t*)buf;
     int32_t* flg = (int32_t*)((char*)buf + T * MGC_TF * 12);
+    if (kind == 2) {
+        x.par([&](int t) {
+            if (t == 0) ((int32_t*)buf)[i] = (int32_t)(L.status[tile] & (MGC_ST_DIRTY | MGC_ST_SUSPECT));
+        });
+        return;
+    }
     x.par([&](int t) {
         if (t < MGC_TF) {
             lab[(int64_t)i * MGC_TF + t] = L.height[(int64_t)tile * MGC_TV + mgc_face_voxel(f, t)];
@@ -599,6 +606,15 @@ MGC_HD void mgc_halo_unpack_tile(X& x, const MgcLattice& L, int side, int kind, 
     const double* flow = (const double*)buf;
     const int32_t* lab = kind ? (const int32_t*)((const char*)buf + T * MGC_TF * 8) : (const int32_t*)buf;
     const int32_t* flg = (const int32_t*)((const char*)buf + T * MGC_TF * 12);
+    if (kind == 2) { /* the ghost mirrors the owner's flags; a ghost that turns suspect keeps the closure going */
+        x.par([&](int t) {
+            if (t != 0) return;
+            const uint32_t old = L.status[ghost], msg = (uint32_t)((const int32_t*)buf)[i];
+            L.status[ghost] = (old & ~(MGC_ST_DIRTY | MGC_ST_SUSPECT)) | msg;
+            if ((msg & MGC_ST_SUSPECT) && !(old & MGC_ST_SUSPECT)) L.count[MGC_CNT_CHANGED] = 1;
+        });
+        return;
+    }
     const bool lowered = x.any([&](int t) -> bool {
         bool low = false;
         if (t < MGC_TF) {

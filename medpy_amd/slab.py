@@ -18,7 +18,9 @@ the same code over the host simulator with gloo (tests/test_slab_*.py).
 """
 import numpy as np
 
-OP_ABSORB_ALL, OP_FILL_INF, OP_ZERO_COUNT, OP_RELABEL_ALL, OP_RELABEL_LIST, OP_ACTIVATE, OP_DISCHARGE = range(7)
+(OP_ABSORB_ALL, OP_FILL_INF, OP_ZERO_COUNT, OP_RELABEL_ALL, OP_RELABEL_LIST, OP_ACTIVATE, OP_DISCHARGE, OP_SUSPECT_PASS,
+ OP_RESET_SUSPECT) = range(9)
+CNT_CHANGED = 10  # MGC_CNT_CHANGED (mgc_common.h)
 
 
 class LoopbackExchange(object):
@@ -149,42 +151,65 @@ class RcclExchange(object):
         return out if out.size > 1 else float(out[0])
 
 
-def solve_slabs(slabs, ex, rounds_per_relabel=8, max_cycles=3, max_sweeps=4, max_outer=100000, check_rounds=4, relabel_batch=8):
+def solve_slabs(slabs, ex, rounds_per_relabel=8, max_cycles=3, max_sweeps=4, max_outer=100000, check_rounds=4, relabel_batch=8,
+                incremental_relabel=True):
     """Drives the local slabs to a maximum preflow.  Returns a stats dict (global numbers).
 
-    Every loop decision is taken on globally summed counters, so all ranks run the same control flow.  The counters
-    are only summed every ``relabel_batch`` relabel passes / ``check_rounds`` colour rounds (a pass over an empty list
-    is a no-op), the borders are exchanged after every pass / phase."""
+    Every loop decision that involves the other ranks is taken on globally summed counters, so all ranks run the same
+    outer control flow.  Between two border exchanges of a global relabel every rank iterates its own slabs to a LOCAL
+    fixpoint (labels only go down during a relabel, so stale ghost labels are upper bounds and the chaotic iteration
+    still converges to the exact distances); the borders are exchanged after every colour phase.  Later global
+    relabels are incremental like the single-GPU driver's (mgc_driver.inl): the DIRTY / SUSPECT flags of the border
+    tiles travel as halo kind 2 until the suspect closure is stable everywhere."""
+    relabel_batch = max(2, relabel_batch + (relabel_batch & 1))  # even: every rank keeps the same list parity
     phase, rep = 4, 2
     for s in slabs:
         s.op(OP_ZERO_COUNT, 8)
         s.op(OP_ZERO_COUNT, 9)
     st = {"outer": 0, "relabel_passes": 0, "phases": 0, "exchanges": 0, "reductions": 0, "converged": 0}
-    for _ in range(max_outer):
-        # ---- global relabel: tile BFS passes + border label exchange, to a global fixpoint
+
+    def exchange(kind, epoch, lst):
+        ex.exchange(kind, epoch, lst)
+        st["exchanges"] += 1
+
+    def global_counts():
+        st["reductions"] += 1
+        return ex.global_counts()
+
+    for outer in range(max_outer):
+        # ---- global relabel: tile BFS passes to a local fixpoint, border label exchange, until nothing moves anywhere
         for s in slabs:
             s.op(OP_ABSORB_ALL)
-            s.op(OP_FILL_INF)
             s.op(OP_ZERO_COUNT, 4)
             s.op(OP_ZERO_COUNT, 5)
         nxt = 4 + ((rep + 1) & 1)
-        for s in slabs:
-            s.op(OP_RELABEL_ALL, rep + 1, nxt)
-        ex.exchange(0, rep + 1, nxt)
-        st["relabel_passes"] += 1
-        st["exchanges"] += 1
-        while True:
-            for _b in range(relabel_batch):
-                rep += 1
-                cur, nxt = 4 + (rep & 1), 4 + ((rep + 1) & 1)
+        if outer == 0 or not incremental_relabel:
+            for s in slabs:
+                s.op(OP_FILL_INF)
+                s.op(OP_RELABEL_ALL, rep + 1, nxt)
+        else:
+            while True:  # which tiles may have lost the support of their labels (closure across the slab borders)
                 for s in slabs:
-                    s.op(OP_ZERO_COUNT, nxt)
-                    s.op(OP_RELABEL_LIST, cur, rep + 1, nxt)
-                ex.exchange(0, rep + 1, nxt)
-                st["relabel_passes"] += 1
-                st["exchanges"] += 1
-            st["reductions"] += 1
-            if ex.global_counts()[4 + ((rep + 1) & 1)] == 0:  # the last pass (and its exchange) woke nobody anywhere
+                    s.op(OP_ZERO_COUNT, CNT_CHANGED)
+                    for _b in range(8):
+                        s.op(OP_SUSPECT_PASS)
+                exchange(2, 0, 0)
+                if global_counts()[CNT_CHANGED] == 0:
+                    break
+            for s in slabs:
+                s.op(OP_RESET_SUSPECT, rep + 1, nxt)
+        st["relabel_passes"] += 1
+        while True:
+            while any(int(s.read_counts()[nxt]) != 0 for s in slabs):  # local read-back, no collective
+                for _b in range(relabel_batch):
+                    rep += 1
+                    cur, nxt = 4 + (rep & 1), 4 + ((rep + 1) & 1)
+                    for s in slabs:
+                        s.op(OP_ZERO_COUNT, nxt)
+                        s.op(OP_RELABEL_LIST, cur, rep + 1, nxt)
+                    st["relabel_passes"] += 1
+            exchange(0, rep + 1, nxt)
+            if global_counts()[nxt] == 0:  # the exchange woke nobody anywhere: global fixpoint
                 break
         st["outer"] += 1
 
@@ -194,8 +219,7 @@ def solve_slabs(slabs, ex, rounds_per_relabel=8, max_cycles=3, max_sweeps=4, max
             for i in (0, 1, 2, 3, 6):
                 s.op(OP_ZERO_COUNT, i)
             s.op(OP_ACTIVATE, phase)
-        st["reductions"] += 1
-        if ex.global_counts()[6] == 0:
+        if global_counts()[6] == 0:
             st["converged"] = 1
             break
 
@@ -206,13 +230,11 @@ def solve_slabs(slabs, ex, rounds_per_relabel=8, max_cycles=3, max_sweeps=4, max
                 for s in slabs:
                     s.op(OP_DISCHARGE, lst, phase, max_cycles, max_sweeps)
                     s.op(OP_ZERO_COUNT, lst)
-                ex.exchange(1, phase, 0)
+                exchange(1, phase, 0)
                 st["phases"] += 1
-                st["exchanges"] += 1
                 phase += 1
             if (r + 1) % check_rounds == 0 and r + 1 < rounds_per_relabel:
-                st["reductions"] += 1
-                c = ex.global_counts()
+                c = global_counts()
                 if c[0] + c[1] + c[2] + c[3] == 0:
                     break
     c = ex.global_counts()

@@ -221,6 +221,8 @@ int hostsim_solver_op(void* h, int op, int64_t a0, int64_t a1, int64_t a2, int64
     case 4: d->relabel_list((int)a0, (uint32_t)a1, (int)a2); break;
     case 5: d->activate_all((uint32_t)a0); break;
     case 6: d->discharge((int)a0, (uint32_t)a1, (int)a2, (int)a3); break;
+    case 7: d->suspect_pass(); break;
+    case 8: d->reset_suspect((uint32_t)a0, (int)a1); break;
     default: return 1;
     }
     return 0;
@@ -228,7 +230,7 @@ int hostsim_solver_op(void* h, int op, int64_t a0, int64_t a1, int64_t a2, int64
 
 int hostsim_read_counts(void* h, int32_t* out) { ((HostDev*)h)->read_counts(out); return 0; }
 
-int hostsim_halo_bytes(void* h, int kind, int64_t* bytes) { *bytes = mgc_halo_bytes(((HostDev*)h)->L, kind ? 1 : 0); return 0; }
+int hostsim_halo_bytes(void* h, int kind, int64_t* bytes) { *bytes = mgc_halo_bytes(((HostDev*)h)->L, kind); return 0; }
 
 int hostsim_halo_pack(void* h, int side, int kind, void* buf, int on_device)
 {
@@ -236,7 +238,7 @@ int hostsim_halo_pack(void* h, int side, int kind, void* buf, int on_device)
     HostDev* d = (HostDev*)h;
     HostBlock x(d->S);
     const int T = d->L.gy * d->L.gx;
-    for (int i = 0; i < T; ++i) mgc_halo_pack_tile(x, d->L, side, kind ? 1 : 0, i, buf);
+    for (int i = 0; i < T; ++i) mgc_halo_pack_tile(x, d->L, side, kind, i, buf);
     return 0;
 }
 
@@ -246,7 +248,7 @@ int hostsim_halo_unpack(void* h, int side, int kind, const void* buf, int on_dev
     HostDev* d = (HostDev*)h;
     HostBlock x(d->S);
     const int T = d->L.gy * d->L.gx;
-    for (int i = 0; i < T; ++i) mgc_halo_unpack_tile(x, d->L, side, kind ? 1 : 0, i, buf, epoch, list);
+    for (int i = 0; i < T; ++i) mgc_halo_unpack_tile(x, d->L, side, kind, i, buf, epoch, list);
     return 0;
 }
 

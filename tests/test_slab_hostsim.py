@@ -101,3 +101,22 @@ def test_two_process_gloo_slabs(tmp_path):
         ranges.append(np.load(tmp_path / ("range_%d.npy" % r)))
     assert ranges[0][1] == ranges[1][0] and ranges[0][2] == 1 and ranges[1][2] == 1 and ranges[0][3] > 0
     np.testing.assert_array_equal(np.concatenate(parts, axis=0), ref)
+
+
+@pytest.mark.parametrize("incremental", [True, False])
+def test_incremental_relabel_across_slabs(incremental):
+    """several global relabels (rounds_per_relabel=1): the incremental closure has to cross the slab borders (halo kind 2)
+    and both schedules must end on the oracle's labels."""
+    import sim
+    from medpy_amd.slab import LoopbackExchange, solve_slabs
+    shape = (48, 24, 24)
+    for gen in ("sphere", "hard"):
+        w, tr, ref = _problem(gen, shape)
+        for nslabs in (2, 3):
+            slabs = [sim.SimSlab(shape, r, nslabs) for r in range(nslabs)]
+            for s in slabs:
+                s.load(w, tr)
+            st = solve_slabs(slabs, LoopbackExchange(slabs), rounds_per_relabel=1, max_cycles=1, max_sweeps=2,
+                             incremental_relabel=incremental)
+            assert st["converged"] == 1 and st["outer"] >= 3
+            np.testing.assert_array_equal(np.concatenate([s.finish()[0] for s in slabs], axis=0), ref)
