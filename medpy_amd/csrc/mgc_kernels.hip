@@ -359,7 +359,7 @@ __global__ __launch_bounds__(MGC_TV) void k_halo_pack(MgcLattice L, int side, in
     __shared__ MgcTileShared S;
     GpuBlock x(S);
     const int T = L.gy * L.gx;
-    for (int i = blockIdx.x; i < T; i += gridDim.x) mgc_halo_pack_tile(x, L, side, kind, i, buf);
+    for (int i = blockIdx.x; i < T; i += gridDim.x) mgc_halo_pack_nd(x, L, side, kind, i, buf);
 }
 
 __global__ __launch_bounds__(MGC_TV) void k_halo_unpack(MgcLattice L, int side, int kind, const void* buf, uint32_t epoch, int list)
@@ -367,7 +367,7 @@ __global__ __launch_bounds__(MGC_TV) void k_halo_unpack(MgcLattice L, int side, 
     __shared__ MgcTileShared S;
     GpuBlock x(S);
     const int T = L.gy * L.gx;
-    for (int i = blockIdx.x; i < T; i += gridDim.x) mgc_halo_unpack_tile(x, L, side, kind, i, buf, epoch, list);
+    for (int i = blockIdx.x; i < T; i += gridDim.x) mgc_halo_unpack_nd(x, L, side, kind, i, buf, epoch, list);
 }
 
 /* ======================================================================================
@@ -995,6 +995,36 @@ struct HipDevT {
 typedef HipDevT<false> HipDev;
 typedef HipDevT<true> HipDev26;
 
+/* one step of the solver schedule (mgc_solver_op), on the kernels of either neighbourhood */
+template <class Dev>
+static int mgc_solver_op_on(mgc_handle h, int op, int64_t a0, int64_t a1, int64_t a2, int64_t a3)
+{
+    Dev dev;
+    dev.h = h;
+    const bool timing = h->timing;
+    h->timing = false; /* per-launch events are resolved by mgc_maxflow only */
+    switch (op) {
+    case MGC_OP_ABSORB_ALL: dev.absorb_all(); break;
+    case MGC_OP_FILL_INF: dev.fill_heights_inf(); break;
+    case MGC_OP_ZERO_COUNT:
+        if (a0 < 0 || a0 >= MGC_NCOUNT) { h->timing = timing; return mgc_fail(h, MGC_ERR_INVALID, "counter index"); }
+        dev.zero_count((int)a0);
+        break;
+    case MGC_OP_RELABEL_ALL: dev.relabel_all((uint32_t)a0, (int)a1); break;
+    case MGC_OP_RELABEL_LIST: dev.relabel_list((int)a0, (uint32_t)a1, (int)a2); break;
+    case MGC_OP_ACTIVATE: dev.activate_all((uint32_t)a0); break;
+    case MGC_OP_DISCHARGE: dev.discharge((int)a0, (uint32_t)a1, (int)a2, (int)a3); break;
+    case MGC_OP_SUSPECT_PASS: dev.suspect_pass(); break;
+    case MGC_OP_RESET_SUSPECT: dev.reset_suspect((uint32_t)a0, (int)a1); break;
+    default: h->timing = timing; return mgc_fail(h, MGC_ERR_INVALID, "unknown solver op %d", op);
+    }
+    h->timing = timing;
+    h->solved = false;
+    if (dev.first_error != hipSuccess) return mgc_fail(h, MGC_ERR_HIP, "solver op %d: %s", op, hipGetErrorString(dev.first_error));
+    return MGC_OK;
+}
+
+
 extern "C" {
 
 int mgc_device_count(int* count)
@@ -1019,7 +1049,6 @@ static int mgc_create_impl(int ndim, const int64_t* shape, int connectivity, int
     if (connectivity != 2 * ndim && connectivity != full)
         return mgc_fail(nullptr, MGC_ERR_UNSUPPORTED, "mgc_create: connectivity %d not implemented (2*ndim = %d is the reference's, %d the full neighbourhood)",
                         connectivity, 2 * ndim, full);
-    if (slab && connectivity != 2 * ndim) return mgc_fail(nullptr, MGC_ERR_UNSUPPORTED, "Z-slabs are implemented for the 2*ndim neighbourhood only");
     int ndev = 0;
     if (hipGetDeviceCount(&ndev) != hipSuccess || ndev <= 0)
         return mgc_fail(nullptr, MGC_ERR_NO_DEVICE, "no HIP device: libmedpyhip has no CPU fallback");
@@ -1115,31 +1144,9 @@ int mgc_solver_op(mgc_handle h, int op, int64_t a0, int64_t a1, int64_t a2, int6
 {
     if (!h) return MGC_ERR_INVALID;
     if (!h->built) return mgc_fail(h, MGC_ERR_STATE, "mgc_solver_op before mgc_build");
-    if (h->L.ndir != 6) return mgc_fail(h, MGC_ERR_UNSUPPORTED, "the stepwise (slab) driver covers the 2*ndim neighbourhood only");
     MGC_HIP(h, hipSetDevice(h->device));
-    HipDev dev;
-    dev.h = h;
-    const bool timing = h->timing;
-    h->timing = false; /* per-launch events are resolved by mgc_maxflow only */
-    switch (op) {
-    case MGC_OP_ABSORB_ALL: dev.absorb_all(); break;
-    case MGC_OP_FILL_INF: dev.fill_heights_inf(); break;
-    case MGC_OP_ZERO_COUNT:
-        if (a0 < 0 || a0 >= MGC_NCOUNT) { h->timing = timing; return mgc_fail(h, MGC_ERR_INVALID, "counter index"); }
-        dev.zero_count((int)a0);
-        break;
-    case MGC_OP_RELABEL_ALL: dev.relabel_all((uint32_t)a0, (int)a1); break;
-    case MGC_OP_RELABEL_LIST: dev.relabel_list((int)a0, (uint32_t)a1, (int)a2); break;
-    case MGC_OP_ACTIVATE: dev.activate_all((uint32_t)a0); break;
-    case MGC_OP_DISCHARGE: dev.discharge((int)a0, (uint32_t)a1, (int)a2, (int)a3); break;
-    case MGC_OP_SUSPECT_PASS: dev.suspect_pass(); break;
-    case MGC_OP_RESET_SUSPECT: dev.reset_suspect((uint32_t)a0, (int)a1); break;
-    default: h->timing = timing; return mgc_fail(h, MGC_ERR_INVALID, "unknown solver op %d", op);
-    }
-    h->timing = timing;
-    h->solved = false;
-    if (dev.first_error != hipSuccess) return mgc_fail(h, MGC_ERR_HIP, "solver op %d: %s", op, hipGetErrorString(dev.first_error));
-    return MGC_OK;
+    if (h->L.ndir == MGC26_NDIR) return mgc_solver_op_on<HipDevT<true>>(h, op, a0, a1, a2, a3);
+    return mgc_solver_op_on<HipDevT<false>>(h, op, a0, a1, a2, a3);
 }
 
 int mgc_read_counts(mgc_handle h, int32_t* out)
@@ -1155,7 +1162,7 @@ int mgc_read_counts(mgc_handle h, int32_t* out)
 int mgc_halo_bytes(mgc_handle h, int kind, int64_t* bytes)
 {
     if (!h || !bytes) return MGC_ERR_INVALID;
-    *bytes = mgc_halo_bytes(h->L, kind);
+    *bytes = mgc_halo_bytes_nd(h->L, kind);
     return MGC_OK;
 }
 
@@ -1175,7 +1182,7 @@ int mgc_halo_pack(mgc_handle h, int side, int kind, void* buf, int buf_on_device
     if (!h->built) return mgc_fail(h, MGC_ERR_STATE, "mgc_halo_pack before mgc_build");
     if (side == 0 ? h->L.tz_own_lo == 0 : h->L.tz_own_hi == h->L.gz) return mgc_fail(h, MGC_ERR_INVALID, "no neighbour slab on side %d", side);
     MGC_HIP(h, hipSetDevice(h->device));
-    const int64_t bytes = mgc_halo_bytes(h->L, kind);
+    const int64_t bytes = mgc_halo_bytes_nd(h->L, kind);
     void* dst = buf;
     if (!buf_on_device) {
         const int rc = mgc_halo_staging(h, bytes);
@@ -1183,6 +1190,7 @@ int mgc_halo_pack(mgc_handle h, int side, int kind, void* buf, int buf_on_device
         dst = h->d_halo;
     }
     const int T = h->L.gy * h->L.gx;
+    if (h->L.ndir == MGC26_NDIR && kind == 1) MGC_HIP(h, hipMemsetAsync((char*)dst + mgc26_halo_off_count(h->L), 0, 4, h->stream));
     hipLaunchKernelGGL(k_halo_pack, dim3(T < 2048 ? T : 2048), dim3(MGC_TV), 0, h->stream, h->L, side, kind, dst);
     MGC_HIP(h, hipGetLastError());
     if (!buf_on_device) MGC_HIP(h, hipMemcpyAsync(buf, dst, (size_t)bytes, hipMemcpyDeviceToHost, h->stream));
@@ -1196,7 +1204,7 @@ int mgc_halo_unpack(mgc_handle h, int side, int kind, const void* buf, int buf_o
     if (!h->built) return mgc_fail(h, MGC_ERR_STATE, "mgc_halo_unpack before mgc_build");
     if (side == 0 ? h->L.tz_own_lo == 0 : h->L.tz_own_hi == h->L.gz) return mgc_fail(h, MGC_ERR_INVALID, "no neighbour slab on side %d", side);
     MGC_HIP(h, hipSetDevice(h->device));
-    const int64_t bytes = mgc_halo_bytes(h->L, kind);
+    const int64_t bytes = mgc_halo_bytes_nd(h->L, kind);
     const void* src = buf;
     if (!buf_on_device) {
         const int rc = mgc_halo_staging(h, bytes);
@@ -1307,7 +1315,7 @@ int mgc_halo_exchange(mgc_handle h, int kind, uint32_t epoch, int list)
     if (!h->comm) return mgc_fail(h, MGC_ERR_STATE, "mgc_halo_exchange before mgc_comm_init");
     MGC_HIP(h, hipSetDevice(h->device));
     if (kind < 0 || kind > 2) return mgc_fail(h, MGC_ERR_INVALID, "mgc_halo_exchange: kind must be 0, 1 or 2");
-    const int64_t bytes = mgc_halo_bytes(h->L, 1); /* size for the larger kind; reused for both */
+    const int64_t bytes = mgc_halo_bytes_nd(h->L, 1); /* size for the larger kind; reused for both */
     if (h->xchg_cap < bytes) {
         for (int i = 0; i < 4; ++i) {
             if (h->d_xchg[i]) (void)hipFree(h->d_xchg[i]);
@@ -1316,12 +1324,15 @@ int mgc_halo_exchange(mgc_handle h, int kind, uint32_t epoch, int list)
         }
         h->xchg_cap = bytes;
     }
-    const int64_t nb = mgc_halo_bytes(h->L, kind);
+    /* 26-neighbourhood phases: fixed header first, then only the records that were filled (mgc26_halo_pack_tile) */
+    const bool compact = h->L.ndir == MGC26_NDIR && kind == 1;
+    const int64_t nb = compact ? mgc26_halo_off_rec(h->L) : mgc_halo_bytes_nd(h->L, kind);
     const bool has[2] = {h->L.tz_own_lo > 0, h->L.tz_own_hi < h->L.gz};
     const int peer[2] = {h->rank - 1, h->rank + 1};
     const int T = h->L.gy * h->L.gx, grid = T < 2048 ? T : 2048;
     for (int side = 0; side < 2; ++side)
         if (has[side]) {
+            if (compact) MGC_HIP(h, hipMemsetAsync((char*)h->d_xchg[2 * side] + mgc26_halo_off_count(h->L), 0, 4, h->stream));
             hipLaunchKernelGGL(k_halo_pack, dim3(grid), dim3(MGC_TV), 0, h->stream, h->L, side, kind, h->d_xchg[2 * side]);
             MGC_HIP(h, hipGetLastError());
         }
@@ -1332,6 +1343,25 @@ int mgc_halo_exchange(mgc_handle h, int kind, uint32_t epoch, int list)
             MGC_NCCL(h, g_rccl.Recv(h->d_xchg[2 * side + 1], (size_t)nb, ncclUint8, peer[side], h->comm, h->stream));
         }
     MGC_NCCL(h, g_rccl.GroupEnd());
+    if (compact) {
+        /* how many records each direction carries: mine (packed above) and the neighbour's (just received) */
+        int32_t* hc = h->h_count; /* pinned scratch, 4 of MGC_NCOUNT slots */
+        for (int i = 0; i < 4; ++i)
+            if (has[i >> 1]) MGC_HIP(h, hipMemcpyAsync(hc + i, (char*)h->d_xchg[i] + mgc26_halo_off_count(h->L), 4, hipMemcpyDeviceToHost, h->stream));
+        MGC_HIP(h, hipStreamSynchronize(h->stream));
+        const int64_t off = mgc26_halo_off_rec(h->L), rb = (int64_t)MGC26_REC * 8;
+        bool any = false;
+        for (int i = 0; i < 4; ++i) any |= has[i >> 1] && hc[i] > 0;
+        if (any) {
+            MGC_NCCL(h, g_rccl.GroupStart());
+            for (int side = 0; side < 2; ++side)
+                if (has[side]) {
+                    if (hc[2 * side] > 0) MGC_NCCL(h, g_rccl.Send((char*)h->d_xchg[2 * side] + off, (size_t)(hc[2 * side] * rb), ncclUint8, peer[side], h->comm, h->stream));
+                    if (hc[2 * side + 1] > 0) MGC_NCCL(h, g_rccl.Recv((char*)h->d_xchg[2 * side + 1] + off, (size_t)(hc[2 * side + 1] * rb), ncclUint8, peer[side], h->comm, h->stream));
+                }
+            MGC_NCCL(h, g_rccl.GroupEnd());
+        }
+    }
     for (int side = 0; side < 2; ++side)
         if (has[side]) {
             hipLaunchKernelGGL(k_halo_unpack, dim3(grid), dim3(MGC_TV), 0, h->stream, h->L, side, kind, (const void*)h->d_xchg[2 * side + 1], epoch, list);
@@ -1498,6 +1528,16 @@ int mgc_build(mgc_handle h)
         MGC_HIP(h, hipGetLastError());
         hipLaunchKernelGGL(k_refresh_mask, dim3(grid), dim3(MGC_TV), 0, h->stream, L);
         MGC_HIP(h, hipGetLastError());
+    }
+    if (L.ndir == MGC26_NDIR) {
+        /* slabs: a ghost tile's excess / residuals only collect what is pushed over the border (mgc26_halo_pack_tile) */
+        const int64_t T = (int64_t)L.gy * L.gx;
+        for (int side = 0; side < 2; ++side) {
+            if (side == 0 ? L.tz_own_lo == 0 : L.tz_own_hi == L.gz) continue;
+            const int64_t t0 = (side ? L.tz_own_hi : L.tz_own_lo - 1) * T;
+            MGC_HIP(h, hipMemsetAsync(L.excess + t0 * MGC_TV, 0, (size_t)T * MGC_TV * sizeof(double), h->stream));
+            MGC_HIP(h, hipMemsetAsync(L.rcap + t0 * MGC26_NDIR * MGC_TV, 0, (size_t)T * MGC26_NDIR * MGC_TV * sizeof(double), h->stream));
+        }
     }
     MGC_HIP(h, hipMemsetAsync(L.count, 0, MGC_NCOUNT * sizeof(int32_t), h->stream));
     MGC_HIP(h, hipEventRecord(h->ev[1], h->stream));

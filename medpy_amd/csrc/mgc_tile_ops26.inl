@@ -114,7 +114,7 @@ MGC_HD void mgc26_tile_bfs(X& x, MaskFn mask)
 template <class X>
 MGC_HD void mgc26_relabel_tile(X& x, const MgcLattice& L, int tile, uint32_t next_epoch, int next_list, bool first_pass)
 {
-    if (first_pass && !(L.status[tile] & 2u)) return;
+    if (!mgc_owned(L, tile) || (first_pass && !(L.status[tile] & 2u))) return;
     typename X::template Reg<uint32_t> m;
     typename X::template Reg<int> h0;
     const int64_t base = (int64_t)tile * MGC_TV;
@@ -149,6 +149,7 @@ MGC_HD void mgc26_relabel_tile(X& x, const MgcLattice& L, int tile, uint32_t nex
 template <class X>
 MGC_HD void mgc26_activate_tile(X& x, const MgcLattice& L, int tile, uint32_t phase)
 {
+    if (!mgc_owned(L, tile)) return; /* a ghost tile's excess / rcap only accumulate what was pushed into it */
     const int64_t base = (int64_t)tile * MGC_TV;
     const bool act = x.any([&](int t) -> bool { return L.excess[base + t] > 0.0 && L.height[base + t] < MGC_HINF; });
     x.par([&](int t) {
@@ -288,10 +289,139 @@ MGC_HD void mgc26_discharge_tile(X& x, const MgcLattice& L, int tile, uint32_t p
             const int theirs = mgc26_colour(L, tz + t / 9 - 1, ty + (t / 3) % 3 - 1, tx + t % 3 - 1);
             const uint32_t target = phase + (uint32_t)((theirs - mine) & 7);
             mgc_enqueue(x, L, (int)(target & 15u), L.stamp, target, x.S.nbr[t]);
+            if (!mgc_owned(L, x.S.nbr[t])) x.atomic_or(&L.oflags[x.S.nbr[t]], 1u); /* ghost: the halo exchange ships what it received */
         }
         if (t == 27 && active) mgc_enqueue(x, L, (int)((phase + 8) & 15u), L.stamp, phase + 8, tile);
         if (t == 28) L.status[tile] = (L.status[tile] & ~2u) | (has_sink ? 2u : 0u);
     });
+}
+
+/* ---------------------------------------------------------------------------------------
+ * Z-slab halo exchange, 26-neighbourhood.  There are no outboxes: a push over the slab border lands in the GHOST
+ * tile's excess and reverse residuals, which are kept at zero otherwise (mgc_build) and therefore ACCUMULATE what the
+ * neighbour slab has to add to its own border tile.  Per border tile the message carries the labels of the OWNED
+ * border layer and, only for ghost tiles that received something, a 5 KiB record of the ghost's border voxel layer:
+ * excess and the 9 residuals that point back over the border (dz = -1: directions 0..8 for the upper ghost,
+ * dz = +1: directions 17..25 for the lower ghost).  Records are COMPACTED (slot = order of arrival), so the
+ * transport moves the fixed header plus `count` records (mgc_halo_exchange) instead of 5 KiB for every tile:
+ *     int32 label[T][64] ; int32 slot1[T] (0 = nothing, else 1 + record index) ; int32 count ; pad to 16 B ;
+ *     double record[count][10][64]                                     (kind 1: discharge phases)
+ *     int32 label[T][64]                                              (kind 0: relabel passes)
+ * The sender zeroes `count` before packing.
+ * ------------------------------------------------------------------------------------- */
+#define MGC26_REC (10 * MGC_TF) /* doubles per record */
+
+MGC_HD int64_t mgc26_halo_off_slot(const MgcLattice& L) { return (int64_t)L.gy * L.gx * MGC_TF * 4; }
+MGC_HD int64_t mgc26_halo_off_count(const MgcLattice& L) { return mgc26_halo_off_slot(L) + (int64_t)L.gy * L.gx * 4; }
+MGC_HD int64_t mgc26_halo_off_rec(const MgcLattice& L) { return (mgc26_halo_off_count(L) + 4 + 15) / 16 * 16; }
+
+MGC_HD int64_t mgc26_halo_bytes(const MgcLattice& L, int kind)
+{
+    const int64_t T = (int64_t)L.gy * L.gx;
+    return kind == 1 ? mgc26_halo_off_rec(L) + T * MGC26_REC * 8 : T * MGC_TF * 4;
+}
+
+template <class X>
+MGC_HD void mgc26_halo_pack_tile(X& x, const MgcLattice& L, int side, int kind, int i, void* buf)
+{
+    const int64_t T = (int64_t)L.gy * L.gx;
+    const int own = (side ? L.tz_own_hi - 1 : L.tz_own_lo) * (int)T + i;
+    const int ghost = (side ? L.tz_own_hi : L.tz_own_lo - 1) * (int)T + i;
+    const int f_own = side ? 5 : 4, f_ghost = side ? 4 : 5, dbase = side ? 0 : 17;
+    int32_t* lab = (int32_t*)buf;
+    int32_t* slot1 = (int32_t*)((char*)buf + mgc26_halo_off_slot(L));
+    int32_t* count = (int32_t*)((char*)buf + mgc26_halo_off_count(L));
+    double* rec = (double*)((char*)buf + mgc26_halo_off_rec(L));
+    x.par([&](int t) {
+        if (t < MGC_TF) lab[(int64_t)i * MGC_TF + t] = L.height[(int64_t)own * MGC_TV + mgc_face_voxel(f_own, t)];
+        if (kind && t == 0) {
+            const uint32_t fl = L.oflags[ghost] & 1u;
+            const int sl = fl ? x.atomic_add(count, 1) : -1;
+            x.S.flag[0] = sl;
+            slot1[i] = sl + 1;
+            if (fl) L.oflags[ghost] = 0;
+        }
+    });
+    if (!kind) return;
+    x.par([&](int t) {
+        const int sl = x.S.flag[0];
+        if (sl < 0) return;
+        for (int k = t; k < MGC26_REC; k += MGC_TV) {
+            const int q = k >> 6, v = mgc_face_voxel(f_ghost, k & 63);
+            double* src = q == 0 ? &L.excess[(int64_t)ghost * MGC_TV + v] : &L.rcap[((int64_t)ghost * MGC26_NDIR + dbase + q - 1) * MGC_TV + v];
+            rec[(int64_t)sl * MGC26_REC + k] = *src;
+            *src = 0.0; /* the flow now travels in the message */
+        }
+    });
+    x.par([&](int) {}); /* x.S.flag[0] is reused by the next tile of this block */
+}
+
+template <class X>
+MGC_HD void mgc26_halo_unpack_tile(X& x, const MgcLattice& L, int side, int kind, int i, const void* buf, uint32_t epoch, int list)
+{
+    const int64_t T = (int64_t)L.gy * L.gx;
+    const int own_layer = side ? L.tz_own_hi - 1 : L.tz_own_lo;
+    const int own = own_layer * (int)T + i;
+    const int ghost = (side ? L.tz_own_hi : L.tz_own_lo - 1) * (int)T + i;
+    const int f_own = side ? 5 : 4, f_ghost = side ? 4 : 5, dbase = side ? 17 : 0; /* the sender packed ITS other side */
+    const int32_t* lab = (const int32_t*)buf;
+    const int32_t* slot1 = (const int32_t*)((const char*)buf + mgc26_halo_off_slot(L));
+    const double* rec = (const double*)((const char*)buf + mgc26_halo_off_rec(L));
+    const int sl = kind ? slot1[i] - 1 : -1;
+    const bool lowered = x.any([&](int t) -> bool {
+        bool low = false;
+        if (t < MGC_TF) {
+            int32_t* hp = &L.height[(int64_t)ghost * MGC_TV + mgc_face_voxel(f_ghost, t)];
+            const int32_t hn = lab[(int64_t)i * MGC_TF + t];
+            low = hn < *hp;
+            *hp = hn;
+            if (sl >= 0) {
+                const double* r = rec + (int64_t)sl * MGC26_REC;
+                const int v = mgc_face_voxel(f_own, t);
+                const double de = r[t];
+                if (de != 0.0) L.excess[(int64_t)own * MGC_TV + v] += de;
+                uint32_t bits = 0;
+                for (int q = 0; q < 9; ++q) {
+                    const double d = r[(1 + q) * MGC_TF + t];
+                    if (d != 0.0) {
+                        L.rcap[((int64_t)own * MGC26_NDIR + dbase + q) * MGC_TV + v] += d;
+                        bits |= 1u << (dbase + q);
+                    }
+                }
+                if (bits) L.rmask32[(int64_t)own * MGC_TV + v] |= bits;
+            }
+        }
+        return low;
+    });
+    x.par([&](int t) {
+        if (kind) {
+            if (t == 0 && sl >= 0) { /* the tile runs in the next phase of its colour */
+                const int ty = i / L.gx, tx = i % L.gx;
+                const uint32_t target = epoch + 1 + (((uint32_t)mgc26_colour(L, own_layer, ty, tx) - (epoch + 1)) & 7u);
+                mgc_enqueue(x, L, (int)(target & 15u), L.stamp, target, own);
+            }
+        } else if (lowered && t < 9) { /* every owned tile that touches the ghost: face, edge and corner neighbours */
+            const int ty = i / L.gx + t / 3 - 1, tx = i % L.gx + t % 3 - 1;
+            if (ty >= 0 && ty < L.gy && tx >= 0 && tx < L.gx) mgc_enqueue(x, L, list, L.rstamp, epoch, mgc_tile_id(L, own_layer, ty, tx));
+        }
+    });
+}
+
+/* neighbourhood-agnostic entry points used by the kernels / the host simulator */
+MGC_HD int64_t mgc_halo_bytes_nd(const MgcLattice& L, int kind) { return L.ndir == MGC26_NDIR ? mgc26_halo_bytes(L, kind) : mgc_halo_bytes(L, kind); }
+
+template <class X>
+MGC_HD void mgc_halo_pack_nd(X& x, const MgcLattice& L, int side, int kind, int i, void* buf)
+{
+    if (L.ndir == MGC26_NDIR) mgc26_halo_pack_tile(x, L, side, kind, i, buf);
+    else mgc_halo_pack_tile(x, L, side, kind, i, buf);
+}
+
+template <class X>
+MGC_HD void mgc_halo_unpack_nd(X& x, const MgcLattice& L, int side, int kind, int i, const void* buf, uint32_t epoch, int list)
+{
+    if (L.ndir == MGC26_NDIR) mgc26_halo_unpack_tile(x, L, side, kind, i, buf, epoch, list);
+    else mgc_halo_unpack_tile(x, L, side, kind, i, buf, epoch, list);
 }
 
 #endif /* MGC_TILE_OPS26_INL */

@@ -162,10 +162,16 @@ def solve_slabs(slabs, ex, rounds_per_relabel=8, max_cycles=3, max_sweeps=4, max
     relabels are incremental like the single-GPU driver's (mgc_driver.inl): the DIRTY / SUSPECT flags of the border
     tiles travel as halo kind 2 until the suspect closure is stable everywhere."""
     relabel_batch = max(2, relabel_batch + (relabel_batch & 1))  # even: every rank keeps the same list parity
-    phase, rep = 4, 2
+    # where the solver variant keeps its lists / counters (MgcLayout, mgc_driver.inl:51-62)
+    if getattr(slabs[0], "ndir", 6) == 26:
+        ncol, lmask, rl, c_act, c_dis, c_rel = 8, 15, 16, 18, 19, 20
+        incremental_relabel = False  # the full-neighbourhood kernels keep no support faces
+    else:
+        ncol, lmask, rl, c_act, c_dis, c_rel = 2, 3, 4, 6, 8, 9
+    phase, rep = 2 * (lmask + 1), 2
     for s in slabs:
-        s.op(OP_ZERO_COUNT, 8)
-        s.op(OP_ZERO_COUNT, 9)
+        s.op(OP_ZERO_COUNT, c_dis)
+        s.op(OP_ZERO_COUNT, c_rel)
     st = {"outer": 0, "relabel_passes": 0, "phases": 0, "exchanges": 0, "reductions": 0, "converged": 0}
 
     def exchange(kind, epoch, lst):
@@ -180,9 +186,9 @@ def solve_slabs(slabs, ex, rounds_per_relabel=8, max_cycles=3, max_sweeps=4, max
         # ---- global relabel: tile BFS passes to a local fixpoint, border label exchange, until nothing moves anywhere
         for s in slabs:
             s.op(OP_ABSORB_ALL)
-            s.op(OP_ZERO_COUNT, 4)
-            s.op(OP_ZERO_COUNT, 5)
-        nxt = 4 + ((rep + 1) & 1)
+            s.op(OP_ZERO_COUNT, rl)
+            s.op(OP_ZERO_COUNT, rl + 1)
+        nxt = rl + ((rep + 1) & 1)
         if outer == 0 or not incremental_relabel:
             for s in slabs:
                 s.op(OP_FILL_INF)
@@ -203,7 +209,7 @@ def solve_slabs(slabs, ex, rounds_per_relabel=8, max_cycles=3, max_sweeps=4, max
             while any(int(s.read_counts()[nxt]) != 0 for s in slabs):  # local read-back, no collective
                 for _b in range(relabel_batch):
                     rep += 1
-                    cur, nxt = 4 + (rep & 1), 4 + ((rep + 1) & 1)
+                    cur, nxt = rl + (rep & 1), rl + ((rep + 1) & 1)
                     for s in slabs:
                         s.op(OP_ZERO_COUNT, nxt)
                         s.op(OP_RELABEL_LIST, cur, rep + 1, nxt)
@@ -214,19 +220,19 @@ def solve_slabs(slabs, ex, rounds_per_relabel=8, max_cycles=3, max_sweeps=4, max
         st["outer"] += 1
 
         # ---- who can still push towards the sink?
-        phase += 8
+        phase += 2 * (lmask + 1)  # fresh stamps: anything queued before the relabel is void
         for s in slabs:
-            for i in (0, 1, 2, 3, 6):
+            for i in list(range(lmask + 1)) + [c_act]:
                 s.op(OP_ZERO_COUNT, i)
             s.op(OP_ACTIVATE, phase)
-        if global_counts()[6] == 0:
+        if global_counts()[c_act] == 0:
             st["converged"] = 1
             break
 
         # ---- colour phases, border (labels + outbox flow) exchanged after each
         for r in range(rounds_per_relabel):
-            for _c in range(2):
-                lst = phase & 3
+            for _c in range(ncol):
+                lst = phase & lmask
                 for s in slabs:
                     s.op(OP_DISCHARGE, lst, phase, max_cycles, max_sweeps)
                     s.op(OP_ZERO_COUNT, lst)
@@ -235,17 +241,17 @@ def solve_slabs(slabs, ex, rounds_per_relabel=8, max_cycles=3, max_sweeps=4, max
                 phase += 1
             if (r + 1) % check_rounds == 0 and r + 1 < rounds_per_relabel:
                 c = global_counts()
-                if c[0] + c[1] + c[2] + c[3] == 0:
+                if int(np.sum(c[:lmask + 1])) == 0:
                     break
     c = ex.global_counts()
-    st["discharge_tiles"], st["relabel_tiles"] = int(c[8]), int(c[9])
+    st["discharge_tiles"], st["relabel_tiles"] = int(c[c_dis]), int(c[c_rel])
     return st
 
 
 class HipSlab(object):
     """One Z-slab of a volume on one MI355X (C ABI: mgc_create_slab ... mgc_finish)."""
 
-    def __init__(self, global_shape, rank, nranks, device=0):
+    def __init__(self, global_shape, rank, nranks, device=0, connectivity=6):
         import ctypes as C
         from . import _lib
         self._C, self._lib = C, _lib
@@ -254,7 +260,10 @@ class HipSlab(object):
             raise _lib.MedpyHipError(_lib.ERR_NO_DEVICE, "no HIP device visible; medpy_amd has no CPU fallback")
         shp = (C.c_int64 * 3)(*[int(v) for v in global_shape])
         h = C.c_void_p()
-        rc = lib.mgc_create_slab(3, shp, 6, int(device), int(rank), int(nranks), C.byref(h))
+        if connectivity not in (6, 26):
+            raise ValueError("slabs are cut from 3-D volumes: connectivity is 6 or 26")
+        self.ndir = int(connectivity)
+        rc = lib.mgc_create_slab(3, shp, self.ndir, int(device), int(rank), int(nranks), C.byref(h))
         self._h = h if h.value else None
         if rc != _lib.OK:
             msg = (lib.mgc_last_error(self._h) or b"").decode()
@@ -369,16 +378,18 @@ class HipSlab(object):
 
 
 def graphcut_voxel_slabs(image, fg, bg, term="difference_exponential", sigma=None, spacing=False, nslabs=2, device=0,
-                         **schedule):
+                         connectivity=6, regional=None, **schedule):
     """Cut one volume as ``nslabs`` Z-slabs time-multiplexed on ONE GPU with the loopback transport.
 
     Exercises exactly the code path of the multi-GPU run (ghost layers, halo pack/unpack, the
     distributed schedule) where only one MI355X is available.  Returns (labels, flow, stats)."""
     image, fg, bg = np.asarray(image), np.asarray(fg), np.asarray(bg)
-    slabs = [HipSlab(image.shape, r, nslabs, device=device) for r in range(nslabs)]
+    slabs = [HipSlab(image.shape, r, nslabs, device=device, connectivity=connectivity) for r in range(nslabs)]
     for s in slabs:
         sl = slice(s.plane0, s.plane1)
         s.set_boundary(term, image[sl], sigma, spacing)
+        if regional is not None:  # (probability map, alpha): regional_probability_map, energy_voxel.py:33-65
+            s.set_regional(np.asarray(regional[0])[sl], regional[1])
         s.set_markers(fg[sl], bg[sl])
         s.build()
     st = solve_slabs(slabs, LoopbackExchange(slabs), **schedule)

@@ -317,61 +317,151 @@ struct HostDev26 {
         L.count[MGC26_CNT_DIS] += n;
         for (int i = 0; i < n; ++i) mgc26_discharge_tile(x, L, L.list[lst][i], phase, cycles, sweeps);
     }
+    std::vector<uint32_t> oflags;
+    MgcSlabSpec spec;
+
+    void init(int64_t d0, int64_t d1, int64_t d2, const MgcSlabSpec* sp)
+    {
+        memset(&L, 0, sizeof(L));
+        L.dz = d0; L.dy = d1; L.dx = d2;
+        L.nvox = d0 * d1 * d2;
+        L.gz = (int)((d0 + 7) / 8); L.gy = (int)((d1 + 7) / 8); L.gx = (int)((d2 + 7) / 8);
+        L.ntiles = L.gz * L.gy * L.gx;
+        L.tz_own_lo = 0; L.tz_own_hi = L.gz; L.tz_global0 = 0; L.ndir = 26;
+        if (sp) { spec = *sp; L.tz_own_lo = sp->own_lo; L.tz_own_hi = sp->own_hi; L.tz_global0 = sp->tz_global0; }
+        else { memset(&spec, 0, sizeof(spec)); spec.nranks = 1; spec.own_hi = L.gz; spec.plane1 = spec.own1 = d0; }
+        const int64_t nt = L.ntiles;
+        rcap.assign(nt * 26 * MGC_TV, 0.0); excess.assign(nt * MGC_TV, 0.0); sink.assign(nt * MGC_TV, 0.0);
+        height.assign(nt * MGC_TV, MGC_HINF); lists.assign(18 * nt, 0); count.assign(MGC_NCOUNT, 0);
+        rmask32.assign(nt * MGC_TV, 0); stamp.assign(nt, 0); rstamp.assign(nt, 0); status.assign(nt, 0); oflags.assign(nt, 0);
+        L.rcap = rcap.data(); L.excess = excess.data(); L.sink = sink.data(); L.height = height.data();
+        L.rmask32 = rmask32.data(); L.oflags = oflags.data();
+        for (int i = 0; i < 18; ++i) L.list[i] = lists.data() + i * nt;
+        L.count = count.data(); L.stamp = stamp.data(); L.rstamp = rstamp.data(); L.status = status.data();
+    }
+
+    /* w[d*N + id] = capacity of the arc from LOCAL voxel id in direction d (0..25, mgc26_offset order), 0 where there
+     * is no neighbour; trcap[N].  Ghost tiles keep zero excess / residuals: they accumulate pushes over the border. */
+    void load(const double* w, const double* trcap)
+    {
+        const int64_t N = L.nvox;
+        for (int64_t id = 0; id < N; ++id) {
+            int tile, loc;
+            mgc_node_to_tile(L, id, tile, loc);
+            if (!mgc_owned(L, tile)) continue;
+            uint32_t m = 0;
+            for (int dir = 0; dir < 26; ++dir) {
+                const double c = w[(int64_t)dir * N + id];
+                rcap[((int64_t)tile * 26 + dir) * MGC_TV + loc] = c;
+                if (c > 0.0) m |= 1u << dir;
+            }
+            const double tr = trcap[id];
+            excess[(int64_t)tile * MGC_TV + loc] = tr > 0 ? tr : 0.0;
+            sink[(int64_t)tile * MGC_TV + loc] = tr < 0 ? -tr : 0.0;
+            if (tr < 0) { m |= MGC26_MASK_SINK; status[tile] |= 2u; }
+            rmask32[(int64_t)tile * MGC_TV + loc] = m;
+        }
+    }
+
+    void labels(uint8_t* out)
+    {
+        for (int64_t id = 0; id < L.nvox; ++id) {
+            int tile, loc;
+            mgc_node_to_tile(L, id, tile, loc);
+            out[id] = height[(int64_t)tile * MGC_TV + loc] < MGC_HINF ? 0 : 1;
+        }
+    }
 };
 
 extern "C" {
 
-/* w[d*N + id] = capacity of the arc from voxel id in direction d (0..25, mgc26_offset order), 0 where there is
- * no neighbour; trcap[N].  labels_out: 0 = sink side.  stats_out[8] = MgcSolveStats. */
 int hostsim_solve26(const int64_t* shape, const double* w, const double* trcap, int rounds, int cycles, int sweeps, int max_outer,
                     uint8_t* labels_out, int64_t* stats_out)
 {
     HostDev26* d = new HostDev26();
-    MgcLattice& L = d->L;
-    memset(&L, 0, sizeof(L));
-    L.dz = shape[0]; L.dy = shape[1]; L.dx = shape[2];
-    L.nvox = L.dz * L.dy * L.dx;
-    L.gz = (int)((L.dz + 7) / 8); L.gy = (int)((L.dy + 7) / 8); L.gx = (int)((L.dx + 7) / 8);
-    L.ntiles = L.gz * L.gy * L.gx;
-    L.tz_own_lo = 0; L.tz_own_hi = L.gz; L.tz_global0 = 0; L.ndir = 26;
-    const int64_t nt = L.ntiles, N = L.nvox;
-    d->rcap.assign(nt * 26 * MGC_TV, 0.0); d->excess.assign(nt * MGC_TV, 0.0); d->sink.assign(nt * MGC_TV, 0.0);
-    d->height.assign(nt * MGC_TV, MGC_HINF); d->lists.assign(18 * nt, 0); d->count.assign(MGC_NCOUNT, 0);
-    d->rmask32.assign(nt * MGC_TV, 0); d->stamp.assign(nt, 0); d->rstamp.assign(nt, 0); d->status.assign(nt, 0);
-    L.rcap = d->rcap.data(); L.excess = d->excess.data(); L.sink = d->sink.data(); L.height = d->height.data();
-    L.rmask32 = d->rmask32.data();
-    for (int i = 0; i < 18; ++i) L.list[i] = d->lists.data() + i * nt;
-    L.count = d->count.data(); L.stamp = d->stamp.data(); L.rstamp = d->rstamp.data(); L.status = d->status.data();
-    for (int64_t id = 0; id < N; ++id) {
-        int tile, loc;
-        mgc_node_to_tile(L, id, tile, loc);
-        uint32_t m = 0;
-        for (int dir = 0; dir < 26; ++dir) {
-            const double c = w[(int64_t)dir * N + id];
-            d->rcap[((int64_t)tile * 26 + dir) * MGC_TV + loc] = c;
-            if (c > 0.0) m |= 1u << dir;
-        }
-        const double tr = trcap[id];
-        d->excess[(int64_t)tile * MGC_TV + loc] = tr > 0 ? tr : 0.0;
-        d->sink[(int64_t)tile * MGC_TV + loc] = tr < 0 ? -tr : 0.0;
-        if (tr < 0) { m |= MGC26_MASK_SINK; d->status[tile] |= 2u; }
-        d->rmask32[(int64_t)tile * MGC_TV + loc] = m;
-    }
+    d->init(shape[0], shape[1], shape[2], NULL);
+    d->load(w, trcap);
     MgcSolveParams P = mgc_default_params();
     if (rounds > 0) P.rounds_per_relabel = rounds;
     if (cycles > 0) P.max_cycles = cycles;
     if (sweeps > 0) P.max_sweeps = sweeps;
     if (max_outer > 0) P.max_outer = max_outer;
     MgcSolveStats st;
-    const int rc = mgc_solve(*d, L, P, st, mgc_layout26());
+    const int rc = mgc_solve(*d, d->L, P, st, mgc_layout26());
     memcpy(stats_out, &st, sizeof(st));
-    for (int64_t id = 0; id < N; ++id) {
-        int tile, loc;
-        mgc_node_to_tile(L, id, tile, loc);
-        labels_out[id] = d->height[(int64_t)tile * MGC_TV + loc] < MGC_HINF ? 0 : 1;
-    }
+    d->labels(labels_out);
     delete d;
     return rc;
 }
+
+/* ---- handle API of a 26-neighbourhood slab (same calls as the 6-neighbourhood one above) ---- */
+void* hostsim26_create(const int64_t* gshape, int rank, int nranks)
+{
+    HostDev26* d = new HostDev26();
+    if (nranks <= 1) {
+        d->init(gshape[0], gshape[1], gshape[2], NULL);
+    } else {
+        MgcSlabSpec sp;
+        if (mgc_slab_spec(gshape[0], rank, nranks, &sp)) { delete d; return NULL; }
+        d->init(sp.plane1 - sp.plane0, gshape[1], gshape[2], &sp);
+    }
+    return d;
+}
+
+void hostsim26_destroy(void* h) { delete (HostDev26*)h; }
+
+int hostsim26_slab_info(void* h, int64_t* info)
+{
+    HostDev26* d = (HostDev26*)h;
+    info[0] = d->spec.plane0; info[1] = d->spec.plane1; info[2] = d->spec.own0; info[3] = d->spec.own1;
+    info[4] = d->L.tz_own_lo > 0; info[5] = d->L.tz_own_hi < d->L.gz; info[6] = (int64_t)d->L.gy * d->L.gx; info[7] = d->spec.nranks;
+    return 0;
+}
+
+int hostsim26_load(void* h, const double* w, const double* trcap) { ((HostDev26*)h)->load(w, trcap); return 0; }
+
+int hostsim26_solver_op(void* h, int op, int64_t a0, int64_t a1, int64_t a2, int64_t a3)
+{
+    HostDev26* d = (HostDev26*)h;
+    switch (op) {
+    case 0: d->absorb_all(); break;
+    case 1: d->fill_heights_inf(); break;
+    case 2: d->zero_count((int)a0); break;
+    case 3: d->relabel_all((uint32_t)a0, (int)a1); break;
+    case 4: d->relabel_list((int)a0, (uint32_t)a1, (int)a2); break;
+    case 5: d->activate_all((uint32_t)a0); break;
+    case 6: d->discharge((int)a0, (uint32_t)a1, (int)a2, (int)a3); break;
+    case 7: d->suspect_pass(); break;
+    case 8: d->reset_suspect((uint32_t)a0, (int)a1); break;
+    default: return 1;
+    }
+    return 0;
+}
+
+int hostsim26_read_counts(void* h, int32_t* out) { ((HostDev26*)h)->read_counts(out); return 0; }
+int hostsim26_halo_bytes(void* h, int kind, int64_t* bytes) { *bytes = mgc_halo_bytes_nd(((HostDev26*)h)->L, kind); return 0; }
+
+int hostsim26_halo_pack(void* h, int side, int kind, void* buf, int on_device)
+{
+    (void)on_device;
+    HostDev26* d = (HostDev26*)h;
+    HostBlock26 x(d->S);
+    const int T = d->L.gy * d->L.gx;
+    if (kind == 1) memset((char*)buf + mgc26_halo_off_count(d->L), 0, 4);
+    for (int i = 0; i < T; ++i) mgc_halo_pack_nd(x, d->L, side, kind, i, buf);
+    return 0;
+}
+
+int hostsim26_halo_unpack(void* h, int side, int kind, const void* buf, int on_device, uint32_t epoch, int list)
+{
+    (void)on_device;
+    HostDev26* d = (HostDev26*)h;
+    HostBlock26 x(d->S);
+    const int T = d->L.gy * d->L.gx;
+    for (int i = 0; i < T; ++i) mgc_halo_unpack_nd(x, d->L, side, kind, i, buf, epoch, list);
+    return 0;
+}
+
+int hostsim26_labels(void* h, uint8_t* out) { ((HostDev26*)h)->labels(out); return 0; }
 
 } /* extern "C" */

@@ -54,6 +54,8 @@ def solve(shape, weights, trcap, rounds=0, cycles=0, sweeps=0, max_outer=0):
 # distributed schedule (medpy_amd/slab.py:solve_slabs) and the transports are tested on CPU.
 # ------------------------------------------------------------------------------------------
 class SimSlab(object):
+    ndir = 6
+
     def __init__(self, global_shape, rank, nranks):
         L = lib()
         vp, i64 = C.c_void_p, C.c_int64
@@ -122,16 +124,10 @@ class SimSlab(object):
         return out.reshape(self.local_shape)[self.own0 - self.plane0:self.own1 - self.plane0].astype(np.bool_), 0.0
 
 
-def solve26(shape, weights_by_offset, trcap, rounds=0, cycles=0, sweeps=0, max_outer=0):
-    """26-neighbourhood: weights_by_offset = {offset: array (NaN where no neighbour)} for the 13 forward offsets
-    (oracle/energy_numpy.py:boundary_weights_offsets).  Returns (labels, stats)."""
-    L = lib()
-    pf = np.ctypeslib.ndpointer(np.float64, flags="C_CONTIGUOUS")
-    L.hostsim_solve26.restype = C.c_int
-    L.hostsim_solve26.argtypes = [np.ctypeslib.ndpointer(np.int64), pf, pf, C.c_int, C.c_int, C.c_int, C.c_int,
-                                  np.ctypeslib.ndpointer(np.uint8), np.ctypeslib.ndpointer(np.int64)]
+def weights26(shape, weights_by_offset):
+    """{offset: array (NaN where no neighbour)} for the 13 forward offsets -> dense (26,) + shape array of arc
+    capacities in mgc26_offset order (reverse arcs mirrored: the capacities are symmetric)."""
     shape = tuple(int(v) for v in shape)
-    n = int(np.prod(shape))
     w = np.zeros((26,) + shape)
     for o, arr in weights_by_offset.items():
         code = (o[0] + 1) * 9 + (o[1] + 1) * 3 + (o[2] + 1)
@@ -142,6 +138,20 @@ def solve26(shape, weights_by_offset, trcap, rounds=0, cycles=0, sweeps=0, max_o
         src = tuple(slice(max(0, -k), shape[a] - max(0, k)) for a, k in enumerate(o))
         dst = tuple(slice(max(0, k), shape[a] - max(0, -k)) for a, k in enumerate(o))
         w[25 - d][dst] = fwd[src]
+    return w
+
+
+def solve26(shape, weights_by_offset, trcap, rounds=0, cycles=0, sweeps=0, max_outer=0):
+    """26-neighbourhood: weights_by_offset = {offset: array (NaN where no neighbour)} for the 13 forward offsets
+    (oracle/energy_numpy.py:boundary_weights_offsets).  Returns (labels, stats)."""
+    L = lib()
+    pf = np.ctypeslib.ndpointer(np.float64, flags="C_CONTIGUOUS")
+    L.hostsim_solve26.restype = C.c_int
+    L.hostsim_solve26.argtypes = [np.ctypeslib.ndpointer(np.int64), pf, pf, C.c_int, C.c_int, C.c_int, C.c_int,
+                                  np.ctypeslib.ndpointer(np.uint8), np.ctypeslib.ndpointer(np.int64)]
+    shape = tuple(int(v) for v in shape)
+    n = int(np.prod(shape))
+    w = weights26(shape, weights_by_offset)
     labels = np.empty(n, np.uint8)
     stats = np.zeros(8, np.int64)
     rc = L.hostsim_solve26(np.asarray(shape, np.int64), np.ascontiguousarray(w).ravel(), np.ascontiguousarray(trcap, dtype=np.float64).ravel(),
@@ -149,3 +159,72 @@ def solve26(shape, weights_by_offset, trcap, rounds=0, cycles=0, sweeps=0, max_o
     st = dict(zip(STAT_NAMES, stats.tolist()))
     st["rc"] = rc
     return labels.reshape(shape), st
+
+
+class SimSlab26(object):
+    """26-neighbourhood slab over the host simulator (same surface as SimSlab / medpy_amd.slab.HipSlab)."""
+    ndir = 26
+
+    def __init__(self, global_shape, rank, nranks):
+        L = lib()
+        vp, i64 = C.c_void_p, C.c_int64
+        L.hostsim26_create.restype = vp
+        L.hostsim26_create.argtypes = [np.ctypeslib.ndpointer(np.int64), C.c_int, C.c_int]
+        L.hostsim26_destroy.argtypes = [vp]
+        L.hostsim26_slab_info.argtypes = [vp, np.ctypeslib.ndpointer(np.int64)]
+        pf = np.ctypeslib.ndpointer(np.float64, flags="C_CONTIGUOUS")
+        L.hostsim26_load.argtypes = [vp, pf, pf]
+        L.hostsim26_solver_op.argtypes = [vp, C.c_int, i64, i64, i64, i64]
+        L.hostsim26_read_counts.argtypes = [vp, np.ctypeslib.ndpointer(np.int32)]
+        L.hostsim26_halo_bytes.argtypes = [vp, C.c_int, C.POINTER(i64)]
+        L.hostsim26_halo_pack.argtypes = [vp, C.c_int, C.c_int, vp, C.c_int]
+        L.hostsim26_halo_unpack.argtypes = [vp, C.c_int, C.c_int, vp, C.c_int, C.c_uint32, C.c_int]
+        L.hostsim26_labels.argtypes = [vp, np.ctypeslib.ndpointer(np.uint8)]
+        self._L = L
+        self._h = L.hostsim26_create(np.asarray(global_shape, dtype=np.int64), rank, nranks)
+        assert self._h, "cannot cut the volume into that many slabs"
+        info = np.zeros(8, np.int64)
+        L.hostsim26_slab_info(self._h, info)
+        self.plane0, self.plane1, self.own0, self.own1 = (int(v) for v in info[:4])
+        self.has_lo, self.has_hi = bool(info[4]), bool(info[5])
+        self.local_shape = (self.plane1 - self.plane0, int(global_shape[1]), int(global_shape[2]))
+        self.rank, self.nranks = rank, nranks
+
+    def close(self):
+        if self._h:
+            self._L.hostsim26_destroy(self._h)
+            self._h = None
+
+    def __del__(self):
+        self.close()
+
+    def load(self, w26_global, trcap_global):
+        """w26_global: (26,) + global shape (weights26); the LOCAL planes are sliced out"""
+        a, b = self.plane0, self.plane1
+        w = np.ascontiguousarray(w26_global[:, a:b], dtype=np.float64).ravel()
+        tr = np.ascontiguousarray(np.asarray(trcap_global).reshape((-1,) + self.local_shape[1:])[a:b], dtype=np.float64).ravel()
+        self._L.hostsim26_load(self._h, w, tr)
+
+    def op(self, op, a0=0, a1=0, a2=0, a3=0):
+        assert self._L.hostsim26_solver_op(self._h, int(op), int(a0), int(a1), int(a2), int(a3)) == 0
+
+    def read_counts(self):
+        out = np.zeros(32, np.int32)
+        self._L.hostsim26_read_counts(self._h, out)
+        return out
+
+    def halo_bytes(self, kind):
+        n = C.c_int64(0)
+        self._L.hostsim26_halo_bytes(self._h, int(kind), C.byref(n))
+        return n.value
+
+    def halo_pack(self, side, kind, buf, on_device=False):
+        self._L.hostsim26_halo_pack(self._h, int(side), int(kind), C.c_void_p(buf.ctypes.data), 0)
+
+    def halo_unpack(self, side, kind, buf, epoch, lst, on_device=False):
+        self._L.hostsim26_halo_unpack(self._h, int(side), int(kind), C.c_void_p(buf.ctypes.data), 0, int(epoch), int(lst))
+
+    def finish(self):
+        out = np.empty(int(np.prod(self.local_shape)), np.uint8)
+        self._L.hostsim26_labels(self._h, out)
+        return out.reshape(self.local_shape)[self.own0 - self.plane0:self.own1 - self.plane0].astype(np.bool_), 0.0

@@ -120,3 +120,28 @@ def test_incremental_relabel_across_slabs(incremental):
                              incremental_relabel=incremental)
             assert st["converged"] == 1 and st["outer"] >= 3
             np.testing.assert_array_equal(np.concatenate([s.finish()[0] for s in slabs], axis=0), ref)
+
+
+@pytest.mark.parametrize("gen,shape,nslabs", [("sphere", (32, 16, 24), 2), ("hard", (40, 24, 24), 3), ("sphere", (64, 16, 16), 8),
+                                              ("sphere", (21, 17, 24), 2)])
+def test_full_neighbourhood_slabs_match_oracle(gen, shape, nslabs):
+    """26-neighbourhood across slabs (BASELINE config 5): pushes over the border accumulate in the ghost tiles and
+    travel as halo kind 1 (mgc26_halo_pack_tile); labels must equal the BK oracle fed the 26-neighbour edge list."""
+    import sim
+    from medpy_amd import synthetic
+    from medpy_amd.slab import LoopbackExchange, solve_slabs
+    from oracle import energy_numpy, pipeline
+    s = getattr(synthetic, gen)(shape)
+    offs = energy_numpy.forward_offsets(3, 26)
+    w = energy_numpy.boundary_weights_offsets(s["term"], s["image"], offs, s["sigma"])
+    g = pipeline.build_graph(s["fg"], s["bg"], weights=w, connectivity=26)
+    tr = np.array([g.get_trcap(i) for i in range(s["fg"].size)])
+    g.maxflow()
+    ref = g.labels().reshape(shape).astype(bool)
+    w26 = sim.weights26(shape, w)
+    slabs = [sim.SimSlab26(shape, r, nslabs) for r in range(nslabs)]
+    for sl in slabs:
+        sl.load(w26, tr)
+    st = solve_slabs(slabs, LoopbackExchange(slabs), rounds_per_relabel=2)
+    assert st["converged"] == 1
+    np.testing.assert_array_equal(np.concatenate([sl.finish()[0] for sl in slabs], axis=0), ref)
