@@ -1244,7 +1244,8 @@ struct MgcRccl {
             const size_t slash = sibling.rfind('/');
             sibling = (slash == std::string::npos ? std::string() : sibling.substr(0, slash + 1)) + "librccl.so.1";
         }
-        const char* names[] = {sibling.c_str(), "/opt/rocm/lib/librccl.so.1", "librccl.so.1", "librccl.so"};
+        const char* forced = getenv("MEDPY_HIP_RCCL"); /* explicit path: site installs, and the in-process mock of the tests */
+        const char* names[] = {forced ? forced : "", sibling.c_str(), "/opt/rocm/lib/librccl.so.1", "librccl.so.1", "librccl.so"};
         for (const char* n : names)
             /* DEEPBIND: librccl must bind to the HIP runtime it is linked against (the system one this library
              * uses too), not to another copy a host application may have put in the global scope (PyTorch wheels

@@ -1,0 +1,65 @@
+"""TEST ONLY (run as a subprocess by tests/test_gpu_slabs.py): N threads = N ranks on ONE GPU, each driving its own slab
+handle through the library's native transport (mgc_comm_init / mgc_halo_exchange / mgc_allreduce_counts) with the
+in-process mock of librccl (tests/hostsim/mock_rccl.cpp, selected by MEDPY_HIP_RCCL).  Prints one JSON line."""
+import json
+import os
+import sys
+import threading
+
+import numpy as np
+
+root, nranks, conn, gen = sys.argv[1], int(sys.argv[2]), int(sys.argv[3]), sys.argv[4]
+shape = tuple(int(v) for v in sys.argv[5].split("x"))
+sys.path.insert(0, root)
+from medpy_amd import synthetic  # noqa: E402
+from medpy_amd.slab import HipSlab, solve_slabs  # noqa: E402
+
+
+class ThreadRcclExchange(object):
+    """RcclExchange without torch.distributed: the unique id is handed over in-process"""
+
+    def __init__(self, slab, id_bytes):
+        self.slabs = [slab]
+        slab.comm_init(id_bytes)
+
+    def exchange(self, kind, epoch, lst):
+        self.slabs[0].exchange(kind, epoch, lst)
+
+    def global_counts(self):
+        return self.slabs[0].allreduce_counts()
+
+
+s = getattr(synthetic, gen)(shape)
+slabs = [HipSlab(shape, r, nranks, connectivity=conn) for r in range(nranks)]
+uid = slabs[0].comm_unique_id()
+out, errs = [None] * nranks, []
+
+
+def run(r):
+    try:
+        sl = slabs[r]
+        z = slice(sl.plane0, sl.plane1)
+        sl.set_boundary(s["term"], s["image"][z], s["sigma"], False)
+        sl.set_markers(s["fg"][z], s["bg"][z])
+        sl.build()
+        st = solve_slabs([sl], ThreadRcclExchange(sl, uid), rounds_per_relabel=2)
+        lab, part = sl.finish()
+        out[r] = (lab, part, st)
+    except Exception as e:  # noqa: BLE001
+        errs.append("rank %d: %r" % (r, e))
+
+
+threads = [threading.Thread(target=run, args=(r,), daemon=True) for r in range(nranks)]
+for t in threads:
+    t.start()
+for t in threads:
+    t.join(240)
+if errs or any(t.is_alive() for t in threads):
+    print(json.dumps({"error": errs or ["a rank did not finish (protocol deadlock)"]}))
+    sys.stdout.flush()
+    os._exit(1)
+labels = np.concatenate([o[0] for o in out], axis=0)
+np.save(sys.argv[6], labels)
+print(json.dumps({"flow": float(sum(o[1] for o in out)), "stats": [o[2] for o in out]}))
+sys.stdout.flush()
+os._exit(0)

@@ -19,6 +19,14 @@ def build():
     subprocess.check_call(["g++", "-O2", "-std=c++17", "-Wno-unknown-pragmas", "-fPIC", "-shared", "-o", _SO, src])
 
 
+def build_mock_rccl():
+    """tests/hostsim/libmockrccl.so: in-process stand-in for librccl (mock_rccl.cpp); needs hipcc"""
+    so, src = os.path.join(_HERE, "libmockrccl.so"), os.path.join(_HERE, "mock_rccl.cpp")
+    if not (os.path.exists(so) and os.path.getmtime(so) >= os.path.getmtime(src)):
+        subprocess.check_call(["/opt/rocm/bin/hipcc", "-O2", "-std=c++17", "-fPIC", "-shared", "-o", so, src])
+    return so
+
+
 def lib():
     global _lib
     if _lib is None:

@@ -102,3 +102,32 @@ def test_full_neighbourhood_slabs_equal_single_and_oracle(gen, shape, nslabs, re
     np.testing.assert_array_equal(labels, ref.labels)
     assert flow == pytest.approx(ref.flow, rel=1e-9)
     assert flow == pytest.approx(sflow, rel=1e-9)
+
+
+@pytest.mark.parametrize("nranks,conn,gen,shape", [(2, 6, "sphere", (64, 40, 48)), (3, 6, "hard", (48, 48, 40)), (2, 26, "sphere", (64, 40, 48)),
+                                                   (4, 26, "sphere", (64, 32, 32))])
+def test_native_transport_protocol_with_mock_rccl(nranks, conn, gen, shape, tmp_path):
+    """The multi-rank protocol of mgc_halo_exchange / mgc_allreduce_counts (grouped sends and receives to rank-1 / rank+1,
+    the two-stage compacted records of the 26-neighbourhood, every rank taking the same decisions) with N ranks as N
+    threads on ONE GPU over an in-process stand-in for librccl (tests/hostsim/mock_rccl.cpp: FIFO channels, a Send and
+    its Recv must agree on the size).  Real RCCL refuses two ranks on one device; with it this path runs at
+    bench.py --gpus N."""
+    import json
+    import os
+    import subprocess
+    import sys
+    sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), "hostsim"))
+    import sim
+    from medpy_amd import synthetic
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    out = str(tmp_path / "labels.npy")
+    env = dict(os.environ, MEDPY_HIP_RCCL=sim.build_mock_rccl())
+    res = subprocess.run([sys.executable, os.path.join(root, "tests", "hostsim", "mock_rccl_worker.py"), root, str(nranks), str(conn), gen,
+                          "x".join(str(v) for v in shape), out], env=env, capture_output=True, text=True, timeout=600)
+    assert res.returncode == 0, (res.stdout[-2000:], res.stderr[-2000:])
+    info = json.loads(res.stdout.strip().splitlines()[-1])
+    assert all(st["converged"] == 1 for st in info["stats"])
+    s = getattr(synthetic, gen)(shape)
+    ref = pipeline.graphcut_voxel(s["fg"], s["bg"], term=s["term"], image=s["image"], sigma=s["sigma"], connectivity=conn)
+    np.testing.assert_array_equal(np.load(out), ref.labels)
+    assert info["flow"] == pytest.approx(ref.flow, rel=1e-9)
