@@ -183,6 +183,64 @@ int mgc_comm_init(mgc_handle h, const uint8_t* id128);
 int mgc_halo_exchange(mgc_handle h, int kind, uint32_t epoch, int list);
 int mgc_allreduce_counts(mgc_handle h, int64_t* out32);
 
+
+/* ======================================================================================
+ * Sparse graphs ("msg"): everything that is not a 1-D..3-D voxel lattice -- the region graph of
+ * graph_from_labels (reference medpy/graphcut/generate.py:177-338) with the terms of energy_label.py:33-404, voxel
+ * graphs of more than three dimensions, and graphs assembled edge by edge through GCGraph.set_nweight
+ * (graph.py:382-440).  One handle = one maxflow.GraphDouble (wrapper.cpp:59-89).
+ * ==================================================================================== */
+typedef struct msg_graph* msg_handle;
+
+/* region terms, reference energy_label.py */
+typedef enum msg_label_term {
+    MSG_LABEL_STAWIASKI = 1,            /* energy_label.py:123-214; image = gradient image                         */
+    MSG_LABEL_STAWIASKI_DIRECTED = 2,   /* energy_label.py:217-353; param = directedness (sign picks the direction) */
+    MSG_LABEL_DIFFERENCE_OF_MEANS = 3   /* energy_label.py:33-120;  image = original image                          */
+} msg_label_term;
+
+typedef struct msg_stats {
+    double  build_ms;        /* edge list -> CSR residual graph (sort, duplicate sums, reverse index) */
+    double  solve_ms;
+    int64_t rounds;          /* push + gather rounds                                               */
+    int64_t global_relabels;
+    int64_t relabel_passes;
+    int64_t nodes;
+    int64_t arcs;            /* distinct directed arcs                                             */
+    int64_t edges_added;     /* sum_edge calls represented in the edge list                        */
+    int64_t reserved[4];
+} msg_stats;
+
+/* GraphDouble(nodes, edges) + add_node(nodes) (graph.py:294-308, graph.cpp:12-31) */
+int msg_create(int64_t nodes, int device, msg_handle* out);
+int msg_destroy(msg_handle h);
+const char* msg_last_error(msg_handle h);
+int msg_set_param(msg_handle h, const char* name, int64_t value);
+
+/* n calls of GCGraph.set_nweight(i, j, cap, rev) -> Graph::sum_edge (graph.py:382-440, graph.h:457-480): appended in
+ * order, repeated (i, j) are added up in that order when the graph is solved */
+int msg_add_edges(msg_handle h, int64_t n, const int64_t* i, const int64_t* j, const double* cap, const double* rev);
+/* the n-links a voxel boundary term adds for an image of ANY number of axes (energy_voxel.py:611-664), generated
+ * in HBM in the reference's order; term = mgc_term, spacing NULL = False */
+int msg_add_lattice_edges(msg_handle h, int term, int ndim, const int64_t* shape, const void* image, int dtype, double sigma,
+                          const double* spacing);
+/* the n-links a region term adds for a label image with labels 1..nodes (energy_label.py); labels int64, C-order */
+int msg_add_label_edges(msg_handle h, int term, int ndim, const int64_t* shape, const int64_t* labels, const void* image, int dtype,
+                        double param);
+/* per-region sums of `values` (and voxel counts) for labels 1..nregions: scipy.ndimage.mean / numpy.sum over a region
+ * (energy_label.py:88, 394-397); accumulate_f32 = keep a float32 accumulator as numpy.sum does for float32 maps */
+int msg_region_sums(int device, int64_t n, const int64_t* labels, const void* values, int dtype, int accumulate_f32, int64_t nregions,
+                    double* sums, int64_t* counts);
+/* merged t-links: tr[i] = tr_cap after all add_tweights calls, flow_const = what they added to the flow (graph.h:416-425) */
+int msg_set_tweights_merged(msg_handle h, const double* tr, double flow_const);
+/* GraphDouble.maxflow / what_segment / get_edge (pythongraph.h:20-21, graph.h:482-498, 561-571) */
+int msg_maxflow(msg_handle h, double* flow);
+int msg_labels(msg_handle h, uint8_t* out);
+int msg_what_segment(msg_handle h, int64_t i, int* segment);
+int msg_get_edge(msg_handle h, int64_t i, int64_t j, double* cap);
+int msg_get_counts(msg_handle h, int64_t* nodes, int64_t* edges_added, int64_t* arcs);
+int msg_get_stats(msg_handle h, msg_stats* out);
+
 #ifdef __cplusplus
 }
 #endif

@@ -179,8 +179,69 @@ def main_b0():
     print("reference_b0.npz", os.path.getsize(os.path.join(OUT, "reference_b0.npz")))
 
 
+def label_cases():
+    """deterministic label images (block partitions with a ragged edge), images and markers for the region graph cut"""
+    cases = []
+    for name, shape, block, dtype in (("l2d_f32", (24, 30), 4, np.float32), ("l2d_f64", (20, 20), 5, np.float64),
+                                      ("l3d_f32", (12, 14, 10), 3, np.float32), ("l3d_i16", (10, 12, 12), 4, np.int16)):
+        rng = np.random.default_rng(len(cases) + 7)
+        idx = np.indices(shape)
+        coarse = tuple((idx[d] + (idx[(d + 1) % len(shape)] // 7)) // block for d in range(len(shape)))  # ragged borders
+        dims = [int(c.max()) + 1 for c in coarse]
+        flat = np.ravel_multi_index(coarse, dims)
+        _, lab = np.unique(flat, return_inverse=True)
+        lab = (lab.reshape(shape) + 1).astype(np.int32)
+        centre = np.asarray(shape) / 2.0
+        r = np.sqrt(sum((idx[d] - centre[d]) ** 2 for d in range(len(shape))))
+        img = 100.0 * (r < 0.3 * min(shape)) + rng.normal(0, 10, shape)
+        grad = np.abs(np.gradient(img)[0]) * (1 if len(cases) % 2 else -1)  # signed values exercise the abs()
+        if np.issubdtype(dtype, np.integer):
+            img, grad = np.round(img).astype(dtype), np.round(grad).astype(dtype)
+        else:
+            img, grad = img.astype(dtype), grad.astype(dtype)
+        fg = r < 0.12 * min(shape)
+        bg = np.zeros(shape, bool)
+        bg[0], bg[-1] = True, True
+        prob = np.clip(0.3 + 0.4 * (r < 0.3 * min(shape)) + rng.normal(0, 0.1, shape), 0, 1).astype(np.float32 if dtype == np.float32 else np.float64)
+        cases.append(dict(name=name, labels=lab, image=img, gradient=grad, fg=fg, bg=bg, prob=prob))
+    return cases
+
+
+def main_labels():
+    """The region graph cut: reference graph_from_labels (generate.py:177-338) + energy_label.py terms + BK."""
+    gc = import_reference_graphcut()
+    from medpy.graphcut import energy_label as el
+    store = {}
+    for c in label_cases():
+        lab = c["labels"]
+        n = int(lab.max())
+        for tname, fn, args in (("stawiaski", el.boundary_stawiaski, c["gradient"]),
+                                # positive directedness cannot be run: the reference calls addition_directed_ltd with four
+                                # arguments although it takes five (energy_label.py:304, 347) -> TypeError
+                                ("stawiaski_directed_neg", el.boundary_stawiaski_directed, (c["gradient"], -0.5)),
+                                ("difference_of_means", el.boundary_difference_of_means, c["image"]),
+                                ("stawiaski_atlas", el.boundary_stawiaski, c["gradient"])):
+            kw = dict(boundary_term=fn, boundary_term_args=args)
+            if tname.endswith("atlas"):
+                kw.update(regional_term=el.regional_atlas, regional_term_args=(c["prob"], 0.5))
+            g = gc.graph_from_labels(lab, c["fg"], c["bg"], **kw)
+            edges = np.array([[g.get_edge(i, j) for j in range(n)] for i in range(n)])
+            trcap = np.array([g.get_trcap(i) for i in range(n)])
+            flow = g.maxflow()
+            seg = np.array([0 if g.what_segment(i) == g.termtype.SINK else 1 for i in range(n)], dtype=np.uint8)
+            key = "%s/%s" % (c["name"], tname)
+            store[key + "/edges"], store[key + "/trcap"], store[key + "/flow"], store[key + "/segments"] = edges, trcap, flow, seg
+            print(key, "regions", n, "flow", flow, "fg regions", int(seg.sum()))
+        for k in ("labels", "image", "gradient", "fg", "bg", "prob"):
+            store["%s/%s" % (c["name"], k)] = c[k]
+    np.savez_compressed(os.path.join(OUT, "reference_labels.npz"), **store)
+    print("reference_labels.npz", os.path.getsize(os.path.join(OUT, "reference_labels.npz")))
+
+
 if __name__ == "__main__":
     if len(sys.argv) > 1 and sys.argv[1] == "b0":
         main_b0()
+    elif len(sys.argv) > 1 and sys.argv[1] == "labels":
+        main_labels()
     else:
         main()
