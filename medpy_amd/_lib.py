@@ -39,6 +39,17 @@ class Stats(C.Structure):
         return d
 
 
+class SparseStats(C.Structure):
+    _fields_ = [("build_ms", C.c_double), ("solve_ms", C.c_double), ("rounds", C.c_int64), ("global_relabels", C.c_int64),
+                ("relabel_passes", C.c_int64), ("nodes", C.c_int64), ("arcs", C.c_int64), ("edges_added", C.c_int64),
+                ("reserved", C.c_int64 * 4)]
+
+    def as_dict(self):
+        return {k: getattr(self, k) for k, _ in self._fields_ if k != "reserved"}
+
+
+LABEL_TERM_IDS = {"stawiaski": 1, "stawiaski_directed": 2, "difference_of_means": 3}
+
 # every symbol include/medpy_hip.h declares: (restype, argtypes)
 _VP, _I64, _DBL, _INT = C.c_void_p, C.c_int64, C.c_double, C.c_int
 SIGNATURES = {
@@ -76,6 +87,22 @@ SIGNATURES = {
     "mgc_comm_init": (_INT, [_VP, _VP]),
     "mgc_halo_exchange": (_INT, [_VP, _INT, C.c_uint32, _INT]),
     "mgc_allreduce_counts": (_INT, [_VP, _VP]),
+    # sparse graphs (region graph cut, n-D voxel graphs, edge-by-edge plug-ins)
+    "msg_create": (_INT, [_I64, _INT, C.POINTER(_VP)]),
+    "msg_destroy": (_INT, [_VP]),
+    "msg_last_error": (C.c_char_p, [_VP]),
+    "msg_set_param": (_INT, [_VP, C.c_char_p, _I64]),
+    "msg_add_edges": (_INT, [_VP, _I64, _VP, _VP, _VP, _VP]),
+    "msg_add_lattice_edges": (_INT, [_VP, _INT, _INT, C.POINTER(_I64), _VP, _INT, _DBL, C.POINTER(_DBL)]),
+    "msg_add_label_edges": (_INT, [_VP, _INT, _INT, C.POINTER(_I64), _VP, _VP, _INT, _DBL]),
+    "msg_region_sums": (_INT, [_INT, _I64, _VP, _VP, _INT, _INT, _I64, _VP, _VP]),
+    "msg_set_tweights_merged": (_INT, [_VP, _VP, _DBL]),
+    "msg_maxflow": (_INT, [_VP, C.POINTER(_DBL)]),
+    "msg_labels": (_INT, [_VP, _VP]),
+    "msg_what_segment": (_INT, [_VP, _I64, C.POINTER(_INT)]),
+    "msg_get_edge": (_INT, [_VP, _I64, _I64, C.POINTER(_DBL)]),
+    "msg_get_counts": (_INT, [_VP, C.POINTER(_I64), C.POINTER(_I64), C.POINTER(_I64)]),
+    "msg_get_stats": (_INT, [_VP, C.POINTER(SparseStats)]),
 }
 
 _lib = None
@@ -115,6 +142,12 @@ def device_count():
 def check(handle, rc):
     if rc != OK:
         msg = load().mgc_last_error(handle)
+        raise MedpyHipError(rc, (msg or b"").decode("utf-8", "replace"))
+
+
+def check_sparse(handle, rc):
+    if rc != OK:
+        msg = load().msg_last_error(handle)
         raise MedpyHipError(rc, (msg or b"").decode("utf-8", "replace"))
 
 

@@ -1,14 +1,15 @@
-"""medpy_amd.graphcut -- the voxel half of ``medpy.graphcut`` on MI355X.
+"""medpy_amd.graphcut -- ``medpy.graphcut`` on MI355X.
 
-Same public names as reference medpy/graphcut/__init__.py for the voxel path:
-``graph_from_voxels``, ``energy_voxel``, ``GCGraph``, ``split_marker``; ``GraphDouble`` is the
-class of the returned solver object.
+Same public names as reference medpy/graphcut/__init__.py: ``graph_from_voxels`` / ``energy_voxel`` (voxel lattices:
+the tile solver), ``graph_from_labels`` / ``energy_label`` (region graphs: the sparse-graph solver), ``GCGraph``,
+``split_marker``, ``graphcut_stawiaski``; ``GraphDouble`` is the class of the solver object for arbitrary graphs.
 """
-from . import energy_voxel
-from .generate import graph_from_voxels
-from .graph import GCGraph, VoxelGraph, termtype
-from .wrapper import split_marker
+from . import energy_label, energy_voxel
+from .generate import graph_from_labels, graph_from_voxels
+from .graph import GCGraph, SparseGraph, VoxelGraph, termtype
+from .wrapper import graphcut_stawiaski, split_marker
 
-GraphDouble = VoxelGraph
+GraphDouble = SparseGraph
 
-__all__ = ["graph_from_voxels", "energy_voxel", "GCGraph", "VoxelGraph", "GraphDouble", "termtype", "split_marker"]
+__all__ = ["graph_from_voxels", "graph_from_labels", "energy_voxel", "energy_label", "GCGraph", "VoxelGraph", "SparseGraph",
+           "GraphDouble", "termtype", "split_marker", "graphcut_stawiaski"]

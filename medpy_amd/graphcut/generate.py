@@ -76,6 +76,69 @@ def graph_from_voxels(
     return graph.get_graph()
 
 
+def graph_from_labels(
+    label_image,
+    fg_markers,
+    bg_markers,
+    regional_term=False,
+    boundary_term=False,
+    regional_term_args=False,
+    boundary_term_args=False,
+):
+    """Create a graph-cut ready graph to segment an nD image using the region neighbourhood.
+
+    Drop-in for ``medpy.graphcut.graph_from_labels`` (reference generate.py:177-338): every region of the label image
+    (labels 1..n) is a node, regions that touch under the ``ndim*2`` voxel neighbourhood are joined by arcs whose
+    weights the ``boundary_term(graph, label_image, boundary_term_args)`` plug-in supplies (see
+    :mod:`medpy_amd.graphcut.energy_label`), ``regional_term(graph, label_image, regional_term_args)`` supplies
+    t-weights, and the regions under the markers are wired to the terminals with ``GCGraph.MAX``.  The region adjacency
+    graph is assembled and solved in MI355X HBM; the returned object is the stand-in for ``maxflow.GraphDouble``.
+
+    Raises ``AttributeError`` for a malformed label image or terms that do not take three parameters."""
+    label_image = numpy.asarray(label_image)
+    fg_markers = numpy.asarray(fg_markers, dtype=numpy.bool_)
+    bg_markers = numpy.asarray(bg_markers, dtype=numpy.bool_)
+    __check_label_image(label_image)
+
+    if not regional_term:
+        regional_term = __regional_term_label
+    if not boundary_term:
+        boundary_term = __boundary_term_label
+    if not hasattr(regional_term, "__call__") or not 3 == len(inspect.getfullargspec(regional_term)[0]):
+        raise AttributeError("regional_term has to be a callable object which takes three parameters.")
+    if not hasattr(boundary_term, "__call__") or not 3 == len(inspect.getfullargspec(boundary_term)[0]):
+        raise AttributeError("boundary_term has to be a callable object which takes three parameters.")
+
+    nodes = len(numpy.unique(label_image))
+    edges = 10 * nodes  # the reference's guess (generate.py:296-300); sizes nothing here
+    graph = GCGraph(nodes, edges)
+
+    regional_term(graph, label_image, regional_term_args)
+    boundary_term(graph, label_image, boundary_term_args)
+
+    graph.set_source_nodes(numpy.unique(label_image[fg_markers] - 1))  # node ids start at 0
+    graph.set_sink_nodes(numpy.unique(label_image[bg_markers] - 1))
+    return graph.get_graph()
+
+
+def __check_label_image(label_image):
+    """labels have to be 1..n without gaps (reference generate.py:352-360 / energy_label.py:451-461)"""
+    encountered_indices = numpy.unique(label_image)
+    expected_indices = numpy.arange(1, label_image.max() + 1)
+    if not encountered_indices.size == expected_indices.size or not (encountered_indices == expected_indices).all():
+        raise AttributeError("The supplied label image does either not contain any regions or they are not labeled consecutively starting from 1.")
+
+
+def __regional_term_label(graph, label_image, regional_term_args):
+    """Fake regional_term function with the appropriate signature."""
+    return {}
+
+
+def __boundary_term_label(graph, label_image, boundary_term_args):
+    """Fake boundary_term function with the appropriate signature."""
+    return {}
+
+
 def __regional_term_voxel(graph, regional_term_args):
     """Fake regional_term function with the appropriate signature (generate.py:341-343)."""
     return {}

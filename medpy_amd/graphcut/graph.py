@@ -176,6 +176,192 @@ class VoxelGraph(object):
         return st.as_dict()
 
 
+class SparseGraph(object):
+    """``maxflow.GraphDouble`` (reference lib/maxflow/src/wrapper.cpp:59-89) for ARBITRARY graphs, solved in HBM by the
+    library's sparse-graph solver (C ABI ``msg_*``).  Returned by ``graph_from_labels``, by ``graph_from_voxels`` for
+    images of more than three dimensions and by ``GCGraph.get_graph()`` for graphs that plug-in terms assemble edge by
+    edge.  Besides the facade hooks (``_add_*``) it takes the raw GraphDouble calls ``add_node``, ``add_edge``,
+    ``sum_edge`` and ``add_tweights``; edges are buffered and uploaded in batches."""
+
+    termtype = termtype
+
+    def __init__(self, nodes, edges=0, device=0):
+        lib = _lib.load()
+        if _lib.device_count() < 1:
+            raise _lib.MedpyHipError(_lib.ERR_NO_DEVICE, "no HIP device visible; medpy_amd has no CPU fallback")
+        self._nodes = max(int(nodes), 1)
+        h = C.c_void_p()
+        rc = lib.msg_create(self._nodes, int(device), C.byref(h))
+        self._h = h if h.value else None
+        if rc != _lib.OK:
+            msg = (lib.msg_last_error(self._h) or b"").decode()
+            self.close()
+            raise _lib.MedpyHipError(rc, msg)
+        self._labels = None
+        self._pending = ([], [], [], [])
+        self._tr = None
+        self._flow_const = 0.0
+        self._declared = 0
+
+    def close(self):
+        if getattr(self, "_h", None):
+            _lib.load().msg_destroy(self._h)
+            self._h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def _call(self, name, *args):
+        _lib.check_sparse(self._h, getattr(_lib.load(), name)(self._h, *args))
+
+    @staticmethod
+    def _image(image):
+        image = numpy.ascontiguousarray(image)
+        if image.dtype == numpy.bool_:
+            image = image.astype(numpy.uint8)
+        if image.dtype == numpy.float16:
+            image = image.astype(numpy.float32)
+        if image.dtype not in _lib.DTYPE_IDS:
+            image = image.astype(numpy.float64)
+        return image
+
+    # -- inputs
+    def _flush(self):
+        i, j, cap, rev = self._pending
+        if i:
+            self._pending = ([], [], [], [])
+            self._add_edges(i, j, cap, rev)
+
+    def _add_edges(self, i, j, cap, rev):
+        i = numpy.ascontiguousarray(i, dtype=numpy.int64)
+        j = numpy.ascontiguousarray(j, dtype=numpy.int64)
+        cap = numpy.ascontiguousarray(cap, dtype=numpy.float64)
+        rev = numpy.ascontiguousarray(rev, dtype=numpy.float64)
+        self._call("msg_add_edges", i.size, _lib.ptr(i), _lib.ptr(j), _lib.ptr(cap), _lib.ptr(rev))
+        self._labels = None
+
+    def _add_lattice_edges(self, term, image, sigma, spacing):
+        self._flush()
+        image = self._image(image)
+        shp = (C.c_int64 * image.ndim)(*image.shape)
+        sp = (C.c_double * image.ndim)(*[float(v) for v in spacing]) if spacing else None
+        self._call("msg_add_lattice_edges", _lib.TERM_IDS[term], image.ndim, shp, _lib.ptr(image), _lib.DTYPE_IDS[image.dtype],
+                   float(sigma) if sigma is not None else 0.0, sp)
+        self._labels = None
+
+    def _add_label_edges(self, term, label_image, image, param=0.0):
+        self._flush()
+        lab = numpy.ascontiguousarray(label_image, dtype=numpy.int64)
+        image = self._image(numpy.asarray(image))
+        if image.shape != lab.shape:
+            raise ValueError("label image {} and image {} differ in shape".format(lab.shape, image.shape))
+        shp = (C.c_int64 * lab.ndim)(*lab.shape)
+        self._call("msg_add_label_edges", _lib.LABEL_TERM_IDS[term], lab.ndim, shp, _lib.ptr(lab), _lib.ptr(image),
+                   _lib.DTYPE_IDS[image.dtype], float(param))
+        self._labels = None
+
+    def _set_tweights_merged(self, tr, flow_const):
+        self._tr = numpy.array(tr, dtype=numpy.float64)
+        self._flow_const = float(flow_const)
+        self._labels = None
+
+    def set_param(self, name, value):
+        self._call("msg_set_param", name.encode(), int(value))
+
+    # -- raw GraphDouble calls (graph.h:388-480)
+    def add_node(self, num=1):
+        first = self._declared
+        self._declared += int(num)
+        return first
+
+    def sum_edge(self, i, j, cap, rev_cap):
+        p = self._pending
+        p[0].append(int(i)); p[1].append(int(j)); p[2].append(float(cap)); p[3].append(float(rev_cap))
+        if len(p[0]) >= 1 << 20:
+            self._flush()
+
+    add_edge = sum_edge  # parallel arcs carry the same flow as one arc with the summed capacity
+
+    def add_tweights(self, i, cap_source, cap_sink):
+        if self._tr is None:
+            self._tr = numpy.zeros(self._nodes, dtype=numpy.float64)
+        cs, ck = float(cap_source), float(cap_sink)
+        delta = self._tr[i]
+        if delta > 0:
+            cs += delta
+        else:
+            ck -= delta
+        self._flow_const += cs if cs < ck else ck
+        self._tr[i] = cs - ck
+        self._labels = None
+
+    # -- GraphDouble surface
+    def maxflow(self):
+        """GraphDouble.maxflow(), reference maxflow.cpp:472-604"""
+        self._flush()
+        if self._tr is not None:
+            tr = numpy.ascontiguousarray(self._tr, dtype=numpy.float64)
+            self._call("msg_set_tweights_merged", _lib.ptr(tr), self._flow_const)
+        flow = C.c_double(0.0)
+        self._call("msg_maxflow", C.byref(flow))
+        self._labels = None
+        return flow.value
+
+    def labels(self):
+        """every node at once: bool array, False where what_segment == SINK"""
+        if self._labels is None:
+            out = numpy.empty(self._nodes, dtype=numpy.uint8)
+            self._call("msg_labels", _lib.ptr(out))
+            self._labels = out.astype(numpy.bool_)
+        return self._labels
+
+    def what_segment(self, i):
+        seg = C.c_int(0)
+        self._call("msg_what_segment", int(i), C.byref(seg))
+        return termtype(seg.value)
+
+    def get_edge(self, i, j):
+        self._flush()
+        out = C.c_double(0.0)
+        self._call("msg_get_edge", int(i), int(j), C.byref(out))
+        return out.value
+
+    def get_trcap(self, i):
+        return 0.0 if self._tr is None else float(self._tr[int(i)])
+
+    def get_node_num(self):
+        return self._nodes
+
+    def get_arc_num(self):
+        self._flush()
+        n = C.c_int64(0)
+        self._call("msg_get_counts", None, None, C.byref(n))
+        return n.value
+
+    def stats(self):
+        st = _lib.SparseStats()
+        self._call("msg_get_stats", C.byref(st))
+        return st.as_dict()
+
+
+def region_sums(label_image, values, nregions, device=0):
+    """per-region sums of ``values`` for labels 1..nregions, computed in HBM (``msg_region_sums``); float32 maps keep a
+    float32 accumulator like numpy.sum does (reference energy_label.py:394-397).  Returns (sums, counts)."""
+    lab = numpy.ascontiguousarray(label_image, dtype=numpy.int64)
+    values = SparseGraph._image(numpy.asarray(values))
+    if values.shape != lab.shape:
+        raise ValueError("label image {} and map {} differ in shape".format(lab.shape, values.shape))
+    sums = numpy.zeros(int(nregions), dtype=numpy.float64)
+    counts = numpy.zeros(int(nregions), dtype=numpy.int64)
+    rc = _lib.load().msg_region_sums(int(device), lab.size, _lib.ptr(lab), _lib.ptr(values), _lib.DTYPE_IDS[values.dtype],
+                                     int(values.dtype == numpy.float32), int(nregions), _lib.ptr(sums), _lib.ptr(counts))
+    _lib.check_sparse(None, rc)
+    return sums, counts
+
+
 class EmbeddedLatticeGraph(object):
     """`nodes` graph nodes of which the first prod(lattice_shape) form a voxel lattice (the boundary image had another
     shape than the markers, see GCGraph.record_boundary); the other nodes carry only their marker t-links.  Same surface
@@ -239,6 +425,8 @@ class GCGraph(object):
         self.__connectivity = connectivity
         self.__nodes = int(nodes)
         self.__edges = int(edges)
+        self.__general = shape is None or len(tuple(shape)) > 3  # not a 1-D..3-D voxel lattice: sparse-graph solver
+        self.__label_terms = []
         self.__shape = tuple(shape) if shape is not None else (int(nodes),)
         if int(numpy.prod(self.__shape)) != self.__nodes:
             raise ValueError("shape {} does not hold {} nodes".format(self.__shape, nodes))
@@ -269,6 +457,28 @@ class GCGraph(object):
         if self.__boundary is not None:
             raise NotImplementedError("medpy_amd: only one built-in boundary term per graph")
         self.__boundary = (term, image, sigma, spacing)
+
+    def record_label_boundary(self, term, label_image, image, param=0.0):
+        """fast path of the region terms (medpy_amd.graphcut.energy_label): the RAG edges are generated in HBM"""
+        self.__general = True
+        self.__label_terms.append((term, numpy.asarray(label_image), numpy.asarray(image), float(param)))
+
+    def merge_tweights(self, nodes, weights_source, weights_sink):
+        """vectorised ``set_tweight`` for DISTINCT node ids, Graph::add_tweights call by call (graph.h:416-425)"""
+        nodes = numpy.asarray(nodes, dtype=numpy.int64)
+        if nodes.size == 0:
+            return
+        if nodes.max() >= self.__nodes or nodes.min() < 0:
+            raise ValueError("Invalid node id of {} or {}. Valid values are 0 to {}.".format(nodes.max(), nodes.min(), self.__nodes - 1))
+        if self.__tr is None:
+            self.__tr = numpy.zeros(self.__nodes, dtype=numpy.float64)
+        cs = numpy.array(weights_source, dtype=numpy.float64)
+        ck = numpy.array(weights_sink, dtype=numpy.float64)
+        delta = self.__tr[nodes]
+        cs = cs + numpy.where(delta > 0, delta, 0.0)
+        ck = ck - numpy.where(delta > 0, 0.0, delta)
+        self.__flow_const = float(numpy.cumsum(numpy.concatenate([[self.__flow_const], numpy.minimum(cs, ck)]))[-1])  # in call order
+        self.__tr[nodes] = cs - ck
 
     def record_regional(self, probability_map, alpha):
         pm = numpy.asarray(probability_map)
@@ -350,6 +560,8 @@ class GCGraph(object):
 
     def get_graph(self):
         """Builds the residual lattice in HBM (once) and returns the solver object."""
+        if self.__graph is None and self.__general:
+            self.__graph = self.__sparse_graph()
         if self.__graph is None and self.__lattice_shape is not None:
             self.__graph = EmbeddedLatticeGraph(self.__nodes, self.__lattice_shape, self.__boundary, self.__fg, self.__bg,
                                                 device=self.__device, connectivity=self.__connectivity)
@@ -368,6 +580,35 @@ class GCGraph(object):
             g._build()
             self.__graph = g
         return self.__graph
+
+    def __sparse_graph(self):
+        """the same calls in the same order (regional term, boundary term, explicit edges, markers last:
+        generate.py:159-172, 322-338) on the sparse-graph solver"""
+        if self.__connectivity not in (None, 2 * len(self.__shape)):
+            raise NotImplementedError("medpy_amd: the full neighbourhood exists for 1-D..3-D voxel lattices only")
+        g = SparseGraph(self.__nodes, self.__edges, device=self.__device)
+        if self.__regional is not None:  # energy_voxel.py:61-65 in the map's dtype, then graph.py:551-552
+            pm, alpha = self.__regional
+            pm = numpy.asarray(pm)
+            if pm.dtype not in (numpy.float32, numpy.float64):
+                pm = pm.astype(numpy.float64)
+            self.merge_tweights(numpy.arange(self.__nodes), (pm * alpha).ravel().astype(numpy.float64),
+                                ((1 - pm) * alpha).ravel().astype(numpy.float64))
+            self.__regional = None
+        if self.__boundary is not None:
+            g._add_lattice_edges(*self.__boundary)
+        for term, lab, img, param in self.__label_terms:
+            g._add_label_edges(term, lab, img, param)
+        if self.__edge_i:
+            g._add_edges(self.__edge_i, self.__edge_j, self.__edge_w, self.__edge_r)
+        for marks, src, snk in ((self.__fg, float(self.MAX), 0.0), (self.__bg, 0.0, float(self.MAX))):
+            if marks is not None:
+                ids = numpy.flatnonzero(numpy.asarray(marks).ravel())
+                self.merge_tweights(ids, numpy.full(ids.size, src), numpy.full(ids.size, snk))
+        self.__fg = self.__bg = None
+        if self.__tr is not None:
+            g._set_tweights_merged(self.__tr, self.__flow_const)
+        return g
 
     def get_node_count(self):
         return self.__nodes

@@ -1,0 +1,154 @@
+"""-m gpu: the region (label) graph cut and the other sparse-graph users on the MI355X.
+graph_from_labels + energy_label terms -> RAG built in HBM (msg_add_label_edges) -> sparse-graph solver, against what the
+REFERENCE produced for the same inputs (tests/golden/reference_labels.npz) and against the BK oracle."""
+import os
+
+import numpy as np
+import pytest
+
+from oracle import bk, energy_label_numpy as eln, energy_numpy, pipeline
+
+pytestmark = pytest.mark.gpu
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+GOLD = np.load(os.path.join(HERE, "golden", "reference_labels.npz"))
+CASES = ["l2d_f32", "l2d_f64", "l3d_f32", "l3d_i16"]
+
+
+def _terms(case):
+    from medpy_amd.graphcut import energy_label as el
+    g = lambda k: GOLD["%s/%s" % (case, k)]
+    return {
+        "stawiaski": dict(boundary_term=el.boundary_stawiaski, boundary_term_args=g("gradient")),
+        "stawiaski_directed_neg": dict(boundary_term=el.boundary_stawiaski_directed, boundary_term_args=(g("gradient"), -0.5)),
+        "difference_of_means": dict(boundary_term=el.boundary_difference_of_means, boundary_term_args=g("image")),
+        "stawiaski_atlas": dict(boundary_term=el.boundary_stawiaski, boundary_term_args=g("gradient"),
+                                regional_term=el.regional_atlas, regional_term_args=(g("prob"), 0.5)),
+    }
+
+
+@pytest.mark.parametrize("case", CASES)
+@pytest.mark.parametrize("term", ["stawiaski", "stawiaski_directed_neg", "difference_of_means", "stawiaski_atlas"])
+def test_graph_from_labels_matches_reference(case, term):
+    from medpy_amd import graphcut
+    lab = GOLD[case + "/labels"]
+    n = int(lab.max())
+    g = graphcut.graph_from_labels(lab, GOLD[case + "/fg"], GOLD[case + "/bg"], **_terms(case)[term])
+    key = "%s/%s" % (case, term)
+    ref_edges = GOLD[key + "/edges"]
+    pairs = np.argwhere(ref_edges != 0)
+    pairs = pairs[:: max(1, len(pairs) // 60)]  # a sample of the arcs + a few absent ones (get_edge is a per-call read-back)
+    got = np.array([g.get_edge(int(a), int(b)) for a, b in pairs])
+    want = ref_edges[pairs[:, 0], pairs[:, 1]]
+    if term == "difference_of_means":
+        np.testing.assert_allclose(got, want, rtol=1e-9)  # region means: tree-ordered sums (reduce-by-key) vs bincount order
+    else:
+        np.testing.assert_array_equal(got, want)  # duplicate sums in insertion order: bit-exact
+    assert g.get_edge(0, n - 1) == ref_edges[0, n - 1]
+    trcap = np.array([g.get_trcap(i) for i in range(n)])
+    if term.endswith("atlas"):
+        np.testing.assert_allclose(trcap, GOLD[key + "/trcap"], rtol=1e-6)
+    else:
+        np.testing.assert_array_equal(trcap, GOLD[key + "/trcap"])
+    flow = g.maxflow()
+    assert flow == pytest.approx(float(GOLD[key + "/flow"]), rel=1e-6 if term.endswith("atlas") else 1e-9)
+    seg = np.array([0 if g.what_segment(i) == g.termtype.SINK else 1 for i in range(n)], dtype=np.uint8)
+    np.testing.assert_array_equal(seg, GOLD[key + "/segments"])
+    np.testing.assert_array_equal(g.labels().astype(np.uint8), GOLD[key + "/segments"])
+    assert g.get_node_num() == n and g.stats()["arcs"] == 2 * np.count_nonzero(np.triu(ref_edges + ref_edges.T))
+
+
+def test_positive_directedness_against_the_restatement():
+    """the reference raises TypeError for directedness >= 0 (energy_label.py:304,347); pinned by the NumPy restatement only"""
+    from medpy_amd import graphcut
+    from medpy_amd.graphcut import energy_label as el
+    case = "l3d_f32"
+    lab, grad = GOLD[case + "/labels"], GOLD[case + "/gradient"]
+    g = graphcut.graph_from_labels(lab, GOLD[case + "/fg"], GOLD[case + "/bg"], boundary_term=el.boundary_stawiaski_directed,
+                                   boundary_term_args=(grad, 0.25))
+    flow = g.maxflow()
+    oflow, oseg, _ = eln.graphcut_labels(lab, GOLD[case + "/fg"], GOLD[case + "/bg"], "stawiaski_directed", (grad, 0.25))
+    np.testing.assert_array_equal(g.labels(), oseg)
+    assert flow == pytest.approx(oflow, rel=1e-9)
+
+
+def test_larger_label_image_and_wrapper():
+    """a 3-D watershed-like partition with ~4000 regions; graphcut_stawiaski (wrapper.py:239-310) end to end"""
+    from medpy_amd import graphcut, synthetic
+    shape = (48, 64, 56)
+    s = synthetic.sphere(shape)
+    idx = np.indices(shape)
+    coarse = tuple((idx[d] + (idx[(d + 1) % 3] // 5)) // 4 for d in range(3))
+    flat = np.ravel_multi_index(coarse, [int(c.max()) + 1 for c in coarse])
+    regions = flat.astype(np.int64) * 7 + 3  # arbitrary ids: the wrapper relabels
+    grad = np.abs(np.gradient(s["image"].astype(np.float64))[0]).astype(np.float32)
+    seg = graphcut.graphcut_stawiaski(regions, grad, s["fg"], s["bg"])
+    assert seg.shape == shape and seg.dtype == np.bool_
+    from medpy_amd.graphcut.wrapper import relabel
+    lab = relabel(regions)
+    oflow, oseg, _ = eln.graphcut_labels(lab, s["fg"], s["bg"], "stawiaski", grad)
+    np.testing.assert_array_equal(seg, np.concatenate([[False], oseg])[lab])
+    assert 0 < seg.mean() < 1
+
+
+def test_raw_graphdouble_calls_random_graphs():
+    """SparseGraph driven like maxflow.GraphDouble (add_node / sum_edge / add_tweights / maxflow / what_segment)"""
+    from medpy_amd.graphcut import GraphDouble
+    rng = np.random.default_rng(11)
+    for trial in range(6):
+        n = int(rng.integers(2, 400))
+        m = int(rng.integers(1, 6 * n))
+        i, j = rng.integers(0, n, m), rng.integers(0, n, m)
+        keep = i != j
+        i, j = i[keep], j[keep]
+        cap, rev = rng.random(i.size) + 1e-3, rng.random(i.size) * (rng.random(i.size) < 0.7) + 1e-3
+        src = np.where(rng.random(n) < 0.2, rng.random(n) * 3, 0.0)
+        snk = np.where(rng.random(n) < 0.2, rng.random(n) * 3, 0.0)
+        o = bk.BKGraph(n, max(16, i.size))
+        o.sum_edges(i, j, cap, rev)
+        o.add_tweights(None, src, snk)
+        oflow = o.maxflow()
+        g = GraphDouble(n, i.size)
+        assert g.add_node(n) == 0
+        for a, b, c, r in zip(i.tolist(), j.tolist(), cap.tolist(), rev.tolist()):
+            g.sum_edge(a, b, c, r)
+        for u in range(n):
+            if src[u] or snk[u]:
+                g.add_tweights(u, float(src[u]), float(snk[u]))
+        flow = g.maxflow()
+        assert flow == pytest.approx(oflow, rel=1e-9, abs=1e-12)
+        np.testing.assert_array_equal(g.labels().astype(np.uint8), o.labels())
+        assert g.what_segment(0) == (g.termtype.SOURCE if o.labels()[0] else g.termtype.SINK)
+
+
+@pytest.mark.parametrize("term", ["difference_linear", "difference_exponential", "difference_division", "difference_power",
+                                  "maximum_linear", "maximum_exponential", "maximum_division", "maximum_power"])
+def test_four_dimensional_voxel_graph(term):
+    """graph_from_voxels on a 4-D image (ndim*2 = 8 neighbours): n-links generated in HBM for any number of
+    axes (msg_add_lattice_edges), solved by the sparse-graph solver; oracle = the same per-axis weights into BK"""
+    from medpy_amd import graphcut
+    from medpy_amd.graphcut import energy_voxel as ev
+    shape = (6, 7, 5, 4)
+    rng = np.random.default_rng(3)
+    idx = np.indices(shape)
+    r = np.sqrt(sum((idx[d] - (shape[d] - 1) / 2.0) ** 2 for d in range(4)))
+    image = (60.0 * (r < 2.5) + rng.normal(0, 8, shape)).astype(np.float32)
+    fg = r < 1.0
+    bg = np.zeros(shape, bool)
+    bg[0], bg[-1] = True, True
+    spacing = (1.0, 2.0, 0.5, 1.5) if term.endswith("power") else False
+    sigma = 15.0
+    fn = getattr(ev, "boundary_" + term)
+    args = (image, spacing) if term.endswith("linear") else (image, sigma, spacing)
+    g = graphcut.graph_from_voxels(fg, bg, boundary_term=fn, boundary_term_args=args)
+    flow = g.maxflow()
+    ref = pipeline.graphcut_voxel(fg, bg, term=term, image=image, sigma=sigma, spacing=spacing)
+    np.testing.assert_array_equal(g.labels().reshape(shape), ref.labels)
+    assert flow == pytest.approx(ref.flow, rel=1e-9)
+    w = energy_numpy.boundary_weights(term, image, sigma, spacing)
+    got = (g.get_edge(0, 1), g.get_edge(0, int(np.prod(shape[1:]))))
+    want = (w[3].ravel()[0], w[0].ravel()[0])
+    if term.endswith("exponential") or term.endswith("power"):  # device exp / pow are not correctly rounded
+        assert got == pytest.approx(want, rel=1e-12)
+    else:
+        assert got == want

@@ -16,7 +16,7 @@ def test_library_exports_every_declared_symbol():
     from medpy_amd import _lib, build
     build.build_library()
     header = open(os.path.join(ROOT, "include", "medpy_hip.h")).read()
-    declared = set(re.findall(r"\b(mgc_[a-z_]+)\s*\(", header))
+    declared = set(re.findall(r"\b(m[gs][cg]_[a-z_]+)\s*\(", header))
     assert declared == set(_lib.SIGNATURES), declared ^ set(_lib.SIGNATURES)
     lib = ctypes.CDLL(_lib.LIB_PATH)
     for name in declared:
