@@ -239,6 +239,9 @@ int msg_labels(msg_handle h, uint8_t* out);
 int msg_what_segment(msg_handle h, int64_t i, int* segment);
 int msg_get_edge(msg_handle h, int64_t i, int64_t j, double* cap);
 int msg_get_counts(msg_handle h, int64_t* nodes, int64_t* edges_added, int64_t* arcs);
+/* every distinct arc of the graph as built (tail, head, capacity), sorted by (tail, head): bulk counterpart of get_edge,
+ * used by the DIMACS writer (reference medpy/graphcut/write.py:29-76); arrays hold msg_get_counts(..., &arcs) entries */
+int msg_get_arcs(msg_handle h, int32_t* tail, int32_t* head, double* cap);
 int msg_get_stats(msg_handle h, msg_stats* out);
 
 #ifdef __cplusplus

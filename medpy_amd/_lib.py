@@ -102,6 +102,7 @@ SIGNATURES = {
     "msg_what_segment": (_INT, [_VP, _I64, C.POINTER(_INT)]),
     "msg_get_edge": (_INT, [_VP, _I64, _I64, C.POINTER(_DBL)]),
     "msg_get_counts": (_INT, [_VP, C.POINTER(_I64), C.POINTER(_I64), C.POINTER(_I64)]),
+    "msg_get_arcs": (_INT, [_VP, _VP, _VP, _VP]),
     "msg_get_stats": (_INT, [_VP, C.POINTER(SparseStats)]),
 }
 

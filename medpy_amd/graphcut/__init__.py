@@ -6,10 +6,11 @@ the tile solver), ``graph_from_labels`` / ``energy_label`` (region graphs: the s
 """
 from . import energy_label, energy_voxel
 from .generate import graph_from_labels, graph_from_voxels
-from .graph import GCGraph, SparseGraph, VoxelGraph, termtype
+from .graph import GCGraph, Graph, SparseGraph, VoxelGraph, termtype
+from .write import graph_to_dimacs
 from .wrapper import graphcut_stawiaski, split_marker
 
 GraphDouble = SparseGraph
 
 __all__ = ["graph_from_voxels", "graph_from_labels", "energy_voxel", "energy_label", "GCGraph", "VoxelGraph", "SparseGraph",
-           "GraphDouble", "termtype", "split_marker", "graphcut_stawiaski"]
+           "GraphDouble", "Graph", "graph_to_dimacs", "termtype", "split_marker", "graphcut_stawiaski"]

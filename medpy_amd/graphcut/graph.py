@@ -341,6 +341,17 @@ class SparseGraph(object):
         self._call("msg_get_counts", None, None, C.byref(n))
         return n.value
 
+    def arcs(self):
+        """every distinct arc as built: (tail, head, capacity) arrays sorted by (tail, head)"""
+        n = self.get_arc_num()
+        tail, head, cap = numpy.zeros(n, numpy.int32), numpy.zeros(n, numpy.int32), numpy.zeros(n, numpy.float64)
+        if n:
+            self._call("msg_get_arcs", _lib.ptr(tail), _lib.ptr(head), _lib.ptr(cap))
+        return tail, head, cap
+
+    def tweights(self):
+        return numpy.zeros(self._nodes) if self._tr is None else numpy.array(self._tr)
+
     def stats(self):
         st = _lib.SparseStats()
         self._call("msg_get_stats", C.byref(st))
@@ -404,6 +415,82 @@ class EmbeddedLatticeGraph(object):
 
     def stats(self):
         return self._inner.stats()
+
+
+class Graph(object):
+    """Plain container for a graph-cut problem (nodes numbered from 1, dict n-weights ``{(a, b): (w_ab, w_ba)}``, dict
+    t-weights ``{node: (w_source, w_sink)}``): reference medpy/graphcut/graph.py:31-264, consumed by
+    ``graph_to_dimacs`` (write.py:29-76).  Holds no device state."""
+
+    MAX = 65535
+
+    def __init__(self):
+        self.__nodes = 0
+        self.__snodes = []
+        self.__tnodes = []
+        self.__nweights = {}
+        self.__tweights = {}
+
+    def set_nodes(self, nodes):
+        self.__nodes = int(nodes)
+
+    def set_source_nodes(self, source_nodes):
+        self.__snodes = list(source_nodes)
+        for snode in self.__snodes:
+            self.__tweights[snode] = (self.MAX, 0)
+
+    def set_sink_nodes(self, sink_nodes):
+        self.__tnodes = list(sink_nodes)
+        for tnode in self.__tnodes:
+            self.__tweights[tnode] = (0, self.MAX)
+
+    def set_nweights(self, nweights):
+        self.__nweights = nweights
+
+    def add_tweights(self, tweights):
+        self.__tweights.update(tweights)
+
+    def get_node_count(self):
+        return self.__nodes
+
+    def get_nodes(self):
+        return list(range(1, self.__nodes + 1))
+
+    def get_source_nodes(self):
+        return self.__snodes
+
+    def get_sink_nodes(self):
+        return self.__tnodes
+
+    def get_edges(self):
+        return list(self.__nweights.keys())
+
+    def get_nweights(self):
+        return self.__nweights
+
+    def get_tweights(self):
+        return self.__tweights
+
+    def inconsistent(self):
+        """False when the graph is consistent, else a list of messages (graph.py:227-264)"""
+        messages = []
+        for node in list(self.__tweights.keys()):
+            if not node <= self.__nodes:
+                messages.append("Node {} in t-weights but not in nodes.".format(node))
+        for node in self.__snodes:
+            if not node <= self.__nodes:
+                messages.append("Node {} in s-nodes but not in nodes.".format(node))
+        for node in self.__tnodes:
+            if not node <= self.__nodes:
+                messages.append("Node {} in t-nodes but not in nodes.".format(node))
+        for e in list(self.__nweights.keys()):
+            if not e[0] <= self.__nodes:
+                messages.append("Node {} in edge {} but not in nodes.".format(e[0], e))
+            if not e[1] <= self.__nodes:
+                messages.append("Node {} in edge {} but not in nodes.".format(e[1], e))
+            if (e[1], e[0]) in self.__nweights:
+                messages.append("The reversed edges of {} is also in the n-weights.".format(e))
+        return messages if messages else False
 
 
 class GCGraph(object):

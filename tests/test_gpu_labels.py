@@ -152,3 +152,52 @@ def test_four_dimensional_voxel_graph(term):
         assert got == pytest.approx(want, rel=1e-12)
     else:
         assert got == want
+
+
+def _solve_dimacs(text):
+    """parse a DIMACS max-flow file and solve it with the BK oracle -> (flow, {dimacs id: 0 sink side / 1 source side})"""
+    arcs, n = {}, 0
+    for line in text.splitlines():
+        if line.startswith("p max"):
+            n = int(line.split()[2])
+        elif line.startswith("a "):
+            _, a, b, c = line.split()
+            arcs[(int(a), int(b))] = arcs.get((int(a), int(b)), 0.0) + float(c)
+    g = bk.BKGraph(n - 2, max(16, len(arcs)))
+    src, snk = np.zeros(n - 2), np.zeros(n - 2)
+    done = set()
+    for (a, b), c in arcs.items():
+        if a == 1:
+            src[b - 3] += c
+        elif b == 2:
+            snk[a - 3] += c
+        elif (b, a) not in done:
+            g.sum_edges([a - 3], [b - 3], [c], [arcs.get((b, a), 0.0)])
+            done.add((a, b))
+    g.add_tweights(None, src, snk)
+    return g.maxflow(), g.labels()
+
+
+def test_dimacs_export_of_device_graphs_round_trips():
+    """a graph built in HBM, written as DIMACS (write.py:29-76 layout), solved by an independent solver"""
+    import io as _io
+    from medpy_amd import graphcut, synthetic
+    from medpy_amd.graphcut import energy_label as el
+    s = synthetic.sphere((10, 12, 9))
+    g = graphcut.graph_from_voxels(s["fg"], s["bg"], boundary_term=graphcut.energy_voxel.boundary_difference_exponential,
+                                   boundary_term_args=(s["image"], s["sigma"], False))
+    f = _io.StringIO()
+    graphcut.graph_to_dimacs(g, f)
+    flow = g.maxflow()
+    oflow, olabels = _solve_dimacs(f.getvalue())
+    np.testing.assert_array_equal(g.labels().ravel().astype(np.uint8), olabels)
+    case = "l3d_f32"
+    lab = GOLD[case + "/labels"]
+    g = graphcut.graph_from_labels(lab, GOLD[case + "/fg"], GOLD[case + "/bg"], boundary_term=el.boundary_stawiaski_directed,
+                                   boundary_term_args=(GOLD[case + "/gradient"], -0.5))
+    f = _io.StringIO()
+    graphcut.graph_to_dimacs(g, f)
+    g.maxflow()
+    oflow, olabels = _solve_dimacs(f.getvalue())
+    np.testing.assert_array_equal(g.labels().astype(np.uint8), olabels)
+    np.testing.assert_array_equal(olabels, GOLD[case + "/stawiaski_directed_neg/segments"])

@@ -129,3 +129,25 @@ def test_hostsim_full_neighbourhood_matches_bk(gen, shape):
     lab, st = sim.solve26(shape, w, tr)
     assert st["converged"] == 1
     np.testing.assert_array_equal(lab, g.labels().reshape(shape))
+
+
+def test_dimacs_writer_text_equals_the_reference_layout():
+    """reference medpy/graphcut/write.py:29-76 on the dict Graph (graph.py:31-264); expected text written out by hand from
+    the reference's format strings"""
+    import io as _io
+    from medpy_amd.graphcut import Graph, graph_to_dimacs
+    g = Graph()
+    g.set_nodes(3)
+    g.set_source_nodes([1])
+    g.set_sink_nodes([3])
+    g.set_nweights({(1, 2): (0.5, 0.25), (2, 3): (2, 0)})
+    g.add_tweights({2: (0.125, 0)})
+    assert g.inconsistent() is False and g.get_nodes() == [1, 2, 3] and g.get_edges() == [(1, 2), (2, 3)]
+    f = _io.StringIO()
+    graph_to_dimacs(g, f)
+    assert f.getvalue() == ("c Created by medpy\nc Oskar Maier, oskar.maier@googlemail.com\nc\nc problem line\np max 5 2\n"
+                            "c source descriptor\nn 1 s\nc sink descriptor\nn 2 t\nc terminal arcs (t-weights)\n"
+                            "a 1 3 65535\na 5 2 65535\na 1 4 0.125\nc inter-node arcs (n-weights)\n"
+                            "a 3 4 0.5\na 4 3 0.25\na 4 5 2\nc end-of-file")
+    g.set_nweights({(1, 2): (1, 1), (2, 1): (1, 1), (1, 9): (1, 1)})
+    assert len(g.inconsistent()) == 3
