@@ -134,10 +134,21 @@ def _tie_degenerate(term, image):
     return term.startswith("maximum") or np.issubdtype(np.asarray(image).dtype, np.integer)
 
 
-def test_4d_not_implemented(golden_small):
+@pytest.mark.parametrize("term", TERMS)
+def test_4d_volume_against_the_reference(golden_small, term):
+    """a 4-D image (ndim*2 = 8 neighbours, generate.py:44-49): routed to the sparse-graph solver, n-links generated in HBM
+    for any number of axes; fixtures are the reference's own results"""
     top = golden_small.group("c4")
-    with pytest.raises(NotImplementedError):
-        _run(top["fg"], top["bg"], "difference_linear", top["image"])
+    g0 = golden_small.group("c4/%s" % term)
+    spacing = tuple(top["spacing"]) if top["spacing"].size else False
+    g = _run(top["fg"], top["bg"], term, top["image"], float(top["sigma"]), spacing)
+    got = np.array([g.get_edge(int(i), int(j)) for i, j in zip(g0["edges_i"][::7], g0["edges_j"][::7])])
+    _check_energy(term, got, g0["edges_w"][::7])
+    np.testing.assert_array_equal(np.array([g.get_trcap(i) for i in range(top["fg"].size)]), g0["trcap"])
+    flow = g.maxflow()
+    assert flow == pytest.approx(float(g0["flow"]), rel=1e-9)
+    nbad = int((g.labels().reshape(top["fg"].shape) != g0["labels"].astype(bool)).sum())
+    assert nbad == 0 or (_tie_degenerate(term, top["image"]) and nbad <= max(3, top["image"].size // 50))
 
 
 @pytest.mark.parametrize("case", ["r0", "r1"])
