@@ -82,6 +82,26 @@ struct GpuBlockT {
     {
         return __syncthreads_or((int)f(lane())) != 0;
     }
+    /* wave-local step: touches only the lane's own registers / LDS slots, no workgroup barrier */
+    template <class F>
+    __device__ __forceinline__ void wpar(F f)
+    {
+        f(lane());
+    }
+    /* vote inside the wave (one z-layer of the tile): uniform per wave, may differ between waves */
+    template <class F>
+    __device__ __forceinline__ bool wave_any(F f)
+    {
+        return __any((int)f(lane())) != 0;
+    }
+    /* dst[t] = src[t + delta] for lanes of the same wave (same z-layer), 0.0 at the wave's ends: ds_bpermute, no LDS
+     * storage, no barrier.  Collective: call it from wave-uniform control flow. */
+    __device__ __forceinline__ void shift(Reg<double>& dst, Reg<double>& src, int delta)
+    {
+        const int from = (int)(threadIdx.x & 63u) + delta;
+        const double v = __shfl(src.v, from & 63, 64);
+        dst.v = (from >= 0 && from < 64) ? v : 0.0;
+    }
     __device__ __forceinline__ int atomic_add(int32_t* p, int v) { return atomicAdd(p, v); }
     __device__ __forceinline__ uint32_t atomic_exch(uint32_t* p, uint32_t v) { return atomicExch(p, v); }
     __device__ __forceinline__ void atomic_or(uint32_t* p, uint32_t v) { atomicOr(p, v); }
@@ -968,6 +988,7 @@ static int mgc_create_impl(int ndim, const int64_t* shape, int connectivity, int
     L.ntiles = (int)(gz * gy * gx);
     L.tz_own_lo = 0; L.tz_own_hi = L.gz; L.tz_global0 = 0;
     L.ndir = (connectivity == 2 * ndim) ? 6 : 26;
+    h->params = mgc_default_params(L.ndir);
     if (slab) {
         L.tz_own_lo = slab->own_lo; L.tz_own_hi = slab->own_hi; L.tz_global0 = slab->tz_global0;
         h->rank = slab->rank; h->nranks = slab->nranks;

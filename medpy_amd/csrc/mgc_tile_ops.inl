@@ -203,7 +203,7 @@ MGC_HD void mgc_tile_bfs(X& x, MaskFn mask)
 
 /* ---------------------------------------------------------------------------------------
  * Global relabel, one tile of one pass: recompute the tile's labels from its residual mask
- * with the current halo; wake the neighbours across every face whose labels went down.
+ * with the current halo; wake the neighbours across every face where a lowered label could lower theirs.
  * Passes repeat (driver) until no tile changes: exact distances to the sink, MGC_HINF for
  * voxels that cannot reach it -- the set the reference reads out with what_segment().
  * ------------------------------------------------------------------------------------- */
@@ -243,13 +243,12 @@ MGC_HD void mgc_relabel_tile(X& x, const MgcLattice& L, int tile, uint32_t next_
             for (int d = 0; d < 6; ++d)
                 if (((m[t] >> d) & 1) && !mgc_inside(d, z, y, xx) && x.S.hs[me + mgc_hs_step(d)] + 1 == hm) x.S.depflag[d] = 1;
         }
-        if (x.S.hs[mgc_hs_index(z, y, xx)] < h0[t]) {
-            if (xx == 0) x.S.faceflag[0] = 1;
-            if (xx == MGC_T - 1) x.S.faceflag[1] = 1;
-            if (y == 0) x.S.faceflag[2] = 1;
-            if (y == MGC_T - 1) x.S.faceflag[3] = 1;
-            if (z == 0) x.S.faceflag[4] = 1;
-            if (z == MGC_T - 1) x.S.faceflag[5] = 1;
+        if (hm < h0[t]) {
+            /* wake the neighbour across a face only if its adjacent voxel could improve: labels only go down during a
+             * relabel, so a halo value is an upper bound of the neighbour's current label and "hm + 1 >= halo" stays
+             * true.  This drops the back-wakes (the tile the wave came from) and most side-wakes. */
+            for (int d = 0; d < 6; ++d)
+                if (!mgc_inside(d, z, y, xx) && hm + 1 < x.S.hs[me + mgc_hs_step(d)]) x.S.faceflag[d] = 1;
         }
     });
     x.par([&](int t) { /* one block of global traffic: labels + wake-ups */
@@ -394,61 +393,101 @@ MGC_HD void mgc_discharge_tile(X& x, const MgcLattice& L, int tile, uint32_t pha
 
         for (int sw = 0; sw < max_sweeps; ++sw, ++sweep_id) {
             const int fl = sweep_id & 1;
-            /* 7 steps: step s pushes along direction s (s < 6) after receiving direction s-1 */
-            /* unrolled: with a run-time direction the seven steps cost 2.7x more (measured: 10.8k vs 4.0k cycles per
-             * sweep); the price is ~30 hoisted LDS addresses, i.e. some scratch spills at the 64-VGPR budget */
-#if defined(MGC_NOUNROLL_STEPS)
-#pragma nounroll
-#else
-#pragma unroll
-#endif
-            for (int s = 0; s <= 6; ++s) {
-                x.par([&](int t) {
-                    const int z = t >> 6, y = (t >> 3) & 7, xx = t & 7;
-                    if (s == 0) {
-                        /* push to the sink first: always admissible (label 1 -> 0) */
-                        if (e[t] > 0.0 && snk[t] > 0.0) {
-                            const double delta = e[t] < snk[t] ? e[t] : snk[t];
-                            e[t] -= delta;
-                            snk[t] -= delta;
-                            x.S.flag[fl] = 1;
-                            if (snk[t] == 0.0) x.S.satflag = 1;
-                        }
-                    } else {
-                        if (s == 1 && t == 0) x.S.flag[fl ^ 1] = 0; /* everybody has read it by now */
-                        /* receive what the neighbour pushed in direction s-1 */
-                        const int dp = s - 1;
-                        if (mgc_inside(dp ^ 1, z, y, xx)) {
-                            const double din = x.S.out[dp & 1][t - mgc_loc_step(dp)];
-                            if (din != 0.0) {
-                                e[t] += din;
-                                x.S.r[dp ^ 1][t] += din;
-                            }
-                        }
+            /* One sweep = sink, then the six directions in turn; a voxel receives what its neighbour pushed in direction
+             * d before it pushes in direction d + 1 (Gauss-Seidel order).  A wave holds one z-layer of the tile (lane =
+             * (y, x)), so the +-x and +-y neighbours are lanes of the SAME wave: those four exchanges are lane shifts
+             * (ds_bpermute), need no LDS slot and no workgroup barrier, and a wave without excess skips them outright.
+             * Only the +-z exchanges cross waves (LDS slot + barrier): 2 barriers per sweep instead of 7. */
+            typename X::template Reg<double> dl, din;
+            auto push = [&](int t, int d) -> double { /* admissible push of lane t in direction d; returns the amount */
+                double delta = 0.0;
+                if (e[t] > 0.0 && hme[t] < MGC_HINF) {
+                    const double rd = x.S.r[d][t];
+                    if (rd > 0.0 && x.S.hs[mgc_hs_index(t >> 6, (t >> 3) & 7, t & 7) + mgc_hs_step(d)] == hme[t] - 1) {
+                        delta = e[t] < rd ? e[t] : rd;
+                        e[t] -= delta;
+                        x.S.r[d][t] = rd - delta; /* saturating push: rd - rd == 0.0 exactly */
+                        x.S.flag[fl] = 1;
+                        if (delta == rd) x.S.satflag = 1;
                     }
-                    if (s < 6) {
-                        const int d = s;
-                        double delta = 0.0;
-                        if (e[t] > 0.0 && hme[t] < MGC_HINF) {
-                            const double rd = x.S.r[d][t];
-                            if (rd > 0.0 && x.S.hs[mgc_hs_index(z, y, xx) + mgc_hs_step(d)] == hme[t] - 1) {
-                                delta = e[t] < rd ? e[t] : rd;
-                                e[t] -= delta;
-                                x.S.r[d][t] = rd - delta; /* saturating push: rd - rd == 0.0 exactly */
-                                x.S.flag[fl] = 1;
-                                if (delta == rd) x.S.satflag = 1;
-                            }
-                        }
-                        if (mgc_inside(d, z, y, xx)) {
-                            x.S.out[d & 1][t] = delta;
-                        } else if (delta != 0.0) {
-                            if ((d >> 1) == 0) ob0[t] += delta;
-                            else if ((d >> 1) == 1) ob1[t] += delta;
-                            else ob2[t] += delta;
-                        }
-                    }
-                });
+                }
+                return delta;
+            };
+            auto leave = [&](int t, int d, double delta) { /* flow that leaves the tile across face d */
+                if (delta != 0.0) {
+                    if ((d >> 1) == 0) ob0[t] += delta;
+                    else if ((d >> 1) == 1) ob1[t] += delta;
+                    else ob2[t] += delta;
+                }
+            };
+            auto recv = [&](int t, int dp, double v) { /* what the neighbour pushed in direction dp arrives here */
+                if (v != 0.0 && mgc_inside(dp ^ 1, t >> 6, (t >> 3) & 7, t & 7)) {
+                    e[t] += v;
+                    x.S.r[dp ^ 1][t] += v;
+                }
+            };
+            auto inplane = [&](int t, int d) { /* push in direction d (0..3); dl = what stays inside the tile */
+                const double delta = push(t, d);
+                if (mgc_inside(d, t >> 6, (t >> 3) & 7, t & 7)) dl[t] = delta;
+                else { dl[t] = 0.0; leave(t, d, delta); }
+            };
+            x.wpar([&](int t) { /* push to the sink first: always admissible (label 1 -> 0) */
+                if (e[t] > 0.0 && snk[t] > 0.0) {
+                    const double delta = e[t] < snk[t] ? e[t] : snk[t];
+                    e[t] -= delta;
+                    snk[t] -= delta;
+                    x.S.flag[fl] = 1;
+                    if (snk[t] == 0.0) x.S.satflag = 1;
+                }
+                din[t] = 0.0;
+            });
+            if (x.wave_any([&](int t) -> bool { return e[t] > 0.0 && hme[t] < MGC_HINF; })) { /* uniform per wave */
+                x.wpar([&](int t) { inplane(t, 0); });
+                x.shift(din, dl, 1);  /* -x: from the lane at x + 1 */
+                x.wpar([&](int t) { recv(t, 0, din[t]); inplane(t, 1); });
+                x.shift(din, dl, -1); /* +x: from x - 1 */
+                x.wpar([&](int t) { recv(t, 1, din[t]); inplane(t, 2); });
+                x.shift(din, dl, 8);  /* -y: from y + 1 */
+                x.wpar([&](int t) { recv(t, 2, din[t]); inplane(t, 3); });
+                x.shift(din, dl, -8); /* +y: from y - 1 */
             }
+            x.par([&](int t) {
+                recv(t, 3, din[t]);
+                const double delta = push(t, 4);
+                if (mgc_inside(4, t >> 6, (t >> 3) & 7, t & 7)) x.S.out[0][t] = delta;
+                else leave(t, 4, delta);
+            });
+            x.par([&](int t) {
+                if (t == 0) x.S.flag[fl ^ 1] = 0; /* everybody has read it by now */
+                if (mgc_inside(5, t >> 6, (t >> 3) & 7, t & 7)) recv(t, 4, x.S.out[0][t + MGC_TF]);
+                const double delta = push(t, 5);
+                if (mgc_inside(5, t >> 6, (t >> 3) & 7, t & 7)) x.S.out[1][t] = delta;
+                else leave(t, 5, delta);
+            });
+            x.par([&](int t) {
+                if (mgc_inside(4, t >> 6, (t >> 3) & 7, t & 7)) recv(t, 5, x.S.out[1][t - MGC_TF]);
+            });
+            /* local relabel (classic push-relabel step): a voxel that still holds excess and has no admissible arc left
+             * rises to 1 + the lowest label behind a residual arc.  Labels stay valid lower bounds of the distance (no
+             * push runs in this step; a neighbour's label read here is its old or its new one, both lower bounds), so the
+             * next sweep can go on without recomputing the exact labels of the whole tile. */
+            x.par([&](int t) {
+                if (e[t] > 0.0 && hme[t] < MGC_HINF) {
+                    const int me = mgc_hs_index(t >> 6, (t >> 3) & 7, t & 7);
+                    int cand = snk[t] > 0.0 ? 1 : MGC_HINF;
+#pragma unroll
+                    for (int d = 0; d < 6; ++d)
+                        if (x.S.r[d][t] > 0.0) {
+                            const int hv = x.S.hs[me + mgc_hs_step(d)];
+                            cand = (hv < MGC_HINF && hv + 1 < cand) ? hv + 1 : cand;
+                        }
+                    if (cand > hme[t]) {
+                        hme[t] = cand;
+                        x.S.hs[me] = cand;
+                        if (cand < MGC_HINF) x.S.flag[fl] = 1; /* it can push again next sweep */
+                    }
+                }
+            });
             x.mark(L, 2); /* one push sweep */
             if (!x.S.flag[fl]) break; /* uniform: written before the last barrier */
         }

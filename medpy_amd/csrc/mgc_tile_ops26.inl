@@ -131,14 +131,16 @@ MGC_HD void mgc26_relabel_tile(X& x, const MgcLattice& L, int tile, uint32_t nex
         const int h = x.S.hs[mgc_hs_index(z, y, xx)];
         if (h < h0[t]) {
             L.height[base + t] = h;
-            /* wake every neighbour tile this voxel touches (face, edge and corner neighbours) */
-            const int bz = z == 0 ? -1 : (z == 7 ? 1 : 0), by = y == 0 ? -1 : (y == 7 ? 1 : 0), bx = xx == 0 ? -1 : (xx == 7 ? 1 : 0);
-            for (int a = 0; a < 2; ++a)
-                for (int b = 0; b < 2; ++b)
-                    for (int c = 0; c < 2; ++c) {
-                        const int oz = a ? bz : 0, oy = b ? by : 0, ox = c ? bx : 0;
-                        if (oz || oy || ox) x.S.nbrflag[(oz + 1) * 9 + (oy + 1) * 3 + (ox + 1)] = 1;
-                    }
+            /* wake a neighbour tile only if one of its voxels next to this one could improve (see mgc_relabel_tile) */
+            const int me = mgc_hs_index(z, y, xx);
+#pragma unroll
+            for (int d = 0; d < MGC26_NDIR; ++d) {
+                int dz, dy, dx;
+                mgc26_offset(d, dz, dy, dx);
+                const int vz = z + dz, vy = y + dy, vx = xx + dx;
+                const int oz = vz < 0 ? -1 : (vz > 7 ? 1 : 0), oy = vy < 0 ? -1 : (vy > 7 ? 1 : 0), ox = vx < 0 ? -1 : (vx > 7 ? 1 : 0);
+                if ((oz || oy || ox) && h + 1 < x.S.hs[me + mgc26_hs_step(d)]) x.S.nbrflag[(oz + 1) * 9 + (oy + 1) * 3 + (ox + 1)] = 1;
+            }
         }
     });
     x.par([&](int t) {
@@ -263,6 +265,24 @@ MGC_HD void mgc26_discharge_tile(X& x, const MgcLattice& L, int tile, uint32_t p
             MGC26_STEP(17) MGC26_STEP(18) MGC26_STEP(19) MGC26_STEP(20) MGC26_STEP(21) MGC26_STEP(22) MGC26_STEP(23) MGC26_STEP(24)
             MGC26_STEP(25) MGC26_STEP(26)
 #undef MGC26_STEP
+            /* local relabel of stuck active voxels (see mgc_discharge_tile): labels stay valid lower bounds */
+            x.par([&](int t) {
+                if (e[t] > 0.0 && hme[t] < MGC_HINF) {
+                    const int me = mgc_hs_index(t >> 6, (t >> 3) & 7, t & 7);
+                    int cand = snk[t] > 0.0 ? 1 : MGC_HINF;
+#pragma unroll
+                    for (int d = 0; d < MGC26_NDIR; ++d)
+                        if (r[d][t] > 0.0) {
+                            const int hv = x.S.hs[me + mgc26_hs_step(d)];
+                            cand = (hv < MGC_HINF && hv + 1 < cand) ? hv + 1 : cand;
+                        }
+                    if (cand > hme[t]) {
+                        hme[t] = cand;
+                        x.S.hs[me] = cand;
+                        if (cand < MGC_HINF) x.S.flag[fl] = 1;
+                    }
+                }
+            });
             if (!x.S.flag[fl]) break;
         }
     }

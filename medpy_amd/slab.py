@@ -151,7 +151,7 @@ class RcclExchange(object):
         return out if out.size > 1 else float(out[0])
 
 
-def solve_slabs(slabs, ex, rounds_per_relabel=8, max_cycles=3, max_sweeps=4, max_outer=100000, check_rounds=4, relabel_batch=8,
+def solve_slabs(slabs, ex, rounds_per_relabel=8, max_cycles=1, max_sweeps=None, max_outer=100000, check_rounds=4, relabel_batch=8,
                 incremental_relabel=True):
     """Drives the local slabs to a maximum preflow.  Returns a stats dict (global numbers).
 
@@ -165,9 +165,11 @@ def solve_slabs(slabs, ex, rounds_per_relabel=8, max_cycles=3, max_sweeps=4, max
     # where the solver variant keeps its lists / counters (MgcLayout, mgc_driver.inl:51-62)
     if getattr(slabs[0], "ndir", 6) == 26:
         ncol, lmask, rl, c_act, c_dis, c_rel = 8, 15, 16, 18, 19, 20
+        max_sweeps = max_sweeps or 4  # mgc_default_params(26)
         incremental_relabel = False  # the full-neighbourhood kernels keep no support faces
     else:
         ncol, lmask, rl, c_act, c_dis, c_rel = 2, 3, 4, 6, 8, 9
+        max_sweeps = max_sweeps or 12  # mgc_default_params(6)
     phase, rep = 2 * (lmask + 1), 2
     for s in slabs:
         s.op(OP_ZERO_COUNT, c_dis)

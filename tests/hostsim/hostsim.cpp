@@ -44,6 +44,25 @@ struct HostBlockT {
         for (int t = 0; t < MGC_TV; ++t) r |= (bool)f(t);
         return r;
     }
+    template <class F>
+    void wpar(F f)
+    {
+        for (int t = 0; t < MGC_TV; ++t) f(t);
+    }
+    template <class F>
+    bool wave_any(F f) /* the GPU votes per wave and skips idle waves; running them all is equivalent (idle = no-op) */
+    {
+        bool r = false;
+        for (int t = 0; t < MGC_TV; ++t) r |= (bool)f(t);
+        return r;
+    }
+    void shift(Reg<double>& dst, Reg<double>& src, int delta)
+    {
+        for (int t = 0; t < MGC_TV; ++t) {
+            const int from = (t & 63) + delta;
+            dst[t] = (from >= 0 && from < 64) ? src[(t & ~63) + from] : 0.0;
+        }
+    }
     int atomic_add(int32_t* p, int v) { int o = *p; *p += v; return o; }
     uint32_t atomic_exch(uint32_t* p, uint32_t v) { uint32_t o = *p; *p = v; return o; }
     void atomic_or(uint32_t* p, uint32_t v) { *p |= v; }
@@ -381,7 +400,7 @@ int hostsim_solve26(const int64_t* shape, const double* w, const double* trcap, 
     HostDev26* d = new HostDev26();
     d->init(shape[0], shape[1], shape[2], NULL);
     d->load(w, trcap);
-    MgcSolveParams P = mgc_default_params();
+    MgcSolveParams P = mgc_default_params(26);
     if (rounds > 0) P.rounds_per_relabel = rounds;
     if (cycles > 0) P.max_cycles = cycles;
     if (sweeps > 0) P.max_sweeps = sweeps;

@@ -10,14 +10,11 @@ s = getattr(synthetic, gen)((n, n, n))
 g = VoxelGraph((n, n, n))
 g._set_boundary("difference_exponential", s["image"], s["sigma"], False)
 g._set_markers(s["fg"], s["bg"])
-base = dict(rounds_per_relabel=12, max_cycles=4, max_sweeps=8, relabel_batch=8, check_rounds=4, grid_cap=4096)
+base = dict(rounds_per_relabel=8, max_cycles=1, max_sweeps=12, relabel_batch=8, check_rounds=4, grid_cap=4096)
 grid = [dict()]
-for k, vals in dict(rounds_per_relabel=[2, 3, 4, 6, 8, 16], max_cycles=[1, 2, 3, 6, 8], max_sweeps=[2, 4, 6, 12, 16],
-                    check_rounds=[1, 2, 8], grid_cap=[1024, 2048, 8192]).items():
-    grid += [{k: v} for v in vals]
-grid += [dict(rounds_per_relabel=4, max_cycles=2), dict(rounds_per_relabel=4, max_cycles=2, max_sweeps=4), dict(rounds_per_relabel=6, max_cycles=2, max_sweeps=6),
-         dict(rounds_per_relabel=3, max_cycles=2, max_sweeps=4, check_rounds=1), dict(rounds_per_relabel=6, max_cycles=3, max_sweeps=4),
-         dict(rounds_per_relabel=8, max_cycles=2, max_sweeps=4), dict(rounds_per_relabel=4, max_cycles=3, max_sweeps=6, check_rounds=2)]
+grid += [dict(max_cycles=c, max_sweeps=w) for c, w in ((1, 6), (1, 8), (1, 12), (1, 16), (1, 24), (2, 4), (2, 6), (2, 8), (2, 12), (3, 6), (3, 8))]
+grid += [dict(max_cycles=1, max_sweeps=12, rounds_per_relabel=r) for r in (4, 6, 12)]
+grid += [dict(max_cycles=2, max_sweeps=8, rounds_per_relabel=r) for r in (6, 12)]
 g.set_param("kernel_timing", 0)
 ref = None
 for over in grid:
