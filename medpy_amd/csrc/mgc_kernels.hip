@@ -261,12 +261,24 @@ __global__ void k_suspect_pass(MgcLattice L)
 
 __global__ __launch_bounds__(MGC_TV) void k_reset_suspect(MgcLattice L, uint32_t epoch, int list)
 {
+    /* a workgroup scans the status words of 512 consecutive tiles (one per lane), then resets the few that are suspect:
+     * launching a 512-lane tile operation per tile just to test one flag cost 320 us per global relabel at 512^3 */
     __shared__ MgcTileShared S;
+    __shared__ int sel[MGC_TV];
+    __shared__ int nsel;
     GpuBlock x(S);
-    for (int tile = blockIdx.x; tile < L.ntiles; tile += gridDim.x) {
-        x.new_tile();
-        mgc_reset_suspect_tile(x, L, tile, epoch, list);
+    for (int base = blockIdx.x * MGC_TV; base < L.ntiles; base += gridDim.x * MGC_TV) {
+        if (threadIdx.x == 0) nsel = 0;
         __syncthreads();
+        const int mine = base + (int)threadIdx.x;
+        if (mine < L.ntiles && (L.status[mine] & MGC_ST_SUSPECT)) sel[atomicAdd(&nsel, 1)] = mine;
+        __syncthreads();
+        const int n = nsel;
+        for (int i = 0; i < n; ++i) {
+            x.new_tile();
+            mgc_reset_suspect_tile(x, L, sel[i], epoch, list);
+            __syncthreads();
+        }
     }
 }
 
@@ -847,7 +859,7 @@ struct HipDevT {
     {
         if constexpr (!FULL) {
             const int id = time_begin(1);
-            if (!(h->use_filters & 4)) hipLaunchKernelGGL(k_reset_suspect, dim3(grid(h->L.ntiles)), dim3(MGC_TV), 0, h->stream, h->L, epoch, list);
+            if (!(h->use_filters & 4)) hipLaunchKernelGGL(k_reset_suspect, dim3(grid((h->L.ntiles + MGC_TV - 1) / MGC_TV)), dim3(MGC_TV), 0, h->stream, h->L, epoch, list);
             else {
             zero_count(11);
             if (getenv("MGC_DEBUG_SUSPECT")) { hipLaunchKernelGGL(k_count_status, dim3(256), dim3(256), 0, h->stream, h->L, (uint32_t)MGC_ST_SUSPECT, 13); }

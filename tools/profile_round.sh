@@ -1,0 +1,20 @@
+#!/bin/bash
+# rocprofv3 passes whose summaries go to profiles/ (run on the GPU box through gpurun from the repo root):
+#   kernel trace + stats, then FETCH_SIZE and WRITE_SIZE in their own passes (counters never share a run with traces
+#   other than --kernel-trace).  Usage: bash tools/profile_round.sh <tag>
+set -u
+TAG=${1:-r1}
+ROOT=$PWD
+OUT=$ROOT/gpurun_out/prof_$TAG
+mkdir -p $OUT
+cd /tmp && export TMPDIR=/tmp
+timeout 600 rocprofv3 --kernel-trace --stats -d $OUT/trace -- python $ROOT/bench.py --steps 2 --warmup 1 --no-cpu > $OUT/trace.log 2>&1
+timeout 600 rocprofv3 --kernel-trace --pmc FETCH_SIZE -d $OUT/fetch -- python $ROOT/bench.py --steps 1 --warmup 0 --no-cpu > $OUT/fetch.log 2>&1
+timeout 600 rocprofv3 --kernel-trace --pmc WRITE_SIZE -d $OUT/write -- python $ROOT/bench.py --steps 1 --warmup 0 --no-cpu > $OUT/write.log 2>&1
+cd $ROOT
+T=$(find $OUT/trace -name "*.db" | head -1); F=$(find $OUT/fetch -name "*.db" | head -1); W=$(find $OUT/write -name "*.db" | head -1)
+python tools/rocpd_summary.py stats $T > gpurun_out/${TAG}_kernel_stats.csv
+python tools/rocpd_summary.py pmc $F > gpurun_out/${TAG}_pmc_fetch_size.csv
+python tools/rocpd_summary.py pmc $W > gpurun_out/${TAG}_pmc_write_size.csv
+python tools/rocpd_summary.py json $F $W > gpurun_out/pmc_discharge.json
+rm -rf $OUT/trace $OUT/fetch $OUT/write
