@@ -180,13 +180,18 @@ MGC_HD void mgc_tile_bfs(X& x, MaskFn mask)
             const int z = t >> 6, y = (t >> 3) & 7, xx = t & 7;
             const int me = mgc_hs_index(z, y, xx);
             int cand = (m & MGC_MASK_SINK) ? 1 : MGC_HINF;
+            /* branch-free: all six neighbour labels are fetched back to back (one LDS latency) and masked afterwards; with
+             * a branch per direction the compiler issues six DEPENDENT reads, each waiting for the previous one */
+            int hv[6];
 #pragma unroll
-            for (int d = 0; d < 6; ++d)
-                if ((m >> d) & 1) {
-                    const int hv = x.S.hs[me + mgc_hs_step(d)] + 1;
-                    cand = hv < cand ? hv : cand;
-                }
-            if (cand < x.S.hs[me]) {
+            for (int d = 0; d < 6; ++d) hv[d] = x.S.hs[me + mgc_hs_step(d)];
+            const int own = x.S.hs[me];
+#pragma unroll
+            for (int d = 0; d < 6; ++d) {
+                const int c = ((m >> d) & 1) ? hv[d] + 1 : MGC_HINF;
+                cand = c < cand ? c : cand;
+            }
+            if (cand < own) {
                 x.S.hs[me] = cand;
                 return true;
             }
@@ -230,11 +235,10 @@ MGC_HD void mgc_relabel_tile(X& x, const MgcLattice& L, int tile, uint32_t next_
                 nt < 0 ? MGC_HINF : L.height[(int64_t)nt * MGC_TV + mgc_face_voxel(f ^ 1, k)];
         }
     });
-    typename X::template Reg<int> hn;
-    x.tile_labels([&](int t) { return m[t]; }, hn);
-    x.par([&](int t) { /* labels never go up within a relabel: keep the better of the old and the recomputed one */
-        if (h0[t] < hn[t]) x.S.hs[mgc_hs_index(t >> 6, (t >> 3) & 7, t & 7)] = h0[t];
-    });
+    /* relax from the CURRENT labels, not from scratch: inside a global relabel labels only go down, so they are upper
+     * bounds of the distances and the chaotic relaxation converges to the same exact values -- in a few rounds when the
+     * tile is revisited because a neighbour improved (most visits), instead of a full in-tile BFS every time */
+    mgc_tile_bfs(x, [&](int t) { return m[t]; });
     x.par([&](int t) { /* LDS only: which faces saw a label drop; which faces support a label (incremental relabel) */
         const int z = t >> 6, y = (t >> 3) & 7, xx = t & 7;
         const int me = mgc_hs_index(z, y, xx);
@@ -400,16 +404,16 @@ MGC_HD void mgc_discharge_tile(X& x, const MgcLattice& L, int tile, uint32_t pha
              * Only the +-z exchanges cross waves (LDS slot + barrier): 2 barriers per sweep instead of 7. */
             typename X::template Reg<double> dl, din;
             auto push = [&](int t, int d) -> double { /* admissible push of lane t in direction d; returns the amount */
+                /* both operands are fetched unconditionally and together: one LDS latency, not two dependent ones */
+                const double rd = x.S.r[d][t];
+                const int hn = x.S.hs[mgc_hs_index(t >> 6, (t >> 3) & 7, t & 7) + mgc_hs_step(d)];
                 double delta = 0.0;
-                if (e[t] > 0.0 && hme[t] < MGC_HINF) {
-                    const double rd = x.S.r[d][t];
-                    if (rd > 0.0 && x.S.hs[mgc_hs_index(t >> 6, (t >> 3) & 7, t & 7) + mgc_hs_step(d)] == hme[t] - 1) {
-                        delta = e[t] < rd ? e[t] : rd;
-                        e[t] -= delta;
-                        x.S.r[d][t] = rd - delta; /* saturating push: rd - rd == 0.0 exactly */
-                        x.S.flag[fl] = 1;
-                        if (delta == rd) x.S.satflag = 1;
-                    }
+                if (e[t] > 0.0 && rd > 0.0 && hme[t] < MGC_HINF && hn == hme[t] - 1) {
+                    delta = e[t] < rd ? e[t] : rd;
+                    e[t] -= delta;
+                    x.S.r[d][t] = rd - delta; /* saturating push: rd - rd == 0.0 exactly */
+                    x.S.flag[fl] = 1;
+                    if (delta == rd) x.S.satflag = 1;
                 }
                 return delta;
             };
@@ -476,11 +480,11 @@ MGC_HD void mgc_discharge_tile(X& x, const MgcLattice& L, int tile, uint32_t pha
                     const int me = mgc_hs_index(t >> 6, (t >> 3) & 7, t & 7);
                     int cand = snk[t] > 0.0 ? 1 : MGC_HINF;
 #pragma unroll
-                    for (int d = 0; d < 6; ++d)
-                        if (x.S.r[d][t] > 0.0) {
-                            const int hv = x.S.hs[me + mgc_hs_step(d)];
-                            cand = (hv < MGC_HINF && hv + 1 < cand) ? hv + 1 : cand;
-                        }
+                    for (int d = 0; d < 6; ++d) { /* branch-free: twelve independent LDS reads */
+                        const double rd = x.S.r[d][t];
+                        const int hv = x.S.hs[me + mgc_hs_step(d)];
+                        cand = (rd > 0.0 && hv < MGC_HINF && hv + 1 < cand) ? hv + 1 : cand;
+                    }
                     if (cand > hme[t]) {
                         hme[t] = cand;
                         x.S.hs[me] = cand;

@@ -94,13 +94,15 @@ MGC_HD void mgc26_tile_bfs(X& x, MaskFn mask)
             if (!m) return false;
             const int me = mgc_hs_index(t >> 6, (t >> 3) & 7, t & 7);
             int cand = (m & MGC26_MASK_SINK) ? 1 : MGC_HINF;
+            /* branch-free (see mgc_tile_bfs): 26 independent LDS reads in flight, masked afterwards */
+            const int own = x.S.hs[me];
 #pragma unroll
-            for (int d = 0; d < MGC26_NDIR; ++d)
-                if ((m >> d) & 1u) {
-                    const int hv = x.S.hs[me + mgc26_hs_step(d)] + 1;
-                    cand = hv < cand ? hv : cand;
-                }
-            if (cand < x.S.hs[me]) {
+            for (int d = 0; d < MGC26_NDIR; ++d) {
+                const int hv = x.S.hs[me + mgc26_hs_step(d)];
+                const int c = ((m >> d) & 1u) ? hv + 1 : MGC_HINF;
+                cand = c < cand ? c : cand;
+            }
+            if (cand < own) {
                 x.S.hs[me] = cand;
                 return true;
             }
