@@ -56,10 +56,12 @@ struct MgcLayout {
     int rl_base;    /* relabel lists rl_base, rl_base + 1        */
     int cnt_active, cnt_dis, cnt_rel;
     int incremental; /* global relabels after the first recompute only suspect tiles (Dev: suspect_pass, reset_suspect) */
+    int rl_third;    /* third relabel list (rotation: a pass clears the counter of the list consumed one pass earlier, so
+                        no memset sits between two passes) or -1 */
 };
 
-static inline MgcLayout mgc_layout6() { MgcLayout l = {2, 3, 4, 6, 8, 9, 1}; return l; }
-static inline MgcLayout mgc_layout26() { MgcLayout l = {8, 15, 16, 18, 19, 20, 0}; return l; }
+static inline MgcLayout mgc_layout6() { MgcLayout l = {2, 3, 4, 6, 8, 9, 1, 7}; return l; }
+static inline MgcLayout mgc_layout26() { MgcLayout l = {8, 15, 16, 18, 19, 20, 0, -1}; return l; }
 
 static inline MgcSolveParams mgc_default_params(int ndir = 6)
 {
@@ -107,17 +109,35 @@ int mgc_solve(Dev& dev, const MgcLattice& L, const MgcSolveParams& P, MgcSolveSt
             dev.reset_suspect(rep + 1, lay.rl_base + (int)((rep + 1) & 1u));
         }
         st.relabel_passes++;
-        for (;;) {
-            for (int b = 0; b < P.relabel_batch; ++b) {
-                rep++;
-                const int cur = lay.rl_base + (int)(rep & 1u), nxt = lay.rl_base + (int)((rep + 1) & 1u);
-                dev.zero_count(nxt);
-                dev.relabel_list(cur, rep + 1, nxt);
-                st.relabel_passes++;
+        if (lay.rl_third >= 0) {
+            /* three lists rotate: pass k consumes lists[k % 3], appends to lists[(k + 1) % 3] and clears the counter of
+             * lists[(k + 2) % 3] (consumed by pass k - 1) inside the kernel */
+            const int lists[3] = {lay.rl_base, lay.rl_base + 1, lay.rl_third};
+            int k = (int)((rep + 1) & 1u); /* where relabel_all / reset_suspect queued their tiles */
+            dev.zero_count(lists[(k + 1) % 3]);
+            for (;;) {
+                for (int b = 0; b < P.relabel_batch; ++b, ++k) {
+                    rep++;
+                    dev.relabel_list(lists[k % 3], rep + 1, lists[(k + 1) % 3], lists[(k + 2) % 3]);
+                    st.relabel_passes++;
+                }
+                dev.read_counts(cnt);
+                st.readbacks++;
+                if (cnt[lists[k % 3]] == 0) break; /* the last pass woke nobody: fixpoint */
             }
-            dev.read_counts(cnt);
-            st.readbacks++;
-            if (cnt[lay.rl_base + (int)((rep + 1) & 1u)] == 0) break; /* the last pass woke nobody: fixpoint */
+        } else {
+            for (;;) {
+                for (int b = 0; b < P.relabel_batch; ++b) {
+                    rep++;
+                    const int cur = lay.rl_base + (int)(rep & 1u), nxt = lay.rl_base + (int)((rep + 1) & 1u);
+                    dev.zero_count(nxt);
+                    dev.relabel_list(cur, rep + 1, nxt, -1);
+                    st.relabel_passes++;
+                }
+                dev.read_counts(cnt);
+                st.readbacks++;
+                if (cnt[lay.rl_base + (int)((rep + 1) & 1u)] == 0) break; /* the last pass woke nobody: fixpoint */
+            }
         }
         st.outer++;
 

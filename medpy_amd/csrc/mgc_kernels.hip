@@ -237,12 +237,15 @@ __global__ __launch_bounds__(MGC_TV) void k_relabel_all(MgcLattice L, uint32_t e
     if (threadIdx.x == 0 && visited) atomicAdd(&L.count[9], visited);
 }
 
-__global__ __launch_bounds__(MGC_TV) void k_relabel_list(MgcLattice L, int lst, uint32_t epoch, int next_list)
+__global__ __launch_bounds__(MGC_TV) void k_relabel_list(MgcLattice L, int lst, uint32_t epoch, int next_list, int zero_list)
 {
     __shared__ MgcTileShared S;
     GpuBlock x(S);
     const int n = L.count[lst];
-    if (blockIdx.x == 0 && threadIdx.x == 0 && n) atomicAdd(&L.count[9], n);
+    if (blockIdx.x == 0 && threadIdx.x == 0) {
+        if (n) atomicAdd(&L.count[9], n);
+        if (zero_list >= 0) L.count[zero_list] = 0; /* consumed by the previous pass; the next pass appends to it */
+    }
     for (int i = blockIdx.x; i < n; i += gridDim.x) {
         x.new_tile();
         mgc_relabel_tile(x, L, L.list[lst][i], epoch, next_list, false);
@@ -274,11 +277,15 @@ __global__ __launch_bounds__(MGC_TV) void k_reset_suspect(MgcLattice L, uint32_t
         if (mine < L.ntiles && (L.status[mine] & MGC_ST_SUSPECT)) sel[atomicAdd(&nsel, 1)] = mine;
         __syncthreads();
         const int n = nsel;
-        for (int i = 0; i < n; ++i) {
-            x.new_tile();
-            mgc_reset_suspect_tile(x, L, sel[i], epoch, list);
-            __syncthreads();
+        /* same effect as mgc_reset_suspect_tile per selected tile, without a barrier per tile: all lanes stream INF over the
+         * selected tiles' labels, then one lane per tile retires the flags and queues the tile */
+        for (int i = 0; i < n; ++i) L.height[(int64_t)sel[i] * MGC_TV + threadIdx.x] = MGC_HINF;
+        if ((int)threadIdx.x < n) {
+            const int tile = sel[threadIdx.x];
+            L.status[tile] &= ~(MGC_ST_SUSPECT | MGC_ST_DIRTY | (63u << MGC_ST_DEP_SHIFT));
+            mgc_enqueue(x, L, list, L.rstamp, epoch, tile);
         }
+        __syncthreads();
     }
 }
 
@@ -839,11 +846,11 @@ struct HipDevT {
         time_end(id);
         relabel_launches++;
     }
-    void relabel_list(int lst, uint32_t epoch, int next)
+    void relabel_list(int lst, uint32_t epoch, int next, int zero_list = -1)
     {
         const int id = time_begin(1);
         if constexpr (FULL) hipLaunchKernelGGL(k26_relabel_list, dim3(grid(h->L.ntiles)), dim3(MGC_TV), 0, h->stream, h->L, lst, epoch, next);
-        else hipLaunchKernelGGL(k_relabel_list, dim3(grid(h->L.ntiles)), dim3(MGC_TV), 0, h->stream, h->L, lst, epoch, next);
+        else hipLaunchKernelGGL(k_relabel_list, dim3(grid(h->L.ntiles)), dim3(MGC_TV), 0, h->stream, h->L, lst, epoch, next, zero_list);
         check(hipGetLastError());
         time_end(id);
         relabel_launches++;

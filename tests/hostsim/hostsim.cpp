@@ -108,11 +108,12 @@ struct HostDev {
             mgc_relabel_tile(x, L, t, epoch, next, true);
         }
     }
-    void relabel_list(int lst, uint32_t epoch, int next)
+    void relabel_list(int lst, uint32_t epoch, int next, int zero_list = -1)
     {
         HostBlock x(S);
         const int n = L.count[lst];
         L.count[9] += n;
+        if (zero_list >= 0) L.count[zero_list] = 0;
         for (int i = 0; i < n; ++i) mgc_relabel_tile(x, L, L.list[lst][i], epoch, next, false);
     }
     void activate_all(uint32_t phase) { HostBlock x(S); for (int t = 0; t < L.ntiles; ++t) mgc_activate_tile(x, L, t, phase); }
@@ -146,12 +147,12 @@ struct HostDev {
         else { memset(&spec, 0, sizeof(spec)); spec.nranks = 1; spec.own_hi = L.gz; spec.plane1 = spec.own1 = d0; }
         const int64_t nt = L.ntiles;
         rcap.assign(nt * 6 * MGC_TV, 0.0); excess.assign(nt * MGC_TV, 0.0); sink.assign(nt * MGC_TV, 0.0);
-        obox.assign(nt * 6 * MGC_TF, 0.0); height.assign(nt * MGC_TV, MGC_HINF); lists.assign(6 * nt, 0);
+        obox.assign(nt * 6 * MGC_TF, 0.0); height.assign(nt * MGC_TV, MGC_HINF); lists.assign(8 * nt, 0);
         count.assign(MGC_NCOUNT, 0); rmask.assign(nt * MGC_TV, 0);
         oflags.assign(nt, 0); stamp.assign(nt, 0); rstamp.assign(nt, 0); status.assign(nt, 0);
         L.rcap = rcap.data(); L.cap0 = NULL; L.excess = excess.data(); L.sink = sink.data(); L.height = height.data();
         L.rmask = rmask.data(); L.obox = obox.data(); L.oflags = oflags.data();
-        for (int i = 0; i < 6; ++i) L.list[i] = lists.data() + i * nt;
+        for (int i = 0; i < 8; ++i) L.list[i] = lists.data() + i * nt;
         L.count = count.data(); L.stamp = stamp.data(); L.rstamp = rstamp.data(); L.status = status.data();
     }
 
@@ -321,7 +322,7 @@ struct HostDev26 {
             mgc26_relabel_tile(x, L, t, epoch, next, true);
         }
     }
-    void relabel_list(int lst, uint32_t epoch, int next)
+    void relabel_list(int lst, uint32_t epoch, int next, int = -1)
     {
         HostBlock26 x(S);
         const int n = L.count[lst];
