@@ -505,7 +505,7 @@ __global__ __launch_bounds__(MGC_TV) void k_build(MgcLattice L, MgcBuildArgs A)
                 }
                 const int64_t o = ((int64_t)tile * 6 + d) * MGC_TV + t;
                 L.rcap[o] = w;
-                L.cap0[o] = w;
+                if (L.cap0) L.cap0[o] = w;
                 if (w > 0.0) m |= 1u << d; /* NaN (0/0 of the linear terms on a constant image) is not residual */
             }
         } else {
@@ -525,7 +525,7 @@ __global__ __launch_bounds__(MGC_TV) void k_build(MgcLattice L, MgcBuildArgs A)
                 }
                 const int64_t o = ((int64_t)tile * MGC26_NDIR + d) * MGC_TV + t;
                 L.rcap[o] = w;
-                L.cap0[o] = w;
+                if (L.cap0) L.cap0[o] = w;
                 if (w > 0.0) m |= 1u << d;
             }
         }
@@ -640,8 +640,35 @@ __global__ void k_labels(MgcLattice L, uint8_t* out)
     }
 }
 
+/* Capacity, as built, of the arc that leaves voxel (gz, gy, gx) -- lane t of `tile` -- in direction d.  The built
+ * capacities are only materialised (L.cap0) when explicit edges were added on top of the boundary term; otherwise they
+ * are a pure function of the image and are re-evaluated here with exactly the operations of k_build (48 resp. 208 B per
+ * voxel less to write and to hold). */
+__device__ __forceinline__ double mgc_built_capacity(const MgcLattice& L, const MgcBuildArgs& A, int tile, int t, int64_t gz, int64_t gy, int64_t gx, int d)
+{
+    if (L.cap0) return L.cap0[((int64_t)tile * L.ndir + d) * MGC_TV + t];
+    if (A.term == MGC_TERM_NONE) return 0.0;
+    const bool take_abs = (A.term == MGC_TERM_MAXIMUM_LINEAR || A.term == MGC_TERM_MAXIMUM_EXPONENTIAL || A.term == MGC_TERM_MAXIMUM_POWER);
+    int dz, dy, dx;
+    bool fwd;
+    if (L.ndir == 6) {
+        dz = (d >> 1) == 2 ? ((d & 1) ? 1 : -1) : 0;
+        dy = (d >> 1) == 1 ? ((d & 1) ? 1 : -1) : 0;
+        dx = (d >> 1) == 0 ? ((d & 1) ? 1 : -1) : 0;
+        fwd = (d & 1) != 0;
+    } else {
+        mgc26_offset(d, dz, dy, dx);
+        fwd = d >= 13;
+    }
+    const double me = mgc_load_as_double(A.image, A.img_dtype, (gz * L.dy + gy) * L.dx + gx, take_abs);
+    const double nb = mgc_load_as_double(A.image, A.img_dtype, ((gz + dz) * L.dy + (gy + dy)) * L.dx + (gx + dx), take_abs);
+    double w = mgc_boundary_g(A.term, fwd ? me : nb, fwd ? nb : me, A.p0); /* (lower voxel, upper voxel) like the reference slices */
+    if (A.has_spacing) w = w / (L.ndir == 6 ? A.inv_axis[d >> 1] : A.div26[d]);
+    return w;
+}
+
 /* capacity of the cut (S = label 1, T = label 0) from the capacities as built */
-__global__ __launch_bounds__(MGC_TV) void k_cut_value(MgcLattice L, const double* tr0, const uint8_t* labels, double* part)
+__global__ __launch_bounds__(MGC_TV) void k_cut_value(MgcLattice L, MgcBuildArgs A, const double* tr0, const uint8_t* labels, double* part)
 {
     __shared__ double scratch[MGC_TV];
     const int t = threadIdx.x;
@@ -663,7 +690,7 @@ __global__ __launch_bounds__(MGC_TV) void k_cut_value(MgcLattice L, const double
                         const int64_t c = (d >> 1) == 0 ? gx : ((d >> 1) == 1 ? gy : gz);
                         const int64_t lim = (d >> 1) == 0 ? L.dx : ((d >> 1) == 1 ? L.dy : L.dz);
                         const bool has = (d & 1) ? (c + 1 < lim) : (c > 0);
-                        if (has && !labels[id + step[d]]) s += L.cap0[((int64_t)tile * 6 + d) * MGC_TV + t];
+                        if (has && !labels[id + step[d]]) s += mgc_built_capacity(L, A, tile, t, gz, gy, gx, d);
                     }
                 } else {
                     for (int d = 0; d < MGC26_NDIR; ++d) {
@@ -671,7 +698,7 @@ __global__ __launch_bounds__(MGC_TV) void k_cut_value(MgcLattice L, const double
                         mgc26_offset(d, dz, dy, dx);
                         const int64_t nz = gz + dz, ny = gy + dy, nx = gx + dx;
                         if (nz >= 0 && nz < L.dz && ny >= 0 && ny < L.dy && nx >= 0 && nx < L.dx && !labels[(nz * L.dy + ny) * L.dx + nx])
-                            s += L.cap0[((int64_t)tile * MGC26_NDIR + d) * MGC_TV + t];
+                            s += mgc_built_capacity(L, A, tile, t, gz, gy, gx, d);
                     }
                 }
             } else if (tr > 0.0) { /* sink side: pays its source link */
@@ -710,7 +737,7 @@ __global__ __launch_bounds__(MGC_TV) void k_sum_partials(const double* part, int
     if (threadIdx.x == 0) *out = tot;
 }
 
-__global__ void k_get_nweights(MgcLattice L, int axis /* array axis 0..2 */, double* out)
+__global__ void k_get_nweights(MgcLattice L, MgcBuildArgs A, int axis /* array axis 0..2 */, double* out)
 {
     const int64_t sh[3] = {L.dz, L.dy, L.dx};
     int64_t osh[3] = {sh[0], sh[1], sh[2]};
@@ -721,12 +748,12 @@ __global__ void k_get_nweights(MgcLattice L, int axis /* array axis 0..2 */, dou
         const int64_t x = k % osh[2], y = (k / osh[2]) % osh[1], z = k / (osh[2] * osh[1]);
         int tile, loc;
         mgc_node_to_tile(L, (z * L.dy + y) * L.dx + x, tile, loc);
-        out[k] = L.cap0[((int64_t)tile * L.ndir + d) * MGC_TV + loc];
+        out[k] = mgc_built_capacity(L, A, tile, loc, z, y, x, d);
     }
 }
 
 /* weight of the arc (p, p + offset) for every voxel p, NaN where p + offset is outside (parity read-back) */
-__global__ void k_get_nweights_offset(MgcLattice L, int dz, int dy, int dx, double* out)
+__global__ void k_get_nweights_offset(MgcLattice L, MgcBuildArgs A, int dz, int dy, int dx, double* out)
 {
     int d;
     if (L.ndir == 6) d = dx ? (dx > 0 ? 1 : 0) : (dy ? (dy > 0 ? 3 : 2) : (dz > 0 ? 5 : 4));
@@ -738,7 +765,7 @@ __global__ void k_get_nweights_offset(MgcLattice L, int dz, int dy, int dx, doub
         if (nz >= 0 && nz < L.dz && ny >= 0 && ny < L.dy && nx >= 0 && nx < L.dx) {
             int tile, loc;
             mgc_node_to_tile(L, id, tile, loc);
-            w = L.cap0[((int64_t)tile * L.ndir + d) * MGC_TV + loc];
+            w = mgc_built_capacity(L, A, tile, loc, z, y, x, d);
         }
         out[id] = w;
     }
@@ -774,6 +801,7 @@ struct mgc_graph {
     uint8_t* d_fg = nullptr; uint8_t* d_bg = nullptr;
     double* d_tr_in = nullptr; double flow_const_in = 0;
     /* pending explicit edges (host copy kept until build) */
+    MgcBuildArgs build_args{}; /* of the last mgc_build: the built capacities are re-evaluated from it (mgc_built_capacity) */
     int64_t n_edges = 0; int64_t* d_ei = nullptr; int64_t* d_ej = nullptr; double* d_ecap = nullptr; double* d_erev = nullptr;
     /* outputs / scratch */
     double* d_tr0 = nullptr; double* d_part = nullptr; double* d_part2 = nullptr; double* d_scalar = nullptr; uint8_t* d_labels = nullptr;
@@ -1059,7 +1087,7 @@ static int mgc_create_impl(int ndim, const int64_t* shape, int connectivity, int
     const int64_t nt = L.ntiles, nv = nt * MGC_TV;
     int rc;
     if ((rc = mgc_alloc(h, &L.rcap, nv * L.ndir))) return rc;
-    if ((rc = mgc_alloc(h, &L.cap0, nv * L.ndir))) return rc;
+    L.cap0 = nullptr; /* only materialised when explicit edges are added (mgc_build) */
     if ((rc = mgc_alloc(h, &L.excess, nv))) return rc;
     if ((rc = mgc_alloc(h, &L.sink, nv))) return rc;
     if ((rc = mgc_alloc(h, &L.height, nv))) return rc;
@@ -1480,6 +1508,11 @@ int mgc_build(mgc_handle h)
     A.prob = h->d_prob; A.prob_dtype = h->prob_dtype; A.alpha = h->alpha;
     A.fg = h->d_fg; A.bg = h->d_bg; A.tr_in = h->d_tr_in;
     A.tr0 = h->d_tr0; A.fpart = h->d_part;
+    if (h->n_edges && !L.cap0) { /* explicit edges change capacities that the image no longer determines */
+        const int rc = mgc_alloc(h, &L.cap0, (int64_t)L.ntiles * MGC_TV * L.ndir);
+        if (rc) return rc;
+    }
+    h->build_args = A;
     const int grid = L.ntiles < h->grid_cap * 4 ? L.ntiles : h->grid_cap * 4;
     const int bgrid = grid >= 8 ? grid / 8 * 8 : grid; /* k_build deals tiles to XCDs: multiple of 8 */
     if (L.ndir == 6) hipLaunchKernelGGL(k_build<false>, dim3(bgrid), dim3(MGC_TV), 0, h->stream, L, A);
@@ -1557,7 +1590,7 @@ int mgc_maxflow(mgc_handle h, double* flow)
         MGC_HIP(h, hipGetLastError());
         MGC_HIP(h, hipEventRecord(h->ev[1], h->stream));
         const int grid = L.ntiles < h->grid_cap * 4 ? L.ntiles : h->grid_cap * 4;
-        hipLaunchKernelGGL(k_cut_value, dim3(grid), dim3(MGC_TV), 0, h->stream, L, (const double*)h->d_tr0,
+        hipLaunchKernelGGL(k_cut_value, dim3(grid), dim3(MGC_TV), 0, h->stream, L, h->build_args, (const double*)h->d_tr0,
                            (const uint8_t*)h->d_labels, h->d_part);
         MGC_HIP(h, hipGetLastError());
         mgc_sum_partials(h, (int64_t)L.ntiles, h->d_scalar + 1);
@@ -1594,7 +1627,7 @@ int mgc_finish(mgc_handle h, double* flow_partial)
     hipLaunchKernelGGL(k_labels, dim3(2048), dim3(256), 0, h->stream, L, h->d_labels);
     MGC_HIP(h, hipGetLastError());
     const int grid = L.ntiles < h->grid_cap * 4 ? L.ntiles : h->grid_cap * 4;
-    hipLaunchKernelGGL(k_cut_value, dim3(grid), dim3(MGC_TV), 0, h->stream, L, (const double*)h->d_tr0, (const uint8_t*)h->d_labels, h->d_part);
+    hipLaunchKernelGGL(k_cut_value, dim3(grid), dim3(MGC_TV), 0, h->stream, L, h->build_args, (const double*)h->d_tr0, (const uint8_t*)h->d_labels, h->d_part);
     MGC_HIP(h, hipGetLastError());
     mgc_sum_partials(h, (int64_t)L.ntiles, h->d_scalar + 1);
     MGC_HIP(h, hipGetLastError());
@@ -1649,7 +1682,7 @@ int mgc_get_nweights(mgc_handle h, int axis, double* out)
     if (n <= 0) return MGC_OK;
     double* d = nullptr;
     MGC_HIP(h, hipMalloc((void**)&d, (size_t)n * sizeof(double)));
-    hipLaunchKernelGGL(k_get_nweights, dim3(1024), dim3(256), 0, h->stream, h->L, a3, d);
+    hipLaunchKernelGGL(k_get_nweights, dim3(1024), dim3(256), 0, h->stream, h->L, h->build_args, a3, d);
     hipError_t e = hipGetLastError();
     if (e == hipSuccess) e = hipMemcpyAsync(out, d, (size_t)n * sizeof(double), hipMemcpyDeviceToHost, h->stream);
     if (e == hipSuccess) e = hipStreamSynchronize(h->stream);
@@ -1671,7 +1704,7 @@ int mgc_get_nweights_offset(mgc_handle h, const int* offset, double* out)
     MGC_HIP(h, hipSetDevice(h->device));
     double* d = nullptr;
     MGC_HIP(h, hipMalloc((void**)&d, (size_t)h->nvox * sizeof(double)));
-    hipLaunchKernelGGL(k_get_nweights_offset, dim3(1024), dim3(256), 0, h->stream, h->L, o[0], o[1], o[2], d);
+    hipLaunchKernelGGL(k_get_nweights_offset, dim3(1024), dim3(256), 0, h->stream, h->L, h->build_args, o[0], o[1], o[2], d);
     hipError_t e = hipGetLastError();
     if (e == hipSuccess) e = hipMemcpyAsync(out, d, (size_t)h->nvox * sizeof(double), hipMemcpyDeviceToHost, h->stream);
     if (e == hipSuccess) e = hipStreamSynchronize(h->stream);
@@ -1708,7 +1741,8 @@ int mgc_get_edge(mgc_handle h, int64_t i, int64_t j, double* out)
     if (d < 0) return MGC_OK;
     int tile, loc;
     mgc_node_to_tile(L, i, tile, loc);
-    const double* src = (h->solved ? L.rcap : L.cap0) + ((int64_t)tile * L.ndir + d) * MGC_TV + loc;
+    /* residual after maxflow() like Graph::get_edge (graph.h:482-498); before it the residuals ARE the built capacities */
+    const double* src = L.rcap + ((int64_t)tile * L.ndir + d) * MGC_TV + loc;
     MGC_HIP(h, hipMemcpyAsync(h->h_scalar + 6, src, sizeof(double), hipMemcpyDeviceToHost, h->stream));
     MGC_HIP(h, hipStreamSynchronize(h->stream));
     *out = h->h_scalar[6];
