@@ -159,6 +159,7 @@ struct GpuBlockT {
 };
 typedef GpuBlockT<MgcTileShared> GpuBlock;
 typedef GpuBlockT<MgcTileShared26> GpuBlock26;
+typedef GpuBlockT<MgcTileShared26D> GpuBlock26D;
 
 /* ---- 26-neighbourhood solver kernels (bodies: mgc_tile_ops26.inl) ---- */
 __global__ __launch_bounds__(MGC_TV) void k26_relabel_all(MgcLattice L, uint32_t epoch, int next_list)
@@ -199,10 +200,14 @@ __global__ __launch_bounds__(MGC_TV) void k26_activate(MgcLattice L, uint32_t ph
     }
 }
 
-__global__ __launch_bounds__(MGC_TV) void k26_discharge(MgcLattice L, int lst, uint32_t phase, int cycles, int sweeps)
+#ifndef MGC26_DISCHARGE_WAVES
+#define MGC26_DISCHARGE_WAVES 4 /* waves per SIMD the register allocator leaves room for: 128 VGPRs, 2 workgroups per CU
+                                   (13 of the 26 residuals live in LDS, see MgcTileShared26D) */
+#endif
+__global__ __launch_bounds__(MGC_TV, MGC26_DISCHARGE_WAVES) void k26_discharge(MgcLattice L, int lst, uint32_t phase, int cycles, int sweeps)
 {
-    __shared__ MgcTileShared26 S;
-    GpuBlock26 x(S);
+    __shared__ MgcTileShared26D S;
+    GpuBlock26D x(S);
     const int n = L.count[lst];
     if (blockIdx.x == 0 && threadIdx.x == 0 && n) atomicAdd(&L.count[MGC26_CNT_DIS], n);
     for (int i = blockIdx.x; i < n; i += gridDim.x) {

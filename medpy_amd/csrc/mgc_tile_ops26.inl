@@ -41,6 +41,14 @@ struct MgcTileShared26 {
     int32_t flag[2];
 };
 
+/* LDS of the discharge kernel: half of the 26 residuals of every voxel live here (directions 13..25), the other half in
+ * registers.  All 26 in registers need 256 VGPRs (2 waves/SIMD, one workgroup per CU, and still spill); 13 + 13 fits
+ * 128 VGPRs and 66 KiB of LDS, i.e. two workgroups per CU. */
+#define MGC26_NREG 13
+struct MgcTileShared26D : MgcTileShared26 {
+    alignas(16) double rl[MGC26_NDIR - MGC26_NREG][MGC_TV];
+};
+
 MGC_HD void mgc26_offset(int d, int& dz, int& dy, int& dx)
 {
     const int c = d < 13 ? d : d + 1;
@@ -171,7 +179,10 @@ MGC_HD void mgc26_activate_tile(X& x, const MgcLattice& L, int tile, uint32_t ph
 template <class X>
 MGC_HD void mgc26_discharge_tile(X& x, const MgcLattice& L, int tile, uint32_t phase, int max_cycles, int max_sweeps)
 {
-    typename X::template Reg<double> e, snk, r[MGC26_NDIR];
+    typename X::template Reg<double> e, snk, rr[MGC26_NREG];
+    /* residual of lane t in direction d: register for d < 13, LDS slot (own lane only) for d >= 13; d is a compile-time
+     * constant wherever this is used (unrolled loops), so the choice folds away */
+    auto R = [&](int d, int t) -> double& { return d < MGC26_NREG ? rr[d < MGC26_NREG ? d : 0][t] : x.S.rl[d >= MGC26_NREG ? d - MGC26_NREG : 0][t]; };
     typename X::template Reg<int> hme;
     const int64_t base = (int64_t)tile * MGC_TV;
 
@@ -180,7 +191,7 @@ MGC_HD void mgc26_discharge_tile(X& x, const MgcLattice& L, int tile, uint32_t p
         e[t] = L.excess[base + t];
         snk[t] = L.sink[base + t];
 #pragma unroll
-        for (int d = 0; d < MGC26_NDIR; ++d) r[d][t] = L.rcap[((int64_t)tile * MGC26_NDIR + d) * MGC_TV + t];
+        for (int d = 0; d < MGC26_NDIR; ++d) R(d, t) = L.rcap[((int64_t)tile * MGC26_NDIR + d) * MGC_TV + t];
         mgc26_load_halo(x, L, t);
     });
 
@@ -191,7 +202,7 @@ MGC_HD void mgc26_discharge_tile(X& x, const MgcLattice& L, int tile, uint32_t p
         mgc26_tile_bfs(x, [&](int t) {
             uint32_t m = snk[t] > 0.0 ? MGC26_MASK_SINK : 0u;
 #pragma unroll
-            for (int d = 0; d < MGC26_NDIR; ++d) m |= (r[d][t] > 0.0) ? (1u << d) : 0u;
+            for (int d = 0; d < MGC26_NDIR; ++d) m |= (R(d, t) > 0.0) ? (1u << d) : 0u;
             return m;
         });
         active = x.any([&](int t) -> bool {
@@ -224,7 +235,7 @@ MGC_HD void mgc26_discharge_tile(X& x, const MgcLattice& L, int tile, uint32_t p
                             const double din = x.S.out[dp & 1][mgc_local(sz, sy, sx)];
                             if (din != 0.0) {
                                 e[t] += din;
-                                r[25 - dp][t] += din;
+                                R(25 - dp, t) += din;
                             }
                         }
                     }
@@ -235,12 +246,12 @@ MGC_HD void mgc26_discharge_tile(X& x, const MgcLattice& L, int tile, uint32_t p
                         const int vz = z + dz, vy = y + dy, vx = xx + dx;
                         const bool inside = vz >= 0 && vz < 8 && vy >= 0 && vy < 8 && vx >= 0 && vx < 8;
                         double delta = 0.0;
-                        if (e[t] > 0.0 && r[d][t] > 0.0 && hme[t] < MGC_HINF) {
+                        if (e[t] > 0.0 && R(d, t) > 0.0 && hme[t] < MGC_HINF) {
                             const int hv = x.S.hs[mgc_hs_index(z, y, xx) + mgc26_hs_step(d)];
                             if (hv == hme[t] - 1) {
-                                delta = e[t] < r[d][t] ? e[t] : r[d][t];
+                                delta = e[t] < R(d, t) ? e[t] : R(d, t);
                                 e[t] -= delta;
-                                r[d][t] -= delta;
+                                R(d, t) -= delta;
                                 x.S.flag[fl] = 1;
                             }
                         }
@@ -274,7 +285,7 @@ MGC_HD void mgc26_discharge_tile(X& x, const MgcLattice& L, int tile, uint32_t p
                     int cand = snk[t] > 0.0 ? 1 : MGC_HINF;
 #pragma unroll
                     for (int d = 0; d < MGC26_NDIR; ++d)
-                        if (r[d][t] > 0.0) {
+                        if (R(d, t) > 0.0) {
                             const int hv = x.S.hs[me + mgc26_hs_step(d)];
                             cand = (hv < MGC_HINF && hv + 1 < cand) ? hv + 1 : cand;
                         }
@@ -297,8 +308,8 @@ MGC_HD void mgc26_discharge_tile(X& x, const MgcLattice& L, int tile, uint32_t p
         uint32_t m = snk[t] > 0.0 ? MGC26_MASK_SINK : 0u;
 #pragma unroll
         for (int d = 0; d < MGC26_NDIR; ++d) {
-            L.rcap[((int64_t)tile * MGC26_NDIR + d) * MGC_TV + t] = r[d][t];
-            m |= (r[d][t] > 0.0) ? (1u << d) : 0u;
+            L.rcap[((int64_t)tile * MGC26_NDIR + d) * MGC_TV + t] = R(d, t);
+            m |= (R(d, t) > 0.0) ? (1u << d) : 0u;
         }
         L.rmask32[base + t] = m;
         L.height[base + t] = x.S.hs[mgc_hs_index(t >> 6, (t >> 3) & 7, t & 7)];

@@ -86,6 +86,7 @@ struct HostBlockT {
 };
 typedef HostBlockT<MgcTileShared> HostBlock;
 typedef HostBlockT<MgcTileShared26> HostBlock26;
+typedef HostBlockT<MgcTileShared26D> HostBlock26D;
 
 struct HostDev {
     MgcLattice L;
@@ -304,7 +305,7 @@ int hostsim_solve(const int64_t* shape, const double* w0, const double* w1, cons
  * ---------------------------------------------------------------------------------------- */
 struct HostDev26 {
     MgcLattice L;
-    MgcTileShared26 S;
+    MgcTileShared26D S;
     std::vector<double> rcap, excess, sink;
     std::vector<int32_t> height, lists, count;
     std::vector<uint32_t> rmask32, stamp, rstamp, status;
@@ -332,7 +333,7 @@ struct HostDev26 {
     void activate_all(uint32_t phase) { HostBlock26 x(S); for (int t = 0; t < L.ntiles; ++t) mgc26_activate_tile(x, L, t, phase); }
     void discharge(int lst, uint32_t phase, int cycles, int sweeps)
     {
-        HostBlock26 x(S);
+        HostBlock26D x(S);
         const int n = L.count[lst];
         L.count[MGC26_CNT_DIS] += n;
         for (int i = 0; i < n; ++i) mgc26_discharge_tile(x, L, L.list[lst][i], phase, cycles, sweeps);
