@@ -69,9 +69,9 @@ static inline MgcSolveParams mgc_default_params(int ndir = 6)
     /* tuned on MI355X at 256^3 / 512^3 (tools/gpu_sweep.py, tools/gpu_sweep26.py; every schedule gives the same labels).
      * One exact in-tile labelling per discharge, then sweeps with local relabels: 83 ms vs 100 ms for (3 cycles x 4
      * sweeps) at 512^3; a sweep of the 26-neighbourhood costs four times as much, so fewer of them pay there. */
-    p.rounds_per_relabel = 8;
+    p.rounds_per_relabel = ndir == 26 ? 6 : 8;
     p.max_cycles = 1;
-    p.max_sweeps = ndir == 26 ? 4 : 12;
+    p.max_sweeps = ndir == 26 ? 3 : 12;
     p.max_outer = 100000;
     p.relabel_batch = 8;
     p.check_rounds = 4;

@@ -165,7 +165,7 @@ def solve_slabs(slabs, ex, rounds_per_relabel=8, max_cycles=1, max_sweeps=None, 
     # where the solver variant keeps its lists / counters (MgcLayout, mgc_driver.inl:51-62)
     if getattr(slabs[0], "ndir", 6) == 26:
         ncol, lmask, rl, c_act, c_dis, c_rel = 8, 15, 16, 18, 19, 20
-        max_sweeps = max_sweeps or 4  # mgc_default_params(26)
+        max_sweeps = max_sweeps or 3  # mgc_default_params(26)
         incremental_relabel = False  # the full-neighbourhood kernels keep no support faces
     else:
         ncol, lmask, rl, c_act, c_dis, c_rel = 2, 3, 4, 6, 8, 9

@@ -12,9 +12,10 @@ g._set_boundary("difference_exponential", s["image"], s["sigma"], False)
 g._set_markers(s["fg"], s["bg"])
 base = dict(rounds_per_relabel=8, max_cycles=1, max_sweeps=12, relabel_batch=8, check_rounds=4, grid_cap=4096)
 grid = [dict()]
-grid += [dict(max_cycles=c, max_sweeps=w) for c, w in ((1, 6), (1, 8), (1, 12), (1, 16), (1, 24), (2, 4), (2, 6), (2, 8), (2, 12), (3, 6), (3, 8))]
-grid += [dict(max_cycles=1, max_sweeps=12, rounds_per_relabel=r) for r in (4, 6, 12)]
-grid += [dict(max_cycles=2, max_sweeps=8, rounds_per_relabel=r) for r in (6, 12)]
+grid += [dict(max_sweeps=w) for w in (8, 16)]
+grid += [dict(rounds_per_relabel=r) for r in (6, 10, 12)]
+grid += [dict(grid_cap=c) for c in (2048, 8192)]
+grid += [dict(rounds_per_relabel=10, max_sweeps=8), dict(rounds_per_relabel=12, max_sweeps=16), dict(relabel_batch=16), dict(check_rounds=8)]
 g.set_param("kernel_timing", 0)
 ref = None
 for over in grid:

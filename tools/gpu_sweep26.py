@@ -10,7 +10,7 @@ g._set_boundary("difference_exponential", s["image"], s["sigma"], False)
 g._set_markers(s["fg"], s["bg"])
 g._set_regional(r["prob"], r["alpha"])
 ref = None
-for c, w, rr in ((3, 4, 8), (1, 4, 8), (1, 6, 8), (1, 8, 8), (1, 12, 8), (2, 4, 8), (2, 6, 8), (1, 8, 4), (1, 8, 12), (1, 6, 12)):
+for c, w, rr in ((1, 4, 8), (1, 3, 8), (1, 5, 8), (1, 2, 8), (1, 4, 6), (1, 4, 10), (1, 3, 6), (1, 3, 10)):
     g.set_param("max_cycles", c); g.set_param("max_sweeps", w); g.set_param("rounds_per_relabel", rr)
     best = 1e9
     for rep in range(2):
