@@ -296,7 +296,7 @@ __global__ __launch_bounds__(MGC_TV) void k_reset_suspect(MgcLattice L, uint32_t
 
 /* Tile-level filters: ONE THREAD PER TILE decides whether the tile needs the 512-lane operation at all and, if so,
  * appends it to a scratch list (one atomic per wave).  mode 0: a neighbour left flow in its outbox for this tile;
- * mode 1: the tile holds excess (status bit); mode 2: the tile is suspect. */
+ * mode 1: the tile holds excess (status bit); mode 2: the tile is suspect; mode 3: the tile holds an arc to the sink. */
 __global__ void k_filter(MgcLattice L, int mode, int list, int cnt)
 {
     for (int base = blockIdx.x * blockDim.x; base < L.ntiles; base += gridDim.x * blockDim.x) { /* uniform per block */
@@ -312,6 +312,8 @@ __global__ void k_filter(MgcLattice L, int mode, int list, int cnt)
                 }
             } else if (mode == 1) {
                 take = (L.status[tile] & MGC_ST_EXCESS) != 0;
+            } else if (mode == 3) {
+                take = (L.status[tile] & MGC_ST_SINK) != 0;
             } else {
                 take = (L.status[tile] & MGC_ST_SUSPECT) != 0;
             }
@@ -330,6 +332,20 @@ __global__ void k_count_status(MgcLattice L, uint32_t bit, int cnt)
 {
     for (int tile = blockIdx.x * blockDim.x + threadIdx.x; tile < L.ntiles; tile += gridDim.x * blockDim.x)
         if (L.status[tile] & bit) atomicAdd(&L.count[cnt], 1);
+}
+
+/* first pass of a from-scratch global relabel over the tiles the filter found to hold a sink arc (the only seeds) */
+__global__ __launch_bounds__(MGC_TV) void k_relabel_first_list(MgcLattice L, int list, int cnt, uint32_t epoch, int next_list)
+{
+    __shared__ MgcTileShared S;
+    GpuBlock x(S);
+    const int n = L.count[cnt];
+    if (blockIdx.x == 0 && threadIdx.x == 0 && n) atomicAdd(&L.count[9], n);
+    for (int i = blockIdx.x; i < n; i += gridDim.x) {
+        x.new_tile();
+        mgc_relabel_tile(x, L, L.list[list][i], epoch, next_list, true);
+        __syncthreads();
+    }
 }
 
 __global__ __launch_bounds__(MGC_TV) void k_absorb_list(MgcLattice L, int list, int cnt)
@@ -898,7 +914,12 @@ struct HipDevT {
     {
         const int id = time_begin(1);
         if constexpr (FULL) hipLaunchKernelGGL(k26_relabel_all, dim3(grid(h->L.ntiles)), dim3(MGC_TV), 0, h->stream, h->L, epoch, next);
-        else hipLaunchKernelGGL(k_relabel_all, dim3(grid(h->L.ntiles)), dim3(MGC_TV), 0, h->stream, h->L, epoch, next);
+        else if (!(h->use_filters & 1)) hipLaunchKernelGGL(k_relabel_all, dim3(grid(h->L.ntiles)), dim3(MGC_TV), 0, h->stream, h->L, epoch, next);
+        else { /* one thread per tile finds the seeds (tiles with an arc to the sink); only those get a workgroup */
+            zero_count(11);
+            hipLaunchKernelGGL(k_filter, dim3(filter_grid()), dim3(256), 0, h->stream, h->L, 3, 6, 11);
+            hipLaunchKernelGGL(k_relabel_first_list, dim3(grid(h->L.ntiles)), dim3(MGC_TV), 0, h->stream, h->L, 6, 11, epoch, next);
+        }
         check(hipGetLastError());
         time_end(id);
         relabel_launches++;
