@@ -151,3 +151,47 @@ def test_dimacs_writer_text_equals_the_reference_layout():
                             "a 3 4 0.5\na 4 3 0.25\na 4 5 2\nc end-of-file")
     g.set_nweights({(1, 2): (1, 1), (2, 1): (1, 1), (1, 9): (1, 1)})
     assert len(g.inconsistent()) == 3
+
+
+def test_merge_tweights_equals_call_by_call_add_tweights():
+    """GCGraph.merge_tweights (vectorised, distinct ids) must leave exactly what the reference's per-node
+    set_tweight -> Graph::add_tweights sequence leaves (graph.py:490-498, graph.h:416-425): tr_cap and the flow constant"""
+    from medpy_amd.graphcut import GCGraph
+    rng = np.random.default_rng(0)
+    n = 300
+    a, b = GCGraph(n, 10), GCGraph(n, 10)
+    for rnd in range(3):  # three batches on top of each other: regional-like, then fg-like, then bg-like
+        ids = rng.permutation(n)[: int(rng.integers(1, n))]
+        src = rng.random(ids.size) * (rng.random(ids.size) < 0.7) * 10
+        snk = rng.random(ids.size) * (rng.random(ids.size) < 0.7) * 10 - (rnd == 0) * 3  # negative sink weights occur (regional_atlas)
+        a.merge_tweights(ids, src, snk)
+        for i, s, t in zip(ids.tolist(), src.tolist(), snk.tolist()):
+            b.set_tweight(i, s, t)
+    ta, tb = a._GCGraph__tr, b._GCGraph__tr
+    np.testing.assert_array_equal(ta, tb)
+    assert a._GCGraph__flow_const == b._GCGraph__flow_const
+    with pytest.raises(ValueError):
+        a.merge_tweights([n], [1.0], [0.0])
+
+
+def test_graph_from_labels_argument_checks():
+    """reference generate.py:266-291 / energy_label.py:451-461: malformed label images and terms are rejected before
+    anything touches the GPU"""
+    from medpy_amd.graphcut import graph_from_labels
+    good = np.asarray([[1, 1, 2], [3, 3, 2]])
+    m = np.zeros(good.shape, bool)
+    for bad in ([[1, 4, 8], [1, 3, 10]], [[2, 3, 4], [2, 3, 4]], [[0, 1], [1, 2]]):
+        with pytest.raises(AttributeError):
+            graph_from_labels(bad, m, m)
+    with pytest.raises(AttributeError):
+        graph_from_labels(good, m, m, boundary_term=lambda g, args: None)
+    with pytest.raises(AttributeError):
+        graph_from_labels(good, m, m, regional_term=lambda g, l, a, extra: None)
+
+
+def test_relabel_first_appearance_order():
+    """reference medpy/filter/label.py:76-105: consecutive ids in order of first appearance (C order)"""
+    from medpy_amd.graphcut.wrapper import relabel
+    lab = np.asarray([[7, 7, 3], [9, 3, 7], [2, 2, 9]])
+    np.testing.assert_array_equal(relabel(lab), [[1, 1, 2], [3, 2, 1], [4, 4, 3]])
+    np.testing.assert_array_equal(relabel(lab, start=5), np.asarray([[1, 1, 2], [3, 2, 1], [4, 4, 3]]) + 4)
