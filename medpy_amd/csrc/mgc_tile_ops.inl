@@ -19,12 +19,16 @@
  *   X::Reg<T>            per-lane value, indexed with the lane id
  *   x.par(f)             run f(lane) for all 512 lanes, then barrier
  *   x.any(f)             barrier-OR of f(lane) over all lanes
+ *   x.wpar(f)            run f(lane) for all lanes WITHOUT a barrier: f may only touch the lane's own registers / LDS slots
+ *   x.wave_any(f)        OR of f(lane) over the 64 lanes of a wave (one z-layer of the tile); uniform per wave
+ *   x.shift(dst, src, k) dst[lane] = src[lane + k] inside the wave, 0.0 at its ends (ds_bpermute on the GPU): the +-x / +-y
+ *                        hand-offs of a push sweep need neither an LDS slot nor a barrier
  *   x.S                  MgcTileShared& (LDS)
  *   x.atomic_add/or/and/exch   device-scope atomics on global words
+ *   x.async_to_lds / x.async_wait   HBM -> LDS copy without a register round trip (global_load_lds on gfx950)
  *   x.tile_labels(mask, out)   exact in-tile distance labels from scratch given the halo in x.S.hs: out[lane] and the
- *                              tile's own cells of x.S.hs.  The fixpoint is unique, so executors may compute it their own
- *                              way: the host executor relaxes (mgc_tile_bfs below), the GPU executor runs a bit-parallel
- *                              level-synchronous BFS in every wave (mgc_kernels.hip: GpuBlockT::tile_labels)
+ *                              tile's own cells of x.S.hs (chaotic relaxation in LDS, mgc_tile_bfs below; the residual
+ *                              mask is evaluated once)
  */
 #ifndef MGC_TILE_OPS_INL
 #define MGC_TILE_OPS_INL
