@@ -68,11 +68,18 @@ from medpy_amd import synthetic
 from medpy_amd.slab import DistExchange, solve_slabs
 from oracle import energy_numpy, pipeline
 shape = (40, 24, 24)
+conn = int(sys.argv[3]) if len(sys.argv) > 3 else 6
 s = synthetic.sphere(shape)
-w = energy_numpy.boundary_weights(s["term"], s["image"], s["sigma"])
-g = pipeline.build_graph(s["fg"], s["bg"], weights=w)
+if conn == 6:
+    w = energy_numpy.boundary_weights(s["term"], s["image"], s["sigma"])
+    g = pipeline.build_graph(s["fg"], s["bg"], weights=w)
+    slab = sim.SimSlab(shape, rank, world)
+else:
+    w = energy_numpy.boundary_weights_offsets(s["term"], s["image"], energy_numpy.forward_offsets(3, 26), s["sigma"])
+    g = pipeline.build_graph(s["fg"], s["bg"], weights=w, connectivity=26)
+    slab = sim.SimSlab26(shape, rank, world)
+    w = sim.weights26(shape, w)
 tr = np.array([g.get_trcap(i) for i in range(s["fg"].size)])
-slab = sim.SimSlab(shape, rank, world)
 slab.load(w, tr)
 st = solve_slabs([slab], DistExchange(slab))
 lab, _ = slab.finish()
@@ -84,17 +91,24 @@ dist.destroy_process_group()
 
 
 @pytest.mark.timeout(300)
-def test_two_process_gloo_slabs(tmp_path):
-    """world_size 2, gloo, one slab per process: the N>1 path of bench.py / the multi-GPU run."""
+@pytest.mark.parametrize("conn", [6, 26])
+def test_two_process_gloo_slabs(tmp_path, conn):
+    """world_size 2, gloo, one slab per process: the N>1 path of bench.py / the multi-GPU run (both neighbourhoods)."""
     script = tmp_path / "worker.py"
     script.write_text(WORKER)
     env = dict(os.environ, MASTER_ADDR="127.0.0.1", OMP_NUM_THREADS="1")
-    port = 29500 + (os.getpid() % 2000)
+    port = 29500 + ((os.getpid() + conn) % 2000)
     cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node=2", "--master-addr", "127.0.0.1",
-           "--master-port", str(port), str(script), ROOT, str(tmp_path)]
+           "--master-port", str(port), str(script), ROOT, str(tmp_path), str(conn)]
     res = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=280)
     assert res.returncode == 0, res.stderr[-3000:]
-    _, _, ref = _problem("sphere", (40, 24, 24))
+    if conn == 6:
+        _, _, ref = _problem("sphere", (40, 24, 24))
+    else:
+        from medpy_amd import synthetic
+        from oracle import pipeline
+        s = synthetic.sphere((40, 24, 24))
+        ref = pipeline.graphcut_voxel(s["fg"], s["bg"], term=s["term"], image=s["image"], sigma=s["sigma"], connectivity=26).labels
     parts, ranges = [], []
     for r in range(2):
         parts.append(np.load(tmp_path / ("labels_%d.npy" % r)))
