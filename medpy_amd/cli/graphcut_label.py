@@ -1,7 +1,9 @@
 """Region graph-cut command line: the reference's ``bin/medpy_graphcut_label.py`` on MI355X.
 
 Same positional arguments, options and flow as reference bin/medpy_graphcut_label.py:77-200
-(``badditional region markers output [--boundary means|stawiaski] [-f] [-v] [-d]``); the differences are the I/O layer
+(``badditional region markers output [--boundary means|stawiaski] [-f] [-v] [-d]``) plus the options of its sibling
+bin/medpy_graphcut_label_w_regional.py:85-185 (``--regional none|atlas --radditional IMAGE --alpha FLOAT``: the atlas
+regional term on top of the boundary term); the differences are the I/O layer
 (``medpy_amd.io``: .npy / NIfTI-1 instead of SimpleITK) and the read-out (bulk ``labels()`` instead of one
 ``what_segment`` call per region, :150-158).
 """
@@ -43,12 +45,21 @@ def main(argv=None):
         boundary_term = graphcut.energy_label.boundary_difference_of_means
         logger.info("Selected boundary term: difference of means")
 
+    regional_term = graphcut.energy_label.regional_atlas if args.regional == "atlas" else False
+    if regional_term and (args.radditional is None or args.alpha is None):
+        raise ArgumentError("The atlas regional term needs --radditional (the probability image) and --alpha.")
+
     region_image_data, reference_header = load(args.region)
     badditional_image_data, _ = load(args.badditional)
     markers_image_data, _ = load(args.markers)
+    radditional_image_data = load(args.radditional)[0] if regional_term else False
     fgmarkers_image_data, bgmarkers_image_data = split_marker(markers_image_data)
 
     if not (badditional_image_data.shape == region_image_data.shape == fgmarkers_image_data.shape == bgmarkers_image_data.shape):
+        logger.critical("Not all of the supplied images are of the same shape.")
+        raise ArgumentError("Not all of the supplied images are of the same shape.")
+
+    if regional_term and not (radditional_image_data.shape == badditional_image_data.shape):
         logger.critical("Not all of the supplied images are of the same shape.")
         raise ArgumentError("Not all of the supplied images are of the same shape.")
 
@@ -56,9 +67,11 @@ def main(argv=None):
     region_image_data = relabel(region_image_data)
 
     logger.info("Preparing graph...")
-    gcgraph = graphcut.graph_from_labels(region_image_data, fgmarkers_image_data, bgmarkers_image_data, boundary_term=boundary_term,
+    gcgraph = graphcut.graph_from_labels(region_image_data, fgmarkers_image_data, bgmarkers_image_data,
+                                         regional_term=regional_term, boundary_term=boundary_term,
+                                         regional_term_args=(radditional_image_data, args.alpha) if regional_term else False,
                                          boundary_term_args=(badditional_image_data))
-    del fgmarkers_image_data, bgmarkers_image_data, badditional_image_data
+    del fgmarkers_image_data, bgmarkers_image_data, badditional_image_data, radditional_image_data
 
     logger.info("Executing min-cut...")
     maxflow = gcgraph.maxflow()
@@ -87,6 +100,10 @@ def getParser():
     parser.add_argument("--boundary", default="stawiaski", choices=["means", "stawiaski"],
                         help="The boundary term to use. Note that difference of means (means) requires the original image, while "
                              "stawiaski requires the gradient image of the original image to be passed to badditional.")
+    parser.add_argument("--regional", default="none", choices=["none", "atlas"],
+                        help="The regional term to use. Note that the atlas requires to provide an atlas image.")
+    parser.add_argument("--radditional", help="The additional image required by the regional term. See there for details.")
+    parser.add_argument("--alpha", type=float, help="The weight of the regional term compared to the boundary term.")
     parser.add_argument("-f", dest="force", action="store_true", help="Set this flag to silently override files that exist.")
     parser.add_argument("-v", dest="verbose", action="store_true", help="Display more information.")
     parser.add_argument("-d", dest="debug", action="store_true", help="Display debug information.")

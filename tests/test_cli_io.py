@@ -96,7 +96,11 @@ def test_label_cli_parser_matches_reference_surface():
     a = getParser().parse_args(["grad.nii", "regions.nii", "markers.nii", "out.nii", "--boundary", "means", "-f", "-d"])
     assert (a.badditional, a.region, a.markers, a.output, a.boundary, a.force, a.verbose, a.debug) == (
         "grad.nii", "regions.nii", "markers.nii", "out.nii", "means", True, False, True)
-    assert getParser().parse_args(["a", "b", "c", "d"]).boundary == "stawiaski"
+    d = getParser().parse_args(["a", "b", "c", "d"])
+    assert d.boundary == "stawiaski" and d.regional == "none" and d.radditional is None and d.alpha is None
+    # the options of bin/medpy_graphcut_label_w_regional.py:130-150
+    r = getParser().parse_args(["a", "b", "c", "d", "--regional", "atlas", "--radditional", "atlas.nii", "--alpha", "0.5"])
+    assert (r.regional, r.radditional, r.alpha) == ("atlas", "atlas.nii", 0.5)
 
 
 @pytest.mark.gpu
@@ -124,3 +128,43 @@ def test_label_cli_end_to_end(tmp_path):
     np.save(tmp_path / "small.npy", np.zeros((3, 3), np.float32))
     with pytest.raises(ArgumentError):
         main([str(tmp_path / "small.npy"), paths["lab"], paths["markers"], str(tmp_path / "x.npy")])
+
+
+def test_label_cli_flow_with_a_stub_solver(tmp_path, monkeypatch):
+    """the command line's own logic (argument checks, relabelling, term selection, label read-out, save) with the GPU part
+    replaced by a stub: both the plain and the --regional atlas form of reference bin/medpy_graphcut_label*.py"""
+    from medpy_amd import graphcut
+    from medpy_amd.cli import graphcut_label as cli
+    from medpy_amd.graphcut.wrapper import ArgumentError
+    calls = []
+
+    class FakeGraph(object):
+        def __init__(self, n):
+            self.n = n
+
+        def maxflow(self):
+            return 1.0
+
+        def labels(self):
+            return np.arange(self.n) % 2 == 0  # regions 1, 3, 5, ... are foreground
+
+    def fake_graph_from_labels(label_image, fg, bg, regional_term=False, boundary_term=False, regional_term_args=False, boundary_term_args=False):
+        calls.append((regional_term, boundary_term, regional_term_args, np.asarray(boundary_term_args).shape))
+        return FakeGraph(int(label_image.max()))
+    monkeypatch.setattr(graphcut, "graph_from_labels", fake_graph_from_labels)
+    lab = np.asarray([[5, 5, 9], [7, 9, 9]], dtype=np.int32)  # relabelled to 1, 2, 3 in order of first appearance
+    np.save(tmp_path / "lab.npy", lab)
+    np.save(tmp_path / "grad.npy", np.zeros(lab.shape, np.float32))
+    np.save(tmp_path / "atlas.npy", np.full(lab.shape, 0.5, np.float32))
+    np.save(tmp_path / "markers.npy", np.asarray([[1, 0, 0], [0, 0, 2]], np.uint8))
+    out = str(tmp_path / "seg.npy")
+    base = [str(tmp_path / "grad.npy"), str(tmp_path / "lab.npy"), str(tmp_path / "markers.npy"), out]
+    assert cli.main(base) == 0
+    np.testing.assert_array_equal(np.load(out).astype(bool), [[True, True, False], [True, False, False]])  # regions 1 and 3
+    assert calls[-1][0] is False and calls[-1][1] is graphcut.energy_label.boundary_stawiaski and calls[-1][2] is False
+    assert cli.main(base) == -1  # exists, no -f
+    assert cli.main(base + ["-f", "--boundary", "means", "--regional", "atlas", "--radditional", str(tmp_path / "atlas.npy"), "--alpha", "0.25"]) == 0
+    reg, bnd, rargs, _ = calls[-1]
+    assert reg is graphcut.energy_label.regional_atlas and bnd is graphcut.energy_label.boundary_difference_of_means and rargs[1] == 0.25
+    with pytest.raises(ArgumentError):
+        cli.main(base + ["-f", "--regional", "atlas"])  # atlas without image / alpha
