@@ -35,6 +35,7 @@
 #include "../../include/medpy_hip.h"
 #include "mgc_tile_ops.inl"
 #include "mgc_tile_ops26.inl"
+#include "mgc_wave_ops.inl"
 #include "mgc_terms.h"
 #include "mgc_driver.inl"
 
@@ -160,6 +161,122 @@ struct GpuBlockT {
 typedef GpuBlockT<MgcTileShared> GpuBlock;
 typedef GpuBlockT<MgcTileShared26> GpuBlock26;
 typedef GpuBlockT<MgcTileShared26D> GpuBlock26D;
+
+
+/* ======================================================================================
+ * wave executor for the one-wave-per-tile operations (mgc_wave_ops.inl): a workgroup IS one wave64,
+ * Reg<T, N> = N registers, votes = ballots, no workgroup barrier anywhere
+ * ==================================================================================== */
+struct GpuWave {
+    template <class T, int N>
+    struct Reg {
+        T v[N];
+        __device__ __forceinline__ T& operator()(int, int k) { return v[k]; }
+    };
+    MgcWaveShared& S;
+    int lane;
+    __device__ __forceinline__ explicit GpuWave(MgcWaveShared& s) : S(s), lane((int)threadIdx.x) {}
+    /* top of every tile: the lane id becomes opaque to the optimiser, so lane-dependent addresses and masks are recomputed
+     * per tile (a few VALU ops) instead of being hoisted out of the tile loop and kept alive in registers that the
+     * discharge needs for its state */
+    __device__ __forceinline__ void new_tile()
+    {
+        lane = (int)threadIdx.x;
+        asm volatile("" : "+v"(lane));
+    }
+    /* orders this wave's LDS accesses for the compiler; the hardware executes one wave's LDS instructions in order */
+    __device__ __forceinline__ void fence() { __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront"); __builtin_amdgcn_wave_barrier(); }
+    template <class F>
+    __device__ __forceinline__ void lanes(F f)
+    {
+        f(lane);
+        fence();
+    }
+    template <class F>
+    __device__ __forceinline__ bool any(F f)
+    {
+        return __ballot((int)f(lane)) != 0ull;
+    }
+    __device__ __forceinline__ void shift(Reg<double, 1>& dst, Reg<double, 1>& src, int delta)
+    {
+        const int from = lane + delta;
+        const double v = __shfl(src.v[0], from & 63, 64);
+        dst.v[0] = (from >= 0 && from < 64) ? v : 0.0;
+    }
+    __device__ __forceinline__ int atomic_add(int32_t* p, int v) { return atomicAdd(p, v); }
+    __device__ __forceinline__ uint32_t atomic_exch(uint32_t* p, uint32_t v) { return atomicExch(p, v); }
+    __device__ __forceinline__ void atomic_or(uint32_t* p, uint32_t v) { atomicOr(p, v); }
+    __device__ __forceinline__ void atomic_and(uint32_t* p, uint32_t v) { atomicAnd(p, v); }
+    __device__ __forceinline__ void mark(int) {}
+    __device__ __forceinline__ void fresh() { asm volatile("" : "+v"(lane)); }
+    /* p[l], p wave-uniform: SGPR base + zero-extended 32-bit byte offset, the addressing mode of global_load / global_store */
+    template <class T>
+    __device__ __forceinline__ T ld(const T* p, int l) { return *(const T*)((const char*)p + (unsigned)(l * (int)sizeof(T))); }
+    template <class T>
+    __device__ __forceinline__ void st(T* p, int l, T v) { *(T*)((char*)p + (unsigned)(l * (int)sizeof(T))) = v; }
+};
+
+/* Work distribution of the wave kernels: waves draw list positions from a ticket counter (tiles differ a lot in cost, a
+ * static stride leaves a tail); the last wave to leave resets the ticket and the exit counter for the next launch, so
+ * no memset sits between two launches.  `tk` = index of the ticket in L.count, tk + 1 = exit counter. */
+#define MGC_CNT_TICKET_DIS 24
+#define MGC_CNT_TICKET_REL 26
+__device__ __forceinline__ int mgcw_next_ticket(const MgcLattice& L, int tk)
+{
+    int i = 0;
+    if (threadIdx.x == 0) i = atomicAdd(&L.count[tk], 1);
+    return __builtin_amdgcn_readfirstlane(i);
+}
+__device__ __forceinline__ void mgcw_leave(const MgcLattice& L, int tk)
+{
+    if (threadIdx.x == 0) {
+        __threadfence();
+        if (atomicAdd(&L.count[tk + 1], 1) == (int)gridDim.x - 1) {
+            L.count[tk] = 0;
+            L.count[tk + 1] = 0;
+        }
+    }
+}
+
+#ifndef MGCW_DISCHARGE_WAVES
+#define MGCW_DISCHARGE_WAVES 2 /* waves per SIMD the register allocator leaves room for (256 VGPRs each) */
+#endif
+__global__ __launch_bounds__(MGCW_LANES) __attribute__((amdgpu_waves_per_eu(MGCW_DISCHARGE_WAVES, MGCW_DISCHARGE_WAVES)))
+void k_discharge_w(MgcLattice L, int lst, uint32_t phase, int sweeps, int flags)
+{
+    __shared__ MgcWaveShared S;
+    GpuWave w(S);
+    const int n = L.count[lst];
+    if (blockIdx.x == 0 && threadIdx.x == 0 && n) atomicAdd(&L.count[8], n);
+    for (;;) {
+        const int i = mgcw_next_ticket(L, MGC_CNT_TICKET_DIS);
+        if (i >= n) break;
+        w.new_tile();
+        /* the tile id is wave-uniform: keep it (and every base address derived from it) in SGPRs */
+        mgcw_discharge_tile(w, L, __builtin_amdgcn_readfirstlane(L.list[lst][i]), phase, sweeps, flags);
+    }
+    mgcw_leave(L, MGC_CNT_TICKET_DIS);
+}
+
+/* global-relabel pass over a list, one wave per tile; first = the seeding pass of a from-scratch relabel over the
+ * filter's scratch list (`cnt` = its counter), else `cnt` = lst */
+__global__ __launch_bounds__(MGCW_LANES) void k_relabel_w(MgcLattice L, int lst, int cnt, uint32_t epoch, int next_list, int zero_list, int first)
+{
+    __shared__ MgcWaveShared S;
+    GpuWave w(S);
+    const int n = L.count[cnt];
+    if (blockIdx.x == 0 && threadIdx.x == 0) {
+        if (n) atomicAdd(&L.count[9], n);
+        if (zero_list >= 0) L.count[zero_list] = 0; /* consumed by the previous pass; the next pass appends to it */
+    }
+    for (;;) {
+        const int i = mgcw_next_ticket(L, MGC_CNT_TICKET_REL);
+        if (i >= n) break;
+        w.new_tile();
+        mgcw_relabel_tile(w, L, __builtin_amdgcn_readfirstlane(L.list[lst][i]), epoch, next_list, first != 0);
+    }
+    mgcw_leave(L, MGC_CNT_TICKET_REL);
+}
 
 /* ---- 26-neighbourhood solver kernels (bodies: mgc_tile_ops26.inl) ---- */
 __global__ __launch_bounds__(MGC_TV) void k26_relabel_all(MgcLattice L, uint32_t epoch, int next_list)
@@ -838,6 +955,9 @@ struct mgc_graph {
     double flow_const = 0.0, flow = 0.0;
     MgcSolveParams params = mgc_default_params();
     int grid_cap = 4096;
+    int wave_kernels = 3;  /* bit0: region discharge, bit1: global-relabel passes run one wave per tile (mgc_wave_ops.inl);
+                              bit2: the wave discharge starts from exact in-tile labels (MGCW_BFS) */
+    int wave_grid_dis = 0, wave_grid_rel = 0; /* persistent grids of the wave kernels (waves resident on the device) */
     int use_filters = 3; /* bit0 absorb, bit1 activate, bit2 reset-suspect go through the tile-level filter.  Bit2 is off:
                             measured on MI355X it doubles the number of global relabels (cause not understood yet) */
     mgc_stats stats{};
@@ -918,7 +1038,8 @@ struct HipDevT {
         else { /* one thread per tile finds the seeds (tiles with an arc to the sink); only those get a workgroup */
             zero_count(11);
             hipLaunchKernelGGL(k_filter, dim3(filter_grid()), dim3(256), 0, h->stream, h->L, 3, 6, 11);
-            hipLaunchKernelGGL(k_relabel_first_list, dim3(grid(h->L.ntiles)), dim3(MGC_TV), 0, h->stream, h->L, 6, 11, epoch, next);
+            if (h->wave_kernels & 2) hipLaunchKernelGGL(k_relabel_w, dim3(h->wave_grid_rel), dim3(MGCW_LANES), 0, h->stream, h->L, 6, 11, epoch, next, -1, 1);
+            else hipLaunchKernelGGL(k_relabel_first_list, dim3(grid(h->L.ntiles)), dim3(MGC_TV), 0, h->stream, h->L, 6, 11, epoch, next);
         }
         check(hipGetLastError());
         time_end(id);
@@ -928,6 +1049,7 @@ struct HipDevT {
     {
         const int id = time_begin(1);
         if constexpr (FULL) hipLaunchKernelGGL(k26_relabel_list, dim3(grid(h->L.ntiles)), dim3(MGC_TV), 0, h->stream, h->L, lst, epoch, next);
+        else if (h->wave_kernels & 2) hipLaunchKernelGGL(k_relabel_w, dim3(h->wave_grid_rel), dim3(MGCW_LANES), 0, h->stream, h->L, lst, lst, epoch, next, zero_list, 0);
         else hipLaunchKernelGGL(k_relabel_list, dim3(grid(h->L.ntiles)), dim3(MGC_TV), 0, h->stream, h->L, lst, epoch, next, zero_list);
         check(hipGetLastError());
         time_end(id);
@@ -973,6 +1095,7 @@ struct HipDevT {
     {
         const int id = time_begin(0);
         if constexpr (FULL) hipLaunchKernelGGL(k26_discharge, dim3(grid(h->L.ntiles)), dim3(MGC_TV), 0, h->stream, h->L, lst, phase, cycles, sweeps);
+        else if (h->wave_kernels & 1) hipLaunchKernelGGL(k_discharge_w, dim3(h->wave_grid_dis), dim3(MGCW_LANES), 0, h->stream, h->L, lst, phase, sweeps, (h->wave_kernels & 4) ? MGCW_BFS : 0);
         else hipLaunchKernelGGL(k_discharge, dim3(grid(h->L.ntiles)), dim3(MGC_TV), 0, h->stream, h->L, lst, phase, cycles, sweeps);
         check(hipGetLastError());
         time_end(id);
@@ -1139,6 +1262,16 @@ static int mgc_create_impl(int ndim, const int64_t* shape, int connectivity, int
     MGC_HIP(h, hipHostMalloc((void**)&h->h_scalar, 8 * sizeof(double), hipHostMallocDefault));
     MGC_HIP(h, hipMemsetAsync(L.count, 0, MGC_NCOUNT * sizeof(int32_t), h->stream));
     MGC_HIP(h, hipStreamSynchronize(h->stream));
+    if (const char* wv = getenv("MEDPY_HIP_WAVE")) h->wave_kernels = atoi(wv); /* development aid: A/B the kernel forms */
+    { /* persistent grids of the wave kernels: as many waves as the device keeps resident */
+        hipDeviceProp_t prop;
+        MGC_HIP(h, hipGetDeviceProperties(&prop, device));
+        int per_cu_dis = 0, per_cu_rel = 0;
+        MGC_HIP(h, hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu_dis, k_discharge_w, MGCW_LANES, 0));
+        MGC_HIP(h, hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu_rel, k_relabel_w, MGCW_LANES, 0));
+        h->wave_grid_dis = prop.multiProcessorCount * (per_cu_dis > 0 ? per_cu_dis : 8);
+        h->wave_grid_rel = prop.multiProcessorCount * (per_cu_rel > 0 ? per_cu_rel : 16);
+    }
     return MGC_OK;
 }
 
@@ -1797,6 +1930,9 @@ int mgc_set_param(mgc_handle h, const char* name, int64_t value)
     else if (!strcmp(name, "check_rounds") && value > 0) h->params.check_rounds = (int)value;
     else if (!strcmp(name, "incremental_relabel")) h->params.incremental_relabel = value != 0;
     else if (!strcmp(name, "use_filters")) h->use_filters = (int)value;
+    else if (!strcmp(name, "wave_kernels")) h->wave_kernels = (int)value;
+    else if (!strcmp(name, "wave_grid_dis") && value > 0) h->wave_grid_dis = (int)value;
+    else if (!strcmp(name, "wave_grid_rel") && value > 0) h->wave_grid_rel = (int)value;
     else if (!strcmp(name, "kernel_timing")) h->timing = value != 0;
     else if (!strcmp(name, "profile_sections")) {
         if (value && !h->L.prof) {

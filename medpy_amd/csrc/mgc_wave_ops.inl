@@ -1,0 +1,483 @@
+/*
+ * mgc_wave_ops.inl -- ONE WAVE PER TILE forms of the two hot tile operations of the 6-neighbourhood
+ * solver (region discharge, global-relabel pass).  Same state in HBM, same schedule, same result
+ * definition as mgc_tile_ops.inl; what changes is how a tile is mapped onto the machine:
+ *
+ *   a wave64 owns a whole 8x8x8 tile: lane = (y, x), and every lane keeps its z-COLUMN of eight
+ *   voxels in registers (excess, residual sink link, the six residual n-links, the label: 136 VGPRs).
+ *
+ *   - +-z pushes and label reads never leave the lane; visiting the column in push order moves flow
+ *     through all eight layers in ONE step (the 512-thread form needed one sweep, two LDS hand-offs
+ *     and three workgroup barriers per layer);
+ *   - +-x / +-y hand-offs are lane shifts inside the wave;
+ *   - there is no workgroup barrier anywhere: every vote is a ballot, so a slot (z-layer) without
+ *     excess costs one compare + one scalar branch, and a direction in which nobody pushed costs
+ *     nothing after its vote;
+ *   - LDS only holds the 10x10x10 label block (own labels + halo, read by the in-plane neighbours)
+ *     and the staged inbox: 7 KiB per tile, so the number of tiles in flight per CU is set by
+ *     registers, not by LDS.
+ *
+ * Why: the 512-thread kernel was bound by instruction issue (about 500 instructions per wave and
+ * sweep, 40 % of them scalar control flow and address arithmetic repeated by all eight waves of a
+ * tile, plus 24 barriers per discharge; profiles/README.md round 2).  Here the per-tile scalar work is
+ * paid once instead of eight times.
+ *
+ * Replaces (reference): Graph::maxflow, lib/maxflow/src/maxflow.cpp:472-604 -- see mgc_tile_ops.inl
+ * for the algorithm (region-discharge push-relabel, Delong & Boykov 2008) and why its labels are the
+ * ones what_segment() reports (graph.h:561-571).
+ *
+ * Written against a "wave executor" W so that the host simulator (tests/hostsim) runs this very
+ * source in the CPU test tier:
+ *   W::Reg<T, N>          N values per lane; r(l, k)
+ *   w.lanes(f)            f(l) for the 64 lanes; lanes only touch their own registers and LDS cells
+ *                         nobody else touches in the same step (the host runs them one after another)
+ *   w.any(f)              ballot: true if f(l) holds for some lane (wave-uniform)
+ *   w.shift(dst, src, k)  dst(l,0) = src(l + k, 0) inside the wave, 0.0 beyond its ends
+ *   w.S                   MgcWaveShared& (LDS)
+ *   w.atomic_*            device-scope atomics on global words
+ *   w.ld(p, l) / w.st(p, l, v)   p[l] for a wave-uniform pointer p: SGPR base + 32-bit lane offset on the GPU, so the
+ *                         64 + 70 state accesses of a discharge need ONE address register instead of a 64-bit pair each
+ *   w.fresh()             the lane id becomes opaque to the optimiser again (GPU): addresses derived from it before this
+ *                         point are recomputed afterwards instead of being kept alive (or spilled) across the sweeps
+ *   w.mark(id)            work-profile hook (counts sections in the simulator; nothing on the GPU)
+ */
+#ifndef MGC_WAVE_OPS_INL
+#define MGC_WAVE_OPS_INL
+
+#include <utility>
+
+#include "mgc_tile_ops.inl"
+
+#define MGCW_LANES 64
+/* every lambda of this file must be inlined into the kernel: a call would force the register arrays it captures into memory */
+#define MGCW_INL __attribute__((always_inline))
+#define MGCW_BFS 1            /* discharge flag: exact in-tile labels (from scratch) before the sweeps */
+
+struct alignas(16) MgcWaveShared {
+    int32_t hs[1000];          /* 10x10x10 distance labels: the tile plus a one-voxel halo */
+    double  inbox[6][MGC_TF];  /* flow the six neighbours left for this tile, staged by the loading lanes */
+};
+
+/* compile-time loop: f(std::integral_constant<int, 0>) ... f(<N-1>) -- the slot index of a register array must be a
+ * constant, otherwise the array lives in scratch memory */
+template <class F, int... I>
+MGC_HD void mgcw_static_for_impl(F&& f, std::integer_sequence<int, I...>)
+{
+    (f(std::integral_constant<int, I>{}), ...);
+}
+template <int N, class F>
+MGC_HD void mgcw_static_for(F&& f)
+{
+    mgcw_static_for_impl(f, std::make_integer_sequence<int, N>{});
+}
+
+/* hs[] cell of slot k (z-layer) of lane l = (y, x) */
+MGC_HD int mgcw_hs(int l, int k) { return (k + 1) * 100 + ((l >> 3) + 1) * 10 + (l & 7) + 1; }
+
+/* one trip to HBM for what the six neighbours contribute: lane l fetches, per face, the label of the voxel its face
+ * cell touches and the outbox slot the neighbour may have filled for it (emptied if so).  Results go to LDS. */
+template <class W>
+MGC_HD void mgcw_load_halo(W& w, const MgcLattice& L, int tile, int l, bool with_inbox)
+{
+    int tz, ty, tx;
+    mgc_tile_coords(L, tile, tz, ty, tx);
+#pragma unroll
+    for (int f = 0; f < 6; ++f) {
+        const int nt = mgc_tile_nbr(L, tz, ty, tx, f);
+        const int mine = mgc_face_voxel(f, l);
+        int32_t hv = MGC_HINF;
+        double din = 0.0;
+        if (nt >= 0) {
+            hv = w.ld(L.height + (int64_t)nt * MGC_TV, mgc_face_voxel(f ^ 1, l));
+            if (with_inbox) {
+                double* const slots = L.obox + ((int64_t)nt * 6 + (f ^ 1)) * MGC_TF;
+                din = w.ld(slots, l);
+                if (din != 0.0) w.st(slots, l, 0.0);
+            }
+        }
+        w.S.hs[mgc_hs_index(mine >> 6, (mine >> 3) & 7, mine & 7) + mgc_hs_step(f)] = hv;
+        if (with_inbox) w.S.inbox[f][l] = din;
+    }
+}
+
+/* label of the neighbour of (lane l, slot K) in direction d: in-plane neighbours and the tile halo from LDS, the
+ * lane's own column from registers */
+template <int K, int D, class W, class RegI>
+MGC_HD int mgcw_nbr_label(W& w, RegI& h, int l)
+{
+    if constexpr (D == 4) {
+        if constexpr (K > 0) return h(l, K - 1);
+        else return w.S.hs[mgcw_hs(l, 0) - 100];
+    } else if constexpr (D == 5) {
+        if constexpr (K < 7) return h(l, K + 1);
+        else return w.S.hs[mgcw_hs(l, 7) + 100];
+    } else {
+        return w.S.hs[mgcw_hs(l, K) + mgc_hs_step(D)];
+    }
+}
+
+/* ---------------------------------------------------------------------------------------
+ * Label relaxation of a whole tile to its fixpoint: h(u) = min(h(u), 1 if u has a sink arc, 1 + h(v) over residual
+ * arcs u->v), halo frozen.  arc(l, K, D) says whether the arc of (lane, slot) in direction D (6 = sink) is residual.
+ * Slots are visited only while "dirty" (something changed in the slot or in one of its two z-neighbours since its
+ * last visit); in-plane information moves one voxel per visit (Jacobi inside a slot: all lanes read, then all
+ * write), information along z moves through the whole column within one visit sequence (registers).
+ * Labels only decrease, so the fixpoint is the same whatever the order.
+ * ------------------------------------------------------------------------------------- */
+template <class W, class RegI, class ArcFn>
+MGC_HD void mgcw_relax(W& w, RegI& h, ArcFn arc)
+{
+    typename W::template Reg<int, 1> cand;
+    uint32_t dirty = 0xffu;
+    auto visit = [&](auto KK) MGCW_INL {
+        constexpr int K = decltype(KK)::value;
+        if (!(dirty & (1u << K))) return;
+        w.lanes([&](int l) MGCW_INL {
+            int c = arc(l, KK, std::integral_constant<int, 6>{}) ? 1 : MGC_HINF;
+            mgcw_static_for<6>([&](auto DD) MGCW_INL {
+                constexpr int D = decltype(DD)::value;
+                const int hv = mgcw_nbr_label<K, D>(w, h, l);
+                const int cd = arc(l, KK, DD) ? hv + 1 : MGC_HINF;
+                c = cd < c ? cd : c;
+            });
+            cand(l, 0) = c;
+        });
+        const bool changed = w.any([&](int l) MGCW_INL -> bool { return cand(l, 0) < h(l, K); });
+        if (changed) {
+            w.lanes([&](int l) MGCW_INL {
+                if (cand(l, 0) < h(l, K)) {
+                    h(l, K) = cand(l, 0);
+                    w.S.hs[mgcw_hs(l, K)] = cand(l, 0);
+                }
+            });
+            dirty |= (K > 0 ? 1u << (K - 1) : 0u) | (K < 7 ? 1u << (K + 1) : 0u);
+        } else {
+            dirty &= ~(1u << K);
+        }
+    };
+    while (dirty) {
+        mgcw_static_for<8>([&](auto KK) MGCW_INL { visit(KK); });
+        mgcw_static_for<8>([&](auto KK) MGCW_INL { visit(std::integral_constant<int, 7 - decltype(KK)::value>{}); });
+    }
+}
+
+/* ---------------------------------------------------------------------------------------
+ * Region discharge of one tile by one wave (colour phase `phase`; the six face neighbours are idle).
+ *   load -> absorb inbox -> labels -> sweeps { per slot: sink, -x, +x, -y, +y ; -z down the column ; +z up the
+ *   column ; local relabel } -> store (state, masks, labels, outbox, wake-ups).
+ * Every hand-off has one sender per receiver and a fixed order of f64 operations: bit-reproducible, no atomics on
+ * flow data.  Saturating pushes leave an exact 0.0.
+ * ------------------------------------------------------------------------------------- */
+template <class W>
+MGC_HD void mgcw_discharge_tile(W& w, const MgcLattice& L, int tile, uint32_t phase, int max_sweeps, int flags)
+{
+    typename W::template Reg<double, 8> e, snk;
+    typename W::template Reg<double, 8> r[6];
+    typename W::template Reg<int, 8> h;
+    typename W::template Reg<int, 1> mv, sat, cand, fb; /* fb: bit f = this lane pushed flow out across face f */
+    typename W::template Reg<double, 1> dl, din;
+
+    double* const t_excess = L.excess + (int64_t)tile * MGC_TV;
+    double* const t_sink = L.sink + (int64_t)tile * MGC_TV;
+    double* const t_rcap = L.rcap + (int64_t)tile * 6 * MGC_TV;
+    double* const t_obox = L.obox + (int64_t)tile * 6 * MGC_TF;
+    uint8_t* const t_rmask = L.rmask + (int64_t)tile * MGC_TV;
+    int32_t* const t_height = L.height + (int64_t)tile * MGC_TV;
+    int tz, ty, tx;
+    mgc_tile_coords(L, tile, tz, ty, tx);
+
+    /* ---- one trip to HBM: own state, label halo, inbox ---- */
+    w.lanes([&](int l) MGCW_INL {
+        mgcw_static_for<8>([&](auto KK) MGCW_INL {
+            constexpr int K = decltype(KK)::value;
+            e(l, K) = w.ld(t_excess + K * 64, l);
+            snk(l, K) = w.ld(t_sink + K * 64, l);
+            mgcw_static_for<6>([&](auto DD) MGCW_INL {
+                constexpr int D = decltype(DD)::value;
+                r[D](l, K) = w.ld(t_rcap + (D * MGC_TV + K * 64), l);
+            });
+            if (!(flags & MGCW_BFS)) h(l, K) = w.ld(t_height + K * 64, l);
+        });
+        sat(l, 0) = 0;
+        fb(l, 0) = 0;
+        mgcw_load_halo(w, L, tile, l, true);
+        if (l < 6) { /* retire the outbox flags of the slots just emptied */
+            const int nt = mgc_tile_nbr(L, tz, ty, tx, l);
+            if (nt >= 0 && ((L.oflags[nt] >> (l ^ 1)) & 1u)) w.atomic_and(&L.oflags[nt], ~(1u << (l ^ 1)));
+        }
+    });
+    /* ---- absorb the staged inbox: e += delta, reverse residual += delta, fixed face order ---- */
+    w.lanes([&](int l) MGCW_INL {
+        const int y = l >> 3, x = l & 7;
+        mgcw_static_for<8>([&](auto KK) MGCW_INL {
+            constexpr int K = decltype(KK)::value;
+            /* selects on the VALUES, never on which register is updated: a branch per face makes the optimiser merge
+             * the updates into one store through a pointer phi, which pins the residual arrays to scratch memory */
+            const double d0 = x == 0 ? w.S.inbox[0][K * 8 + y] : 0.0;
+            const double d1 = x == 7 ? w.S.inbox[1][K * 8 + y] : 0.0;
+            const double d2 = y == 0 ? w.S.inbox[2][K * 8 + x] : 0.0;
+            const double d3 = y == 7 ? w.S.inbox[3][K * 8 + x] : 0.0;
+            e(l, K) += d0; r[0](l, K) += d0;
+            e(l, K) += d1; r[1](l, K) += d1;
+            e(l, K) += d2; r[2](l, K) += d2;
+            e(l, K) += d3; r[3](l, K) += d3;
+            if constexpr (K == 0) { const double d = w.S.inbox[4][l]; e(l, K) += d; r[4](l, K) += d; }
+            if constexpr (K == 7) { const double d = w.S.inbox[5][l]; e(l, K) += d; r[5](l, K) += d; }
+        });
+    });
+    /* the staged inbox is consumed: the same LDS cells now collect what this discharge pushes OUT across each face
+     * (one owner lane per cell: the lane holding the face voxel) */
+    w.lanes([&](int l) MGCW_INL {
+#pragma unroll
+        for (int f = 0; f < 6; ++f) w.S.inbox[f][l] = 0.0;
+    });
+
+    /* ---- labels: exact in-tile distances given the frozen halo, or the stored (valid lower-bound) labels ---- */
+    if (flags & MGCW_BFS) {
+        w.lanes([&](int l) MGCW_INL {
+            mgcw_static_for<8>([&](auto KK) MGCW_INL {
+                constexpr int K = decltype(KK)::value;
+                h(l, K) = MGC_HINF;
+                w.S.hs[mgcw_hs(l, K)] = MGC_HINF;
+            });
+        });
+        mgcw_relax(w, h, [&](int l, auto KK, auto DD) MGCW_INL -> bool {
+            constexpr int K = decltype(KK)::value;
+            constexpr int D = decltype(DD)::value;
+            if constexpr (D == 6) return snk(l, K) > 0.0;
+            else return r[D](l, K) > 0.0;
+        });
+    } else {
+        w.lanes([&](int l) MGCW_INL {
+            mgcw_static_for<8>([&](auto KK) MGCW_INL {
+                constexpr int K = decltype(KK)::value;
+                w.S.hs[mgcw_hs(l, K)] = h(l, K);
+            });
+        });
+    }
+
+    /* admissible push of (lane, slot K) in direction D towards a neighbour labelled hn; returns the amount */
+    auto push = [&](int l, auto KK, auto DD, int hn) MGCW_INL -> double {
+        constexpr int K = decltype(KK)::value;
+        constexpr int D = decltype(DD)::value;
+        const double rd = r[D](l, K);
+        double delta = 0.0;
+        if (e(l, K) > 0.0 && rd > 0.0 && h(l, K) < MGC_HINF && hn == h(l, K) - 1) {
+            delta = e(l, K) < rd ? e(l, K) : rd;
+            e(l, K) -= delta;
+            r[D](l, K) = rd - delta; /* saturating push: rd - rd == 0.0 exactly */
+            mv(l, 0) = 1;
+            if (delta == rd) sat(l, 0) = 1;
+        }
+        return delta;
+    };
+    auto slot_active = [&](auto KK) MGCW_INL -> bool {
+        constexpr int K = decltype(KK)::value;
+        return w.any([&](int l) MGCW_INL -> bool { return e(l, K) > 0.0 && h(l, K) < MGC_HINF; });
+    };
+
+    bool active = true;
+    for (int sw = 0; sw < max_sweeps; ++sw) {
+        w.lanes([&](int l) MGCW_INL { mv(l, 0) = 0; });
+        /* ---- per slot: sink, then the four in-plane directions as lane shifts ---- */
+        mgcw_static_for<8>([&](auto KK) MGCW_INL {
+            constexpr int K = decltype(KK)::value;
+            if (!slot_active(KK)) return;
+            w.lanes([&](int l) MGCW_INL { /* push to the sink first: always admissible (label 1 -> 0) */
+                if (e(l, K) > 0.0 && snk(l, K) > 0.0) {
+                    const double delta = e(l, K) < snk(l, K) ? e(l, K) : snk(l, K);
+                    e(l, K) -= delta;
+                    snk(l, K) -= delta;
+                    mv(l, 0) = 1;
+                    if (snk(l, K) == 0.0) sat(l, 0) = 1;
+                }
+            });
+            mgcw_static_for<4>([&](auto DD) MGCW_INL {
+                constexpr int D = decltype(DD)::value;
+                w.lanes([&](int l) MGCW_INL {
+                    const int y = l >> 3, x = l & 7;
+                    const double delta = push(l, KK, DD, mgcw_nbr_label<K, D>(w, h, l));
+                    const bool inside = D == 0 ? x > 0 : (D == 1 ? x < 7 : (D == 2 ? y > 0 : y < 7));
+                    dl(l, 0) = inside ? delta : 0.0;
+                    if (!inside && delta != 0.0) { /* flow that leaves the tile across face D */
+                        w.S.inbox[D][K * 8 + (D < 2 ? y : x)] += delta;
+                        fb(l, 0) |= 1 << D;
+                    }
+                });
+                if (!w.any([&](int l) MGCW_INL -> bool { return dl(l, 0) != 0.0; })) return;
+                w.shift(din, dl, D == 0 ? 1 : (D == 1 ? -1 : (D == 2 ? 8 : -8))); /* -x: from the lane at x + 1, ... */
+                w.lanes([&](int l) MGCW_INL { /* what the neighbour pushed in direction D arrives: reverse residual grows */
+                    e(l, K) += din(l, 0);
+                    r[D ^ 1](l, K) += din(l, 0);
+                });
+            });
+        });
+        /* ---- -z down the column, +z up the column: flow crosses all eight layers in one pass ---- */
+        mgcw_static_for<8>([&](auto KK) MGCW_INL {
+            constexpr int K = 7 - decltype(KK)::value;
+            constexpr std::integral_constant<int, K> KC{};
+            if (!slot_active(KC)) return;
+            w.lanes([&](int l) MGCW_INL {
+                const double delta = push(l, KC, std::integral_constant<int, 4>{}, mgcw_nbr_label<K, 4>(w, h, l));
+                if constexpr (K > 0) { e(l, K - 1) += delta; r[5](l, K - 1) += delta; }
+                else if (delta != 0.0) { w.S.inbox[4][l] += delta; fb(l, 0) |= 1 << 4; }
+            });
+        });
+        mgcw_static_for<8>([&](auto KK) MGCW_INL {
+            constexpr int K = decltype(KK)::value;
+            if (!slot_active(KK)) return;
+            w.lanes([&](int l) MGCW_INL {
+                const double delta = push(l, KK, std::integral_constant<int, 5>{}, mgcw_nbr_label<K, 5>(w, h, l));
+                if constexpr (K < 7) { e(l, K + 1) += delta; r[4](l, K + 1) += delta; }
+                else if (delta != 0.0) { w.S.inbox[5][l] += delta; fb(l, 0) |= 1 << 5; }
+            });
+        });
+        /* ---- local relabel (classic push-relabel step): a voxel that still holds excess rises to 1 + the lowest label
+         * behind a residual arc.  Labels stay valid lower bounds of the distance (no push runs in this step; an in-plane
+         * neighbour's label read here is the one it had before the step: all lanes read, then all write). ---- */
+        mgcw_static_for<8>([&](auto KK) MGCW_INL {
+            constexpr int K = decltype(KK)::value;
+            if (!slot_active(KK)) return;
+            w.lanes([&](int l) MGCW_INL {
+                int c = MGC_HINF;
+                if (e(l, K) > 0.0 && h(l, K) < MGC_HINF) {
+                    c = snk(l, K) > 0.0 ? 1 : MGC_HINF;
+                    mgcw_static_for<6>([&](auto DD) MGCW_INL {
+                        constexpr int D = decltype(DD)::value;
+                        const int hv = mgcw_nbr_label<K, D>(w, h, l);
+                        c = (r[D](l, K) > 0.0 && hv < MGC_HINF && hv + 1 < c) ? hv + 1 : c;
+                    });
+                } else {
+                    c = h(l, K);
+                }
+                cand(l, 0) = c;
+            });
+            w.lanes([&](int l) MGCW_INL {
+                if (cand(l, 0) > h(l, K)) {
+                    h(l, K) = cand(l, 0);
+                    w.S.hs[mgcw_hs(l, K)] = cand(l, 0);
+                    if (cand(l, 0) < MGC_HINF) mv(l, 0) = 1; /* it can push again next sweep */
+                }
+            });
+        });
+        w.mark(2); /* one push sweep */
+        if (!w.any([&](int l) MGCW_INL -> bool { return mv(l, 0) != 0; })) { active = false; break; }
+    }
+    if (active) { /* sweep budget exhausted: is there still something to do with the current labels? */
+        active = false;
+        mgcw_static_for<8>([&](auto KK) MGCW_INL { active = active || slot_active(KK); });
+    }
+
+    /* ---- tail: ballots only ---- */
+    bool has_sink = false, has_exc = false;
+    mgcw_static_for<8>([&](auto KK) MGCW_INL {
+        constexpr int K = decltype(KK)::value;
+        has_sink = has_sink || w.any([&](int l) MGCW_INL -> bool { return snk(l, K) > 0.0; });
+        has_exc = has_exc || w.any([&](int l) MGCW_INL -> bool { return e(l, K) > 0.0; });
+    });
+    const bool saturated = w.any([&](int l) MGCW_INL -> bool { return sat(l, 0) != 0; });
+    uint32_t face = 0; /* bit f: flow leaves across face f */
+#pragma unroll
+    for (int f = 0; f < 6; ++f)
+        if (w.any([&](int l) MGCW_INL -> bool { return ((fb(l, 0) >> f) & 1) != 0; })) face |= 1u << f;
+
+    /* ---- ONE block of global stores: state, masks, labels, outbox, wake-ups ---- */
+    w.fresh();
+    w.lanes([&](int l) MGCW_INL {
+        mgcw_static_for<8>([&](auto KK) MGCW_INL {
+            constexpr int K = decltype(KK)::value;
+            w.st(t_excess + K * 64, l, e(l, K));
+            w.st(t_sink + K * 64, l, snk(l, K));
+            int m = snk(l, K) > 0.0 ? MGC_MASK_SINK : 0;
+            mgcw_static_for<6>([&](auto DD) MGCW_INL {
+                constexpr int D = decltype(DD)::value;
+                w.st(t_rcap + (D * MGC_TV + K * 64), l, r[D](l, K));
+                m |= (r[D](l, K) > 0.0) ? (1 << D) : 0;
+            });
+            w.st(t_rmask + K * 64, l, (uint8_t)m);
+            w.st(t_height + K * 64, l, h(l, K));
+        });
+        /* outbox: plain stores -- the neighbour emptied these slots when it last absorbed, and it always runs (or
+         * absorb_all does) between two of our discharges */
+#pragma unroll
+        for (int f = 0; f < 6; ++f) {
+            const double ob = w.S.inbox[f][l];
+            if (ob != 0.0) w.st(t_obox + f * MGC_TF, l, ob);
+        }
+        if (l < 6 && ((face >> l) & 1u)) {
+            w.atomic_or(&L.oflags[tile], 1u << l);
+            mgc_enqueue(w, L, (int)((phase + 1) & 3u), L.stamp, phase + 1, mgc_tile_nbr(L, tz, ty, tx, l));
+        }
+        if (l == 6 && active) mgc_enqueue(w, L, (int)((phase + 2) & 3u), L.stamp, phase + 2, tile);
+        /* DIRTY only if a residual arc disappeared: otherwise no distance in the tile (or through it) can have changed */
+        if (l == 7) L.status[tile] = (L.status[tile] & ~(MGC_ST_SINK | MGC_ST_EXCESS)) | (has_sink ? MGC_ST_SINK : 0u) | (saturated ? MGC_ST_DIRTY : 0u) | (has_exc ? MGC_ST_EXCESS : 0u);
+    });
+}
+
+/* ---------------------------------------------------------------------------------------
+ * Global relabel, one tile of one pass, by one wave: relax the tile's labels from their current values over the
+ * residual masks with the current halo; wake the neighbours across every face where a lowered label could lower
+ * theirs; record which faces support the tile's labels (incremental relabel).  Same contract as mgc_relabel_tile.
+ * ------------------------------------------------------------------------------------- */
+template <class W>
+MGC_HD void mgcw_relabel_tile(W& w, const MgcLattice& L, int tile, uint32_t next_epoch, int next_list, bool first_pass)
+{
+    if (first_pass && (!(L.status[tile] & 2u) || !mgc_owned(L, tile))) return;
+    typename W::template Reg<int, 8> m, h0, h;
+    const int64_t base = (int64_t)tile * MGC_TV;
+    int tz, ty, tx;
+    mgc_tile_coords(L, tile, tz, ty, tx);
+    w.lanes([&](int l) MGCW_INL {
+        mgcw_static_for<8>([&](auto KK) MGCW_INL {
+            constexpr int K = decltype(KK)::value;
+            m(l, K) = w.ld(L.rmask + base + K * 64, l);
+            h0(l, K) = w.ld(L.height + base + K * 64, l);
+            h(l, K) = h0(l, K);
+            w.S.hs[mgcw_hs(l, K)] = h0(l, K);
+        });
+        mgcw_load_halo(w, L, tile, l, false);
+    });
+    mgcw_relax(w, h, [&](int l, auto KK, auto DD) MGCW_INL -> bool {
+        constexpr int K = decltype(KK)::value;
+        constexpr int D = decltype(DD)::value;
+        return ((m(l, K) >> D) & 1) != 0;
+    });
+    /* which faces saw a label drop that could lower the neighbour; which faces support a label */
+    uint32_t wake = 0, dep = 0; /* bit masks: lanes index them with their id */
+    mgcw_static_for<6>([&](auto DD) MGCW_INL {
+        constexpr int D = decltype(DD)::value;
+        bool wk = false, dp = false;
+        mgcw_static_for<8>([&](auto KK) MGCW_INL {
+            constexpr int K = decltype(KK)::value;
+            if constexpr (D == 4 && K != 0) return;
+            if constexpr (D == 5 && K != 7) return;
+            auto on_face = [&](int l) MGCW_INL -> bool {
+                const int y = l >> 3, x = l & 7;
+                return D == 0 ? x == 0 : (D == 1 ? x == 7 : (D == 2 ? y == 0 : (D == 3 ? y == 7 : true)));
+            };
+            dp = dp || w.any([&](int l) MGCW_INL -> bool {
+                return on_face(l) && h(l, K) < MGC_HINF && ((m(l, K) >> D) & 1) && mgcw_nbr_label<K, D>(w, h, l) + 1 == h(l, K);
+            });
+            /* wake the neighbour across a face only if its adjacent voxel could improve: labels only go down during a
+             * relabel, so a halo value is an upper bound of the neighbour's current label */
+            wk = wk || w.any([&](int l) MGCW_INL -> bool {
+                return on_face(l) && h(l, K) < h0(l, K) && h(l, K) + 1 < mgcw_nbr_label<K, D>(w, h, l);
+            });
+        });
+        wake |= wk ? (1u << D) : 0u;
+        dep |= dp ? (1u << D) : 0u;
+    });
+    w.lanes([&](int l) MGCW_INL { /* one block of global traffic: labels + wake-ups */
+        mgcw_static_for<8>([&](auto KK) MGCW_INL {
+            constexpr int K = decltype(KK)::value;
+            if (h(l, K) < h0(l, K)) w.st(L.height + base + K * 64, l, h(l, K));
+        });
+        if (l < 6 && ((wake >> l) & 1u)) {
+            const int nt = mgc_tile_nbr(L, tz, ty, tx, l);
+            if (nt >= 0) mgc_enqueue(w, L, next_list, L.rstamp, next_epoch, nt);
+        }
+        if (l == 6) L.status[tile] = (L.status[tile] & ~(63u << MGC_ST_DEP_SHIFT)) | (dep << MGC_ST_DEP_SHIFT);
+    });
+}
+
+#endif /* MGC_WAVE_OPS_INL */

@@ -21,7 +21,13 @@
 
 #include "../../medpy_amd/csrc/mgc_tile_ops.inl"
 #include "../../medpy_amd/csrc/mgc_tile_ops26.inl"
+#include "../../medpy_amd/csrc/mgc_wave_ops.inl"
 #include "../../medpy_amd/csrc/mgc_driver.inl"
+
+/* work-profile counters (development aid, read with hostsim_prof): [id] = number of mark(id) calls (0 load, 1 labels, 2 sweep,
+ * 3 store, ...); [16]/[17] = waves that voted "active" / waves asked; [18] relaxation rounds of mgc_tile_bfs (par calls inside) */
+static int64_t g_prof[64];
+static std::vector<int32_t> g_tile_discharges;
 
 template <class SH>
 struct HostBlockT {
@@ -53,7 +59,13 @@ struct HostBlockT {
     bool wave_any(F f) /* the GPU votes per wave and skips idle waves; running them all is equivalent (idle = no-op) */
     {
         bool r = false;
-        for (int t = 0; t < MGC_TV; ++t) r |= (bool)f(t);
+        for (int w = 0; w < MGC_TV / 64; ++w) {
+            bool rw = false;
+            for (int t = w * 64; t < w * 64 + 64; ++t) rw |= (bool)f(t);
+            g_prof[16] += rw;
+            g_prof[17]++;
+            r |= rw;
+        }
         return r;
     }
     void shift(Reg<double>& dst, Reg<double>& src, int delta)
@@ -67,7 +79,7 @@ struct HostBlockT {
     uint32_t atomic_exch(uint32_t* p, uint32_t v) { uint32_t o = *p; *p = v; return o; }
     void atomic_or(uint32_t* p, uint32_t v) { *p |= v; }
     void atomic_and(uint32_t* p, uint32_t v) { *p &= v; }
-    void mark(const MgcLattice&, int) {}
+    void mark(const MgcLattice&, int id) { g_prof[id & 15]++; }
     void wave_fence() {}
     /* exact in-tile labels: reference implementation = chaotic relaxation from scratch (mgc_tile_bfs) */
     template <class MaskFn, class RegI>
@@ -84,6 +96,50 @@ struct HostBlockT {
     void async_to_lds(int t, void* dst, const void* src, int bytes) { if (t == 0) memcpy(dst, src, (size_t)bytes); }
     void async_wait() {}
 };
+/* host form of the wave executor of mgc_wave_ops.inl: a "wave" is a loop over its 64 lanes */
+struct HostWave {
+    template <class T, int N>
+    struct Reg {
+        T v[MGCW_LANES][N];
+        T& operator()(int l, int k) { return v[l][k]; }
+    };
+    MgcWaveShared& S;
+    explicit HostWave(MgcWaveShared& s) : S(s) {}
+    template <class F>
+    void lanes(F f)
+    {
+        g_prof[20]++;
+        for (int l = 0; l < MGCW_LANES; ++l) f(l);
+    }
+    template <class F>
+    bool any(F f)
+    {
+        g_prof[21]++;
+        bool r = false;
+        for (int l = 0; l < MGCW_LANES; ++l) r |= (bool)f(l);
+        return r;
+    }
+    void shift(Reg<double, 1>& dst, Reg<double, 1>& src, int delta)
+    {
+        g_prof[22]++;
+        for (int l = 0; l < MGCW_LANES; ++l) {
+            const int from = l + delta;
+            dst(l, 0) = (from >= 0 && from < MGCW_LANES) ? src(from, 0) : 0.0;
+        }
+    }
+    int atomic_add(int32_t* p, int v) { int o = *p; *p += v; return o; }
+    uint32_t atomic_exch(uint32_t* p, uint32_t v) { uint32_t o = *p; *p = v; return o; }
+    void atomic_or(uint32_t* p, uint32_t v) { *p |= v; }
+    void atomic_and(uint32_t* p, uint32_t v) { *p &= v; }
+    void mark(int id) { g_prof[id & 15]++; }
+    template <class T> T ld(const T* p, int l) { return p[l]; }
+    template <class T> void st(T* p, int l, T v) { p[l] = v; }
+    void fresh() {}
+};
+/* which form of the two hot tile operations the simulator runs: bit 0 = wave discharge, bit 1 = wave relabel,
+ * bit 2 = the wave discharge computes exact in-tile labels first (MGCW_BFS) */
+static int g_wave_mode = 0;
+
 typedef HostBlockT<MgcTileShared> HostBlock;
 typedef HostBlockT<MgcTileShared26> HostBlock26;
 typedef HostBlockT<MgcTileShared26D> HostBlock26D;
@@ -91,6 +147,7 @@ typedef HostBlockT<MgcTileShared26D> HostBlock26D;
 struct HostDev {
     MgcLattice L;
     MgcTileShared S;
+    MgcWaveShared WS;
     MgcSlabSpec spec;
     std::vector<double> rcap, excess, sink, obox;
     std::vector<int32_t> height, lists, count;
@@ -104,18 +161,24 @@ struct HostDev {
     void relabel_all(uint32_t epoch, int next)
     {
         HostBlock x(S);
+        HostWave w(WS);
         for (int t = 0; t < L.ntiles; ++t) {
             if (L.status[t] & 2u) L.count[9]++;
-            mgc_relabel_tile(x, L, t, epoch, next, true);
+            if (g_wave_mode & 2) mgcw_relabel_tile(w, L, t, epoch, next, true);
+            else mgc_relabel_tile(x, L, t, epoch, next, true);
         }
     }
     void relabel_list(int lst, uint32_t epoch, int next, int zero_list = -1)
     {
         HostBlock x(S);
+        HostWave w(WS);
         const int n = L.count[lst];
         L.count[9] += n;
         if (zero_list >= 0) L.count[zero_list] = 0;
-        for (int i = 0; i < n; ++i) mgc_relabel_tile(x, L, L.list[lst][i], epoch, next, false);
+        for (int i = 0; i < n; ++i) {
+            if (g_wave_mode & 2) mgcw_relabel_tile(w, L, L.list[lst][i], epoch, next, false);
+            else mgc_relabel_tile(x, L, L.list[lst][i], epoch, next, false);
+        }
     }
     void activate_all(uint32_t phase) { HostBlock x(S); for (int t = 0; t < L.ntiles; ++t) mgc_activate_tile(x, L, t, phase); }
     void suspect_pass()
@@ -133,7 +196,16 @@ struct HostDev {
         HostBlock x(S);
         const int n = L.count[lst];
         L.count[8] += n;
-        for (int i = 0; i < n; ++i) mgc_discharge_tile(x, L, L.list[lst][i], phase, cycles, sweeps);
+        HostWave w(WS);
+        for (int i = 0; i < n; ++i) {
+            if ((int)g_tile_discharges.size() == L.ntiles) g_tile_discharges[L.list[lst][i]]++;
+            if (g_wave_mode & 1) {
+                mgcw_discharge_tile(w, L, L.list[lst][i], phase, sweeps, (g_wave_mode & 4) ? MGCW_BFS : 0);
+                g_prof[3]++;
+            } else {
+                mgc_discharge_tile(x, L, L.list[lst][i], phase, cycles, sweeps);
+            }
+        }
     }
 
     void init(int64_t d0, int64_t d1, int64_t d2, const MgcSlabSpec* sp)
@@ -200,6 +272,17 @@ struct HostDev {
 };
 
 extern "C" {
+
+void hostsim_set_wave_mode(int mode) { g_wave_mode = mode; }
+
+/* work-profile read-out: copies and clears the counters; tiles != NULL with ntiles > 0 arms / returns the per-tile discharge counts */
+void hostsim_prof(int64_t* out, int32_t* tiles, int ntiles)
+{
+    memcpy(out, g_prof, sizeof(g_prof));
+    memset(g_prof, 0, sizeof(g_prof));
+    if (tiles && (int)g_tile_discharges.size() == ntiles) memcpy(tiles, g_tile_discharges.data(), (size_t)ntiles * 4);
+    g_tile_discharges.assign(ntiles > 0 ? ntiles : 0, 0);
+}
 
 /* ---- handle API (mirrors the slab part of include/medpy_hip.h) ---- */
 void* hostsim_create(const int64_t* gshape, int rank, int nranks)

@@ -13,7 +13,7 @@ _lib = None
 def build():
     src = os.path.join(_HERE, "hostsim.cpp")
     deps = [src] + [os.path.join(_HERE, "..", "..", "medpy_amd", "csrc", f) for f in
-                    ("mgc_tile_ops.inl", "mgc_tile_ops26.inl", "mgc_driver.inl", "mgc_common.h")]
+                    ("mgc_tile_ops.inl", "mgc_tile_ops26.inl", "mgc_wave_ops.inl", "mgc_driver.inl", "mgc_common.h")]
     if os.path.exists(_SO) and all(os.path.getmtime(_SO) >= os.path.getmtime(d) for d in deps):
         return
     subprocess.check_call(["g++", "-O2", "-std=c++17", "-Wno-unknown-pragmas", "-fPIC", "-shared", "-o", _SO, src])
@@ -42,8 +42,20 @@ def lib():
 STAT_NAMES = ("outer", "relabel_passes", "relabel_tiles", "phases", "discharge_tiles", "converged", "last_active", "reserved")
 
 
-def solve(shape, weights, trcap, rounds=0, cycles=0, sweeps=0, max_outer=0):
+def set_wave_mode(mode):
+    """which form of the hot tile operations the simulator runs: bit0 wave discharge, bit1 wave relabel (mgc_wave_ops.inl,
+    one wave per tile), bit2 the wave discharge starts from exact in-tile labels; 0 = the 512-lane workgroup forms"""
+    lib().hostsim_set_wave_mode(int(mode))
+
+
+def solve(shape, weights, trcap, rounds=0, cycles=0, sweeps=0, max_outer=0, wave_mode=None):
     """weights: per-axis arrays for a 3-D shape (oracle layout); returns (labels[bool array], stats dict)."""
+    if wave_mode is not None:
+        set_wave_mode(wave_mode)
+        try:
+            return solve(shape, weights, trcap, rounds, cycles, sweeps, max_outer)
+        finally:
+            set_wave_mode(0)
     shape = np.asarray(shape, dtype=np.int64)
     assert shape.size == 3
     ws = [np.ascontiguousarray(w, dtype=np.float64).ravel() for w in weights]

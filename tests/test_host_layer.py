@@ -86,6 +86,31 @@ def test_hostsim_solver_matches_bk(gen, shape):
     np.testing.assert_array_equal(lab, ref)
 
 
+@pytest.mark.parametrize("mode", [1, 2, 3, 7])
+@pytest.mark.parametrize("gen,shape", [("sphere", (16, 16, 16)), ("sphere", (40, 40, 40)), ("hard", (32, 32, 32)),
+                                       ("sphere", (9, 21, 35)), ("sphere", (5, 8, 64)), ("ties", (24, 16, 16))])
+def test_hostsim_wave_forms_match_bk(gen, shape, mode):
+    """One-wave-per-tile discharge / relabel (mgc_wave_ops.inl, same source as k_discharge_w / k_relabel_w): every
+    combination with the workgroup forms reaches the reference labels (ties: dyadic-free input, cut value only)."""
+    kw = dict(wave_mode=mode)
+    if gen == "ties":
+        kw["term"] = "difference_linear"
+    lab, ref, st = _sim_case(gen, shape, **kw)
+    assert st["converged"] == 1
+    if gen == "ties":
+        assert (lab != ref).sum() <= 2
+    else:
+        np.testing.assert_array_equal(lab, ref)
+
+
+def test_hostsim_wave_schedule_independence():
+    for kw in (dict(rounds=1, sweeps=1), dict(rounds=3, sweeps=4), dict(rounds=50, sweeps=64)):
+        for mode in (3, 7):
+            lab, ref, st = _sim_case("sphere", (24, 24, 24), wave_mode=mode, **kw)
+            assert st["converged"] == 1
+            np.testing.assert_array_equal(lab, ref)
+
+
 def test_hostsim_schedule_independence():
     """Any schedule (rounds between global relabels, cycle / sweep budgets) reaches the same cut."""
     base = None

@@ -41,6 +41,25 @@ def test_loopback_slabs_match_oracle(gen, shape, nslabs):
     assert all(a.own1 == b.own0 for a, b in zip(slabs, slabs[1:]))
 
 
+@pytest.mark.parametrize("mode", [3, 7])
+def test_loopback_slabs_wave_forms(mode):
+    """the slab protocol over the one-wave-per-tile operations (what the HIP library runs by default)"""
+    import sim
+    from medpy_amd.slab import LoopbackExchange, solve_slabs
+    shape = (40, 24, 16)
+    w, tr, ref = _problem("sphere", shape)
+    sim.set_wave_mode(mode)
+    try:
+        slabs = [sim.SimSlab(shape, r, 3) for r in range(3)]
+        for s in slabs:
+            s.load(w, tr)
+        st = solve_slabs(slabs, LoopbackExchange(slabs))
+        assert st["converged"] == 1
+        np.testing.assert_array_equal(np.concatenate([s.finish()[0] for s in slabs], axis=0), ref)
+    finally:
+        sim.set_wave_mode(0)
+
+
 def test_schedule_independent_of_slab_count():
     import sim
     from medpy_amd.slab import LoopbackExchange, solve_slabs
