@@ -183,6 +183,7 @@ struct GpuWave {
     {
         lane = (int)threadIdx.x;
         asm volatile("" : "+v"(lane));
+        lane &= 63; /* the range stays known: constant parts of an index fold into the instruction's offset field */
     }
     /* orders this wave's LDS accesses for the compiler; the hardware executes one wave's LDS instructions in order */
     __device__ __forceinline__ void fence() { __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront"); __builtin_amdgcn_wave_barrier(); }
@@ -208,7 +209,7 @@ struct GpuWave {
     __device__ __forceinline__ void atomic_or(uint32_t* p, uint32_t v) { atomicOr(p, v); }
     __device__ __forceinline__ void atomic_and(uint32_t* p, uint32_t v) { atomicAnd(p, v); }
     __device__ __forceinline__ void mark(int) {}
-    __device__ __forceinline__ void fresh() { asm volatile("" : "+v"(lane)); }
+    __device__ __forceinline__ void fresh() { asm volatile("" : "+v"(lane)); lane &= 63; }
     /* p[l], p wave-uniform: SGPR base + zero-extended 32-bit byte offset, the addressing mode of global_load / global_store */
     template <class T>
     __device__ __forceinline__ T ld(const T* p, int l) { return *(const T*)((const char*)p + (unsigned)(l * (int)sizeof(T))); }
@@ -216,51 +217,44 @@ struct GpuWave {
     __device__ __forceinline__ void st(T* p, int l, T v) { *(T*)((char*)p + (unsigned)(l * (int)sizeof(T))) = v; }
 };
 
-/* Work distribution of the wave kernels: waves draw list positions from a ticket counter (tiles differ a lot in cost, a
- * static stride leaves a tail); the last wave to leave resets the ticket and the exit counter for the next launch, so
- * no memset sits between two launches.  `tk` = index of the ticket in L.count, tk + 1 = exit counter. */
-#define MGC_CNT_TICKET_DIS 24
-#define MGC_CNT_TICKET_REL 26
+/* Work distribution of the wave kernels: a wave takes list position blockIdx.x first, then draws further positions from
+ * a ticket counter (tiles differ a lot in cost, a static stride leaves a tail).  Two ticket slots alternate from launch
+ * to launch (the host flips `tk`): a launch clears the slot the NEXT launch will use, which nobody touches meanwhile,
+ * so no memset, no fence and no exit counter sit between two launches. */
+#define MGC_CNT_TICKET_DIS 24 /* and 25 */
+#define MGC_CNT_TICKET_REL 26 /* and 27 */
 __device__ __forceinline__ int mgcw_next_ticket(const MgcLattice& L, int tk)
 {
     int i = 0;
     if (threadIdx.x == 0) i = atomicAdd(&L.count[tk], 1);
-    return __builtin_amdgcn_readfirstlane(i);
-}
-__device__ __forceinline__ void mgcw_leave(const MgcLattice& L, int tk)
-{
-    if (threadIdx.x == 0) {
-        __threadfence();
-        if (atomicAdd(&L.count[tk + 1], 1) == (int)gridDim.x - 1) {
-            L.count[tk] = 0;
-            L.count[tk + 1] = 0;
-        }
-    }
+    return (int)gridDim.x + __builtin_amdgcn_readfirstlane(i);
 }
 
 #ifndef MGCW_DISCHARGE_WAVES
-#define MGCW_DISCHARGE_WAVES 2 /* waves per SIMD the register allocator leaves room for (256 VGPRs each) */
+#define MGCW_DISCHARGE_WAVES 2 /* waves per SIMD the register allocator leaves room for: 256 VGPRs each.  Measured on MI355X at 512^3: 2 -> 24.0 ms
+                                  of discharge kernels per step, 3 (168 VGPRs, 150 of them spilled around the load / store phases) -> 31.8 ms,
+                                  4 -> 57 ms */
 #endif
 __global__ __launch_bounds__(MGCW_LANES) __attribute__((amdgpu_waves_per_eu(MGCW_DISCHARGE_WAVES, MGCW_DISCHARGE_WAVES)))
-void k_discharge_w(MgcLattice L, int lst, uint32_t phase, int sweeps, int flags)
+void k_discharge_w(MgcLattice L, int lst, uint32_t phase, int sweeps, int flags, int tk)
 {
     __shared__ MgcWaveShared S;
     GpuWave w(S);
     const int n = L.count[lst];
-    if (blockIdx.x == 0 && threadIdx.x == 0 && n) atomicAdd(&L.count[8], n);
-    for (;;) {
-        const int i = mgcw_next_ticket(L, MGC_CNT_TICKET_DIS);
-        if (i >= n) break;
+    if (blockIdx.x == 0 && threadIdx.x == 0) {
+        if (n) atomicAdd(&L.count[8], n);
+        L.count[tk ^ 1] = 0;
+    }
+    for (int i = (int)blockIdx.x; i < n; i = mgcw_next_ticket(L, tk)) {
         w.new_tile();
         /* the tile id is wave-uniform: keep it (and every base address derived from it) in SGPRs */
         mgcw_discharge_tile(w, L, __builtin_amdgcn_readfirstlane(L.list[lst][i]), phase, sweeps, flags);
     }
-    mgcw_leave(L, MGC_CNT_TICKET_DIS);
 }
 
 /* global-relabel pass over a list, one wave per tile; first = the seeding pass of a from-scratch relabel over the
  * filter's scratch list (`cnt` = its counter), else `cnt` = lst */
-__global__ __launch_bounds__(MGCW_LANES) void k_relabel_w(MgcLattice L, int lst, int cnt, uint32_t epoch, int next_list, int zero_list, int first)
+__global__ __launch_bounds__(MGCW_LANES) void k_relabel_w(MgcLattice L, int lst, int cnt, uint32_t epoch, int next_list, int zero_list, int first, int tk)
 {
     __shared__ MgcWaveShared S;
     GpuWave w(S);
@@ -268,14 +262,12 @@ __global__ __launch_bounds__(MGCW_LANES) void k_relabel_w(MgcLattice L, int lst,
     if (blockIdx.x == 0 && threadIdx.x == 0) {
         if (n) atomicAdd(&L.count[9], n);
         if (zero_list >= 0) L.count[zero_list] = 0; /* consumed by the previous pass; the next pass appends to it */
+        L.count[tk ^ 1] = 0;
     }
-    for (;;) {
-        const int i = mgcw_next_ticket(L, MGC_CNT_TICKET_REL);
-        if (i >= n) break;
+    for (int i = (int)blockIdx.x; i < n; i = mgcw_next_ticket(L, tk)) {
         w.new_tile();
         mgcw_relabel_tile(w, L, __builtin_amdgcn_readfirstlane(L.list[lst][i]), epoch, next_list, first != 0);
     }
-    mgcw_leave(L, MGC_CNT_TICKET_REL);
 }
 
 /* ---- 26-neighbourhood solver kernels (bodies: mgc_tile_ops26.inl) ---- */
@@ -955,9 +947,10 @@ struct mgc_graph {
     double flow_const = 0.0, flow = 0.0;
     MgcSolveParams params = mgc_default_params();
     int grid_cap = 4096;
-    int wave_kernels = 3;  /* bit0: region discharge, bit1: global-relabel passes run one wave per tile (mgc_wave_ops.inl);
+    int wave_kernels = 1;  /* bit0: region discharge, bit1: global-relabel passes run one wave per tile (mgc_wave_ops.inl);
                               bit2: the wave discharge starts from exact in-tile labels (MGCW_BFS) */
     int wave_grid_dis = 0, wave_grid_rel = 0; /* persistent grids of the wave kernels (waves resident on the device) */
+    int tk_dis = MGC_CNT_TICKET_DIS, tk_rel = MGC_CNT_TICKET_REL; /* ticket slot of the next wave launch (alternates) */
     int use_filters = 3; /* bit0 absorb, bit1 activate, bit2 reset-suspect go through the tile-level filter.  Bit2 is off:
                             measured on MI355X it doubles the number of global relabels (cause not understood yet) */
     mgc_stats stats{};
@@ -1038,7 +1031,7 @@ struct HipDevT {
         else { /* one thread per tile finds the seeds (tiles with an arc to the sink); only those get a workgroup */
             zero_count(11);
             hipLaunchKernelGGL(k_filter, dim3(filter_grid()), dim3(256), 0, h->stream, h->L, 3, 6, 11);
-            if (h->wave_kernels & 2) hipLaunchKernelGGL(k_relabel_w, dim3(h->wave_grid_rel), dim3(MGCW_LANES), 0, h->stream, h->L, 6, 11, epoch, next, -1, 1);
+            if (h->wave_kernels & 2) { hipLaunchKernelGGL(k_relabel_w, dim3(h->wave_grid_rel), dim3(MGCW_LANES), 0, h->stream, h->L, 6, 11, epoch, next, -1, 1, h->tk_rel); h->tk_rel ^= 1; }
             else hipLaunchKernelGGL(k_relabel_first_list, dim3(grid(h->L.ntiles)), dim3(MGC_TV), 0, h->stream, h->L, 6, 11, epoch, next);
         }
         check(hipGetLastError());
@@ -1049,7 +1042,7 @@ struct HipDevT {
     {
         const int id = time_begin(1);
         if constexpr (FULL) hipLaunchKernelGGL(k26_relabel_list, dim3(grid(h->L.ntiles)), dim3(MGC_TV), 0, h->stream, h->L, lst, epoch, next);
-        else if (h->wave_kernels & 2) hipLaunchKernelGGL(k_relabel_w, dim3(h->wave_grid_rel), dim3(MGCW_LANES), 0, h->stream, h->L, lst, lst, epoch, next, zero_list, 0);
+        else if (h->wave_kernels & 2) { hipLaunchKernelGGL(k_relabel_w, dim3(h->wave_grid_rel), dim3(MGCW_LANES), 0, h->stream, h->L, lst, lst, epoch, next, zero_list, 0, h->tk_rel); h->tk_rel ^= 1; }
         else hipLaunchKernelGGL(k_relabel_list, dim3(grid(h->L.ntiles)), dim3(MGC_TV), 0, h->stream, h->L, lst, epoch, next, zero_list);
         check(hipGetLastError());
         time_end(id);
@@ -1095,7 +1088,7 @@ struct HipDevT {
     {
         const int id = time_begin(0);
         if constexpr (FULL) hipLaunchKernelGGL(k26_discharge, dim3(grid(h->L.ntiles)), dim3(MGC_TV), 0, h->stream, h->L, lst, phase, cycles, sweeps);
-        else if (h->wave_kernels & 1) hipLaunchKernelGGL(k_discharge_w, dim3(h->wave_grid_dis), dim3(MGCW_LANES), 0, h->stream, h->L, lst, phase, sweeps, (h->wave_kernels & 4) ? MGCW_BFS : 0);
+        else if (h->wave_kernels & 1) { hipLaunchKernelGGL(k_discharge_w, dim3(h->wave_grid_dis), dim3(MGCW_LANES), 0, h->stream, h->L, lst, phase, sweeps, (h->wave_kernels & 4) ? MGCW_BFS : 0, h->tk_dis); h->tk_dis ^= 1; }
         else hipLaunchKernelGGL(k_discharge, dim3(grid(h->L.ntiles)), dim3(MGC_TV), 0, h->stream, h->L, lst, phase, cycles, sweeps);
         check(hipGetLastError());
         time_end(id);

@@ -44,6 +44,7 @@
 #ifndef MGC_WAVE_OPS_INL
 #define MGC_WAVE_OPS_INL
 
+#include <math.h>
 #include <utility>
 
 #include "mgc_tile_ops.inl"
@@ -55,7 +56,8 @@
 
 struct alignas(16) MgcWaveShared {
     int32_t hs[1000];          /* 10x10x10 distance labels: the tile plus a one-voxel halo */
-    double  inbox[6][MGC_TF];  /* flow the six neighbours left for this tile, staged by the loading lanes */
+    double  inbox[6][MGC_TF];  /* flow the six neighbours left for this tile, staged by the loading lanes; then the outbox */
+    double  snk[MGC_TV];       /* residual sink links of the tile being discharged (tiles that hold any) */
 };
 
 /* compile-time loop: f(std::integral_constant<int, 0>) ... f(<N-1>) -- the slot index of a register array must be a
@@ -167,14 +169,24 @@ MGC_HD void mgcw_relax(W& w, RegI& h, ArcFn arc)
  *   column ; local relabel } -> store (state, masks, labels, outbox, wake-ups).
  * Every hand-off has one sender per receiver and a fixed order of f64 operations: bit-reproducible, no atomics on
  * flow data.  Saturating pushes leave an exact 0.0.
+ *
+ * SINK = the tile holds residual sink links (status bit MGC_ST_SINK; 2 % of the tiles of a volume whose background
+ * markers are its faces).  Only then does the sink plane exist for the kernel at all; it then lives in LDS
+ * (w.S.snk), not in registers: the register budget -- excess, six residual planes, labels = 120 VGPRs -- is what
+ * sets the number of tiles in flight per SIMD.
+ *
+ * Control flow is wave-uniform throughout: a lane never branches on its own data, it computes "can I push" as a
+ * predicate, the wave votes, and the update runs branch-free (selects) only if somebody can -- no EXEC-mask
+ * juggling, and a (slot, direction) pair in which nobody pushes costs three compares and a scalar branch.
  * ------------------------------------------------------------------------------------- */
-template <class W>
-MGC_HD void mgcw_discharge_tile(W& w, const MgcLattice& L, int tile, uint32_t phase, int max_sweeps, int flags)
+template <bool SINK, class W>
+MGC_HD void mgcw_discharge_impl(W& w, const MgcLattice& L, int tile, uint32_t phase, int max_sweeps, int flags)
 {
-    typename W::template Reg<double, 8> e, snk;
+    typename W::template Reg<double, 8> e;
     typename W::template Reg<double, 8> r[6];
     typename W::template Reg<int, 8> h;
-    typename W::template Reg<int, 1> mv, sat, cand, fb; /* fb: bit f = this lane pushed flow out across face f */
+    typename W::template Reg<int, 4> hn;   /* labels of the four in-plane neighbours of the slot being swept */
+    typename W::template Reg<int, 1> cand;
     typename W::template Reg<double, 1> dl, din;
 
     double* const t_excess = L.excess + (int64_t)tile * MGC_TV;
@@ -190,16 +202,14 @@ MGC_HD void mgcw_discharge_tile(W& w, const MgcLattice& L, int tile, uint32_t ph
     w.lanes([&](int l) MGCW_INL {
         mgcw_static_for<8>([&](auto KK) MGCW_INL {
             constexpr int K = decltype(KK)::value;
-            e(l, K) = w.ld(t_excess + K * 64, l);
-            snk(l, K) = w.ld(t_sink + K * 64, l);
+            e(l, K) = w.ld(t_excess, K * 64 + l);
+            if constexpr (SINK) w.S.snk[K * 64 + l] = w.ld(t_sink, K * 64 + l);
             mgcw_static_for<6>([&](auto DD) MGCW_INL {
                 constexpr int D = decltype(DD)::value;
-                r[D](l, K) = w.ld(t_rcap + (D * MGC_TV + K * 64), l);
+                r[D](l, K) = w.ld(t_rcap + D * MGC_TV, K * 64 + l);
             });
-            if (!(flags & MGCW_BFS)) h(l, K) = w.ld(t_height + K * 64, l);
+            h(l, K) = w.ld(t_height, K * 64 + l); /* (overwritten when the exact labelling runs) */
         });
-        sat(l, 0) = 0;
-        fb(l, 0) = 0;
         mgcw_load_halo(w, L, tile, l, true);
         if (l < 6) { /* retire the outbox flags of the slots just emptied */
             const int nt = mgc_tile_nbr(L, tz, ty, tx, l);
@@ -244,8 +254,12 @@ MGC_HD void mgcw_discharge_tile(W& w, const MgcLattice& L, int tile, uint32_t ph
         mgcw_relax(w, h, [&](int l, auto KK, auto DD) MGCW_INL -> bool {
             constexpr int K = decltype(KK)::value;
             constexpr int D = decltype(DD)::value;
-            if constexpr (D == 6) return snk(l, K) > 0.0;
-            else return r[D](l, K) > 0.0;
+            if constexpr (D == 6) {
+                if constexpr (SINK) return w.S.snk[K * 64 + l] > 0.0;
+                else return false;
+            } else {
+                return r[D](l, K) > 0.0;
+            }
         });
     } else {
         w.lanes([&](int l) MGCW_INL {
@@ -256,54 +270,76 @@ MGC_HD void mgcw_discharge_tile(W& w, const MgcLattice& L, int tile, uint32_t ph
         });
     }
 
-    /* admissible push of (lane, slot K) in direction D towards a neighbour labelled hn; returns the amount */
-    auto push = [&](int l, auto KK, auto DD, int hn) MGCW_INL -> double {
+    bool saturated = false; /* some arc (or sink link) of the tile was saturated: the tile is DIRTY for the next global relabel */
+    uint32_t face = 0;      /* bit f: flow left the tile across face f */
+    /* may (lane, slot K) push along direction D towards a neighbour labelled hnb?  (a label of MGC_HINF never matches:
+     * finite labels stay far below MGC_HINF - 1) */
+    auto can_push = [&](int l, auto KK, auto DD, int hnb) MGCW_INL -> bool {
+        constexpr int K = decltype(KK)::value;
+        constexpr int D = decltype(DD)::value;
+        return e(l, K) > 0.0 && r[D](l, K) > 0.0 && hnb == h(l, K) - 1;
+    };
+    /* the push itself, branch-free: returns min(excess, residual) where `can`, 0.0 elsewhere */
+    auto do_push = [&](int l, auto KK, auto DD, bool can) MGCW_INL -> double {
         constexpr int K = decltype(KK)::value;
         constexpr int D = decltype(DD)::value;
         const double rd = r[D](l, K);
-        double delta = 0.0;
-        if (e(l, K) > 0.0 && rd > 0.0 && h(l, K) < MGC_HINF && hn == h(l, K) - 1) {
-            delta = e(l, K) < rd ? e(l, K) : rd;
-            e(l, K) -= delta;
-            r[D](l, K) = rd - delta; /* saturating push: rd - rd == 0.0 exactly */
-            mv(l, 0) = 1;
-            if (delta == rd) sat(l, 0) = 1;
-        }
+        const double delta = can ? fmin(e(l, K), rd) : 0.0;
+        e(l, K) -= delta;
+        r[D](l, K) = rd - delta; /* saturating push: rd - rd == 0.0 exactly */
         return delta;
     };
-    auto slot_active = [&](auto KK) MGCW_INL -> bool {
-        constexpr int K = decltype(KK)::value;
-        return w.any([&](int l) MGCW_INL -> bool { return e(l, K) > 0.0 && h(l, K) < MGC_HINF; });
+    auto slot_mask = [&]() MGCW_INL -> uint32_t { /* bit K: some voxel of slot K holds excess that can reach the sink */
+        uint32_t am = 0;
+        mgcw_static_for<8>([&](auto KK) MGCW_INL {
+            constexpr int K = decltype(KK)::value;
+            if (w.any([&](int l) MGCW_INL -> bool { return e(l, K) > 0.0 && h(l, K) < MGC_HINF; })) am |= 1u << K;
+        });
+        return am;
     };
 
-    bool active = true;
-    for (int sw = 0; sw < max_sweeps; ++sw) {
-        w.lanes([&](int l) MGCW_INL { mv(l, 0) = 0; });
+    uint32_t am = slot_mask();
+    for (int sw = 0; sw < max_sweeps && am; ++sw) {
         /* ---- per slot: sink, then the four in-plane directions as lane shifts ---- */
         mgcw_static_for<8>([&](auto KK) MGCW_INL {
             constexpr int K = decltype(KK)::value;
-            if (!slot_active(KK)) return;
-            w.lanes([&](int l) MGCW_INL { /* push to the sink first: always admissible (label 1 -> 0) */
-                if (e(l, K) > 0.0 && snk(l, K) > 0.0) {
-                    const double delta = e(l, K) < snk(l, K) ? e(l, K) : snk(l, K);
+            if (!(am & (1u << K))) return;
+            if constexpr (SINK) {
+                w.lanes([&](int l) MGCW_INL { /* push to the sink first: always admissible (label 1 -> 0) */
+                    const double sk = w.S.snk[K * 64 + l];
+                    const bool can = e(l, K) > 0.0 && sk > 0.0;
+                    const double delta = can ? fmin(e(l, K), sk) : 0.0;
                     e(l, K) -= delta;
-                    snk(l, K) -= delta;
-                    mv(l, 0) = 1;
-                    if (snk(l, K) == 0.0) sat(l, 0) = 1;
-                }
+                    w.S.snk[K * 64 + l] = sk - delta;
+                    cand(l, 0) = can && delta == sk;
+                });
+                if (w.any([&](int l) MGCW_INL -> bool { return cand(l, 0) != 0; })) saturated = true;
+            }
+            w.lanes([&](int l) MGCW_INL { /* the four in-plane neighbour labels: constant during the push steps */
+                mgcw_static_for<4>([&](auto DD) MGCW_INL {
+                    constexpr int D = decltype(DD)::value;
+                    hn(l, D) = w.S.hs[mgcw_hs(l, K) + mgc_hs_step(D)];
+                });
             });
             mgcw_static_for<4>([&](auto DD) MGCW_INL {
                 constexpr int D = decltype(DD)::value;
+                if (!w.any([&](int l) MGCW_INL -> bool { return can_push(l, KK, DD, hn(l, D)); })) return;
                 w.lanes([&](int l) MGCW_INL {
                     const int y = l >> 3, x = l & 7;
-                    const double delta = push(l, KK, DD, mgcw_nbr_label<K, D>(w, h, l));
+                    const double rd = r[D](l, K);
+                    const double delta = do_push(l, KK, DD, can_push(l, KK, DD, hn(l, D)));
                     const bool inside = D == 0 ? x > 0 : (D == 1 ? x < 7 : (D == 2 ? y > 0 : y < 7));
                     dl(l, 0) = inside ? delta : 0.0;
-                    if (!inside && delta != 0.0) { /* flow that leaves the tile across face D */
-                        w.S.inbox[D][K * 8 + (D < 2 ? y : x)] += delta;
-                        fb(l, 0) |= 1 << D;
-                    }
+                    din(l, 0) = inside ? 0.0 : delta; /* flow that leaves the tile across face D */
+                    cand(l, 0) = delta != 0.0 && delta == rd;
                 });
+                if (w.any([&](int l) MGCW_INL -> bool { return cand(l, 0) != 0; })) saturated = true;
+                if (w.any([&](int l) MGCW_INL -> bool { return din(l, 0) != 0.0; })) {
+                    face |= 1u << D;
+                    w.lanes([&](int l) MGCW_INL {
+                        if (din(l, 0) != 0.0) w.S.inbox[D][K * 8 + (D < 2 ? (l >> 3) : (l & 7))] += din(l, 0);
+                    });
+                }
                 if (!w.any([&](int l) MGCW_INL -> bool { return dl(l, 0) != 0.0; })) return;
                 w.shift(din, dl, D == 0 ? 1 : (D == 1 ? -1 : (D == 2 ? 8 : -8))); /* -x: from the lane at x + 1, ... */
                 w.lanes([&](int l) MGCW_INL { /* what the neighbour pushed in direction D arrives: reverse residual grows */
@@ -312,90 +348,95 @@ MGC_HD void mgcw_discharge_tile(W& w, const MgcLattice& L, int tile, uint32_t ph
                 });
             });
         });
-        /* ---- -z down the column, +z up the column: flow crosses all eight layers in one pass ---- */
+        /* ---- -z down the column, then +z up the column: flow crosses all eight layers in one pass ---- */
         mgcw_static_for<8>([&](auto KK) MGCW_INL {
             constexpr int K = 7 - decltype(KK)::value;
             constexpr std::integral_constant<int, K> KC{};
-            if (!slot_active(KC)) return;
+            constexpr std::integral_constant<int, 4> DC{};
+            if (!w.any([&](int l) MGCW_INL -> bool { return can_push(l, KC, DC, mgcw_nbr_label<K, 4>(w, h, l)); })) return;
             w.lanes([&](int l) MGCW_INL {
-                const double delta = push(l, KC, std::integral_constant<int, 4>{}, mgcw_nbr_label<K, 4>(w, h, l));
+                const double rd = r[4](l, K);
+                const double delta = do_push(l, KC, DC, can_push(l, KC, DC, mgcw_nbr_label<K, 4>(w, h, l)));
+                cand(l, 0) = delta != 0.0 && delta == rd;
                 if constexpr (K > 0) { e(l, K - 1) += delta; r[5](l, K - 1) += delta; }
-                else if (delta != 0.0) { w.S.inbox[4][l] += delta; fb(l, 0) |= 1 << 4; }
+                else if (delta != 0.0) w.S.inbox[4][l] += delta;
             });
+            if constexpr (K == 0) face |= 1u << 4;
+            if (w.any([&](int l) MGCW_INL -> bool { return cand(l, 0) != 0; })) saturated = true;
         });
         mgcw_static_for<8>([&](auto KK) MGCW_INL {
             constexpr int K = decltype(KK)::value;
-            if (!slot_active(KK)) return;
+            constexpr std::integral_constant<int, 5> DC{};
+            if (!w.any([&](int l) MGCW_INL -> bool { return can_push(l, KK, DC, mgcw_nbr_label<K, 5>(w, h, l)); })) return;
             w.lanes([&](int l) MGCW_INL {
-                const double delta = push(l, KK, std::integral_constant<int, 5>{}, mgcw_nbr_label<K, 5>(w, h, l));
+                const double rd = r[5](l, K);
+                const double delta = do_push(l, KK, DC, can_push(l, KK, DC, mgcw_nbr_label<K, 5>(w, h, l)));
+                cand(l, 0) = delta != 0.0 && delta == rd;
                 if constexpr (K < 7) { e(l, K + 1) += delta; r[4](l, K + 1) += delta; }
-                else if (delta != 0.0) { w.S.inbox[5][l] += delta; fb(l, 0) |= 1 << 5; }
+                else if (delta != 0.0) w.S.inbox[5][l] += delta;
             });
+            if constexpr (K == 7) face |= 1u << 5;
+            if (w.any([&](int l) MGCW_INL -> bool { return cand(l, 0) != 0; })) saturated = true;
         });
         /* ---- local relabel (classic push-relabel step): a voxel that still holds excess rises to 1 + the lowest label
          * behind a residual arc.  Labels stay valid lower bounds of the distance (no push runs in this step; an in-plane
-         * neighbour's label read here is the one it had before the step: all lanes read, then all write). ---- */
+         * neighbour's label read here is the one it had before the step: all lanes read, then all write).  A voxel with
+         * excess either rises here or still has an admissible arc, so "some slot is still active" == "another sweep
+         * will move something". ---- */
+        am = 0;
         mgcw_static_for<8>([&](auto KK) MGCW_INL {
             constexpr int K = decltype(KK)::value;
-            if (!slot_active(KK)) return;
+            if (!w.any([&](int l) MGCW_INL -> bool { return e(l, K) > 0.0 && h(l, K) < MGC_HINF; })) return;
             w.lanes([&](int l) MGCW_INL {
                 int c = MGC_HINF;
-                if (e(l, K) > 0.0 && h(l, K) < MGC_HINF) {
-                    c = snk(l, K) > 0.0 ? 1 : MGC_HINF;
-                    mgcw_static_for<6>([&](auto DD) MGCW_INL {
-                        constexpr int D = decltype(DD)::value;
-                        const int hv = mgcw_nbr_label<K, D>(w, h, l);
-                        c = (r[D](l, K) > 0.0 && hv < MGC_HINF && hv + 1 < c) ? hv + 1 : c;
-                    });
-                } else {
-                    c = h(l, K);
-                }
-                cand(l, 0) = c;
+                if constexpr (SINK) c = w.S.snk[K * 64 + l] > 0.0 ? 1 : MGC_HINF;
+                mgcw_static_for<6>([&](auto DD) MGCW_INL {
+                    constexpr int D = decltype(DD)::value;
+                    const int hv = mgcw_nbr_label<K, D>(w, h, l);
+                    const int cd = r[D](l, K) > 0.0 ? hv + 1 : MGC_HINF; /* hv == MGC_HINF gives a value above every candidate */
+                    c = cd < c ? cd : c;
+                });
+                cand(l, 0) = (e(l, K) > 0.0 && h(l, K) < c) ? c : h(l, K);
             });
             w.lanes([&](int l) MGCW_INL {
-                if (cand(l, 0) > h(l, K)) {
+                if (cand(l, 0) != h(l, K)) {
                     h(l, K) = cand(l, 0);
                     w.S.hs[mgcw_hs(l, K)] = cand(l, 0);
-                    if (cand(l, 0) < MGC_HINF) mv(l, 0) = 1; /* it can push again next sweep */
                 }
             });
+            if (w.any([&](int l) MGCW_INL -> bool { return e(l, K) > 0.0 && h(l, K) < MGC_HINF; })) am |= 1u << K;
         });
         w.mark(2); /* one push sweep */
-        if (!w.any([&](int l) MGCW_INL -> bool { return mv(l, 0) != 0; })) { active = false; break; }
     }
-    if (active) { /* sweep budget exhausted: is there still something to do with the current labels? */
-        active = false;
-        mgcw_static_for<8>([&](auto KK) MGCW_INL { active = active || slot_active(KK); });
-    }
+    const bool active = am != 0; /* sweep budget exhausted with work left: run again in the next phase of this colour */
 
     /* ---- tail: ballots only ---- */
     bool has_sink = false, has_exc = false;
     mgcw_static_for<8>([&](auto KK) MGCW_INL {
         constexpr int K = decltype(KK)::value;
-        has_sink = has_sink || w.any([&](int l) MGCW_INL -> bool { return snk(l, K) > 0.0; });
+        if constexpr (SINK) has_sink = has_sink || w.any([&](int l) MGCW_INL -> bool { return w.S.snk[K * 64 + l] > 0.0; });
         has_exc = has_exc || w.any([&](int l) MGCW_INL -> bool { return e(l, K) > 0.0; });
     });
-    const bool saturated = w.any([&](int l) MGCW_INL -> bool { return sat(l, 0) != 0; });
-    uint32_t face = 0; /* bit f: flow leaves across face f */
-#pragma unroll
-    for (int f = 0; f < 6; ++f)
-        if (w.any([&](int l) MGCW_INL -> bool { return ((fb(l, 0) >> f) & 1) != 0; })) face |= 1u << f;
 
     /* ---- ONE block of global stores: state, masks, labels, outbox, wake-ups ---- */
     w.fresh();
     w.lanes([&](int l) MGCW_INL {
         mgcw_static_for<8>([&](auto KK) MGCW_INL {
             constexpr int K = decltype(KK)::value;
-            w.st(t_excess + K * 64, l, e(l, K));
-            w.st(t_sink + K * 64, l, snk(l, K));
-            int m = snk(l, K) > 0.0 ? MGC_MASK_SINK : 0;
+            w.st(t_excess, K * 64 + l, e(l, K));
+            int m = 0;
+            if constexpr (SINK) {
+                const double sk = w.S.snk[K * 64 + l];
+                w.st(t_sink, K * 64 + l, sk);
+                m = sk > 0.0 ? MGC_MASK_SINK : 0;
+            }
             mgcw_static_for<6>([&](auto DD) MGCW_INL {
                 constexpr int D = decltype(DD)::value;
-                w.st(t_rcap + (D * MGC_TV + K * 64), l, r[D](l, K));
+                w.st(t_rcap + D * MGC_TV, K * 64 + l, r[D](l, K));
                 m |= (r[D](l, K) > 0.0) ? (1 << D) : 0;
             });
-            w.st(t_rmask + K * 64, l, (uint8_t)m);
-            w.st(t_height + K * 64, l, h(l, K));
+            w.st(t_rmask, K * 64 + l, (uint8_t)m);
+            w.st(t_height, K * 64 + l, h(l, K));
         });
         /* outbox: plain stores -- the neighbour emptied these slots when it last absorbed, and it always runs (or
          * absorb_all does) between two of our discharges */
@@ -414,6 +455,13 @@ MGC_HD void mgcw_discharge_tile(W& w, const MgcLattice& L, int tile, uint32_t ph
     });
 }
 
+template <class W>
+MGC_HD void mgcw_discharge_tile(W& w, const MgcLattice& L, int tile, uint32_t phase, int max_sweeps, int flags)
+{
+    if (L.status[tile] & MGC_ST_SINK) mgcw_discharge_impl<true>(w, L, tile, phase, max_sweeps, flags);
+    else mgcw_discharge_impl<false>(w, L, tile, phase, max_sweeps, flags);
+}
+
 /* ---------------------------------------------------------------------------------------
  * Global relabel, one tile of one pass, by one wave: relax the tile's labels from their current values over the
  * residual masks with the current halo; wake the neighbours across every face where a lowered label could lower
@@ -430,8 +478,8 @@ MGC_HD void mgcw_relabel_tile(W& w, const MgcLattice& L, int tile, uint32_t next
     w.lanes([&](int l) MGCW_INL {
         mgcw_static_for<8>([&](auto KK) MGCW_INL {
             constexpr int K = decltype(KK)::value;
-            m(l, K) = w.ld(L.rmask + base + K * 64, l);
-            h0(l, K) = w.ld(L.height + base + K * 64, l);
+            m(l, K) = w.ld(L.rmask + base, K * 64 + l);
+            h0(l, K) = w.ld(L.height + base, K * 64 + l);
             h(l, K) = h0(l, K);
             w.S.hs[mgcw_hs(l, K)] = h0(l, K);
         });
@@ -470,7 +518,7 @@ MGC_HD void mgcw_relabel_tile(W& w, const MgcLattice& L, int tile, uint32_t next
     w.lanes([&](int l) MGCW_INL { /* one block of global traffic: labels + wake-ups */
         mgcw_static_for<8>([&](auto KK) MGCW_INL {
             constexpr int K = decltype(KK)::value;
-            if (h(l, K) < h0(l, K)) w.st(L.height + base + K * 64, l, h(l, K));
+            if (h(l, K) < h0(l, K)) w.st(L.height + base, K * 64 + l, h(l, K));
         });
         if (l < 6 && ((wake >> l) & 1u)) {
             const int nt = mgc_tile_nbr(L, tz, ty, tx, l);

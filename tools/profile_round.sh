@@ -18,3 +18,13 @@ python tools/rocpd_summary.py pmc $F > gpurun_out/${TAG}_pmc_fetch_size.csv
 python tools/rocpd_summary.py pmc $W > gpurun_out/${TAG}_pmc_write_size.csv
 python tools/rocpd_summary.py json $F $W > gpurun_out/pmc_discharge.json
 rm -rf $OUT/trace $OUT/fetch $OUT/write
+# instruction mix of the solver kernels (one pass per counter group; counters never share a run with traces other than --kernel-trace)
+cd /tmp
+for C in "SQ_INSTS_VALU SQ_INSTS_SALU" "SQ_INSTS_LDS SQ_INSTS_SMEM" "SQ_WAVE_CYCLES SQ_BUSY_CYCLES" "SQ_INSTS_VMEM_RD SQ_INSTS_VMEM_WR"; do
+  N=$(echo $C | tr ' ' '_')
+  timeout 600 rocprofv3 --kernel-trace --pmc $C -d $OUT/$N -- python $ROOT/bench.py --steps 1 --warmup 0 --no-cpu > $OUT/$N.log 2>&1
+  D=$(find $OUT/$N -name "*.db" | head -1)
+  [ -n "$D" ] && python $ROOT/tools/rocpd_summary.py pmc $D > $ROOT/gpurun_out/${TAG}_pmc_$N.csv
+  rm -rf $OUT/$N
+done
+cd $ROOT
