@@ -236,7 +236,7 @@ __device__ __forceinline__ int mgcw_next_ticket(const MgcLattice& L, int tk)
                                   4 -> 57 ms */
 #endif
 __global__ __launch_bounds__(MGCW_LANES) __attribute__((amdgpu_waves_per_eu(MGCW_DISCHARGE_WAVES, MGCW_DISCHARGE_WAVES)))
-void k_discharge_w(MgcLattice L, int lst, uint32_t phase, int sweeps, int flags, int tk)
+void k_discharge_w(MgcLattice L, int lst, uint32_t phase, int sweeps, int flags, int tk, int zero_idx)
 {
     __shared__ MgcWaveShared S;
     GpuWave w(S);
@@ -244,6 +244,7 @@ void k_discharge_w(MgcLattice L, int lst, uint32_t phase, int sweeps, int flags,
     if (blockIdx.x == 0 && threadIdx.x == 0) {
         if (n) atomicAdd(&L.count[8], n);
         L.count[tk ^ 1] = 0;
+        if (zero_idx >= 0) L.count[zero_idx] = 0; /* the list the previous phase consumed */
     }
     for (int i = (int)blockIdx.x; i < n; i = mgcw_next_ticket(L, tk)) {
         w.new_tile();
@@ -396,7 +397,7 @@ __global__ __launch_bounds__(MGC_TV) void k_reset_suspect(MgcLattice L, uint32_t
         for (int i = 0; i < n; ++i) L.height[(int64_t)sel[i] * MGC_TV + threadIdx.x] = MGC_HINF;
         if ((int)threadIdx.x < n) {
             const int tile = sel[threadIdx.x];
-            L.status[tile] &= ~(MGC_ST_SUSPECT | MGC_ST_DIRTY | (63u << MGC_ST_DEP_SHIFT));
+            L.status[tile] = (L.status[tile] & ~(MGC_ST_SUSPECT | MGC_ST_DIRTY | (63u << MGC_ST_DEP_SHIFT))) | MGC_ST_ALLINF;
             mgc_enqueue(x, L, list, L.rstamp, epoch, tile);
         }
         __syncthreads();
@@ -420,7 +421,7 @@ __global__ void k_filter(MgcLattice L, int mode, int list, int cnt)
                     take = nt >= 0 && ((L.oflags[nt] >> (f ^ 1)) & 1u);
                 }
             } else if (mode == 1) {
-                take = (L.status[tile] & MGC_ST_EXCESS) != 0;
+                take = (L.status[tile] & (MGC_ST_EXCESS | MGC_ST_ALLINF)) == MGC_ST_EXCESS; /* excess that may reach the sink */
             } else if (mode == 3) {
                 take = (L.status[tile] & MGC_ST_SINK) != 0;
             } else {
@@ -508,12 +509,15 @@ __global__ __launch_bounds__(MGC_TV) void k_activate(MgcLattice L, uint32_t phas
 #define MGC_DISCHARGE_WAVES 8 /* waves per SIMD the register allocator must leave room for: 4 workgroups per CU
                                  (measured on MI355X: 151 ms vs 179 ms at 512^3 despite the spills) */
 #endif
-__global__ __launch_bounds__(MGC_TV, MGC_DISCHARGE_WAVES) void k_discharge(MgcLattice L, int lst, uint32_t phase, int cycles, int sweeps)
+__global__ __launch_bounds__(MGC_TV, MGC_DISCHARGE_WAVES) void k_discharge(MgcLattice L, int lst, uint32_t phase, int cycles, int sweeps, int zero_idx)
 {
     __shared__ MgcTileShared S;
     GpuBlock x(S);
     const int n = L.count[lst];
-    if (blockIdx.x == 0 && threadIdx.x == 0 && n) atomicAdd(&L.count[8], n);
+    if (blockIdx.x == 0 && threadIdx.x == 0) {
+        if (n) atomicAdd(&L.count[8], n);
+        if (zero_idx >= 0) L.count[zero_idx] = 0; /* the list the previous phase consumed */
+    }
     for (int i = blockIdx.x; i < n; i += gridDim.x) {
         x.new_tile();
         if (L.prof && threadIdx.x == 0) x.last = clock64();
@@ -583,14 +587,12 @@ __device__ __forceinline__ double mgc_block_sum(double v, double* scratch)
     return scratch[0];
 }
 
-template <bool FULL> /* FULL: 26-neighbourhood */
-__global__ __launch_bounds__(MGC_TV) void k_build(MgcLattice L, MgcBuildArgs A)
+/* TERM: the boundary term as a compile-time constant (the kernel dispatches once), so g(.) is straight-line code */
+template <bool FULL, int TERM> /* FULL: 26-neighbourhood */
+__device__ __forceinline__ void k_build_tiles(const MgcLattice& L, const MgcBuildArgs& A, double* img, double* scratch, double* wf)
 {
-    __shared__ double img[1000]; /* 10x10x10: tile + one-voxel halo, already |.|'d for the maximum terms */
-    __shared__ double scratch[MGC_TV];
     const int t = threadIdx.x;
-    const bool take_abs = (A.term == MGC_TERM_MAXIMUM_LINEAR || A.term == MGC_TERM_MAXIMUM_EXPONENTIAL ||
-                           A.term == MGC_TERM_MAXIMUM_POWER);
+    const bool take_abs = (TERM == MGC_TERM_MAXIMUM_LINEAR || TERM == MGC_TERM_MAXIMUM_EXPONENTIAL || TERM == MGC_TERM_MAXIMUM_POWER);
     /* XCD-aware tile order: workgroups are dealt round-robin to the 8 XCDs, each with its own L2.  Workgroup b therefore
      * works inside the b % 8-th eighth of the tile range, consecutive workgroups of one XCD on consecutive tiles, so the
      * image rows two x-neighbour tiles share (and the halo planes of y / z neighbours) are fetched by ONE L2 instead of
@@ -603,7 +605,7 @@ __global__ __launch_bounds__(MGC_TV) void k_build(MgcLattice L, MgcBuildArgs A)
         int tz, ty, tx;
         mgc_tile_coords(L, tile, tz, ty, tx);
         const int64_t z0 = (int64_t)tz * 8, y0 = (int64_t)ty * 8, x0 = (int64_t)tx * 8;
-        if (A.term != MGC_TERM_NONE) {
+        if (TERM != MGC_TERM_NONE) {
             for (int k = t; k < 1000; k += MGC_TV) {
                 const int64_t gz = z0 + k / 100 - 1, gy = y0 + (k / 10) % 10 - 1, gx = x0 + k % 10 - 1;
                 double v = 0.0;
@@ -620,19 +622,39 @@ __global__ __launch_bounds__(MGC_TV) void k_build(MgcLattice L, MgcBuildArgs A)
         const int me = mgc_hs_index(lz, ly, lx);
         uint32_t m = 0;
         if constexpr (!FULL) {
+            /* Every n-link weight is evaluated ONCE, by the lower voxel of its pair (g(lower, upper), the operand order of the
+             * reference's slices, energy_voxel.py:650-664), and handed to the upper voxel through LDS: wf[axis][c][u][v] =
+             * weight of the pair (c - 1, c) along `axis`.  512 lanes evaluate their three forward pairs, 192 of them also the
+             * pair that enters the tile through a lower face: 1728 evaluations of g per tile instead of 3072. */
+            if (TERM != MGC_TERM_NONE) {
+                auto pair_weight = [&](int axis, int lo, bool ok) -> double { /* lo = img[] index of the lower voxel; ok = both voxels exist */
+                    if (!ok) return 0.0;
+                    double w = mgc_boundary_g(TERM, img[lo], img[lo + (axis == 0 ? 1 : (axis == 1 ? 10 : 100))], A.p0);
+                    if (A.has_spacing) w = w / A.inv_axis[axis]; /* energy_voxel.py:657-658 */
+                    return w;
+                };
+                wf[0 * 576 + (lx + 1) * 64 + lz * 8 + ly] = pair_weight(0, me, valid && gx + 1 < L.dx);
+                wf[1 * 576 + (ly + 1) * 64 + lz * 8 + lx] = pair_weight(1, me, valid && gy + 1 < L.dy);
+                wf[2 * 576 + (lz + 1) * 64 + ly * 8 + lx] = pair_weight(2, me, valid && gz + 1 < L.dz);
+                if (t < 192) { /* the pair that enters the tile through its lower face along `axis`: (halo voxel, voxel 0) */
+                    const int axis = t >> 6, u = (t >> 3) & 7, v = t & 7;
+                    const int lo = axis == 0 ? mgc_hs_index(u, v, -1) : (axis == 1 ? mgc_hs_index(u, -1, v) : mgc_hs_index(-1, u, v));
+                    const bool ok = axis == 0 ? (x0 > 0 && z0 + u < L.dz && y0 + v < L.dy)
+                                              : (axis == 1 ? (y0 > 0 && z0 + u < L.dz && x0 + v < L.dx) : (z0 > 0 && y0 + u < L.dy && x0 + v < L.dx));
+                    wf[axis * 576 + u * 8 + v] = pair_weight(axis, lo, ok);
+                }
+            }
+            __syncthreads();
 #pragma unroll
             for (int d = 0; d < 6; ++d) {
-                const int64_t c = (d >> 1) == 0 ? gx : ((d >> 1) == 1 ? gy : gz);
-                const int64_t lim = (d >> 1) == 0 ? L.dx : ((d >> 1) == 1 ? L.dy : L.dz);
-                const bool has = valid && ((d & 1) ? (c + 1 < lim) : (c > 0));
                 double w = 0.0;
-                if (has && A.term != MGC_TERM_NONE) {
-                    /* evaluate with (lower voxel, upper voxel) operand order like the reference slices */
-                    const double a = (d & 1) ? img[me] : img[me + mgc_hs_step(d)];
-                    const double b = (d & 1) ? img[me + mgc_hs_step(d)] : img[me];
-                    w = mgc_boundary_g(A.term, a, b, A.p0);
-                    if (A.has_spacing) w = w / A.inv_axis[d >> 1]; /* energy_voxel.py:657-658 */
+                if (TERM != MGC_TERM_NONE && valid) {
+                    const int c = ((d >> 1) == 0 ? lx : ((d >> 1) == 1 ? ly : lz)) + (d & 1);
+                    const int uv = (d >> 1) == 0 ? lz * 8 + ly : ((d >> 1) == 1 ? lz * 8 + lx : ly * 8 + lx);
+                    w = wf[(d >> 1) * 576 + c * 64 + uv];
                 }
+                /* (16-byte stores -- two x-neighbours per lane, fetched from wf -- were measured on MI355X: 4.9 ms instead of
+                 * 4.4 ms for this kernel at 512^3; the kernel is bound by instruction issue, not by the store width) */
                 const int64_t o = ((int64_t)tile * 6 + d) * MGC_TV + t;
                 L.rcap[o] = w;
                 if (L.cap0) L.cap0[o] = w;
@@ -646,11 +668,11 @@ __global__ __launch_bounds__(MGC_TV) void k_build(MgcLattice L, MgcBuildArgs A)
                 const int64_t nz = gz + dz, ny = gy + dy, nx = gx + dx;
                 const bool has = valid && nz >= 0 && nz < L.dz && ny >= 0 && ny < L.dy && nx >= 0 && nx < L.dx;
                 double w = 0.0;
-                if (has && A.term != MGC_TERM_NONE) {
+                if (has && TERM != MGC_TERM_NONE) {
                     const bool fwd = d >= 13;
                     const double a = fwd ? img[me] : img[me + mgc26_hs_step(d)];
                     const double b = fwd ? img[me + mgc26_hs_step(d)] : img[me];
-                    w = mgc_boundary_g(A.term, a, b, A.p0);
+                    w = mgc_boundary_g(TERM, a, b, A.p0);
                     if (A.has_spacing) w = w / A.div26[d];
                 }
                 const int64_t o = ((int64_t)tile * MGC26_NDIR + d) * MGC_TV + t;
@@ -690,11 +712,9 @@ __global__ __launch_bounds__(MGC_TV) void k_build(MgcLattice L, MgcBuildArgs A)
             if (tr < 0.0) m |= MGC26_MASK_SINK;
             L.rmask32[v] = m;
         }
-        L.height[v] = MGC_HINF;
-        if (!FULL && t < 6 * MGC_TF / 8) { /* 48 lanes x 8 doubles clear the 6x64 outbox */
-#pragma unroll
-            for (int k = 0; k < 8; ++k) L.obox[(int64_t)tile * 6 * MGC_TF + t * 8 + k] = 0.0;
-        }
+        /* (labels are not initialised here: every solve starts by filling them, mgc_driver.inl) */
+        if (!FULL && t < 6 * MGC_TF / 2) /* 192 lanes x 16 bytes clear the 6x64 outbox */
+            *(double2*)(L.obox + (int64_t)tile * 6 * MGC_TF + t * 2) = make_double2(0.0, 0.0);
         const int any_sink = __syncthreads_or(tr < 0.0);
         const int any_exc = __syncthreads_or(tr > 0.0);
         if (t == 0) {
@@ -703,9 +723,34 @@ __global__ __launch_bounds__(MGC_TV) void k_build(MgcLattice L, MgcBuildArgs A)
             L.rstamp[tile] = 0;
             L.status[tile] = (any_sink ? MGC_ST_SINK : 0u) | (any_exc ? MGC_ST_EXCESS : 0u);
         }
-        const double s = mgc_block_sum(fc, scratch);
-        if (t == 0) A.fpart[tile] = mgc_owned(L, tile) ? s : 0.0;
-        __syncthreads();
+        /* flow constant: only voxels whose t-links were merged more than once contribute (regional term + marker, fg and bg
+         * marker on one voxel): most tiles skip the ten barriers of the tree sum */
+        if (__syncthreads_or(fc != 0.0)) {
+            const double s = mgc_block_sum(fc, scratch);
+            if (t == 0) A.fpart[tile] = mgc_owned(L, tile) ? s : 0.0;
+            __syncthreads();
+        } else if (t == 0) {
+            A.fpart[tile] = 0.0;
+        }
+    }
+}
+
+template <bool FULL> /* FULL: 26-neighbourhood */
+__global__ __launch_bounds__(MGC_TV, FULL ? 2 : 4) void k_build(MgcLattice L, MgcBuildArgs A)
+{
+    __shared__ double img[1000]; /* 10x10x10: tile + one-voxel halo, already |.|'d for the maximum terms */
+    __shared__ double scratch[MGC_TV];
+    __shared__ double wf[FULL ? 1 : 3 * 576]; /* 6-neighbourhood: the forward n-link weights of the tile and its lower faces */
+    switch (A.term) { /* one dispatch per kernel, not one per weight */
+    case MGC_TERM_NONE: k_build_tiles<FULL, MGC_TERM_NONE>(L, A, img, scratch, wf); break;
+    case MGC_TERM_DIFFERENCE_LINEAR: k_build_tiles<FULL, MGC_TERM_DIFFERENCE_LINEAR>(L, A, img, scratch, wf); break;
+    case MGC_TERM_DIFFERENCE_EXPONENTIAL: k_build_tiles<FULL, MGC_TERM_DIFFERENCE_EXPONENTIAL>(L, A, img, scratch, wf); break;
+    case MGC_TERM_DIFFERENCE_DIVISION: k_build_tiles<FULL, MGC_TERM_DIFFERENCE_DIVISION>(L, A, img, scratch, wf); break;
+    case MGC_TERM_DIFFERENCE_POWER: k_build_tiles<FULL, MGC_TERM_DIFFERENCE_POWER>(L, A, img, scratch, wf); break;
+    case MGC_TERM_MAXIMUM_LINEAR: k_build_tiles<FULL, MGC_TERM_MAXIMUM_LINEAR>(L, A, img, scratch, wf); break;
+    case MGC_TERM_MAXIMUM_EXPONENTIAL: k_build_tiles<FULL, MGC_TERM_MAXIMUM_EXPONENTIAL>(L, A, img, scratch, wf); break;
+    case MGC_TERM_MAXIMUM_DIVISION: k_build_tiles<FULL, MGC_TERM_MAXIMUM_DIVISION>(L, A, img, scratch, wf); break;
+    default: k_build_tiles<FULL, MGC_TERM_MAXIMUM_POWER>(L, A, img, scratch, wf); break;
     }
 }
 
@@ -951,6 +996,8 @@ struct mgc_graph {
                               bit2: the wave discharge starts from exact in-tile labels (MGCW_BFS) */
     int wave_grid_dis = 0, wave_grid_rel = 0; /* persistent grids of the wave kernels (waves resident on the device) */
     int tk_dis = MGC_CNT_TICKET_DIS, tk_rel = MGC_CNT_TICKET_REL; /* ticket slot of the next wave launch (alternates) */
+    int pending_zero = -1; /* list counter the schedule asked to clear right after a discharge: the next discharge kernel clears
+                              it (it neither reads nor appends to that list), any other operation flushes it with a memset first */
     int use_filters = 3; /* bit0 absorb, bit1 activate, bit2 reset-suspect go through the tile-level filter.  Bit2 is off:
                             measured on MI355X it doubles the number of global relabels (cause not understood yet) */
     mgc_stats stats{};
@@ -997,14 +1044,26 @@ struct HipDevT {
     hipError_t first_error = hipSuccess;
     float discharge_ms = 0.f, relabel_ms = 0.f;
     int64_t discharge_launches = 0, relabel_launches = 0, readbacks = 0;
+    int last_discharged = -1; /* list consumed by the discharge launched last (see pending_zero) */
     struct Span { int a, b, kind; };
     std::vector<Span> spans;
     void check(hipError_t e) { if (e != hipSuccess && first_error == hipSuccess) first_error = e; }
     int grid(int64_t n) const { return (int)(n < 1 ? 1 : (n < h->grid_cap ? n : h->grid_cap)); }
-    void fill_heights_inf() { check(hipMemsetAsync(h->L.height, 0x3f, (size_t)h->L.ntiles * MGC_TV * sizeof(int32_t), h->stream)); }
-    void zero_count(int i) { check(hipMemsetAsync(h->L.count + i, 0, sizeof(int32_t), h->stream)); }
+    void fill_heights_inf() { flush_zero(); check(hipMemsetAsync(h->L.height, 0x3f, (size_t)h->L.ntiles * MGC_TV * sizeof(int32_t), h->stream)); }
+    void flush_zero()
+    {
+        if (h->pending_zero >= 0) check(hipMemsetAsync(h->L.count + h->pending_zero, 0, sizeof(int32_t), h->stream));
+        h->pending_zero = -1;
+    }
+    void zero_count(int i)
+    {
+        flush_zero();
+        if (!FULL && i == last_discharged) { h->pending_zero = i; last_discharged = -1; return; }
+        check(hipMemsetAsync(h->L.count + i, 0, sizeof(int32_t), h->stream));
+    }
     void read_counts(int* out)
     {
+        flush_zero();
         check(hipMemcpyAsync(h->h_count, h->L.count, MGC_NCOUNT * sizeof(int32_t), hipMemcpyDeviceToHost, h->stream));
         check(hipStreamSynchronize(h->stream));
         memcpy(out, h->h_count, MGC_NCOUNT * sizeof(int32_t));
@@ -1013,6 +1072,7 @@ struct HipDevT {
     int filter_grid() const { const int g = (h->L.ntiles + 255) / 256; return g < 1024 ? g : 1024; }
     void absorb_all()
     {
+        flush_zero();
         if constexpr (FULL) return; /* no outboxes: neighbours are updated in place */
         else if (!(h->use_filters & 1)) { hipLaunchKernelGGL(k_absorb, dim3(grid(h->L.ntiles)), dim3(MGC_TV), 0, h->stream, h->L); check(hipGetLastError()); }
         else {
@@ -1025,6 +1085,7 @@ struct HipDevT {
     }
     void relabel_all(uint32_t epoch, int next)
     {
+        flush_zero();
         const int id = time_begin(1);
         if constexpr (FULL) hipLaunchKernelGGL(k26_relabel_all, dim3(grid(h->L.ntiles)), dim3(MGC_TV), 0, h->stream, h->L, epoch, next);
         else if (!(h->use_filters & 1)) hipLaunchKernelGGL(k_relabel_all, dim3(grid(h->L.ntiles)), dim3(MGC_TV), 0, h->stream, h->L, epoch, next);
@@ -1040,6 +1101,7 @@ struct HipDevT {
     }
     void relabel_list(int lst, uint32_t epoch, int next, int zero_list = -1)
     {
+        flush_zero();
         const int id = time_begin(1);
         if constexpr (FULL) hipLaunchKernelGGL(k26_relabel_list, dim3(grid(h->L.ntiles)), dim3(MGC_TV), 0, h->stream, h->L, lst, epoch, next);
         else if (h->wave_kernels & 2) { hipLaunchKernelGGL(k_relabel_w, dim3(h->wave_grid_rel), dim3(MGCW_LANES), 0, h->stream, h->L, lst, lst, epoch, next, zero_list, 0, h->tk_rel); h->tk_rel ^= 1; }
@@ -1050,6 +1112,7 @@ struct HipDevT {
     }
     void suspect_pass()
     {
+        flush_zero();
         if constexpr (!FULL) {
             hipLaunchKernelGGL(k_suspect_pass, dim3((h->L.ntiles + 255) / 256 < 2048 ? (h->L.ntiles + 255) / 256 : 2048), dim3(256), 0, h->stream, h->L);
             check(hipGetLastError());
@@ -1057,6 +1120,7 @@ struct HipDevT {
     }
     void reset_suspect(uint32_t epoch, int list)
     {
+        flush_zero();
         if constexpr (!FULL) {
             const int id = time_begin(1);
             if (!(h->use_filters & 4)) hipLaunchKernelGGL(k_reset_suspect, dim3(grid((h->L.ntiles + MGC_TV - 1) / MGC_TV)), dim3(MGC_TV), 0, h->stream, h->L, epoch, list);
@@ -1074,6 +1138,7 @@ struct HipDevT {
     }
     void activate_all(uint32_t phase)
     {
+        flush_zero();
         if constexpr (FULL) hipLaunchKernelGGL(k26_activate, dim3(grid(h->L.ntiles)), dim3(MGC_TV), 0, h->stream, h->L, phase);
         else if (!(h->use_filters & 2)) hipLaunchKernelGGL(k_activate, dim3(grid(h->L.ntiles)), dim3(MGC_TV), 0, h->stream, h->L, phase);
         else {
@@ -1086,13 +1151,16 @@ struct HipDevT {
     }
     void discharge(int lst, uint32_t phase, int cycles, int sweeps)
     {
+        const int zero_idx = h->pending_zero; /* cleared inside the kernel: no memset between two colour phases */
+        h->pending_zero = -1;
         const int id = time_begin(0);
         if constexpr (FULL) hipLaunchKernelGGL(k26_discharge, dim3(grid(h->L.ntiles)), dim3(MGC_TV), 0, h->stream, h->L, lst, phase, cycles, sweeps);
-        else if (h->wave_kernels & 1) { hipLaunchKernelGGL(k_discharge_w, dim3(h->wave_grid_dis), dim3(MGCW_LANES), 0, h->stream, h->L, lst, phase, sweeps, (h->wave_kernels & 4) ? MGCW_BFS : 0, h->tk_dis); h->tk_dis ^= 1; }
-        else hipLaunchKernelGGL(k_discharge, dim3(grid(h->L.ntiles)), dim3(MGC_TV), 0, h->stream, h->L, lst, phase, cycles, sweeps);
+        else if (h->wave_kernels & 1) { hipLaunchKernelGGL(k_discharge_w, dim3(h->wave_grid_dis), dim3(MGCW_LANES), 0, h->stream, h->L, lst, phase, sweeps, (h->wave_kernels & 4) ? MGCW_BFS : 0, h->tk_dis, zero_idx); h->tk_dis ^= 1; }
+        else hipLaunchKernelGGL(k_discharge, dim3(grid(h->L.ntiles)), dim3(MGC_TV), 0, h->stream, h->L, lst, phase, cycles, sweeps, zero_idx);
         check(hipGetLastError());
         time_end(id);
         discharge_launches++;
+        last_discharged = lst;
     }
     int time_begin(int kind)
     {
@@ -1730,6 +1798,7 @@ int mgc_maxflow(mgc_handle h, double* flow)
         int rc;
         if (L.ndir == 6) {
             rc = mgc_solve(dev, L, h->params, st);
+            dev.flush_zero();
         } else {
             rc = mgc_solve(dev26, L, h->params, st, mgc_layout26());
             dev.first_error = dev26.first_error;

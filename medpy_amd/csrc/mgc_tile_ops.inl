@@ -266,7 +266,7 @@ MGC_HD void mgc_relabel_tile(X& x, const MgcLattice& L, int tile, uint32_t next_
         if (t == 6) {
             uint32_t dep = 0;
             for (int f = 0; f < 6; ++f) dep |= x.S.depflag[f] ? (1u << f) : 0u;
-            L.status[tile] = (L.status[tile] & ~(63u << MGC_ST_DEP_SHIFT)) | (dep << MGC_ST_DEP_SHIFT);
+            L.status[tile] = (L.status[tile] & ~((63u << MGC_ST_DEP_SHIFT) | MGC_ST_ALLINF)) | (dep << MGC_ST_DEP_SHIFT);
         }
     });
 }
@@ -313,7 +313,7 @@ MGC_HD void mgc_absorb_tile(X& x, const MgcLattice& L, int tile)
 template <class X>
 MGC_HD void mgc_activate_tile(X& x, const MgcLattice& L, int tile, uint32_t phase)
 {
-    if (!mgc_owned(L, tile)) return;
+    if (!mgc_owned(L, tile) || (L.status[tile] & MGC_ST_ALLINF)) return; /* all labels INF: nothing can reach the sink */
     const int64_t base = (int64_t)tile * MGC_TV;
     const bool act = x.any([&](int t) -> bool { return L.excess[base + t] > 0.0 && L.height[base + t] < MGC_HINF; });
     x.par([&](int t) {
@@ -582,7 +582,7 @@ MGC_HD void mgc_reset_suspect_tile(X& x, const MgcLattice& L, int tile, uint32_t
         x.par([&](int t) {
             L.height[(int64_t)tile * MGC_TV + t] = MGC_HINF;
             if (t == 0) {
-                L.status[tile] = st & ~(MGC_ST_SUSPECT | MGC_ST_DIRTY | (63u << MGC_ST_DEP_SHIFT));
+                L.status[tile] = (st & ~(MGC_ST_SUSPECT | MGC_ST_DIRTY | (63u << MGC_ST_DEP_SHIFT))) | MGC_ST_ALLINF;
                 mgc_enqueue(x, L, list, L.rstamp, epoch, tile);
             }
         });

@@ -233,6 +233,14 @@ MGC_HD void mgcw_discharge_impl(W& w, const MgcLattice& L, int tile, uint32_t ph
             if constexpr (K == 7) { const double d = w.S.inbox[5][l]; e(l, K) += d; r[5](l, K) += d; }
         });
     });
+    /* residual planes this discharge changes (bit D): a plane nobody pushed along, received along or absorbed into goes
+     * back to HBM as it came -- so it does not go back at all (a discharge typically moves flow along one or two axes) */
+    uint32_t dirty = 0;
+#pragma unroll
+    for (int f = 0; f < 6; ++f)
+        if (w.any([&](int l) MGCW_INL -> bool { return w.S.inbox[f][l] != 0.0; })) dirty |= 1u << f;
+    bool relabelled = (flags & MGCW_BFS) != 0; /* some label of the tile changed */
+
     /* ---- labels: exact in-tile distances given the frozen halo, or the stored (valid lower-bound) labels ---- */
     if (flags & MGCW_BFS) {
         w.lanes([&](int l) MGCW_INL {
@@ -337,6 +345,7 @@ MGC_HD void mgcw_discharge_impl(W& w, const MgcLattice& L, int tile, uint32_t ph
             mgcw_static_for<4>([&](auto DD) MGCW_INL {
                 constexpr int D = decltype(DD)::value;
                 if (!w.any([&](int l) MGCW_INL -> bool { return can_push(l, KK, DD, hn(l, 4 * J + D)); })) return;
+                dirty |= 3u << (D & ~1);
                 w.lanes([&](int l) MGCW_INL {
                     const int y = l >> 3, x = l & 7;
                     const double delta = push(l, KK, DD, hn(l, 4 * J + D));
@@ -364,6 +373,7 @@ MGC_HD void mgcw_discharge_impl(W& w, const MgcLattice& L, int tile, uint32_t ph
                 else return hz(l, 0);
             };
             if (!w.any([&](int l) MGCW_INL -> bool { return can_push(l, KC, DC, below(l)); })) return;
+            dirty |= 3u << 4;
             w.lanes([&](int l) MGCW_INL {
                 const double delta = push(l, KC, DC, below(l));
                 if constexpr (K > 0) { e(l, K - 1) += delta; r[5](l, K - 1) += delta; }
@@ -378,6 +388,7 @@ MGC_HD void mgcw_discharge_impl(W& w, const MgcLattice& L, int tile, uint32_t ph
                 else return hz(l, 1);
             };
             if (!w.any([&](int l) MGCW_INL -> bool { return can_push(l, KK, DC, above(l)); })) return;
+            dirty |= 3u << 4;
             w.lanes([&](int l) MGCW_INL {
                 const double delta = push(l, KK, DC, above(l));
                 if constexpr (K < 7) { e(l, K + 1) += delta; r[4](l, K + 1) += delta; }
@@ -390,6 +401,7 @@ MGC_HD void mgcw_discharge_impl(W& w, const MgcLattice& L, int tile, uint32_t ph
          * has an admissible arc, so "some slot is still active afterwards" == "another sweep will move something". ---- */
         am = slot_mask();
         if (!am) break;
+        relabelled = true; /* (conservative: some voxel with excess is looked at; nearly always one of them rises) */
         mgcw_static_for<8>([&](auto KK) MGCW_INL {
             constexpr int K = decltype(KK)::value;
             constexpr int J = K & 3;
@@ -460,12 +472,30 @@ MGC_HD void mgcw_discharge_impl(W& w, const MgcLattice& L, int tile, uint32_t ph
             }
             mgcw_static_for<6>([&](auto DD) MGCW_INL {
                 constexpr int D = decltype(DD)::value;
-                w.st(t_rcap + D * MGC_TV, K * 64 + l, r[D](l, K));
                 m |= (r[D](l, K) > 0.0) ? (1 << D) : 0;
             });
             w.st(t_rmask, K * 64 + l, (uint8_t)m);
-            w.st(t_height, K * 64 + l, h(l, K));
         });
+    });
+    mgcw_static_for<6>([&](auto DD) MGCW_INL { /* only the residual planes that changed */
+        constexpr int D = decltype(DD)::value;
+        if (!(dirty & (1u << D))) return;
+        w.lanes([&](int l) MGCW_INL {
+            mgcw_static_for<8>([&](auto KK) MGCW_INL {
+                constexpr int K = decltype(KK)::value;
+                w.st(t_rcap + D * MGC_TV, K * 64 + l, r[D](l, K));
+            });
+        });
+    });
+    if (relabelled) {
+        w.lanes([&](int l) MGCW_INL {
+            mgcw_static_for<8>([&](auto KK) MGCW_INL {
+                constexpr int K = decltype(KK)::value;
+                w.st(t_height, K * 64 + l, h(l, K));
+            });
+        });
+    }
+    w.lanes([&](int l) MGCW_INL {
         /* outbox: plain stores -- the neighbour emptied these slots when it last absorbed, and it always runs (or
          * absorb_all does) between two of our discharges */
 #pragma unroll
@@ -552,7 +582,7 @@ MGC_HD void mgcw_relabel_tile(W& w, const MgcLattice& L, int tile, uint32_t next
             const int nt = mgc_tile_nbr(L, tz, ty, tx, l);
             if (nt >= 0) mgc_enqueue(w, L, next_list, L.rstamp, next_epoch, nt);
         }
-        if (l == 6) L.status[tile] = (L.status[tile] & ~(63u << MGC_ST_DEP_SHIFT)) | (dep << MGC_ST_DEP_SHIFT);
+        if (l == 6) L.status[tile] = (L.status[tile] & ~((63u << MGC_ST_DEP_SHIFT) | MGC_ST_ALLINF)) | (dep << MGC_ST_DEP_SHIFT);
     });
 }
 
