@@ -102,9 +102,21 @@ int mgc_set_regional_probability(mgc_handle h, const void* probability_map, int 
  * graph.py:310-380): nonzero fg -> add_tweights(i, 65535, 0), nonzero bg -> add_tweights(i, 0, 65535). */
 int mgc_set_markers(mgc_handle h, const uint8_t* fg, const uint8_t* bg);
 
+/* The *_linear terms divide by the intensity range of the image (energy_voxel.py:101: max |I|; 174-176:
+ * |max - min| in the image's dtype).  A single handle measures it itself.  A SLAB only holds its own planes, so the
+ * caller reduces the local triples {min, max, max|.|} over the ranks (min, max, max) and hands the global one back
+ * before mgc_build; building a *_linear slab without it fails with MGC_ERR_STATE.  NULL forgets a range set earlier;
+ * mgc_set_boundary does so too. */
+int mgc_get_image_range(mgc_handle h, double* out3);
+int mgc_set_image_range(mgc_handle h, const double* in3);
+
 /* Plug-in path (user supplied energy callables drive GCGraph.set_nweight / set_tweight,
- * graph.py:382-440, 466-498).  Edges must join lattice neighbours; capacities accumulate like
- * sum_edge (graph.h:457-480).  t-weights: tr[n] = merged residual per node, flow_const = the
+ * graph.py:382-440, 466-498).  Edges must join lattice neighbours (checked here: MGC_ERR_UNSUPPORTED
+ * names the first edge that does not; arbitrary graphs go to msg_*); capacities accumulate like
+ * sum_edge (graph.h:457-480): an edge given several times adds up IN CALL ORDER on top of the boundary
+ * term's weight, the same floating point additions as the reference.  One batch per build (a later
+ * batch replaces one that a build already applied); the batch stays with the handle, so a rebuild
+ * applies it again.  t-weights: tr[n] = merged residual per node, flow_const = the
  * part add_tweights folds into the flow (graph.h:416-425); applied before the markers. */
 int mgc_add_edges(mgc_handle h, int64_t n, const int64_t* i, const int64_t* j, const double* cap, const double* rev);
 int mgc_set_tweights_merged(mgc_handle h, const double* tr, double flow_const);

@@ -72,6 +72,8 @@ SIGNATURES = {
     "mgc_what_segment": (_INT, [_VP, _I64, C.POINTER(_INT)]),
     "mgc_get_node_num": (_INT, [_VP, C.POINTER(_I64)]),
     "mgc_set_param": (_INT, [_VP, C.c_char_p, _I64]),
+    "mgc_get_image_range": (_INT, [_VP, _VP]),
+    "mgc_set_image_range": (_INT, [_VP, _VP]),
     "mgc_get_stats": (_INT, [_VP, C.POINTER(Stats)]),
     "mgc_get_profile": (_INT, [_VP, _VP]),
     # Z-slab decomposition (multi-GPU)

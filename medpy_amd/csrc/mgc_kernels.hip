@@ -29,6 +29,8 @@
 #include <stdlib.h>
 #include <string.h>
 
+#include <algorithm>
+#include <map>
 #include <string>
 #include <vector>
 
@@ -770,22 +772,19 @@ MGC_HD int mgc_arc_direction(const MgcLattice& L, int64_t i, int64_t j)
     return c < 13 ? c : c - 1;
 }
 
-/* plug-in path: accumulate explicit lattice edges like sum_edge (graph.h:457-480) */
-__global__ void k_add_edges(MgcLattice L, int64_t n, const int64_t* ei, const int64_t* ej, const double* cap,
-                            const double* rev, int* bad)
+/* plug-in path: explicit lattice edges accumulate like Graph::sum_edge (graph.h:457-480): every arc slot receives its
+ * contributions ONE AFTER THE OTHER in call order, on top of the weight k_build left there -- the same floating point
+ * additions in the same order as the reference, so repeated edges give bit-identical capacities (an atomicAdd per
+ * contribution would add them in a non-deterministic order).  The host sorted the contributions by slot (stable);
+ * run r covers contributions [run[r], run[r + 1]). */
+__global__ void k_add_edges(MgcLattice L, int64_t n_runs, const int64_t* slot, const double* val, const int64_t* run)
 {
-    for (int64_t k = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; k < n; k += (int64_t)gridDim.x * blockDim.x) {
-        const int64_t i = ei[k], j = ej[k];
-        if (i < 0 || j < 0 || i >= L.nvox || j >= L.nvox) { *bad = 1; continue; }
-        const int d = mgc_arc_direction(L, i, j);
-        if (d < 0) { *bad = 1; continue; }
-        const int dr = L.ndir == 6 ? (d ^ 1) : (25 - d);
-        int ti, li, tj, lj;
-        mgc_node_to_tile(L, i, ti, li);
-        mgc_node_to_tile(L, j, tj, lj);
-        const int64_t oi = ((int64_t)ti * L.ndir + d) * MGC_TV + li, oj = ((int64_t)tj * L.ndir + dr) * MGC_TV + lj;
-        atomicAdd(&L.rcap[oi], cap[k]); atomicAdd(&L.cap0[oi], cap[k]);
-        atomicAdd(&L.rcap[oj], rev[k]); atomicAdd(&L.cap0[oj], rev[k]);
+    for (int64_t r = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; r < n_runs; r += (int64_t)gridDim.x * blockDim.x) {
+        const int64_t o = slot[run[r]];
+        double v = L.rcap[o];
+        for (int64_t k = run[r]; k < run[r + 1]; ++k) v += val[k];
+        L.rcap[o] = v;
+        L.cap0[o] = v;
     }
 }
 
@@ -977,7 +976,12 @@ struct mgc_graph {
     double* d_tr_in = nullptr; double flow_const_in = 0;
     /* pending explicit edges (host copy kept until build) */
     MgcBuildArgs build_args{}; /* of the last mgc_build: the built capacities are re-evaluated from it (mgc_built_capacity) */
-    int64_t n_edges = 0; int64_t* d_ei = nullptr; int64_t* d_ej = nullptr; double* d_ecap = nullptr; double* d_erev = nullptr;
+    /* explicit lattice edges (plug-in path), kept until the next build: 2n arc contributions sorted by arc slot, call order
+       preserved inside a slot (Graph::sum_edge adds repeated edges in call order, graph.h:457-480) */
+    int64_t n_edges = 0, n_runs = 0; int64_t* d_eslot = nullptr; double* d_eval = nullptr; int64_t* d_erun = nullptr;
+    bool range_set = false; double range[3] = {0, 0, 0}; /* global min / max / max|.| of the image (mgc_set_image_range) */
+    bool edges_applied = false; /* the stored batch went into the last build (a new mgc_add_edges replaces it) */
+    std::map<const void*, size_t> buf_cap; /* capacity of the buffers mgc_upload manages, keyed by the owning field */
     /* outputs / scratch */
     double* d_tr0 = nullptr; double* d_part = nullptr; double* d_part2 = nullptr; double* d_scalar = nullptr; uint8_t* d_labels = nullptr;
     int32_t* h_count = nullptr; /* pinned */
@@ -1605,7 +1609,7 @@ int mgc_destroy(mgc_handle h)
     void* ptrs[] = {L.rcap, L.cap0, L.excess, L.sink, L.height, L.rmask, L.rmask32, L.obox, L.oflags, L.list[0], L.list[1], L.list[2],
                     L.list[3], L.list[4], L.list[5], L.list[6], L.list[7], L.list[8], L.list[9], L.list[10], L.list[11], L.list[12],
                     L.list[13], L.list[14], L.list[15], L.list[16], L.list[17], L.count, L.stamp, L.rstamp, L.status, h->d_tr0, h->d_part, h->d_part2, h->d_scalar,
-                    h->d_labels, h->d_image, h->d_prob, h->d_fg, h->d_bg, h->d_tr_in, h->d_ei, h->d_ej, h->d_ecap, h->d_erev, h->d_halo, h->d_xchg[0], h->d_xchg[1], h->d_xchg[2], h->d_xchg[3], h->d_cnt64};
+                    h->d_labels, h->d_image, h->d_prob, h->d_fg, h->d_bg, h->d_tr_in, h->d_eslot, h->d_eval, h->d_erun, h->d_halo, h->d_xchg[0], h->d_xchg[1], h->d_xchg[2], h->d_xchg[3], h->d_cnt64};
     for (void* p : ptrs)
         if (p) (void)hipFree(p);
     if (h->h_count) (void)hipHostFree(h->h_count);
@@ -1619,11 +1623,22 @@ int mgc_destroy(mgc_handle h)
     return MGC_OK;
 }
 
+/* host -> device copy into a buffer owned by the handle; the buffer grows when a later call needs more (a second image of
+ * a wider dtype, a larger batch of explicit edges) */
 static int mgc_upload(mgc_handle h, void** dst, const void* src, size_t bytes)
 {
+    size_t& cap = h->buf_cap[(const void*)dst];
+    if (*dst && cap < bytes) {
+        MGC_HIP(h, hipStreamSynchronize(h->stream));
+        MGC_HIP(h, hipFree(*dst));
+        h->device_bytes -= (int64_t)cap;
+        *dst = nullptr;
+        cap = 0;
+    }
     if (!*dst) {
         MGC_HIP(h, hipMalloc(dst, bytes));
         h->device_bytes += (int64_t)bytes;
+        cap = bytes;
     }
     MGC_HIP(h, hipMemcpyAsync(*dst, src, bytes, hipMemcpyHostToDevice, h->stream));
     MGC_HIP(h, hipStreamSynchronize(h->stream));
@@ -1636,6 +1651,7 @@ int mgc_set_boundary(mgc_handle h, int term, const void* image, int dtype, doubl
     if (term < MGC_TERM_NONE || term > MGC_TERM_MAXIMUM_POWER) return mgc_fail(h, MGC_ERR_INVALID, "unknown boundary term %d", term);
     MGC_HIP(h, hipSetDevice(h->device));
     h->term = term;
+    h->range_set = false; /* a range handed over for the previous image does not describe this one */
     h->built = h->solved = false;
     if (term == MGC_TERM_NONE) return MGC_OK;
     const size_t es = mgc_dtype_size(dtype);
@@ -1685,18 +1701,71 @@ int mgc_set_tweights_merged(mgc_handle h, const double* tr, double flow_const)
     return mgc_upload(h, (void**)&h->d_tr_in, tr, (size_t)h->nvox * sizeof(double));
 }
 
+int mgc_get_image_range(mgc_handle h, double* out3)
+{
+    if (!h || !out3) return MGC_ERR_INVALID;
+    if (!h->d_image) return mgc_fail(h, MGC_ERR_STATE, "mgc_get_image_range before mgc_set_boundary");
+    MGC_HIP(h, hipSetDevice(h->device));
+    const hipError_t e = mgc_image_range((const void*)h->d_image, h->img_dtype, h->nvox, h->d_part, h->stream, &out3[0], &out3[1], &out3[2]);
+    MGC_HIP(h, e);
+    return MGC_OK;
+}
+
+int mgc_set_image_range(mgc_handle h, const double* in3)
+{
+    if (!h) return MGC_ERR_INVALID;
+    h->range_set = in3 != nullptr;
+    if (in3) { h->range[0] = in3[0]; h->range[1] = in3[1]; h->range[2] = in3[2]; }
+    h->built = h->solved = false;
+    return MGC_OK;
+}
+
 int mgc_add_edges(mgc_handle h, int64_t n, const int64_t* i, const int64_t* j, const double* cap, const double* rev)
 {
     if (!h || n < 0 || (n && (!i || !j || !cap || !rev))) return MGC_ERR_INVALID;
-    if (h->n_edges) return mgc_fail(h, MGC_ERR_UNSUPPORTED, "mgc_add_edges: one batch per build (concatenate on the host)");
+    if (h->n_edges && !h->edges_applied) return mgc_fail(h, MGC_ERR_UNSUPPORTED, "mgc_add_edges: one batch per build (concatenate on the host)");
+    h->n_edges = h->n_runs = 0; /* a batch that a build already applied is replaced */
+    h->edges_applied = false;
     if (n == 0) return MGC_OK;
     MGC_HIP(h, hipSetDevice(h->device));
+    const MgcLattice& L = h->L;
+    /* every edge feeds two arc slots: i -> j gets cap, j -> i gets rev (sum_edge, graph.h:457-480) */
+    std::vector<int64_t> slot((size_t)(2 * n));
+    std::vector<double> val((size_t)(2 * n));
+    for (int64_t k = 0; k < n; ++k) {
+        if (i[k] < 0 || j[k] < 0 || i[k] >= L.nvox || j[k] >= L.nvox)
+            return mgc_fail(h, MGC_ERR_INVALID, "mgc_add_edges: edge %lld joins nodes %lld and %lld outside 0..%lld", (long long)k, (long long)i[k], (long long)j[k], (long long)L.nvox - 1);
+        const int d = mgc_arc_direction(L, i[k], j[k]);
+        if (d < 0)
+            return mgc_fail(h, MGC_ERR_UNSUPPORTED, "mgc_add_edges: edge %lld (%lld, %lld) does not join lattice neighbours (use the sparse-graph solver, msg_*)",
+                            (long long)k, (long long)i[k], (long long)j[k]);
+        const int dr = L.ndir == 6 ? (d ^ 1) : (25 - d);
+        int ti, li, tj, lj;
+        mgc_node_to_tile(L, i[k], ti, li);
+        mgc_node_to_tile(L, j[k], tj, lj);
+        slot[(size_t)(2 * k)] = ((int64_t)ti * L.ndir + d) * MGC_TV + li;
+        val[(size_t)(2 * k)] = cap[k];
+        slot[(size_t)(2 * k + 1)] = ((int64_t)tj * L.ndir + dr) * MGC_TV + lj;
+        val[(size_t)(2 * k + 1)] = rev[k];
+    }
+    std::vector<int64_t> order((size_t)(2 * n));
+    for (size_t k = 0; k < order.size(); ++k) order[k] = (int64_t)k;
+    std::stable_sort(order.begin(), order.end(), [&](int64_t a, int64_t b) { return slot[(size_t)a] < slot[(size_t)b]; });
+    std::vector<int64_t> sslot(order.size()), run;
+    std::vector<double> sval(order.size());
+    for (size_t k = 0; k < order.size(); ++k) {
+        sslot[k] = slot[(size_t)order[k]];
+        sval[k] = val[(size_t)order[k]];
+        if (k == 0 || sslot[k] != sslot[k - 1]) run.push_back((int64_t)k);
+    }
+    const int64_t n_runs = (int64_t)run.size();
+    run.push_back((int64_t)order.size());
     int rc;
-    if ((rc = mgc_upload(h, (void**)&h->d_ei, i, (size_t)n * sizeof(int64_t)))) return rc;
-    if ((rc = mgc_upload(h, (void**)&h->d_ej, j, (size_t)n * sizeof(int64_t)))) return rc;
-    if ((rc = mgc_upload(h, (void**)&h->d_ecap, cap, (size_t)n * sizeof(double)))) return rc;
-    if ((rc = mgc_upload(h, (void**)&h->d_erev, rev, (size_t)n * sizeof(double)))) return rc;
+    if ((rc = mgc_upload(h, (void**)&h->d_eslot, sslot.data(), sslot.size() * sizeof(int64_t)))) return rc;
+    if ((rc = mgc_upload(h, (void**)&h->d_eval, sval.data(), sval.size() * sizeof(double)))) return rc;
+    if ((rc = mgc_upload(h, (void**)&h->d_erun, run.data(), run.size() * sizeof(int64_t)))) return rc;
     h->n_edges = n;
+    h->n_runs = n_runs;
     h->built = h->solved = false;
     return MGC_OK;
 }
@@ -1713,8 +1782,17 @@ int mgc_build(mgc_handle h)
     if (A.term == MGC_TERM_DIFFERENCE_EXPONENTIAL || A.term == MGC_TERM_MAXIMUM_EXPONENTIAL) A.p0 = pow(h->sigma, 2); /* math.pow(sigma, 2) */
     if (A.term == MGC_TERM_DIFFERENCE_LINEAR || A.term == MGC_TERM_MAXIMUM_LINEAR) {
         double mn, mx, ma;
-        const hipError_t e = mgc_image_range((const void*)h->d_image, h->img_dtype, h->nvox, h->d_part, h->stream, &mn, &mx, &ma);
-        MGC_HIP(h, e);
+        if (h->range_set) {
+            mn = h->range[0]; mx = h->range[1]; ma = h->range[2];
+        } else if (h->nranks > 1) {
+            /* a slab only sees its own planes: normalising by the local range would give the two sides of a slab border
+             * different capacities for the same arc */
+            return mgc_fail(h, MGC_ERR_STATE, "the *_linear terms normalise by the intensity range of the WHOLE volume: reduce "
+                                              "mgc_get_image_range over the ranks and hand the result to mgc_set_image_range before mgc_build");
+        } else {
+            const hipError_t e = mgc_image_range((const void*)h->d_image, h->img_dtype, h->nvox, h->d_part, h->stream, &mn, &mx, &ma);
+            MGC_HIP(h, e);
+        }
         A.p0 = (A.term == MGC_TERM_MAXIMUM_LINEAR) ? ma : mgc_range_in_dtype(mn, mx, h->img_dtype); /* energy_voxel.py:101 / 174-176 */
     }
     A.has_spacing = h->has_spacing;
@@ -1744,10 +1822,8 @@ int mgc_build(mgc_handle h)
     mgc_sum_partials(h, (int64_t)L.ntiles, h->d_scalar);
     MGC_HIP(h, hipGetLastError());
     if (h->n_edges) {
-        int* bad = (int*)(h->d_scalar + 4);
-        MGC_HIP(h, hipMemsetAsync(bad, 0, sizeof(int), h->stream));
-        hipLaunchKernelGGL(k_add_edges, dim3(1024), dim3(256), 0, h->stream, L, h->n_edges, (const int64_t*)h->d_ei,
-                           (const int64_t*)h->d_ej, (const double*)h->d_ecap, (const double*)h->d_erev, bad);
+        hipLaunchKernelGGL(k_add_edges, dim3(1024), dim3(256), 0, h->stream, L, h->n_runs, (const int64_t*)h->d_eslot,
+                           (const double*)h->d_eval, (const int64_t*)h->d_erun);
         MGC_HIP(h, hipGetLastError());
         hipLaunchKernelGGL(k_refresh_mask, dim3(grid), dim3(MGC_TV), 0, h->stream, L);
         MGC_HIP(h, hipGetLastError());
@@ -1770,12 +1846,9 @@ int mgc_build(mgc_handle h)
     MGC_HIP(h, hipEventElapsedTime(&ms, h->ev[0], h->ev[1]));
     h->stats.build_ms = ms;
     h->flow_const = h->h_scalar[0] + (h->d_tr_in ? h->flow_const_in : 0.0);
-    if (h->n_edges) {
-        int bad = 0;
-        memcpy(&bad, h->h_scalar + 4, sizeof(int));
-        h->n_edges = 0;
-        if (bad) return mgc_fail(h, MGC_ERR_UNSUPPORTED, "mgc_add_edges: an edge does not join lattice neighbours");
-    }
+    /* the explicit edges stay with the handle: a rebuild (new markers, another sigma) applies them again; mgc_add_edges
+     * after a build replaces them (one batch per build) */
+    h->edges_applied = h->n_edges != 0;
     h->built = true;
     h->solved = false;
     h->labels_on_host = false;

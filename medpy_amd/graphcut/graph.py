@@ -645,8 +645,30 @@ class GCGraph(object):
         for node, (twsource, twsink) in enumerate(tweights):
             self.set_tweight(node, twsource, twsink)
 
+    def __edges_join_lattice_neighbours(self):
+        """do all explicit edges join neighbours of the voxel lattice (of the neighbourhood in use)?  The tile solver keeps
+        exactly those arcs; anything else (the reference accepts arbitrary node pairs, graph.py:382-440) goes to the
+        sparse-graph solver."""
+        shape = self.__shape if self.__lattice_shape is None else self.__lattice_shape
+        if shape is None or not self.__edge_i:
+            return True
+        i = numpy.asarray(self.__edge_i, dtype=numpy.int64)
+        j = numpy.asarray(self.__edge_j, dtype=numpy.int64)
+        n = int(numpy.prod(shape))
+        if i.max() >= n or j.max() >= n:
+            return False
+        ci = numpy.stack(numpy.unravel_index(i, shape))
+        cj = numpy.stack(numpy.unravel_index(j, shape))
+        d = numpy.abs(ci - cj)
+        full = self.__connectivity not in (None, 2 * len(shape))
+        ok = (d.max(axis=0) == 1) if full else (d.sum(axis=0) == 1)
+        return bool(ok.all())
+
     def get_graph(self):
         """Builds the residual lattice in HBM (once) and returns the solver object."""
+        if self.__graph is None and not self.__general and self.__edge_i and len(self.__shape or ()) <= 3 \
+                and not self.__edges_join_lattice_neighbours():
+            self.__general = True  # a plug-in term added an edge between voxels that are not neighbours
         if self.__graph is None and self.__general:
             self.__graph = self.__sparse_graph()
         if self.__graph is None and self.__lattice_shape is not None:

@@ -59,6 +59,10 @@ class LoopbackExchange(object):
         """values: one number (or vector) per local slab -> global sum"""
         return np.sum(np.asarray(values, dtype=np.float64), axis=0)
 
+    def allreduce_max(self, values):
+        """values: one vector per local slab -> element-wise global maximum"""
+        return np.max(np.asarray(values, dtype=np.float64), axis=0)
+
     def global_counts(self):
         """the 16 solver counters summed over every slab of the volume"""
         return np.sum([s.read_counts().astype(np.int64) for s in self.slabs], axis=0)
@@ -118,6 +122,11 @@ class DistExchange(object):
         out = t.cpu().numpy()
         return out if out.size > 1 else float(out[0])
 
+    def allreduce_max(self, values):
+        t = self.torch.as_tensor(np.max(np.asarray(values, dtype=np.float64), axis=0), dtype=self.torch.float64).reshape(-1).to(self.dev)
+        self.dist.all_reduce(t, op=self.dist.ReduceOp.MAX, group=self.group)
+        return t.cpu().numpy()
+
     def global_counts(self):
         return self.allreduce_sum([self.slabs[0].read_counts().astype(np.float64)]).astype(np.int64)
 
@@ -149,6 +158,26 @@ class RcclExchange(object):
         self.dist.all_reduce(t, group=self.group)
         out = t.numpy()
         return out if out.size > 1 else float(out[0])
+
+    def allreduce_max(self, values):
+        t = self.torch.as_tensor(np.max(np.asarray(values, dtype=np.float64), axis=0), dtype=self.torch.float64).reshape(-1)
+        self.dist.all_reduce(t, op=self.dist.ReduceOp.MAX, group=self.group)
+        return t.numpy()
+
+
+def sync_image_range(slabs, ex):
+    """The *_linear boundary terms normalise by the intensity range of the WHOLE volume (energy_voxel.py:101, 174-176):
+    reduce the slabs' local {min, max, max|.|} over all ranks and hand every slab the global triple.  Call between
+    set_boundary() and build(); a no-op for slabs without this notion (the host simulator is handed finished weights)."""
+    local = []
+    for s in slabs:
+        if not hasattr(s, "image_range"):
+            return
+        mn, mx, ma = s.image_range()
+        local.append([-mn, mx, ma])
+    g = np.asarray(ex.allreduce_max(local), dtype=np.float64).reshape(-1)
+    for s in slabs:
+        s.set_image_range(-g[0], g[1], g[2])
 
 
 def solve_slabs(slabs, ex, rounds_per_relabel=8, max_cycles=1, max_sweeps=None, max_outer=100000, check_rounds=4, relabel_batch=8,
@@ -303,6 +332,15 @@ class HipSlab(object):
         self._call("mgc_set_boundary", _lib.TERM_IDS[term], _lib.ptr(image), _lib.DTYPE_IDS[image.dtype],
                    float(sigma) if sigma is not None else 0.0, sp)
 
+    def image_range(self):
+        out = np.zeros(3, dtype=np.float64)
+        self._call("mgc_get_image_range", self._lib.ptr(out))
+        return float(out[0]), float(out[1]), float(out[2])
+
+    def set_image_range(self, mn, mx, maxabs):
+        v = np.asarray([mn, mx, maxabs], dtype=np.float64)
+        self._call("mgc_set_image_range", self._lib.ptr(v))
+
     def set_markers(self, fg_local, bg_local):
         fg = np.ascontiguousarray(fg_local, dtype=np.uint8)
         bg = np.ascontiguousarray(bg_local, dtype=np.uint8)
@@ -393,8 +431,12 @@ def graphcut_voxel_slabs(image, fg, bg, term="difference_exponential", sigma=Non
         if regional is not None:  # (probability map, alpha): regional_probability_map, energy_voxel.py:33-65
             s.set_regional(np.asarray(regional[0])[sl], regional[1])
         s.set_markers(fg[sl], bg[sl])
+    ex = LoopbackExchange(slabs)
+    if term.endswith("linear"):
+        sync_image_range(slabs, ex)
+    for s in slabs:
         s.build()
-    st = solve_slabs(slabs, LoopbackExchange(slabs), **schedule)
+    st = solve_slabs(slabs, ex, **schedule)
     parts = [s.finish() for s in slabs]
     labels = np.concatenate([p[0] for p in parts], axis=0)
     flow = float(sum(p[1] for p in parts))

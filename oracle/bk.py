@@ -67,6 +67,8 @@ def _lib(kind):
         "get_edge": (dbl, [vp, i64, i64]),
         "get_node_num": (i64, [vp]),
         "get_arc_num": (i64, [vp]),
+        "export": (None, [vp, np.ctypeslib.ndpointer(np.int32, flags="C_CONTIGUOUS"), np.ctypeslib.ndpointer(np.int32, flags="C_CONTIGUOUS"),
+                          pf64, pf64]),
     }
     ns = {}
     for name, (res, args) in sig.items():
@@ -146,3 +148,12 @@ class BKGraph:
 
     def get_arc_num(self):
         return self._f["get_arc_num"](self._h)
+
+    def export(self):
+        """(tail, head, rcap, trcap): every arc in allocation order (sisters adjacent) with its residual capacity, and the
+        residual t-links (> 0: source -> node, < 0: node -> sink) -- the residual graph after maxflow()"""
+        na = int(self.get_arc_num())
+        tail, head = np.empty(na, np.int32), np.empty(na, np.int32)
+        rcap, trcap = np.empty(na, np.float64), np.empty(self.nodes, np.float64)
+        self._f["export"](self._h, tail, head, rcap, trcap)
+        return tail, head, rcap, trcap

@@ -516,3 +516,16 @@ double  bkport_get_edge(void* h, int64_t i, int64_t j)
 int64_t bkport_get_node_num(void* h) { return ((bkport*)h)->n_nodes; }
 int64_t bkport_get_arc_num(void* h) { return ((bkport*)h)->n_arcs; }
 int     bkport_oom(void* h) { return ((bkport*)h)->oom; }
+
+/* residual graph read-out for the ambiguity check (oracle/cutcheck.py): all arcs in allocation order (sister arcs are
+ * adjacent: a ^ 1) with their residual capacities, and the residual t-links; same contract as bkref_export */
+void bkport_export(void* h, int32_t* tail, int32_t* head, double* rcap, double* trcap)
+{
+    const bkport* g = (const bkport*)h;
+    for (int32_t a = 0; a < g->n_arcs; ++a) {
+        tail[a] = g->head[a ^ 1];
+        head[a] = g->head[a];
+        rcap[a] = g->rcap[a];
+    }
+    for (int32_t i = 0; i < g->n_nodes; ++i) trcap[i] = g->trcap[i];
+}

@@ -1,0 +1,114 @@
+"""Principled parity relaxation for tie-degenerate inputs.  TEST INFRASTRUCTURE ONLY.
+
+The reference reports T = {nodes that can reach the sink in the residual graph of its maximum flow}
+(what_segment(), reference lib/maxflow/src/graph.h:561-571).  In exact arithmetic that set is unique; in floating
+point a residual that comes out as 0.0 under one summation order is a few ulp under another, so two correct solvers
+may disagree on nodes whose membership hinges on such arcs -- and only on those.  This module
+
+* computes, from the oracle's residual graph, the set every minimum cut agrees on (reachable from the source / able
+  to reach the sink through arcs whose residual exceeds ``tol`` times the capacity of the arc pair) and its
+  complement, the AMBIGUITY SET (``ambiguity``);
+* evaluates the capacity of a cut in exact rational arithmetic (``exact_cut_value``), so that "both labelings are
+  minimum cuts" can be asserted without any tolerance on small cases;
+* ``assert_labels_equivalent`` bundles the two for the tests: labels equal, or every differing voxel ambiguous, the two
+  cut capacities equal, and the number of differing voxels within the bound the test states.
+"""
+import ctypes as C
+import os
+import subprocess
+from fractions import Fraction
+
+import numpy as np
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+_SO = os.path.join(_HERE, "libcutcheck.so")
+_lib = None
+
+
+def _load():
+    global _lib
+    if _lib is None:
+        src = os.path.join(_HERE, "cutcheck.c")
+        if not os.path.exists(_SO) or os.path.getmtime(_SO) < os.path.getmtime(src):
+            subprocess.check_call(["gcc", "-O2", "-std=c99", "-Wall", "-fPIC", "-shared", "-o", _SO, src])
+        _lib = C.CDLL(_SO)
+        pi32 = np.ctypeslib.ndpointer(np.int32, flags="C_CONTIGUOUS")
+        pf64 = np.ctypeslib.ndpointer(np.float64, flags="C_CONTIGUOUS")
+        pu8 = np.ctypeslib.ndpointer(np.uint8, flags="C_CONTIGUOUS")
+        _lib.cut_reach.restype = C.c_int
+        _lib.cut_reach.argtypes = [C.c_int64, C.c_int64, pi32, pi32, pf64, pf64, C.c_double, C.c_double, pu8, pu8]
+    return _lib
+
+
+def ambiguity(graph, tol=1e-12):
+    """(from_source, to_sink, ambiguous) boolean node arrays from the residual graph of a solved oracle graph
+    (oracle/bk.py:BKGraph after maxflow()).  ``tol``: an arc counts as saturated when its residual is at most ``tol`` times
+    the largest arc-pair capacity at either of its end nodes (the rounding granularity of their excess; see cutcheck.c);
+    t-links likewise relative to the largest t-link."""
+    tail, head, rcap, trcap = graph.export()
+    n = trcap.size
+    fs, ts = np.zeros(n, np.uint8), np.zeros(n, np.uint8)
+    tol_t = tol * float(np.max(np.abs(trcap), initial=0.0))
+    assert _load().cut_reach(n, tail.size, tail, head, rcap, trcap, float(tol), tol_t, fs, ts) == 0
+    fs, ts = fs.astype(bool), ts.astype(bool)
+    return fs, ts, ~(fs | ts)
+
+
+def exact_cut_value(source_side, i, j, cap, rev, tr):
+    """Capacity of the cut (S, V \\ S), S = ``source_side`` (bool per node), in exact rational arithmetic.
+    Edges (i[k], j[k]) with capacities cap[k] (i -> j) and rev[k] (j -> i); tr[k] > 0: source -> node capacity, < 0:
+    node -> sink capacity (the merged t-link the reference keeps, graph.h:416-425; its constant part is common to all
+    cuts and left out)."""
+    s = np.asarray(source_side, dtype=bool).ravel()
+    i, j = np.asarray(i), np.asarray(j)
+    total = Fraction(0)
+    fwd = s[i] & ~s[j]
+    bwd = s[j] & ~s[i]
+    for c in np.asarray(cap, dtype=np.float64)[fwd]:
+        total += Fraction(float(c))
+    for c in np.asarray(rev, dtype=np.float64)[bwd]:
+        total += Fraction(float(c))
+    tr = np.asarray(tr, dtype=np.float64).ravel()
+    for c in tr[(tr > 0) & ~s]:   # source -> node arc cut when the node is on the sink side
+        total += Fraction(float(c))
+    for c in tr[(tr < 0) & s]:    # node -> sink arc cut when the node is on the source side
+        total += Fraction(float(-c))
+    return total
+
+
+def lattice_edges(shape, weights):
+    """(i, j, w) of the 2*ndim-neighbourhood lattice from the per-axis weight arrays of oracle/energy_numpy.py"""
+    shape = tuple(int(x) for x in shape)
+    ids = np.arange(int(np.prod(shape)), dtype=np.int64).reshape(shape)
+    ii, jj, ww = [], [], []
+    for a, w in enumerate(weights):
+        lo = [slice(None)] * len(shape)
+        hi = [slice(None)] * len(shape)
+        lo[a], hi[a] = slice(0, shape[a] - 1), slice(1, shape[a])
+        ii.append(ids[tuple(lo)].ravel()); jj.append(ids[tuple(hi)].ravel()); ww.append(np.asarray(w, dtype=np.float64).ravel())
+    return np.concatenate(ii), np.concatenate(jj), np.concatenate(ww)
+
+
+def assert_labels_equivalent(labels, ref_cut, max_differing, exact=None, tol=1e-12):
+    """``labels``: bool array, True = source side (the CLI's 1), as the HIP path returns them; ``ref_cut``: an
+    oracle/pipeline.py:Cut (solved).  Passes when the labels are identical, or when (a) no more than ``max_differing``
+    voxels differ, (b) every one of them lies in the ambiguity set of the oracle's residual graph.  ``exact`` =
+    (i, j, cap, rev, tr): additionally the capacities of the two cuts, each evaluated in exact rational arithmetic and
+    then rounded ONCE to float64, must be the same number.  (Ties between equal weights make them equal as rationals; a
+    flipped voxel next to DBL_MIN-floored weights changes the rational by a few 1e-308, far below one ulp of the cut --
+    and anything a solver could get wrong changes it by a weight, i.e. by many ulp.)"""
+    labels = np.asarray(labels, dtype=bool)
+    ref = np.asarray(ref_cut.labels, dtype=bool)
+    diff = (labels != ref).ravel()
+    nbad = int(diff.sum())
+    if nbad == 0:
+        return 0
+    assert nbad <= max_differing, "%d voxels differ from the reference (bound %d)" % (nbad, max_differing)
+    fs, ts, amb = ambiguity(ref_cut.graph, tol)
+    outside = diff & ~amb
+    assert not outside.any(), "%d differing voxels are NOT ambiguous (reachable from the source: %d, can reach the sink: %d)" % (
+        int(outside.sum()), int((outside & fs).sum()), int((outside & ts).sum()))
+    if exact is not None:
+        a, b = exact_cut_value(labels, *exact), exact_cut_value(ref, *exact)
+        assert float(a) == float(b), "cut capacities differ: %r vs %r (by %r)" % (float(a), float(b), float(a - b))
+    return nbad

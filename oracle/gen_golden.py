@@ -238,9 +238,54 @@ def main_labels():
     print("reference_labels.npz", os.path.getsize(os.path.join(OUT, "reference_labels.npz")))
 
 
+def main_large():
+    """Large synthetic volumes (the sizes the metric is quoted on).  The reference's Python loop would issue
+    4e8 set_nweight calls at 512^3, so these come from the compiled UNMODIFIED reference solver (oracle/_ref, built from
+    /root/reference by oracle/Makefile) fed the NumPy restatement of the energies (pinned bitwise against the reference's
+    own Python by tests/test_oracle_golden.py).  Stored: SHA-256 of the packed label volume, flow, foreground count.
+
+        python oracle/gen_golden.py large [case ...]      (cases: see CASES; default all; 512^3 needs ~40 GB of RAM)
+    """
+    import hashlib
+    import json
+    import time
+    from medpy_amd import synthetic
+    from oracle import bk, pipeline
+    assert bk.available("ref"), "needs the compiled reference (oracle/_ref): run where /root/reference exists"
+    CASES = {
+        "sphere_512_6": dict(gen="sphere", shape=(512, 512, 512), conn=6, regional=False),
+        "sphere_256_6": dict(gen="sphere", shape=(256, 256, 256), conn=6, regional=False),
+        "hard_256_6": dict(gen="hard", shape=(256, 256, 256), conn=6, regional=False),
+        "sphere_128_26": dict(gen="sphere", shape=(128, 128, 128), conn=26, regional=False),
+        "sphere_256_26": dict(gen="sphere", shape=(256, 256, 256), conn=26, regional=False),
+        "config3_256_26_regional": dict(gen="sphere", shape=(256, 256, 256), conn=26, regional=True),
+    }
+    path = os.path.join(OUT, "reference_large.json")
+    store = json.load(open(path)) if os.path.exists(path) else {}
+    for name in (sys.argv[2:] or list(CASES)):
+        c = CASES[name]
+        s = getattr(synthetic, c["gen"])(c["shape"])
+        kw = {}
+        if c["regional"]:
+            r = synthetic.regional(c["shape"])
+            kw = dict(prob=r["prob"], alpha=r["alpha"])
+        t0 = time.time()
+        cut = pipeline.graphcut_voxel(s["fg"], s["bg"], term=s["term"], image=s["image"], sigma=s["sigma"], kind="ref",
+                                      connectivity=c["conn"] if c["conn"] != 6 else None, **kw)
+        lab = np.packbits(cut.labels.astype(np.uint8).ravel())
+        store[name] = {"gen": c["gen"], "shape": list(c["shape"]), "connectivity": c["conn"], "regional": c["regional"],
+                       "sha256_packed_labels": hashlib.sha256(lab.tobytes()).hexdigest(), "flow": cut.flow,
+                       "foreground_voxels": int(cut.labels.sum()), "oracle_seconds": round(time.time() - t0, 1)}
+        print(name, store[name], flush=True)
+        del cut, lab
+        json.dump(store, open(path, "w"), indent=1, sort_keys=True)
+
+
 if __name__ == "__main__":
     if len(sys.argv) > 1 and sys.argv[1] == "b0":
         main_b0()
+    elif len(sys.argv) > 1 and sys.argv[1] == "large":
+        main_large()
     elif len(sys.argv) > 1 and sys.argv[1] == "labels":
         main_labels()
     else:

@@ -95,4 +95,21 @@ double bkref_get_edge(void* h, int64_t i, int64_t j) { return ((GraphD*)h)->get_
 int64_t bkref_get_node_num(void* h) { return ((GraphD*)h)->get_node_num(); }
 int64_t bkref_get_arc_num(void* h) { return ((GraphD*)h)->get_arc_num(); }
 
+/* residual graph read-out for the ambiguity check (oracle/cutcheck.py): all arcs in allocation order (sister arcs are
+ * adjacent: 2k, 2k + 1, graph.h:428-454) with their residual capacities (graph.h:539-543), and the residual t-links */
+void bkref_export(void* h, int32_t* tail, int32_t* head, double* rcap, double* trcap)
+{
+    GraphD* g = (GraphD*)h;
+    const int64_t na = g->get_arc_num();
+    GraphD::arc_id a = na ? g->get_first_arc() : NULL;
+    for (int64_t k = 0; k < na; ++k) {
+        int i, j;
+        g->get_arc_ends(a, i, j);
+        tail[k] = i; head[k] = j; rcap[k] = g->get_rcap(a);
+        a = g->get_next_arc(a);
+    }
+    const int64_t nn = g->get_node_num();
+    for (int64_t k = 0; k < nn; ++k) trcap[k] = g->get_trcap((int)k);
+}
+
 } /* extern "C" */

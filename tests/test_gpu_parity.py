@@ -4,11 +4,18 @@
      same seeded inputs.
 Bars: labels bit-exact; t-links bit-exact; n-link energies bit-exact for the terms made of
 IEEE basic operations (linear / division), |delta| <= 1e-6 for exp / pow (libm vs OCML);
-flow relative 1e-9."""
+flow relative 1e-9.
+
+Tie-degenerate inputs (integer-valued images, the maximum_* terms): several minimum cuts exist EXACTLY and which one a
+floating point solver reports hinges on its rounding history.  There the tests do not accept "a few" differing voxels:
+they require (oracle/cutcheck.py) that every differing voxel lies in the AMBIGUITY SET of the reference's own residual
+graph (neither reachable from the source nor able to reach the sink once residuals of a few ulp count as saturated),
+that the two cuts have exactly the same capacity in rational arithmetic, and that their number stays within the bound
+observed on MI355X."""
 import numpy as np
 import pytest
 
-from oracle import bk, energy_numpy, pipeline
+from oracle import bk, cutcheck, energy_numpy, pipeline
 
 pytestmark = pytest.mark.gpu
 
@@ -119,13 +126,21 @@ def test_small_volumes_all_terms(golden_small, case, term):
     np.testing.assert_array_equal(g.tweights().ravel(), g0["trcap"])
     flow = g.maxflow()
     assert flow == pytest.approx(float(g0["flow"]), rel=1e-9)  # the cut found IS a minimum cut
-    nbad = int((g.labels() != g0["labels"].astype(bool)).sum())
-    if _tie_degenerate(term, top["image"]):
-        # several minimum cuts exist and which one a solver reports hinges on its rounding history
-        # (DESIGN.md "Parity limits"): require an equally cheap cut and at most a few ambiguous voxels
-        assert nbad <= max(3, top["image"].size // 25), nbad
-    else:
-        assert nbad == 0
+    labels = g.labels()
+    if (labels != g0["labels"].astype(bool)).any():
+        assert _tie_degenerate(term, top["image"]), "labels differ on an input without exact ties"
+        _assert_equivalent_to_reference(labels, top, term, sigma, spacing, g0, max_differing=3)
+
+
+def _assert_equivalent_to_reference(labels, top, term, sigma, spacing, g0, max_differing):
+    """the oracle re-solves the case (its labels are the fixture's, checked), then every differing voxel must be ambiguous
+    in ITS residual graph and the two cuts must cost exactly the same (rational arithmetic)"""
+    ref = pipeline.graphcut_voxel(top["fg"], top["bg"], term=term, image=top["image"], sigma=sigma, spacing=spacing)
+    np.testing.assert_array_equal(ref.labels, g0["labels"].astype(bool))
+    w = energy_numpy.boundary_weights(term, top["image"], sigma, spacing)
+    i, j, ww = cutcheck.lattice_edges(top["image"].shape, w)
+    nbad = cutcheck.assert_labels_equivalent(labels, ref, max_differing, exact=(i, j, ww, ww, g0["trcap"]))
+    print("tie-degenerate case: %d ambiguous voxel(s) labelled differently, cut capacities exactly equal" % nbad)
 
 
 def _tie_degenerate(term, image):
@@ -147,8 +162,10 @@ def test_4d_volume_against_the_reference(golden_small, term):
     np.testing.assert_array_equal(np.array([g.get_trcap(i) for i in range(top["fg"].size)]), g0["trcap"])
     flow = g.maxflow()
     assert flow == pytest.approx(float(g0["flow"]), rel=1e-9)
-    nbad = int((g.labels().reshape(top["fg"].shape) != g0["labels"].astype(bool)).sum())
-    assert nbad == 0 or (_tie_degenerate(term, top["image"]) and nbad <= max(3, top["image"].size // 50))
+    labels = g.labels().reshape(top["fg"].shape)
+    if (labels != g0["labels"].astype(bool)).any():
+        assert _tie_degenerate(term, top["image"]), "labels differ on an input without exact ties"
+        _assert_equivalent_to_reference(labels, top, term, float(top["sigma"]), spacing, g0, max_differing=3)
 
 
 @pytest.mark.parametrize("case", ["r0", "r1"])
@@ -173,11 +190,15 @@ def test_golden_synthetic(golden_synth):
         g = _run(s["fg"], s["bg"], s["term"], s["image"], s["sigma"])
         flow = g.maxflow()
         lab = np.unpackbits(golden_synth[key + "/labels"])[: int(np.prod(shape))].reshape(shape).astype(bool)
-        nbad = int((g.labels() != lab).sum())
-        if gen == "ties":
-            assert nbad <= 2, nbad  # degenerate ties under float rounding: see DESIGN.md "Parity limits"
-        else:
-            assert nbad == 0
+        labels = g.labels()
+        if (labels != lab).any():
+            assert gen == "ties", "labels differ on an input without exact ties"
+            ref = pipeline.graphcut_voxel(s["fg"], s["bg"], term=s["term"], image=s["image"], sigma=s["sigma"])
+            np.testing.assert_array_equal(ref.labels, lab)
+            w = energy_numpy.boundary_weights(s["term"], s["image"], s["sigma"])
+            i, j, ww = cutcheck.lattice_edges(shape, w)
+            tr = np.where(s["fg"], 65535.0, 0.0) - np.where(s["bg"], 65535.0, 0.0)
+            cutcheck.assert_labels_equivalent(labels, ref, 2, exact=(i, j, ww, ww, tr))
         assert flow == pytest.approx(float(golden_synth[key + "/flow"]), rel=1e-9)
 
 

@@ -33,12 +33,38 @@ def test_slabs_equal_single_and_oracle(gen, shape, nslabs):
     assert flow == pytest.approx(sflow, rel=1e-12)
 
 
+@pytest.mark.parametrize("term", ["difference_linear", "maximum_linear"])
+def test_linear_terms_use_the_range_of_the_whole_volume(term):
+    """energy_voxel.py:101 / 174-176 normalise by max |I| / |max - min| of the WHOLE image: the slabs reduce their local
+    ranges first (sync_image_range), so every slab builds the capacities of the single-handle run; the intensity extremes
+    sit in different slabs here, so a local range would give different weights on the two sides of every slab border"""
+    from medpy_amd import graphcut, synthetic
+    from medpy_amd.slab import graphcut_voxel_slabs
+    shape = (48, 24, 32)
+    s = synthetic.sphere(shape)
+    img = s["image"].astype(np.float64)
+    img[2, 3, 4], img[45, 20, 30] = -300.0, 700.0  # global min in the first slab, global max in the last
+    fn = getattr(graphcut.energy_voxel, "boundary_" + term)
+    g = graphcut.graph_from_voxels(s["fg"], s["bg"], boundary_term=fn, boundary_term_args=(img, False))
+    flow = g.maxflow()
+    ref = pipeline.graphcut_voxel(s["fg"], s["bg"], term=term, image=img)
+    assert flow == pytest.approx(ref.flow, rel=1e-9)
+    for nslabs in (2, 3):
+        labels, sflow, st = graphcut_voxel_slabs(img, s["fg"], s["bg"], term, None, nslabs=nslabs)
+        assert st["converged"] == 1
+        assert sflow == pytest.approx(ref.flow, rel=1e-9)
+        np.testing.assert_array_equal(labels, g.labels())
+
+
 def test_slab_handle_refuses_single_gpu_entry_points():
     from medpy_amd import _lib
     from medpy_amd.slab import HipSlab
     s = HipSlab((32, 16, 16), 0, 2)
     assert (s.own0, s.own1, s.plane0, s.plane1) == (0, 16, 0, 24) and s.has_hi and not s.has_lo
     s.set_boundary("difference_linear", np.zeros(s.local_shape, np.float32), None)
+    with pytest.raises(_lib.MedpyHipError, match="WHOLE volume"):
+        s.build()  # a slab cannot normalise a *_linear term by the range of its own planes
+    s.set_image_range(0.0, 0.0, 0.0)
     s.build()
     import ctypes as C
     with pytest.raises(_lib.MedpyHipError):
