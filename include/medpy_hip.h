@@ -75,6 +75,31 @@ typedef struct mgc_stats {
     int64_t reserved[3];
 } mgc_stats;
 
+/* Invariants of a maximum preflow, checked on the device (mgc_validate).  The reference has the same idea as a debugging
+ * aid: Graph::test_consistency, lib/maxflow/src/maxflow.cpp:610-682.  It is the only check available for volumes no CPU
+ * oracle can reach (BASELINE.json configs 4 and 5).  Counts are over the OWNED voxels of the handle (a slab: its planes);
+ * everything must be zero, the two errors of the order of rounding, and the two flow values equal -- summed over the
+ * ranks first when the volume is cut into slabs. */
+typedef struct mgc_validation {
+    int64_t voxels;                 /* owned voxels looked at                                                     */
+    int64_t negative_values;        /* a residual, an excess or a sink link below zero                            */
+    int64_t active_excess;          /* excess on a voxel that can still reach the sink: the preflow is not maximum */
+    int64_t residual_arcs_across;   /* residual arc from a voxel that cannot reach the sink to one that can       */
+    int64_t sink_links_across;      /* residual sink link on a voxel labelled "cannot reach the sink"             */
+    int64_t pair_violations;        /* rcap(u,v) + rcap(v,u) != cap(u,v) + cap(v,u) beyond rounding               */
+    int64_t node_violations;        /* from the source != excess + into the sink + net outflow beyond rounding    */
+    int64_t pending_outbox;         /* flow pushed across a tile face and not yet absorbed (6-neighbourhood)      */
+    int64_t reserved[4];
+    double  max_pair_error;         /* largest relative error of the two conservation checks                      */
+    double  max_node_error;
+    double  flow_into_sink;         /* sum over the owned voxels of (sink link as built - residual sink link)     */
+    double  cut_capacity;           /* capacity of the cut the labels define, this handle's part (without the constant) */
+    double  flow_constant;          /* the part add_tweights folds into the flow (graph.h:416-425), this handle's  */
+    double  sink_capacity_used;     /* sum of the built sink links that carry flow.  flow_into_sink is a sum of differences
+                                       (65535 - residual) and only known to about 1e-13 of this; cut_capacity is exact */
+    double  reserved_d[2];
+} mgc_validation;
+
 /* number of usable devices (0 => every other call fails with MGC_ERR_NO_DEVICE) */
 int mgc_device_count(int* count);
 
@@ -107,6 +132,10 @@ int mgc_set_markers(mgc_handle h, const uint8_t* fg, const uint8_t* bg);
  * caller reduces the local triples {min, max, max|.|} over the ranks (min, max, max) and hands the global one back
  * before mgc_build; building a *_linear slab without it fails with MGC_ERR_STATE.  NULL forgets a range set earlier;
  * mgc_set_boundary does so too. */
+/* After mgc_maxflow (or the slab driver's last step): see mgc_validation.  Also works on a graph whose solve was cut
+ * short (MGC_ERR_NOT_CONVERGED): it then reports the excess that is still active. */
+int mgc_validate(mgc_handle h, mgc_validation* out);
+
 int mgc_get_image_range(mgc_handle h, double* out3);
 int mgc_set_image_range(mgc_handle h, const double* in3);
 

@@ -39,6 +39,39 @@ class Stats(C.Structure):
         return d
 
 
+class Validation(C.Structure):
+    """mgc_validation (include/medpy_hip.h): invariants of a maximum preflow, counted on the device"""
+    _fields_ = [("voxels", C.c_int64), ("negative_values", C.c_int64), ("active_excess", C.c_int64),
+                ("residual_arcs_across", C.c_int64), ("sink_links_across", C.c_int64), ("pair_violations", C.c_int64),
+                ("node_violations", C.c_int64), ("pending_outbox", C.c_int64), ("reserved", C.c_int64 * 4),
+                ("max_pair_error", C.c_double), ("max_node_error", C.c_double), ("flow_into_sink", C.c_double),
+                ("cut_capacity", C.c_double), ("flow_constant", C.c_double), ("sink_capacity_used", C.c_double),
+                ("reserved_d", C.c_double * 2)]
+
+    def as_dict(self):
+        return {k: getattr(self, k) for k, _ in self._fields_ if not k.startswith("reserved")}
+
+
+VIOLATION_KEYS = ("negative_values", "active_excess", "residual_arcs_across", "sink_links_across", "pair_violations",
+                  "node_violations", "pending_outbox")
+
+
+def assert_valid(v, rel=1e-9):
+    """v: Validation.as_dict() (summed over the ranks for a volume cut into slabs).  Raises AssertionError naming the
+    violated invariant; returns the relative difference between the flow into the sink and the capacity of the cut."""
+    bad = {k: v[k] for k in VIOLATION_KEYS if v[k]}
+    assert not bad, "max-flow invariants violated: %r" % (bad,)
+    # The flow that reached the sink is a sum of differences (built sink link - residual): every push into a sink link of
+    # 65535 rounds at 7e-12, so the sum is only known to ~1e-13 of the sink capacity in use (hundreds of pushes per link).
+    # The capacity of the cut is exact; the zero counts above already imply flow == cut (every arc across the cut saturated,
+    # conservation on the sink side).  This comparison is the independent, coarser cross-check.
+    scale = max(abs(v["flow_into_sink"]), abs(v["cut_capacity"]), 1e-300)
+    diff = abs(v["flow_into_sink"] - v["cut_capacity"])
+    assert diff <= rel * scale + 1e-13 * v["sink_capacity_used"], "flow into the sink %r != capacity of the cut %r" % (
+        v["flow_into_sink"], v["cut_capacity"])
+    return diff / scale
+
+
 class SparseStats(C.Structure):
     _fields_ = [("build_ms", C.c_double), ("solve_ms", C.c_double), ("rounds", C.c_int64), ("global_relabels", C.c_int64),
                 ("relabel_passes", C.c_int64), ("nodes", C.c_int64), ("arcs", C.c_int64), ("edges_added", C.c_int64),
@@ -72,6 +105,7 @@ SIGNATURES = {
     "mgc_what_segment": (_INT, [_VP, _I64, C.POINTER(_INT)]),
     "mgc_get_node_num": (_INT, [_VP, C.POINTER(_I64)]),
     "mgc_set_param": (_INT, [_VP, C.c_char_p, _I64]),
+    "mgc_validate": (_INT, [_VP, _VP]),
     "mgc_get_image_range": (_INT, [_VP, _VP]),
     "mgc_set_image_range": (_INT, [_VP, _VP]),
     "mgc_get_stats": (_INT, [_VP, C.POINTER(Stats)]),

@@ -885,6 +885,104 @@ __global__ __launch_bounds__(MGC_TV) void k_cut_value(MgcLattice L, MgcBuildArgs
     }
 }
 
+
+/* ======================================================================================
+ * invariants of a maximum preflow (mgc_validate; the reference's Graph::test_consistency, maxflow.cpp:610-682, in spirit)
+ * ==================================================================================== */
+struct MgcValidateOut {
+    unsigned long long cnt[8]; /* voxels, negative, active excess, residual arcs across, sink links across, pair, node, pending outbox */
+    unsigned long long max_pair_bits, max_node_bits; /* non-negative doubles compare like their bit patterns */
+    double sink_cap_used; /* sum of the built sink links that carry flow: scale of the rounding in flow_into_sink */
+};
+
+__device__ __forceinline__ int mgc_label_of(const MgcLattice& L, int64_t gz, int64_t gy, int64_t gx)
+{
+    const int tile = mgc_tile_id(L, (int)(gz >> 3), (int)(gy >> 3), (int)(gx >> 3));
+    return L.height[(int64_t)tile * MGC_TV + mgc_local((int)(gz & 7), (int)(gy & 7), (int)(gx & 7))] < MGC_HINF ? 0 : 1;
+}
+
+__global__ __launch_bounds__(MGC_TV) void k_validate(MgcLattice L, MgcBuildArgs A, const double* tr0, double* part, MgcValidateOut* out)
+{
+    __shared__ double scratch[MGC_TV];
+    __shared__ unsigned long long sc[8];
+    __shared__ unsigned long long smax[2];
+    const int t = threadIdx.x;
+    const double TOL = 1e-9;
+    for (int tile = blockIdx.x; tile < L.ntiles; tile += gridDim.x) {
+        if (t < 8) sc[t] = 0;
+        if (t < 2) smax[t] = 0;
+        __syncthreads();
+        int tz, ty, tx;
+        mgc_tile_coords(L, tile, tz, ty, tx);
+        const int lz = t >> 6, ly = (t >> 3) & 7, lx = t & 7;
+        const int64_t gz = (int64_t)tz * 8 + lz, gy = (int64_t)ty * 8 + ly, gx = (int64_t)tx * 8 + lx;
+        double into_sink = 0.0;
+        const bool owned = mgc_owned(L, tile);
+        if (owned && gz < L.dz && gy < L.dy && gx < L.dx) {
+            const int64_t v = (int64_t)tile * MGC_TV + t;
+            const double e = L.excess[v], sk = L.sink[v], tr = tr0[v];
+            const int lab = L.height[v] < MGC_HINF ? 0 : 1;
+            const double src0 = tr > 0.0 ? tr : 0.0, snk0 = tr < 0.0 ? -tr : 0.0;
+            unsigned neg = (e < 0.0) | (sk < 0.0);
+            unsigned across = 0;
+            double outflow = 0.0, scale = fmax(fmax(src0, snk0), fmax(e, 1e-300));
+            into_sink = snk0 - sk;
+            if (into_sink != 0.0) atomicAdd(&out->sink_cap_used, snk0);
+            for (int d = 0; d < L.ndir; ++d) {
+                int dz, dy, dx;
+                if (L.ndir == 6) {
+                    dz = (d >> 1) == 2 ? ((d & 1) ? 1 : -1) : 0;
+                    dy = (d >> 1) == 1 ? ((d & 1) ? 1 : -1) : 0;
+                    dx = (d >> 1) == 0 ? ((d & 1) ? 1 : -1) : 0;
+                } else {
+                    mgc26_offset(d, dz, dy, dx);
+                }
+                const double r = L.rcap[((int64_t)tile * L.ndir + d) * MGC_TV + t];
+                neg |= r < 0.0;
+                const int64_t nz = gz + dz, ny = gy + dy, nx = gx + dx;
+                if (nz < 0 || nz >= L.dz || ny < 0 || ny >= L.dy || nx < 0 || nx >= L.dx) continue;
+                const double c = mgc_built_capacity(L, A, tile, t, gz, gy, gx, d);
+                outflow += c - r;
+                scale = fmax(scale, fmax(c, r));
+                if (lab == 1 && r > 0.0 && mgc_label_of(L, nz, ny, nx) == 0) across++;
+                /* the arc pair conserves its total capacity; each pair once (from its lower end), both ends owned */
+                const bool fwd = L.ndir == 6 ? (d & 1) != 0 : d >= 13;
+                const int nt = mgc_tile_id(L, (int)(nz >> 3), (int)(ny >> 3), (int)(nx >> 3));
+                if (fwd && mgc_owned(L, nt)) {
+                    const int nl = mgc_local((int)(nz & 7), (int)(ny & 7), (int)(nx & 7));
+                    const int dr = L.ndir == 6 ? (d ^ 1) : (25 - d);
+                    const double rr = L.rcap[((int64_t)nt * L.ndir + dr) * MGC_TV + nl];
+                    const double cr = L.cap0 ? L.cap0[((int64_t)nt * L.ndir + dr) * MGC_TV + nl] : c; /* the built-in terms are symmetric */
+                    const double err = fabs((r + rr) - (c + cr)) / fmax(c + cr, 1e-300);
+                    if (err == err) { /* (NaN capacities of a constant image under a *_linear term: nothing to conserve) */
+                        atomicMax(&smax[0], (unsigned long long)__double_as_longlong(err));
+                        if (err > TOL) atomicAdd(&sc[5], 1ull);
+                    }
+                }
+            }
+            /* what came from the source = what is still here + what went into the sink + what left along the n-links */
+            const double nerr = fabs(src0 - e - into_sink - outflow) / scale;
+            if (nerr == nerr) {
+                atomicMax(&smax[1], (unsigned long long)__double_as_longlong(nerr));
+                if (nerr > TOL) atomicAdd(&sc[6], 1ull);
+            }
+            atomicAdd(&sc[0], 1ull);
+            if (neg) atomicAdd(&sc[1], 1ull);
+            if (lab == 0 && e > 0.0) atomicAdd(&sc[2], 1ull);
+            if (across) atomicAdd(&sc[3], (unsigned long long)across);
+            if (lab == 1 && sk > 0.0) atomicAdd(&sc[4], 1ull);
+        }
+        if (L.obox && t < 6 * MGC_TF && L.obox[(int64_t)tile * 6 * MGC_TF + t] != 0.0) atomicAdd(&sc[7], 1ull);
+        const double tot = mgc_block_sum(into_sink, scratch);
+        if (t == 0) part[tile] = tot;
+        __syncthreads();
+        if (t < 8 && sc[t]) atomicAdd(&out->cnt[t], sc[t]);
+        if (t == 8 && smax[0]) atomicMax(&out->max_pair_bits, smax[0]);
+        if (t == 9 && smax[1]) atomicMax(&out->max_node_bits, smax[1]);
+        __syncthreads();
+    }
+}
+
 /* fixed-order sum of n partials by one block */
 /* first stage for long vectors: block b adds the contiguous chunk [b * len, (b + 1) * len) in a fixed order */
 __global__ __launch_bounds__(256) void k_sum_chunks(const double* part, int64_t n, int64_t len, double* out)
@@ -1699,6 +1797,44 @@ int mgc_set_tweights_merged(mgc_handle h, const double* tr, double flow_const)
     h->flow_const_in = flow_const;
     h->built = h->solved = false;
     return mgc_upload(h, (void**)&h->d_tr_in, tr, (size_t)h->nvox * sizeof(double));
+}
+
+int mgc_validate(mgc_handle h, mgc_validation* out)
+{
+    if (!h || !out) return MGC_ERR_INVALID;
+    if (!h->built) return mgc_fail(h, MGC_ERR_STATE, "mgc_validate before mgc_build");
+    MGC_HIP(h, hipSetDevice(h->device));
+    MgcLattice& L = h->L;
+    memset(out, 0, sizeof(*out));
+    MgcValidateOut* d_out = nullptr;
+    MGC_HIP(h, hipMalloc((void**)&d_out, sizeof(MgcValidateOut)));
+    MGC_HIP(h, hipMemsetAsync(d_out, 0, sizeof(MgcValidateOut), h->stream));
+    const int grid = L.ntiles < h->grid_cap * 4 ? L.ntiles : h->grid_cap * 4;
+    hipLaunchKernelGGL(k_validate, dim3(grid), dim3(MGC_TV), 0, h->stream, L, h->build_args, (const double*)h->d_tr0, h->d_part, d_out);
+    MGC_HIP(h, hipGetLastError());
+    mgc_sum_partials(h, (int64_t)L.ntiles, h->d_scalar + 2);
+    /* the capacity of the cut the current labels define (the labels are read from the distance labels, as k_labels does) */
+    hipLaunchKernelGGL(k_labels, dim3(2048), dim3(256), 0, h->stream, L, h->d_labels);
+    hipLaunchKernelGGL(k_cut_value, dim3(grid), dim3(MGC_TV), 0, h->stream, L, h->build_args, (const double*)h->d_tr0, (const uint8_t*)h->d_labels, h->d_part);
+    MGC_HIP(h, hipGetLastError());
+    mgc_sum_partials(h, (int64_t)L.ntiles, h->d_scalar + 3);
+    MGC_HIP(h, hipGetLastError());
+    MgcValidateOut ho;
+    MGC_HIP(h, hipMemcpyAsync(&ho, d_out, sizeof(ho), hipMemcpyDeviceToHost, h->stream));
+    MGC_HIP(h, hipMemcpyAsync(h->h_scalar, h->d_scalar, 8 * sizeof(double), hipMemcpyDeviceToHost, h->stream));
+    MGC_HIP(h, hipStreamSynchronize(h->stream));
+    (void)hipFree(d_out);
+    h->labels_on_host = false;
+    out->voxels = (int64_t)ho.cnt[0]; out->negative_values = (int64_t)ho.cnt[1]; out->active_excess = (int64_t)ho.cnt[2];
+    out->residual_arcs_across = (int64_t)ho.cnt[3]; out->sink_links_across = (int64_t)ho.cnt[4];
+    out->pair_violations = (int64_t)ho.cnt[5]; out->node_violations = (int64_t)ho.cnt[6]; out->pending_outbox = (int64_t)ho.cnt[7];
+    memcpy(&out->max_pair_error, &ho.max_pair_bits, sizeof(double));
+    memcpy(&out->max_node_error, &ho.max_node_bits, sizeof(double));
+    out->flow_into_sink = h->h_scalar[2];
+    out->cut_capacity = h->h_scalar[3];
+    out->flow_constant = h->flow_const;
+    out->sink_capacity_used = ho.sink_cap_used;
+    return MGC_OK;
 }
 
 int mgc_get_image_range(mgc_handle h, double* out3)

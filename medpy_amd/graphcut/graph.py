@@ -110,6 +110,13 @@ class VoxelGraph(object):
     def set_param(self, name, value):
         self._call("mgc_set_param", name.encode(), int(value))
 
+    def validate(self):
+        """invariants of the maximum preflow in HBM (mgc_validate): dict of violation counts (all zero for a correct
+        solve), the two conservation errors, the flow into the sink and the capacity of the cut"""
+        v = _lib.Validation()
+        self._call("mgc_validate", C.byref(v))
+        return v.as_dict()
+
     # -- GraphDouble surface
     def maxflow(self):
         """GraphDouble.maxflow(), reference maxflow.cpp:472-604."""

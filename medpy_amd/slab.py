@@ -416,6 +416,26 @@ class HipSlab(object):
         self._call("mgc_get_stats", self._C.byref(st))
         return st.as_dict()
 
+    def validate(self):
+        """this slab's part of the max-flow invariants (mgc_validate); sum the dicts over the slabs (validate_slabs)"""
+        v = self._lib.Validation()
+        self._call("mgc_validate", self._C.byref(v))
+        return v.as_dict()
+
+
+def validate_slabs(slabs, ex):
+    """Invariants of the maximum preflow of a volume cut into slabs: every rank counts over its own planes, the counts
+    and the two flow values are summed over all ranks (the conservation errors: maximum).  Returns the global dict;
+    medpy_amd._lib.assert_valid(dict) raises on a violation.  The only check there is for volumes no CPU oracle reaches."""
+    from . import _lib
+    parts = [s.validate() for s in slabs]
+    keys = [k for k in parts[0] if k not in ("max_pair_error", "max_node_error")]
+    sums = np.asarray(ex.allreduce_sum([[float(p[k]) for k in keys] for p in parts]), dtype=np.float64).reshape(-1)
+    mx = np.asarray(ex.allreduce_max([[p["max_pair_error"], p["max_node_error"]] for p in parts]), dtype=np.float64).reshape(-1)
+    out = {k: (float(v) if k in ("flow_into_sink", "cut_capacity", "flow_constant", "sink_capacity_used") else int(round(v))) for k, v in zip(keys, sums)}
+    out["max_pair_error"], out["max_node_error"] = float(mx[0]), float(mx[1])
+    return out
+
 
 def graphcut_voxel_slabs(image, fg, bg, term="difference_exponential", sigma=None, spacing=False, nslabs=2, device=0,
                          connectivity=6, regional=None, **schedule):

@@ -107,7 +107,7 @@ def test_hostsim_wave_forms_match_bk(gen, shape, mode):
         np.testing.assert_array_equal(cut.labels, ref.astype(bool))
         i, j, ww = cutcheck.lattice_edges(shape, energy_numpy.boundary_weights("difference_linear", s["image"]))
         tr = np.where(s["fg"], 65535.0, 0.0) - np.where(s["bg"], 65535.0, 0.0)
-        cutcheck.assert_labels_equivalent(lab.astype(bool), cut, 2, exact=(i, j, ww, ww, tr))
+        cutcheck.assert_labels_equivalent(lab.astype(bool), cut, exact=(i, j, ww, ww, tr))
     else:
         np.testing.assert_array_equal(lab, ref)
 
