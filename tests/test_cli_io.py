@@ -179,3 +179,42 @@ def test_label_cli_flow_with_a_stub_solver(tmp_path, monkeypatch):
     assert reg is graphcut.energy_label.regional_atlas and bnd is graphcut.energy_label.boundary_difference_of_means and rargs[1] == 0.25
     with pytest.raises(ArgumentError):
         cli.main(base + ["-f", "--regional", "atlas"])  # atlas without image / alpha
+
+
+@pytest.mark.gpu
+def test_overlay_runs_a_medpy_style_script_on_the_gpu(tmp_path):
+    """medpy_amd.overlay on the GPU box (no /root/reference there): a script written against the MedPy import surface --
+    ``from medpy import graphcut``, ``medpy.core``, ``medpy.io``, ``medpy.graphcut.wrapper`` -- runs on the HIP path.  (The
+    reference's own script is executed the same way in tests/test_overlay_reference_script.py, where the reference is.)"""
+    import sys
+    from medpy_amd import io, overlay, synthetic
+    s = synthetic.sphere((20, 24, 28))
+    np.save(tmp_path / "img.npy", s["image"])
+    np.save(tmp_path / "markers.npy", s["fg"].astype(np.uint8) + 2 * s["bg"].astype(np.uint8))
+    script = tmp_path / "my_medpy_script.py"
+    script.write_text(
+        "import sys, numpy\n"
+        "from medpy import graphcut\n"
+        "from medpy.core import ArgumentError, Logger\n"
+        "from medpy.graphcut.wrapper import split_marker\n"
+        "from medpy.io import header, load, save\n"
+        "logger = Logger.getInstance()\n"
+        "img, hdr = load(sys.argv[1]); markers, _ = load(sys.argv[2])\n"
+        "fg, bg = split_marker(markers)\n"
+        "g = graphcut.graph_from_voxels(fg, bg, boundary_term=graphcut.energy_voxel.boundary_difference_exponential,\n"
+        "                               boundary_term_args=(img, 15.0, header.get_pixel_spacing(hdr)))\n"
+        "g.maxflow()\n"
+        "res = numpy.array([0 if g.termtype.SINK == g.what_segment(i) else 1 for i in range(img.size)], dtype=numpy.bool_)\n"
+        "save(res.reshape(img.shape), sys.argv[3], hdr, True)\n")
+    saved = {k: v for k, v in sys.modules.items() if k == "medpy" or k.startswith("medpy.")}
+    for k in saved:
+        del sys.modules[k]
+    try:
+        out = str(tmp_path / "seg.npy")
+        overlay.run(str(script), [str(tmp_path / "img.npy"), str(tmp_path / "markers.npy"), out])
+    finally:
+        for k in [k for k in sys.modules if k == "medpy" or k.startswith("medpy.")]:
+            del sys.modules[k]
+        sys.modules.update(saved)
+    ref = pipeline.graphcut_voxel(s["fg"], s["bg"], term="difference_exponential", image=s["image"], sigma=15.0, spacing=(1.0, 1.0, 1.0))
+    np.testing.assert_array_equal(np.load(out).astype(bool), ref.labels)
