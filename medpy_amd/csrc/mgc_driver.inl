@@ -174,7 +174,12 @@ int mgc_solve(Dev& dev, const MgcLattice& L, const MgcSolveParams& P, MgcSolveSt
             }
         }
     }
-    return 1; /* not converged within max_outer */
+    {   /* not converged within max_outer: leave the work counters of the truncated run */
+        dev.read_counts(cnt);
+        st.discharge_tiles = cnt[lay.cnt_dis];
+        st.relabel_tiles = cnt[lay.cnt_rel];
+    }
+    return 1;
 }
 
 #endif /* MGC_DRIVER_INL */

@@ -46,7 +46,7 @@
 /* ======================================================================================
  * block executor for the single-source tile operations
  * ==================================================================================== */
-template <class SH>
+template <class SH, bool LAUNDER_EVERY_STEP = false>
 struct GpuBlockT {
     template <class T>
     struct Reg {
@@ -69,9 +69,9 @@ struct GpuBlockT {
     __device__ __forceinline__ int lane() const
     {
         int t = tid;
-#if defined(MGC_LAUNDER_EVERY_STEP)
-        asm volatile("" : "+v"(t));
-#endif
+        /* LAUNDER_EVERY_STEP: the lane id is opaque at every step, so nothing derived from it (the 26 x {inside predicate,
+         * LDS address, halo offset} of the full neighbourhood) is hoisted out of the sweep loop and kept alive */
+        if (LAUNDER_EVERY_STEP) asm volatile("" : "+v"(t));
         return t;
     }
     template <class F>
@@ -162,7 +162,10 @@ struct GpuBlockT {
 };
 typedef GpuBlockT<MgcTileShared> GpuBlock;
 typedef GpuBlockT<MgcTileShared26> GpuBlock26;
-typedef GpuBlockT<MgcTileShared26D> GpuBlock26D;
+#ifndef MGC26_LAUNDER
+#define MGC26_LAUNDER true
+#endif
+typedef GpuBlockT<MgcTileShared26D, MGC26_LAUNDER> GpuBlock26D;
 
 
 /* ======================================================================================
@@ -273,7 +276,109 @@ __global__ __launch_bounds__(MGCW_LANES) void k_relabel_w(MgcLattice L, int lst,
     }
 }
 
+
+/* ======================================================================================
+ * block executor with V voxels per thread (512 / V threads per tile): the global-relabel passes.
+ * A relabel visit is short (masks + labels + halo in, a few relaxation rounds, labels out) and there are only a few
+ * thousand tiles per pass: with 256 threads a CU keeps 8 tiles in flight instead of 4, every barrier joins 4 waves
+ * instead of 8 and the scalar bookkeeping of a tile is paid by half as many waves.
+ * ==================================================================================== */
+struct alignas(16) MgcTileSharedR { /* what the relabel / activate operations touch of MgcTileShared (4 KiB instead of 40) */
+    int32_t hs[1000];
+    int32_t nbr[8], inflag[8], faceflag[8], depflag[8], flag[2], satflag, excflag;
+};
+
+template <int V, class SH = MgcTileSharedR, bool LAUNDER_EVERY_STEP = false>
+struct GpuBlockV {
+    static constexpr int NT = MGC_TV / V;
+    static constexpr int LOG_NT = NT == 512 ? 9 : (NT == 256 ? 8 : 7);
+    template <class T>
+    struct Reg {
+        T v[V];
+        /* t = thread + k * NT with thread < NT: the slot index k = t >> LOG_NT folds to a constant (the lane id is masked
+         * to its range after it was made opaque, see new_tile) */
+        __device__ __forceinline__ T& operator[](int t) { return v[t >> LOG_NT]; }
+    };
+    SH& S;
+    int tid;
+    __device__ __forceinline__ explicit GpuBlockV(SH& s) : S(s), tid((int)threadIdx.x) {}
+    __device__ __forceinline__ void new_tile()
+    {
+        tid = (int)threadIdx.x;
+        asm volatile("" : "+v"(tid));
+        tid &= NT - 1;
+    }
+    __device__ __forceinline__ int lane() const
+    {
+        int t = tid;
+        if (LAUNDER_EVERY_STEP) { asm volatile("" : "+v"(t)); t &= NT - 1; }
+        return t;
+    }
+    template <class F>
+    __device__ __forceinline__ void par(F f)
+    {
+        const int t0 = lane();
+#pragma unroll
+        for (int k = 0; k < V; ++k) f(t0 + k * NT);
+        __syncthreads();
+    }
+    template <class F>
+    __device__ __forceinline__ bool any(F f)
+    {
+        const int t0 = lane();
+        int r = 0;
+#pragma unroll
+        for (int k = 0; k < V; ++k) r |= (int)f(t0 + k * NT);
+        return __syncthreads_or(r) != 0;
+    }
+    __device__ __forceinline__ int atomic_add(int32_t* p, int v) { return atomicAdd(p, v); }
+    __device__ __forceinline__ uint32_t atomic_exch(uint32_t* p, uint32_t v) { return atomicExch(p, v); }
+    __device__ __forceinline__ void atomic_or(uint32_t* p, uint32_t v) { atomicOr(p, v); }
+    __device__ __forceinline__ void atomic_and(uint32_t* p, uint32_t v) { atomicAnd(p, v); }
+};
+
+#ifndef MGC_RELABEL_V
+#define MGC_RELABEL_V 2 /* voxels per thread of the relabel passes */
+#endif
+typedef GpuBlockV<MGC_RELABEL_V> GpuBlockR;
+
+/* one kernel for the three kinds of relabel pass: over a list (`cnt` = index of its length: the list's own counter, or the
+ * scratch counter of the tile filter for the seeding pass `first`), clearing `zero_list` for the pass after next */
+__global__ __launch_bounds__(MGC_TV / MGC_RELABEL_V) void k_relabel_v(MgcLattice L, int lst, int cnt, uint32_t epoch, int next_list, int zero_list, int first)
+{
+    __shared__ MgcTileSharedR S;
+    GpuBlockR x(S);
+    const int n = L.count[cnt];
+    if (blockIdx.x == 0 && threadIdx.x == 0) {
+        if (n) atomicAdd(&L.count[9], n);
+        if (zero_list >= 0) L.count[zero_list] = 0; /* consumed by the previous pass; the next pass appends to it */
+    }
+    for (int i = blockIdx.x; i < n; i += gridDim.x) {
+        x.new_tile();
+        mgc_relabel_tile(x, L, L.list[lst][i], epoch, next_list, first != 0);
+        __syncthreads();
+    }
+}
+
 /* ---- 26-neighbourhood solver kernels (bodies: mgc_tile_ops26.inl) ---- */
+struct MgcTileShared26V : MgcTileShared26 { /* all 26 residuals in registers: rl is never addressed (NREG = 26) */
+    double rl[1][1];
+};
+/* region discharge with two voxels per thread and all 26 residuals of both in registers (see mgc26_discharge_tile) */
+__global__ __launch_bounds__(MGC_TV / 2) __attribute__((amdgpu_waves_per_eu(2, 2)))
+void k26_discharge_v(MgcLattice L, int lst, uint32_t phase, int cycles, int sweeps)
+{
+    __shared__ MgcTileShared26V S;
+    GpuBlockV<2, MgcTileShared26V, true> x(S);
+    const int n = L.count[lst];
+    if (blockIdx.x == 0 && threadIdx.x == 0 && n) atomicAdd(&L.count[MGC26_CNT_DIS], n);
+    for (int i = blockIdx.x; i < n; i += gridDim.x) {
+        x.new_tile();
+        mgc26_discharge_tile<26>(x, L, L.list[lst][i], phase, cycles, sweeps);
+        __syncthreads();
+    }
+}
+
 __global__ __launch_bounds__(MGC_TV) void k26_relabel_all(MgcLattice L, uint32_t epoch, int next_list)
 {
     __shared__ MgcTileShared26 S;
@@ -1094,8 +1199,9 @@ struct mgc_graph {
     double flow_const = 0.0, flow = 0.0;
     MgcSolveParams params = mgc_default_params();
     int grid_cap = 4096;
-    int wave_kernels = 1;  /* bit0: region discharge, bit1: global-relabel passes run one wave per tile (mgc_wave_ops.inl);
-                              bit2: the wave discharge starts from exact in-tile labels (MGCW_BFS) */
+    int wave_kernels = 9;  /* bit0: region discharge, bit1: global-relabel passes run one wave per tile (mgc_wave_ops.inl);
+                              bit2: the wave discharge starts from exact in-tile labels (MGCW_BFS); bit3: relabel passes with
+                              MGC_RELABEL_V voxels per thread (k_relabel_v) instead of one (k_relabel_list) */
     int wave_grid_dis = 0, wave_grid_rel = 0; /* persistent grids of the wave kernels (waves resident on the device) */
     int tk_dis = MGC_CNT_TICKET_DIS, tk_rel = MGC_CNT_TICKET_REL; /* ticket slot of the next wave launch (alternates) */
     int pending_zero = -1; /* list counter the schedule asked to clear right after a discharge: the next discharge kernel clears
@@ -1194,7 +1300,8 @@ struct HipDevT {
         else { /* one thread per tile finds the seeds (tiles with an arc to the sink); only those get a workgroup */
             zero_count(11);
             hipLaunchKernelGGL(k_filter, dim3(filter_grid()), dim3(256), 0, h->stream, h->L, 3, 6, 11);
-            if (h->wave_kernels & 2) { hipLaunchKernelGGL(k_relabel_w, dim3(h->wave_grid_rel), dim3(MGCW_LANES), 0, h->stream, h->L, 6, 11, epoch, next, -1, 1, h->tk_rel); h->tk_rel ^= 1; }
+            if (h->wave_kernels & 8) hipLaunchKernelGGL(k_relabel_v, dim3(grid(h->L.ntiles)), dim3(MGC_TV / MGC_RELABEL_V), 0, h->stream, h->L, 6, 11, epoch, next, -1, 1);
+            else if (h->wave_kernels & 2) { hipLaunchKernelGGL(k_relabel_w, dim3(h->wave_grid_rel), dim3(MGCW_LANES), 0, h->stream, h->L, 6, 11, epoch, next, -1, 1, h->tk_rel); h->tk_rel ^= 1; }
             else hipLaunchKernelGGL(k_relabel_first_list, dim3(grid(h->L.ntiles)), dim3(MGC_TV), 0, h->stream, h->L, 6, 11, epoch, next);
         }
         check(hipGetLastError());
@@ -1206,6 +1313,7 @@ struct HipDevT {
         flush_zero();
         const int id = time_begin(1);
         if constexpr (FULL) hipLaunchKernelGGL(k26_relabel_list, dim3(grid(h->L.ntiles)), dim3(MGC_TV), 0, h->stream, h->L, lst, epoch, next);
+        else if (h->wave_kernels & 8) hipLaunchKernelGGL(k_relabel_v, dim3(grid(h->L.ntiles)), dim3(MGC_TV / MGC_RELABEL_V), 0, h->stream, h->L, lst, lst, epoch, next, zero_list, 0);
         else if (h->wave_kernels & 2) { hipLaunchKernelGGL(k_relabel_w, dim3(h->wave_grid_rel), dim3(MGCW_LANES), 0, h->stream, h->L, lst, lst, epoch, next, zero_list, 0, h->tk_rel); h->tk_rel ^= 1; }
         else hipLaunchKernelGGL(k_relabel_list, dim3(grid(h->L.ntiles)), dim3(MGC_TV), 0, h->stream, h->L, lst, epoch, next, zero_list);
         check(hipGetLastError());
@@ -1256,7 +1364,10 @@ struct HipDevT {
         const int zero_idx = h->pending_zero; /* cleared inside the kernel: no memset between two colour phases */
         h->pending_zero = -1;
         const int id = time_begin(0);
-        if constexpr (FULL) hipLaunchKernelGGL(k26_discharge, dim3(grid(h->L.ntiles)), dim3(MGC_TV), 0, h->stream, h->L, lst, phase, cycles, sweeps);
+        if constexpr (FULL) {
+            if (h->wave_kernels & 16) hipLaunchKernelGGL(k26_discharge_v, dim3(grid(h->L.ntiles)), dim3(MGC_TV / 2), 0, h->stream, h->L, lst, phase, cycles, sweeps);
+            else hipLaunchKernelGGL(k26_discharge, dim3(grid(h->L.ntiles)), dim3(MGC_TV), 0, h->stream, h->L, lst, phase, cycles, sweeps);
+        }
         else if (h->wave_kernels & 1) { hipLaunchKernelGGL(k_discharge_w, dim3(h->wave_grid_dis), dim3(MGCW_LANES), 0, h->stream, h->L, lst, phase, sweeps, (h->wave_kernels & 4) ? MGCW_BFS : 0, h->tk_dis, zero_idx); h->tk_dis ^= 1; }
         else hipLaunchKernelGGL(k_discharge, dim3(grid(h->L.ntiles)), dim3(MGC_TV), 0, h->stream, h->L, lst, phase, cycles, sweeps, zero_idx);
         check(hipGetLastError());
@@ -2017,7 +2128,15 @@ int mgc_maxflow(mgc_handle h, double* flow)
         }
         if (dev.first_error != hipSuccess)
             return mgc_fail(h, MGC_ERR_HIP, "solver: HIP error %s", hipGetErrorString(dev.first_error));
-        if (rc) return mgc_fail(h, MGC_ERR_NOT_CONVERGED, "solver did not converge within %d global relabels", h->params.max_outer);
+        if (rc) { /* the work counters of the truncated run stay readable (mgc_get_stats) */
+            (void)hipStreamSynchronize(h->stream);
+            dev.resolve_timing();
+            h->stats.discharge_ms = dev.discharge_ms; h->stats.relabel_ms = dev.relabel_ms;
+            h->stats.discharge_launches = dev.discharge_launches; h->stats.relabel_launches = dev.relabel_launches;
+            h->stats.discharge_tiles = st.discharge_tiles; h->stats.relabel_tiles = st.relabel_tiles;
+            h->stats.global_relabels = st.outer; h->stats.phases = st.phases;
+            return mgc_fail(h, MGC_ERR_NOT_CONVERGED, "solver did not converge within %d global relabels", h->params.max_outer);
+        }
         /* read-out: labels, then the capacity of the cut they define */
         hipLaunchKernelGGL(k_labels, dim3(2048), dim3(256), 0, h->stream, L, h->d_labels);
         MGC_HIP(h, hipGetLastError());

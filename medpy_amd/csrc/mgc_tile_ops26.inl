@@ -175,14 +175,19 @@ MGC_HD void mgc26_activate_tile(X& x, const MgcLattice& L, int tile, uint32_t ph
     });
 }
 
-/* region discharge of one tile in colour phase `phase` (all 26 neighbour tiles are idle) */
-template <class X>
+/* region discharge of one tile in colour phase `phase` (all 26 neighbour tiles are idle).
+ * NREG of the 26 residuals of a voxel live in registers, the rest in the LDS slots x.S.rl (own lane only):
+ *   NREG = 13, 512 threads, 128 VGPRs  -- two workgroups per CU, but the 27 unrolled steps spill ~440 B per lane
+ *                                          (measured: 4x the tile state goes to scratch and back per discharge);
+ *   NREG = 26, 256 threads x 2 voxels  -- everything in registers under the 256-VGPR budget of two waves per SIMD,
+ *                                          the same two tiles per CU in flight, no residuals in LDS, no spills. */
+template <int NREG = MGC26_NREG, class X>
 MGC_HD void mgc26_discharge_tile(X& x, const MgcLattice& L, int tile, uint32_t phase, int max_cycles, int max_sweeps)
 {
-    typename X::template Reg<double> e, snk, rr[MGC26_NREG];
-    /* residual of lane t in direction d: register for d < 13, LDS slot (own lane only) for d >= 13; d is a compile-time
+    typename X::template Reg<double> e, snk, rr[NREG];
+    /* residual of lane t in direction d: register for d < NREG, LDS slot for d >= NREG; d is a compile-time
      * constant wherever this is used (unrolled loops), so the choice folds away */
-    auto R = [&](int d, int t) -> double& { return d < MGC26_NREG ? rr[d < MGC26_NREG ? d : 0][t] : x.S.rl[d >= MGC26_NREG ? d - MGC26_NREG : 0][t]; };
+    auto R = [&](int d, int t) -> double& { return d < NREG ? rr[d < NREG ? d : 0][t] : x.S.rl[d >= NREG ? d - NREG : 0][t]; };
     typename X::template Reg<int> hme;
     const int64_t base = (int64_t)tile * MGC_TV;
 
