@@ -1,25 +1,33 @@
 #!/usr/bin/env python3
 """bench.py -- Mvoxels/s of the voxel graph cut (build + solve) on MI355X.
 
-    python bench.py [--gpus N] [--steps K] [--warmup W] [--size 512]
+    python bench.py [--gpus N] [--steps K] [--warmup W] [--config C] [--strong] [--no-cpu] [--cpu-full]
 
-A "step" = one pass of the hot path over one synthetic volume: n-link/t-link construction
-(mgc_build) + max-flow solve (mgc_maxflow) with image and markers already resident in HBM and
-the label array left in HBM (SURVEY.md 8(d) "headline, device-resident").  Workload = the
-configuration BASELINE.json's metric is quoted on: 512^3 "sphere" volume, 6-connectivity,
-boundary_difference_exponential, sigma 15.
+A "step" = one pass of the hot path over one synthetic volume: n-link / t-link construction (mgc_build) + max-flow solve
+with image and markers already resident in HBM and the label array left in HBM (SURVEY.md 8(d) "headline,
+device-resident").
 
-Prints ONE JSON line (rank 0) with `roofline` (dominant kernel, HIP-event timed on the launch
-stream inside the library) and `cpu_baseline` (the reference's own BK solver, compiled in place
-as oracle/_ref, timed on a bounded sample on the host cores).
+Workloads (BASELINE.json `configs`; shapes are (Z, Y, X)):
 
-N > 1: one process per GPU (torch.distributed launch contract, backend nccl = RCCL).  ONE volume of
-(size*N, size, size) voxels -- N sphere blocks stacked along axis 0 -- is cut as N exact Z-slabs, one
-per GPU (medpy_amd/slab.py): after every relabel pass / colour phase the packed slab borders
-(labels + outbox flow) travel to the neighbour ranks with RCCL send/recv over xGMI and tiny
-all-reduces decide termination.  Per-GPU work is fixed as N grows: weak scaling.
+    N = 1  (default)        512^3 sphere volume, 6-neighbourhood, boundary_difference_exponential sigma 15: the headline
+    N > 1  (default)        (256 N) x 1024 x 1024, 6-neighbourhood, one exact Z-slab of 256 planes per GPU (weak scaling):
+                            N = 4 IS config 4 (1024^3, 6-conn, 4 GPUs), N = 8 has config 5's shape
+    --config 2              256^3, 6-conn, one GPU            --config 3   512^3, 26-conn + regional_probability_map, one GPU
+    --config 4              = --gpus 4 default                --config 5   2048 x 1024 x 1024, 26-conn, 8 slabs (needs --gpus 8)
+    --strong                1024^3, 6-conn, cut into N slabs: the SAME volume at N = 1, 2, 4, 8 (strong scaling)
+
+The multi-GPU volume is a grid of 512^3 sphere blocks sharing one connected medium (only the outer faces of the whole
+volume are background); no CPU oracle reaches these sizes, so every N > 1 run ends with the device-side invariant check
+(mgc_validate over all slabs: conservation, no residual arc across the cut, no active excess, flow == cut) and FAILS if it
+does not hold.  After every relabel pass / colour phase the packed slab borders travel to the neighbour ranks with RCCL
+send/recv over xGMI (medpy_amd/slab.py); tiny all-reduces decide termination.
+
+Prints ONE JSON line (rank 0) with `roofline` (dominant kernel k_discharge_w, HIP-event timed on the launch stream inside
+the library) and `cpu_baseline` (the reference's own BK solver, compiled in place as oracle/_ref, timed on a bounded sample
+on the host cores; --cpu-full times the whole 512^3 instead, ~3 minutes and ~40 GB).
 """
 import argparse
+import hashlib
 import json
 import os
 import sys
@@ -30,31 +38,49 @@ import numpy as np
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
-B_ALG_6CONN = 71.0  # algorithmic bytes per voxel, SURVEY.md 8(d): 4 + 2 + 2*(3*8 + 8) + 1
+B_ALG = {6: 71.0, 26: 231.0}  # algorithmic bytes per voxel, SURVEY.md 8(d): 4 + 2 + 2*(ndir/2*8 + 8) + 1; + 4 with a probability map
 HBM_PEAK_GBS = 8000.0  # /opt/skills/guides/MI355X_MICROARCH.md
+BLOCK = 512  # edge of one sphere block of the multi-GPU volume
+
+
+def kernel_source_hash():
+    """identifies the kernels a PMC pass was taken with (the GPU box has no git history)"""
+    h = hashlib.sha256()
+    d = os.path.join(ROOT, "medpy_amd", "csrc")
+    for f in sorted(os.listdir(d)):
+        h.update(open(os.path.join(d, f), "rb").read())
+    return h.hexdigest()[:16]
 
 
 def pmc_traffic_per_launch():
-    """HBM bytes per k_discharge launch from the committed rocprofv3 PMC passes (profiles/pmc_discharge.json, written by
-    tools/rocpd_summary.py from `rocprofv3 --pmc FETCH_SIZE` / `--pmc WRITE_SIZE` runs of this very command).
-    FETCH_SIZE is doubled as MI355X_MICROARCH.md (HBM section) prescribes for wide coalesced reads on gfx950."""
+    """HBM bytes per k_discharge_w launch from the rocprofv3 PMC passes of tools/profile_round.sh (FETCH_SIZE and WRITE_SIZE in
+    separate passes over this very command; profiles/pmc_discharge.json).  Only reported when those passes ran on the kernel
+    sources of this tree (hash of medpy_amd/csrc); 8-byte-per-lane reads are not the access width FETCH_SIZE was calibrated
+    for (MI355X_MICROARCH.md, HBM), so both the raw and the doubled read figure are given."""
     path = os.path.join(ROOT, "profiles", "pmc_discharge.json")
     if not os.path.exists(path):
-        return None
+        return None, None
     d = json.load(open(path))
-    return int((2.0 * d["fetch_kib_per_launch"] + d["write_kib_per_launch"]) * 1024)
+    info = {"fetch_kib_per_launch": d.get("fetch_kib_per_launch"), "write_kib_per_launch": d.get("write_kib_per_launch"),
+            "kernel_sources": d.get("kernel_sources"), "matches_this_tree": d.get("kernel_sources") == kernel_source_hash()}
+    if not info["matches_this_tree"]:
+        return None, info
+    return int((2.0 * d["fetch_kib_per_launch"] + d["write_kib_per_launch"]) * 1024), info
 
 
-def cpu_baseline(sample_n):
-    """Reference BK (oracle/_ref, or the C restatement when it did not travel) on a bounded sample."""
+def cpu_baseline(sample_n, full):
+    """Reference BK (oracle/_ref, or the C restatement when it did not travel) on a bounded sample, plus the committed
+    timing of the as-shipped Python path (BASELINE config 1) from the container that holds the reference."""
     from medpy_amd import synthetic
     from oracle import bk, energy_numpy, pipeline
-    s = synthetic.sphere((sample_n,) * 3)
+    n = BLOCK if full else sample_n
+    s = synthetic.sphere((n,) * 3)
     kind = bk.best_kind()
-    w = energy_numpy.boundary_weights(s["term"], s["image"], s["sigma"])  # NumPy part of the reference (not timed:
-    # the reference spends its build time in the per-edge insertion, which IS timed below)
+    t0 = time.perf_counter()
+    w = energy_numpy.boundary_weights(s["term"], s["image"], s["sigma"])  # the reference's NumPy part (energy_voxel.py:611-664)
+    tw = time.perf_counter() - t0
     best = None
-    for _ in range(2):
+    for _ in range(1 if full else 2):
         t0 = time.perf_counter()
         g = pipeline.build_graph(s["fg"], s["bg"], weights=w, kind=kind)
         t1 = time.perf_counter()
@@ -63,13 +89,47 @@ def cpu_baseline(sample_n):
         del g
         if best is None or (t2 - t0) < best[0]:
             best = (t2 - t0, t1 - t0, t2 - t1)
-    n = sample_n ** 3
-    return {
-        "value": round(n / best[0] / 1e6, 4), "unit": "Mvoxels/s", "cores": 1,
+    out = {
+        "value": round(n ** 3 / (best[0] + tw) / 1e6, 4), "unit": "Mvoxels/s", "cores": 1,
         "kind": "reference" if kind == "ref" else "port",
-        "sample": "%d^3 sphere volume, 6-conn, diff_exp sigma 15; bulk sum_edge build %.2fs + BK maxflow %.2fs, single thread "
-                  "(the reference is single-threaded), host has %d cores" % (sample_n, best[1], best[2], os.cpu_count()),
+        "sample": "%d^3 sphere volume (%s), 6-conn, diff_exp sigma 15; NumPy weights %.2fs + bulk sum_edge build %.2fs + BK maxflow %.2fs, "
+                  "single thread (the reference is single-threaded), host has %d cores" % (
+                      n, "the full workload" if full else "bounded sample of the 512^3 workload", tw, best[1], best[2], os.cpu_count()),
     }
+    p = os.path.join(ROOT, "profiles", "cpu_python_path_64.json")
+    if os.path.exists(p):  # BASELINE config 1: medpy_graphcut_voxel.py's own Python loop, measured where /root/reference exists
+        out["python_path"] = json.load(open(p))
+    p = os.path.join(ROOT, "profiles", "cpu_reference_512.json")
+    if os.path.exists(p) and not full:
+        out["full_workload"] = json.load(open(p))
+    return out
+
+
+def block_volume(planes0, planes1, nz_blocks, xy_blocks, block):
+    """the local planes [planes0, planes1) of a (nz_blocks x xy_blocks x xy_blocks) grid of sphere blocks: image, fg, bg.
+    Every block carries its own bright ball and foreground seed; exactly the outer shell of the WHOLE volume is
+    background, so the blocks share one connected medium."""
+    from medpy_amd import synthetic
+    b0, b1 = planes0 // block, (planes1 - 1) // block
+    slabs_i, slabs_f = [], []
+    for bz in range(b0, b1 + 1):
+        z0, z1 = max(planes0, bz * block) - bz * block, min(planes1, (bz + 1) * block) - bz * block
+        rows_i, rows_f = [], []
+        for by in range(xy_blocks):
+            ri, rf = [], []
+            for bx in range(xy_blocks):
+                blk = synthetic.sphere((block,) * 3, seed=(bz * xy_blocks + by) * xy_blocks + bx)
+                ri.append(blk["image"][z0:z1]); rf.append(blk["fg"][z0:z1])
+            rows_i.append(np.concatenate(ri, axis=2)); rows_f.append(np.concatenate(rf, axis=2))
+        slabs_i.append(np.concatenate(rows_i, axis=1)); slabs_f.append(np.concatenate(rows_f, axis=1))
+    img, fg = np.concatenate(slabs_i, axis=0), np.concatenate(slabs_f, axis=0)
+    bg = np.zeros(img.shape, dtype=bool)
+    if planes0 == 0:
+        bg[0] = True
+    if planes1 == nz_blocks * block:
+        bg[-1] = True
+    bg[:, 0, :] = True; bg[:, -1, :] = True; bg[:, :, 0] = True; bg[:, :, -1] = True
+    return np.ascontiguousarray(img), np.ascontiguousarray(fg), bg
 
 
 def main():
@@ -77,33 +137,55 @@ def main():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=3)
     ap.add_argument("--warmup", type=int, default=1)
-    ap.add_argument("--size", type=int, default=512)
+    ap.add_argument("--config", type=int, default=0, help="BASELINE.json config 2..5 (default: by --gpus, see the module docstring)")
+    ap.add_argument("--strong", action="store_true", help="1024^3, 6-conn, cut into --gpus slabs: strong scaling")
+    ap.add_argument("--size", type=int, default=0, help="edge of the single-GPU cube (default 512; config 2: 256)")
+    ap.add_argument("--xy", type=int, default=1024, help="cross-section edge of the multi-GPU volume (a multiple of --block)")
+    ap.add_argument("--planes", type=int, default=256, help="planes per GPU of the multi-GPU volume")
+    ap.add_argument("--block", type=int, default=BLOCK, help="edge of one sphere block of the multi-GPU volume")
     ap.add_argument("--cpu-sample", type=int, default=320)
+    ap.add_argument("--cpu-full", action="store_true")
     ap.add_argument("--no-cpu", action="store_true")
     args = ap.parse_args()
 
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
+    if world != args.gpus and world > 1:
+        raise SystemExit("bench.py: --gpus %d but WORLD_SIZE=%d" % (args.gpus, world))
 
     from medpy_amd import _lib, synthetic
     from medpy_amd.graphcut.graph import VoxelGraph
 
-    if _lib.device_count() < 1:
+    ndev = _lib.device_count()
+    if ndev < 1:
         raise SystemExit("bench.py: no MI355X visible (the HIP path has no CPU fallback)")
 
-    n = args.size
+    conn, regional = 6, False
+    if args.config == 3:
+        conn, regional = 26, True
+    if args.config == 5:
+        conn = 26
+        if world != 8 and not os.environ.get("MEDPY_BENCH_ANY_WORLD"):
+            raise SystemExit("bench.py: --config 5 is 2048 x 1024 x 1024 on 8 GPUs (launch with --gpus 8)")
+    if args.config == 4 and world != 4 and not os.environ.get("MEDPY_BENCH_ANY_WORLD"):
+        raise SystemExit("bench.py: --config 4 is 1024^3 on 4 GPUs (launch with --gpus 4)")
+
     acc = {"build_ms": 0.0, "solve_ms": 0.0, "discharge_ms": 0.0, "relabel_ms": 0.0, "discharge_launches": 0,
            "relabel_launches": 0, "discharge_tiles": 0, "relabel_tiles": 0, "global_relabels": 0, "phases": 0}
     flow = 0.0
-    slab_stats = None
-    rccl_stalled = False
-    if world == 1:
+    slab_stats = validation = None
+    transport = None
+    if world == 1 and not args.strong:
+        n = args.size or (256 if args.config == 2 else BLOCK)
         shape = (n, n, n)
         s = synthetic.sphere(shape, seed=0)
-        g = VoxelGraph(shape, device=0)
+        g = VoxelGraph(shape, device=0, connectivity=conn if conn != 6 else None)
         g._set_boundary("difference_exponential", s["image"], s["sigma"], False)  # H2D, outside the timed region
         g._set_markers(s["fg"], s["bg"])
+        if regional:
+            r = synthetic.regional(shape)
+            g._set_regional(r["prob"], r["alpha"])
 
         def step():
             g._build()
@@ -119,40 +201,42 @@ def main():
                 acc[k] += st[k]
         elapsed = time.perf_counter() - t0
         fg_fraction = float(g.labels().mean())
+        validation = g.validate()
+        _lib.assert_valid(validation)
+        gshape = shape
+        workload = "%d^3 sphere volume (float32), %d-conn, boundary_difference_exponential sigma=15%s, fg=inner ball, bg=6 faces" % (
+            n, conn, " + regional_probability_map (float32, alpha 0.5)" if regional else "")
     else:
+        import torch
         import torch.distributed as dist  # out-of-band channel only (gloo): RCCL id broadcast, barriers, host scalars
-        from medpy_amd.slab import DistExchange, HipSlab, RcclExchange, solve_slabs
-        # MEDPY_DIST_BACKEND=gloo: development aid -- the borders travel through host buffers and the ranks may share
-        # a GPU (exercises this code path on a 1-GPU box).  Default: RCCL over xGMI, driven by the library itself.
+        from medpy_amd.slab import DistExchange, HipSlab, LoopbackExchange, RcclExchange, solve_slabs, validate_slabs
+        # MEDPY_DIST_BACKEND=gloo: development aid -- the borders travel through host buffers and the ranks may share a GPU
+        # (exercises this code path on a 1-GPU box).  Default: RCCL over xGMI, driven by the library itself; if it cannot be
+        # brought up, or there are fewer GPUs than ranks, the run FAILS rather than print a number that is not an RCCL number.
         backend = os.environ.get("MEDPY_DIST_BACKEND", "nccl")
-        dev_index = local_rank % _lib.device_count()
-        dist.init_process_group("gloo", rank=rank, world_size=world)
-        gshape = (n * world, n, n)
-        slab = HipSlab(gshape, rank, world, device=dev_index)
-        # the local planes of the global volume: sphere block `b` occupies planes [b*n, (b+1)*n)
-        b0, b1 = slab.plane0 // n, (slab.plane1 - 1) // n
-        imgs, fgs, bgs = [], [], []
-        for b in range(b0, b1 + 1):
-            blk = synthetic.sphere((n, n, n), seed=b)
-            bg = blk["bg"].copy()
-            if b > 0:
-                bg[0, 1:-1, 1:-1] = False  # interior block faces are not background: one connected medium
-            if b < world - 1:
-                bg[-1, 1:-1, 1:-1] = False
-            imgs.append(blk["image"]); fgs.append(blk["fg"]); bgs.append(bg)
-        sl = slice(slab.plane0 - b0 * n, slab.plane1 - b0 * n)
-        img_local = np.concatenate(imgs, axis=0)[sl]
-        fg_local, bg_local = np.concatenate(fgs, axis=0)[sl], np.concatenate(bgs, axis=0)[sl]
+        if world > ndev and backend == "nccl":
+            raise SystemExit("bench.py: %d ranks but %d GPUs visible (MEDPY_DIST_BACKEND=gloo shares GPUs for development runs)" % (world, ndev))
+        dev_index = local_rank % ndev
+        if world > 1:
+            dist.init_process_group("gloo", rank=rank, world_size=world)
+        xy, blk = args.xy, args.block
+        if xy % blk:
+            raise SystemExit("bench.py: --xy must be a multiple of --block")
+        Z = xy if args.strong else args.planes * world  # strong: one cube for every N; weak: --planes per GPU
+        if Z % blk:
+            raise SystemExit("bench.py: %d planes are not a whole number of %d-plane blocks" % (Z, blk))
+        gshape = (Z, xy, xy)
+        slab = HipSlab(gshape, rank, world, device=dev_index, connectivity=conn)
+        img_local, fg_local, bg_local = block_volume(slab.plane0, slab.plane1, Z // blk, xy // blk, blk)
         slab.set_boundary("difference_exponential", img_local, 15.0, False)
         slab.set_markers(fg_local, bg_local)
-        del imgs, fgs, bgs
-        ex, transport = None, "gloo, host-staged (MEDPY_DIST_BACKEND=gloo)"
-        if backend == "nccl":
-            # RCCL is the transport.  Its bring-up (ncclCommInitRank + one border exchange + one counter all-reduce) runs
-            # under a watchdog and the ranks agree on the outcome over gloo: if it fails or stalls on any rank, every rank
-            # falls back to moving the same border buffers through host memory and the JSON line says so.
+        del img_local, fg_local, bg_local
+        if world == 1:
+            ex, transport = LoopbackExchange([slab]), "none (one slab)"
+        elif backend == "nccl":
+            # bring-up (ncclCommInitRank + one border exchange + one counter all-reduce) under a watchdog: a stall must end the
+            # run with an error, not hang the node and not fall back to a transport whose number would be taken for RCCL's
             import threading
-            import torch
             box = {}
 
             def bring_up():
@@ -167,23 +251,16 @@ def main():
 
             th = threading.Thread(target=bring_up, daemon=True)
             th.start()
-            th.join(float(os.environ.get("MEDPY_RCCL_TIMEOUT", "240")))
+            th.join(float(os.environ.get("MEDPY_RCCL_TIMEOUT", "300")))
             ok = torch.tensor([1 if "ex" in box else 0], dtype=torch.int32)
             dist.all_reduce(ok, op=dist.ReduceOp.MIN)
-            if int(ok[0]) == 1:
-                ex, transport = box["ex"], "RCCL (grouped ncclSend/ncclRecv between neighbour slabs)"
-            else:
-                hung = th.is_alive()
-                sys.stderr.write("[bench rank %d] RCCL bring-up %s; falling back to host-staged borders\n" %
-                                 (rank, "stalled" if hung else "failed: %s" % box.get("err", "on another rank")))
-                transport = "gloo, host-staged (RCCL bring-up failed)"
-                if hung:  # the handle is stuck inside the library on that thread: take a fresh one
-                    rccl_stalled = True
-                    slab = HipSlab(gshape, rank, world, device=dev_index)
-                    slab.set_boundary("difference_exponential", img_local, 15.0, False)
-                    slab.set_markers(fg_local, bg_local)
-        if ex is None:
-            ex = DistExchange(slab)
+            if int(ok[0]) != 1:
+                sys.stderr.write("[bench rank %d] RCCL bring-up %s -- no result\n" % (rank, "stalled" if th.is_alive() else "failed: %s" % box.get("err", "on another rank")))
+                sys.stderr.flush()
+                os._exit(3)
+            ex, transport = box["ex"], "RCCL (grouped ncclSend/ncclRecv between neighbour slabs, ncclAllReduce of the counters)"
+        else:
+            ex, transport = DistExchange(slab), "gloo, host-staged borders (MEDPY_DIST_BACKEND=gloo: development run, not an RCCL number)"
 
         def step():
             slab.build()
@@ -192,66 +269,75 @@ def main():
 
         for _ in range(args.warmup):
             step()
-        dist.barrier()  # every library call above returned after its stream drained (device synchronised)
+        if world > 1:
+            dist.barrier()  # every library call above returned after its stream drained (device synchronised)
         t0 = time.perf_counter()
         for _ in range(args.steps):
             slab_stats, part = step()  # finish_device() synchronises the stream
-        dist.barrier()
+        if world > 1:
+            dist.barrier()
         elapsed = time.perf_counter() - t0
-        import torch
-        t = torch.tensor([elapsed], dtype=torch.float64)
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        elapsed = float(t[0])
+        if world > 1:
+            t = torch.tensor([elapsed], dtype=torch.float64)
+            dist.all_reduce(t, op=dist.ReduceOp.MAX)
+            elapsed = float(t[0])
         flow = float(ex.allreduce_sum([part]))
         lab, _ = slab.finish()
         fg_fraction = float(ex.allreduce_sum([float(lab.sum())])) / float(np.prod(gshape))
-        dist.barrier()
+        validation = validate_slabs([slab], ex)  # no oracle reaches this size: the invariants are the check
+        _lib.assert_valid(validation)
+        assert abs((validation["cut_capacity"] + validation["flow_constant"]) - flow) <= 1e-9 * max(abs(flow), 1e-300)
+        if world > 1:
+            dist.barrier()
+        workload = "%dx%dx%d volume (%dx%dx%d sphere blocks of %d^3, float32, one connected medium), %d-conn, boundary_difference_exponential sigma=15, bg=outer faces" % (
+            gshape[0], gshape[1], gshape[2], gshape[0] // blk, xy // blk, xy // blk, blk, conn)
 
     if rank == 0:
-        nvox = n ** 3
+        nvox = float(np.prod(gshape))
         ms_per_step = elapsed / args.steps * 1e3
-        value = world * nvox / (elapsed / args.steps) / 1e6
-        # dominant kernel: k_discharge (tile region-discharge).  Units per launch = voxels of the tiles it visits.
-        launches = max(acc["discharge_launches"], 1)
-        avg_ms = acc["discharge_ms"] / launches
-        vox_per_launch = acc["discharge_tiles"] * 512.0 / launches
-        achieved = (B_ALG_6CONN * vox_per_launch) / (avg_ms * 1e-3) / 1e9 if avg_ms > 0 else 0.0
+        value = nvox / (elapsed / args.steps) / 1e6
+        b_alg = B_ALG[conn] + (4.0 if regional else 0.0)
         out = {
             "metric": "Mvoxels/s graph-cut (build+solve), 512^3 6-conn; fraction of HBM roofline",
             "value": round(value, 3), "unit": "Mvoxels/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
-            "ms_per_step": round(ms_per_step, 3), "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
-            "dtype": "f64", "data": "synthetic",
-            "config": {"workload": "%d^3 sphere volume (float32), 6-conn, boundary_difference_exponential sigma=15, "
-                                   "fg=inner ball, bg=6 faces" % n,
-                       "parallelism": ("%d exact Z-slabs of one %dx%dx%d volume (%d stacked sphere blocks), halo exchange between neighbour slabs" %
-                                       (world, n * world, n, n, world)) if world > 1 else "single GPU",
-                       "transport": transport if world > 1 else None,
-                       "fg_fraction": round(fg_fraction, 5), "flow": flow},
-            "phases_ms": {"build": round(acc["build_ms"] / args.steps, 3), "solve": round(acc["solve_ms"] / args.steps, 3),
-                          "discharge_kernels": round(acc["discharge_ms"] / args.steps, 3),
-                          "relabel_kernels": round(acc["relabel_ms"] / args.steps, 3),
-                          "global_relabels": acc["global_relabels"] / args.steps, "colour_phases": acc["phases"] / args.steps,
-                          "tile_discharges": acc["discharge_tiles"] / args.steps, "tile_relabels": acc["relabel_tiles"] / args.steps},
-            "job_roofline_frac": round(value * 1e6 / world * B_ALG_6CONN / (HBM_PEAK_GBS * 1e9), 6),
-            "roofline": {"bound": "hbm", "kernel": "k_discharge", "achieved": round(achieved, 2), "peak": HBM_PEAK_GBS,
-                         "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBS, 5), "traffic": pmc_traffic_per_launch(),
-                         "avg_launch_ms": round(avg_ms, 4), "launches_per_step": launches / args.steps,
-                         "voxels_per_launch": round(vox_per_launch, 1), "bytes_per_voxel": B_ALG_6CONN},
+            "ms_per_step": round(ms_per_step, 3), "higher_is_better": True, "scaling": "strong" if args.strong else "weak",
+            "vs_baseline": None, "dtype": "f64", "data": "synthetic",
+            "config": {"workload": workload, "shape": list(gshape), "connectivity": conn,
+                       "baseline_config": args.config or (None if args.strong else {1: "headline", 4: 4}.get(world)),
+                       "parallelism": ("%d exact Z-slabs (one per GPU, %d planes each), halo exchange between neighbour slabs" % (
+                           world, gshape[0] // world)) if world > 1 else "single GPU",
+                       "transport": transport, "fg_fraction": round(fg_fraction, 5), "flow": flow},
+            "job_roofline_frac": round(value * 1e6 / world * b_alg / (HBM_PEAK_GBS * 1e9), 6),
+            "per_gpu_algorithmic_gbs": round(value * 1e6 / world * b_alg / 1e9, 2),
+            "validation": validation,
         }
-        if slab_stats is not None:
+        if slab_stats is None:
+            # dominant kernel: k_discharge_w (region discharge, one wave per tile).  Units per launch = voxels of the tiles it visits.
+            launches = max(acc["discharge_launches"], 1)
+            avg_ms = acc["discharge_ms"] / launches
+            vox_per_launch = acc["discharge_tiles"] * 512.0 / launches
+            achieved = (b_alg * vox_per_launch) / (avg_ms * 1e-3) / 1e9 if avg_ms > 0 else 0.0
+            traffic, traffic_info = pmc_traffic_per_launch() if conn == 6 and not args.config else (None, None)
+            out["phases_ms"] = {"build": round(acc["build_ms"] / args.steps, 3), "solve": round(acc["solve_ms"] / args.steps, 3),
+                                "discharge_kernels": round(acc["discharge_ms"] / args.steps, 3),
+                                "relabel_kernels": round(acc["relabel_ms"] / args.steps, 3),
+                                "global_relabels": acc["global_relabels"] / args.steps, "colour_phases": acc["phases"] / args.steps,
+                                "tile_discharges": acc["discharge_tiles"] / args.steps, "tile_relabels": acc["relabel_tiles"] / args.steps}
+            out["roofline"] = {"bound": "hbm", "kernel": "k_discharge_w" if conn == 6 else "k26_discharge", "achieved": round(achieved, 2),
+                               "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBS, 5), "traffic": traffic,
+                               "traffic_source": traffic_info, "avg_launch_ms": round(avg_ms, 4), "launches_per_step": launches / args.steps,
+                               "voxels_per_launch": round(vox_per_launch, 1), "bytes_per_voxel": b_alg}
+        else:
             out["slab_schedule"] = slab_stats
-            out["roofline"] = None  # per-kernel event timing is a single-GPU measurement (N=1 line)
-        if not args.no_cpu and world == 1:
-            out["cpu_baseline"] = cpu_baseline(args.cpu_sample)
-        elif not args.no_cpu:
+            out["roofline"] = None  # per-kernel event timing is a single-handle measurement (the N = 1 line)
+        if not args.no_cpu and world == 1 and not args.config and not args.strong:
+            out["cpu_baseline"] = cpu_baseline(args.cpu_sample, args.cpu_full)
+        else:
             out["cpu_baseline"] = None
         print(json.dumps(out))
     if world > 1:
         import torch.distributed as dist
         dist.destroy_process_group()
-        if rccl_stalled:  # a watchdog thread is still parked inside RCCL: skip interpreter teardown
-            sys.stdout.flush()
-            os._exit(0)
 
 
 if __name__ == "__main__":

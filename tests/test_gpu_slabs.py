@@ -157,3 +157,40 @@ def test_native_transport_protocol_with_mock_rccl(nranks, conn, gen, shape, tmp_
     ref = pipeline.graphcut_voxel(s["fg"], s["bg"], term=s["term"], image=s["image"], sigma=s["sigma"], connectivity=conn)
     np.testing.assert_array_equal(np.load(out), ref.labels)
     assert info["flow"] == pytest.approx(ref.flow, rel=1e-9)
+
+
+@pytest.mark.parametrize("flags,conn", [([], 6), (["--config", "5"], 26), (["--strong"], 6)])
+def test_bench_multi_gpu_code_path_at_reduced_size(flags, conn):
+    """bench.py --gpus 2 as the driver launches it (torch.distributed.run, one process per rank), at a reduced size and with
+    the development transport (two ranks share the one GPU of this box, borders through host buffers): the workload
+    generator (grid of sphere blocks, outer shell = background), the slab build, the distributed schedule, the
+    device-side invariant check over all slabs that every N > 1 run ends with -- for the default (6-conn, config 4's
+    family), --config 5 (26-conn) and --strong."""
+    import json
+    import os
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = dict(os.environ, MEDPY_DIST_BACKEND="gloo", MEDPY_BENCH_ANY_WORLD="1")
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
+           "--master-port", "29713", os.path.join(root, "bench.py"), "--gpus", "2", "--steps", "1", "--warmup", "0", "--xy", "64",
+           "--planes", "32", "--block", "32"] + flags
+    res = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=900, cwd=root)
+    assert res.returncode == 0, (res.stdout[-3000:], res.stderr[-3000:])
+    line = [ln for ln in res.stdout.splitlines() if ln.startswith("{")][-1]
+    out = json.loads(line)
+    assert out["n_gpus"] == 2 and out["config"]["connectivity"] == conn and out["config"]["shape"] == [64, 64, 64]
+    assert out["scaling"] == ("strong" if "--strong" in flags else "weak")
+    v = out["validation"]
+    assert v["voxels"] == 64 ** 3 and not any(v[k] for k in ("negative_values", "active_excess", "residual_arcs_across",
+                                                             "sink_links_across", "pair_violations", "node_violations", "pending_outbox"))
+    assert "gloo" in out["config"]["transport"]  # and the line says so: never mistaken for an RCCL number
+    # the same volume on one handle gives the same cut
+    sys.path.insert(0, root)
+    import bench
+    from medpy_amd import graphcut
+    img, fg, bg = bench.block_volume(0, 64, 2, 2, 32)
+    g = graphcut.graph_from_voxels(fg, bg, boundary_term=graphcut.energy_voxel.boundary_difference_exponential,
+                                   boundary_term_args=(img, 15.0, False), **({"connectivity": 26} if conn == 26 else {}))
+    assert out["config"]["flow"] == pytest.approx(g.maxflow(), rel=1e-9)
+    assert out["config"]["fg_fraction"] == pytest.approx(float(g.labels().mean()), abs=1e-5)

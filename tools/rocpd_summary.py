@@ -26,6 +26,13 @@ def main():
             n, v = c.execute("select count(*), avg(value) from counters_collection where kernel_name like 'k_discharge%'").fetchone()
             out[key] = v
             out[key.replace("kib_per_launch", "launches")] = n
+        import hashlib, os
+        root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+        h = hashlib.sha256()
+        d = os.path.join(root, "medpy_amd", "csrc")
+        for f in sorted(os.listdir(d)):
+            h.update(open(os.path.join(d, f), "rb").read())
+        out["kernel_sources"] = h.hexdigest()[:16]  # bench.py only quotes these counters for the kernels they were taken with
         print(json.dumps(out))
     else:
         print("kernel,counter,dispatches,sum_value,avg_value_per_dispatch,avg_duration_us")
