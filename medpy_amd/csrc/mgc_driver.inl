@@ -18,7 +18,7 @@
  * `relabel_batch` passes / `check_rounds` rounds (a pass over an empty list is a no-op).
  *
  * Dev concept (every call is asynchronous on the device's stream unless it returns a value):
- *   fill_heights_inf()  zero_count(i)  read_counts(int out[MGC_NCOUNT])   absorb_all()
+ *   fill_heights_inf()  zero_count(i)  read_counts(int out[MGC_NCOUNT])   absorb_all()   suspect_pass()  suspect_batch()
  *   relabel_all(epoch, next_list)  relabel_list(list, epoch, next_list)
  *   activate_all(phase)  discharge(list, phase, max_cycles, max_sweeps)
  */
@@ -101,7 +101,7 @@ int mgc_solve(Dev& dev, const MgcLattice& L, const MgcSolveParams& P, MgcSolveSt
             /* which tiles could have lost the support of their labels? (tile-level closure, cheap passes) */
             for (;;) {
                 dev.zero_count(MGC_CNT_CHANGED);
-                for (int b = 0; b < 8; ++b) dev.suspect_pass();
+                for (int b = 0; b < dev.suspect_batch(); ++b) dev.suspect_pass();
                 dev.read_counts(cnt);
                 st.readbacks++;
                 if (cnt[MGC_CNT_CHANGED] == 0) break;

@@ -475,12 +475,27 @@ __global__ __launch_bounds__(MGC_TV) void k_relabel_list(MgcLattice L, int lst, 
     }
 }
 
-/* incremental global relabel: tile-level suspect closure (one thread per tile) and reset of the suspect tiles */
-__global__ void k_suspect_pass(MgcLattice L)
+/* incremental global relabel: tile-level suspect closure (one thread per tile) and reset of the suspect tiles.
+ * A workgroup owns a BRICK of 8x8x8 tiles and iterates the closure inside it to a fixpoint before it leaves (the flags
+ * only ever get set, so racing with the neighbour bricks is benign: what they add is picked up by the next pass).  The
+ * closure then advances a brick per launch instead of a tile per launch: ~30 launches per 512^3 step instead of 200. */
+__global__ __launch_bounds__(MGC_TV) void k_suspect_pass(MgcLattice L)
 {
+    const int bxn = (L.gx + 7) / 8, byn = (L.gy + 7) / 8, bzn = (L.gz + 7) / 8;
+    const int t = threadIdx.x;
     bool any = false;
-    for (int tile = blockIdx.x * blockDim.x + threadIdx.x; tile < L.ntiles; tile += gridDim.x * blockDim.x)
-        any |= mgc_suspect_tile(L, tile);
+    for (int b = blockIdx.x; b < bxn * byn * bzn; b += gridDim.x) {
+        const int bx = b % bxn, by = (b / bxn) % byn, bz = b / (bxn * byn);
+        const int tz = bz * 8 + (t >> 6), ty = by * 8 + ((t >> 3) & 7), tx = bx * 8 + (t & 7);
+        const bool in = tz < L.gz && ty < L.gy && tx < L.gx;
+        const int tile = in ? mgc_tile_id(L, tz, ty, tx) : 0;
+        for (int it = 0; it < 24; ++it) { /* a brick is at most 22 steps across */
+            const bool ch = in && mgc_suspect_tile(L, tile);
+            any |= ch;
+            __threadfence_block();
+            if (!__syncthreads_or(ch)) break;
+        }
+    }
     if (any) L.count[MGC_CNT_CHANGED] = 1;
 }
 
@@ -1253,6 +1268,7 @@ struct HipDevT {
     float discharge_ms = 0.f, relabel_ms = 0.f;
     int64_t discharge_launches = 0, relabel_launches = 0, readbacks = 0;
     int last_discharged = -1; /* list consumed by the discharge launched last (see pending_zero) */
+    int suspect_batch() const { return 2; } /* closure passes between two looks at the "changed" flag: a pass settles a brick */
     struct Span { int a, b, kind; };
     std::vector<Span> spans;
     void check(hipError_t e) { if (e != hipSuccess && first_error == hipSuccess) first_error = e; }
@@ -1324,7 +1340,8 @@ struct HipDevT {
     {
         flush_zero();
         if constexpr (!FULL) {
-            hipLaunchKernelGGL(k_suspect_pass, dim3((h->L.ntiles + 255) / 256 < 2048 ? (h->L.ntiles + 255) / 256 : 2048), dim3(256), 0, h->stream, h->L);
+            const int nb = ((h->L.gx + 7) / 8) * ((h->L.gy + 7) / 8) * ((h->L.gz + 7) / 8);
+            hipLaunchKernelGGL(k_suspect_pass, dim3(nb < 4096 ? nb : 4096), dim3(MGC_TV), 0, h->stream, h->L);
             check(hipGetLastError());
         }
     }
@@ -2312,7 +2329,7 @@ int mgc_set_param(mgc_handle h, const char* name, int64_t value)
 {
     if (!h || !name) return MGC_ERR_INVALID;
     if (!strcmp(name, "rounds_per_relabel") && value > 0) h->params.rounds_per_relabel = (int)value;
-    else if (!strcmp(name, "max_cycles") && value > 0) h->params.max_cycles = (int)value;
+    else if (!strcmp(name, "max_cycles") && value != 0) h->params.max_cycles = (int)value; /* < 0 (26-neighbourhood): stored labels, no in-tile BFS */
     else if (!strcmp(name, "max_sweeps") && value > 0) h->params.max_sweeps = (int)value;
     else if (!strcmp(name, "max_outer") && value > 0) h->params.max_outer = (int)value;
     else if (!strcmp(name, "grid_cap") && value > 0) h->grid_cap = (int)value;

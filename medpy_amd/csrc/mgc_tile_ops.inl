@@ -252,6 +252,7 @@ MGC_HD void mgc_relabel_tile(X& x, const MgcLattice& L, int tile, uint32_t next_
                 if (((m[t] >> d) & 1) && !mgc_inside(d, z, y, xx) && x.S.hs[me + mgc_hs_step(d)] + 1 == hm) x.S.depflag[d] = 1;
         }
         if (hm < h0[t]) {
+            x.S.flag[0] = 1; /* some label of the tile came down: it is not "all INF" (any more) */
             /* wake the neighbour across a face only if its adjacent voxel could improve: labels only go down during a
              * relabel, so a halo value is an upper bound of the neighbour's current label and "hm + 1 >= halo" stays
              * true.  This drops the back-wakes (the tile the wave came from) and most side-wakes. */
@@ -266,7 +267,7 @@ MGC_HD void mgc_relabel_tile(X& x, const MgcLattice& L, int tile, uint32_t next_
         if (t == 6) {
             uint32_t dep = 0;
             for (int f = 0; f < 6; ++f) dep |= x.S.depflag[f] ? (1u << f) : 0u;
-            L.status[tile] = (L.status[tile] & ~((63u << MGC_ST_DEP_SHIFT) | MGC_ST_ALLINF)) | (dep << MGC_ST_DEP_SHIFT);
+            L.status[tile] = (L.status[tile] & ~((63u << MGC_ST_DEP_SHIFT) | (x.S.flag[0] ? MGC_ST_ALLINF : 0u))) | (dep << MGC_ST_DEP_SHIFT);
         }
     });
 }

@@ -202,14 +202,22 @@ MGC_HD void mgc26_discharge_tile(X& x, const MgcLattice& L, int tile, uint32_t p
 
     bool active = false;
     int sweep_id = 0;
+    /* max_cycles < 0: no exact in-tile labelling at all -- the stored labels are valid lower bounds (distances only grow),
+     * and the local relabel at the end of every sweep raises the voxels that are stuck; -max_cycles sweep blocks */
+    const bool stored_labels = max_cycles < 0;
+    if (stored_labels) max_cycles = -max_cycles;
     for (int cyc = 0; cyc < max_cycles; ++cyc) {
-        x.par([&](int t) { x.S.hs[mgc_hs_index(t >> 6, (t >> 3) & 7, t & 7)] = MGC_HINF; });
-        mgc26_tile_bfs(x, [&](int t) {
-            uint32_t m = snk[t] > 0.0 ? MGC26_MASK_SINK : 0u;
+        if (stored_labels) {
+            if (cyc == 0) x.par([&](int t) { x.S.hs[mgc_hs_index(t >> 6, (t >> 3) & 7, t & 7)] = L.height[base + t]; });
+        } else {
+            x.par([&](int t) { x.S.hs[mgc_hs_index(t >> 6, (t >> 3) & 7, t & 7)] = MGC_HINF; });
+            mgc26_tile_bfs(x, [&](int t) {
+                uint32_t m = snk[t] > 0.0 ? MGC26_MASK_SINK : 0u;
 #pragma unroll
-            for (int d = 0; d < MGC26_NDIR; ++d) m |= (R(d, t) > 0.0) ? (1u << d) : 0u;
-            return m;
-        });
+                for (int d = 0; d < MGC26_NDIR; ++d) m |= (R(d, t) > 0.0) ? (1u << d) : 0u;
+                return m;
+            });
+        }
         active = x.any([&](int t) -> bool {
             hme[t] = x.S.hs[mgc_hs_index(t >> 6, (t >> 3) & 7, t & 7)];
             return e[t] > 0.0 && hme[t] < MGC_HINF;

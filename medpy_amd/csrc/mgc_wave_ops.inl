@@ -369,8 +369,9 @@ MGC_HD void mgcw_discharge_impl(W& w, const MgcLattice& L, int tile, uint32_t ph
             constexpr std::integral_constant<int, K> KC{};
             constexpr std::integral_constant<int, 4> DC{};
             auto below = [&](int l) MGCW_INL -> int {
-                if constexpr (K > 0) return h(l, K - 1);
-                else return hz(l, 0);
+                int hb = hz(l, 0);
+                if constexpr (K > 0) hb = h(l, K - 1);
+                return hb;
             };
             if (!w.any([&](int l) MGCW_INL -> bool { return can_push(l, KC, DC, below(l)); })) return;
             dirty |= 3u << 4;
@@ -384,8 +385,9 @@ MGC_HD void mgcw_discharge_impl(W& w, const MgcLattice& L, int tile, uint32_t ph
             constexpr int K = decltype(KK)::value;
             constexpr std::integral_constant<int, 5> DC{};
             auto above = [&](int l) MGCW_INL -> int {
-                if constexpr (K < 7) return h(l, K + 1);
-                else return hz(l, 1);
+                int ha = hz(l, 1);
+                if constexpr (K < 7) ha = h(l, K + 1);
+                return ha;
             };
             if (!w.any([&](int l) MGCW_INL -> bool { return can_push(l, KK, DC, above(l)); })) return;
             dirty |= 3u << 4;
@@ -573,6 +575,11 @@ MGC_HD void mgcw_relabel_tile(W& w, const MgcLattice& L, int tile, uint32_t next
         wake |= wk ? (1u << D) : 0u;
         dep |= dp ? (1u << D) : 0u;
     });
+    bool lowered = false; /* some label of the tile came down: it is not "all INF" (any more) */
+    mgcw_static_for<8>([&](auto KK) MGCW_INL {
+        constexpr int K = decltype(KK)::value;
+        lowered = lowered || w.any([&](int l) MGCW_INL -> bool { return h(l, K) < h0(l, K); });
+    });
     w.lanes([&](int l) MGCW_INL { /* one block of global traffic: labels + wake-ups */
         mgcw_static_for<8>([&](auto KK) MGCW_INL {
             constexpr int K = decltype(KK)::value;
@@ -582,7 +589,7 @@ MGC_HD void mgcw_relabel_tile(W& w, const MgcLattice& L, int tile, uint32_t next
             const int nt = mgc_tile_nbr(L, tz, ty, tx, l);
             if (nt >= 0) mgc_enqueue(w, L, next_list, L.rstamp, next_epoch, nt);
         }
-        if (l == 6) L.status[tile] = (L.status[tile] & ~((63u << MGC_ST_DEP_SHIFT) | MGC_ST_ALLINF)) | (dep << MGC_ST_DEP_SHIFT);
+        if (l == 6) L.status[tile] = (L.status[tile] & ~((63u << MGC_ST_DEP_SHIFT) | (lowered ? MGC_ST_ALLINF : 0u))) | (dep << MGC_ST_DEP_SHIFT);
     });
 }
 

@@ -181,6 +181,7 @@ struct HostDev {
         }
     }
     void activate_all(uint32_t phase) { HostBlock x(S); for (int t = 0; t < L.ntiles; ++t) mgc_activate_tile(x, L, t, phase); }
+    int suspect_batch() const { return 8; }
     void suspect_pass()
     {
         for (int t = 0; t < L.ntiles; ++t)
@@ -396,6 +397,7 @@ struct HostDev26 {
     void zero_count(int i) { L.count[i] = 0; }
     void read_counts(int* out) { memcpy(out, L.count, MGC_NCOUNT * sizeof(int)); }
     void absorb_all() {}
+    int suspect_batch() const { return 1; }
     void suspect_pass() {}
     void reset_suspect(uint32_t, int) {}
     void relabel_all(uint32_t epoch, int next)
@@ -487,7 +489,7 @@ int hostsim_solve26(const int64_t* shape, const double* w, const double* trcap, 
     d->load(w, trcap);
     MgcSolveParams P = mgc_default_params(26);
     if (rounds > 0) P.rounds_per_relabel = rounds;
-    if (cycles > 0) P.max_cycles = cycles;
+    if (cycles != 0) P.max_cycles = cycles; /* < 0: stored labels instead of the exact in-tile labelling */
     if (sweeps > 0) P.max_sweeps = sweeps;
     if (max_outer > 0) P.max_outer = max_outer;
     MgcSolveStats st;

@@ -1,4 +1,4 @@
-"""Schedule sweep for the 26-neighbourhood solver (development aid)"""
+"""Schedule sweep of the 26-neighbourhood solver on BASELINE config 3 (development aid): cycles < 0 = stored labels."""
 import sys, os, time, json
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 from medpy_amd import synthetic
@@ -10,14 +10,12 @@ g._set_boundary("difference_exponential", s["image"], s["sigma"], False)
 g._set_markers(s["fg"], s["bg"])
 g._set_regional(r["prob"], r["alpha"])
 ref = None
-for c, w, rr in ((1, 4, 8), (1, 3, 8), (1, 5, 8), (1, 2, 8), (1, 4, 6), (1, 4, 10), (1, 3, 6), (1, 3, 10)):
+for c, w, rr in [tuple(int(v) for v in a.split(":")) for a in sys.argv[2:]] or [(1, 3, 6), (-1, 3, 6), (-1, 6, 6), (1, 6, 6)]:
     g.set_param("max_cycles", c); g.set_param("max_sweeps", w); g.set_param("rounds_per_relabel", rr)
     best = 1e9
     for rep in range(2):
         t0 = time.perf_counter(); g._build(); f = g.maxflow(); best = min(best, time.perf_counter() - t0)
-    lab = g.labels()
-    if ref is None:
-        ref = lab.copy()
-    st = g.stats()
-    print(json.dumps({"n": n, "cycles": c, "sweeps": w, "rounds": rr, "ms": round(best * 1e3, 2), "same": bool((lab == ref).all()),
-                      "relabels": st["global_relabels"], "phases": st["phases"], "dis_tiles": st["discharge_tiles"], "rel_tiles": st["relabel_tiles"]}), flush=True)
+    st = g.stats(); lab = g.labels()
+    ref = lab if ref is None else ref
+    print(json.dumps({"n": n, "cycles": c, "sweeps": w, "rounds": rr, "ms": round(best * 1e3, 2), "same_labels": bool((lab == ref).all()), "flow": f,
+                      **{k: (round(st[k], 2) if isinstance(st[k], float) else st[k]) for k in ("build_ms", "discharge_ms", "relabel_ms", "global_relabels", "phases", "discharge_tiles", "relabel_tiles")}}), flush=True)
