@@ -213,7 +213,25 @@ struct GpuWave {
     __device__ __forceinline__ uint32_t atomic_exch(uint32_t* p, uint32_t v) { return atomicExch(p, v); }
     __device__ __forceinline__ void atomic_or(uint32_t* p, uint32_t v) { atomicOr(p, v); }
     __device__ __forceinline__ void atomic_and(uint32_t* p, uint32_t v) { atomicAnd(p, v); }
+#if defined(MGCW_PROFILE) /* development build (tools/gpu_sections.py): cycles per section of a tile discharge, per wave */
+    unsigned long long last = 0, acc[4] = {0, 0, 0, 0};
+    unsigned int cnt[4] = {0, 0, 0, 0};
+    __device__ __forceinline__ void mark(int id)
+    {
+        const unsigned long long now = __builtin_readcyclecounter();
+        if (last) { acc[id & 3] += now - last; cnt[id & 3]++; }
+        last = now;
+    }
+    __device__ __forceinline__ void flush_marks(const MgcLattice& L)
+    {
+        if (L.prof && threadIdx.x == 0)
+            for (int i = 0; i < 4; ++i)
+                if (cnt[i]) { atomicAdd(&L.prof[i], acc[i]); atomicAdd(&L.prof[i + 8], (unsigned long long)cnt[i]); }
+    }
+#else
     __device__ __forceinline__ void mark(int) {}
+    __device__ __forceinline__ void flush_marks(const MgcLattice&) {}
+#endif
     __device__ __forceinline__ void fresh() { asm volatile("" : "+v"(lane)); lane &= 63; }
     /* p[l], p wave-uniform: SGPR base + zero-extended 32-bit byte offset, the addressing mode of global_load / global_store */
     template <class T>
@@ -253,9 +271,11 @@ void k_discharge_w(MgcLattice L, int lst, uint32_t phase, int sweeps, int flags,
     }
     for (int i = (int)blockIdx.x; i < n; i = mgcw_next_ticket(L, tk)) {
         w.new_tile();
+        w.mark(1); /* between two tiles: the ticket, the list entry */
         /* the tile id is wave-uniform: keep it (and every base address derived from it) in SGPRs */
         mgcw_discharge_tile(w, L, __builtin_amdgcn_readfirstlane(L.list[lst][i]), phase, sweeps, flags);
     }
+    w.flush_marks(L);
 }
 
 /* global-relabel pass over a list, one wave per tile; first = the seeding pass of a from-scratch relabel over the
@@ -1219,6 +1239,9 @@ struct mgc_graph {
                               MGC_RELABEL_V voxels per thread (k_relabel_v) instead of one (k_relabel_list) */
     int wave_grid_dis = 0, wave_grid_rel = 0; /* persistent grids of the wave kernels (waves resident on the device) */
     int tk_dis = MGC_CNT_TICKET_DIS, tk_rel = MGC_CNT_TICKET_REL; /* ticket slot of the next wave launch (alternates) */
+    int est_phase_tiles = 1 << 30; /* length of the discharge lists at the last counter read-back */
+    int wave_min_tiles = 512;      /* shorter lists are discharged by the workgroup-per-tile kernel (measured: 128^3 4.8 -> 3.4 ms, 256^3 10.8 -> 10.5 ms,
+                                      512^3 unchanged; 1024 costs 512^3 8 % more discharges) */
     int pending_zero = -1; /* list counter the schedule asked to clear right after a discharge: the next discharge kernel clears
                               it (it neither reads nor appends to that list), any other operation flushes it with a memset first */
     int use_filters = 3; /* bit0 absorb, bit1 activate, bit2 reset-suspect go through the tile-level filter.  Bit2 is off:
@@ -1293,6 +1316,11 @@ struct HipDevT {
         check(hipStreamSynchronize(h->stream));
         memcpy(out, h->h_count, MGC_NCOUNT * sizeof(int32_t));
         readbacks++;
+        if (!FULL) { /* how long are the discharge lists at the moment?  (picks the form of the discharge kernel) */
+            int m = out[6] / 2; /* tiles the last activation found, two colours */
+            for (int i = 0; i < 4; ++i) m = out[i] > m ? out[i] : m;
+            h->est_phase_tiles = m;
+        }
     }
     int filter_grid() const { const int g = (h->L.ntiles + 255) / 256; return g < 1024 ? g : 1024; }
     void absorb_all()
@@ -1386,8 +1414,12 @@ struct HipDevT {
             if (h->wave_kernels & 16) hipLaunchKernelGGL(k26_discharge_v, dim3(grid(h->L.ntiles)), dim3(MGC_TV / 2), 0, h->stream, h->L, lst, phase, cycles, sweeps);
             else hipLaunchKernelGGL(k26_discharge, dim3(grid(h->L.ntiles)), dim3(MGC_TV), 0, h->stream, h->L, lst, phase, cycles, sweeps);
         }
-        else if (h->wave_kernels & 1) { hipLaunchKernelGGL(k_discharge_w, dim3(h->wave_grid_dis), dim3(MGCW_LANES), 0, h->stream, h->L, lst, phase, sweeps, (h->wave_kernels & 4) ? MGCW_BFS : 0, h->tk_dis, zero_idx); h->tk_dis ^= 1; }
-        else hipLaunchKernelGGL(k_discharge, dim3(grid(h->L.ntiles)), dim3(MGC_TV), 0, h->stream, h->L, lst, phase, cycles, sweeps, zero_idx);
+        /* one wave per tile has the higher throughput (2 048 tiles in flight, fewer instructions per tile), eight waves per tile
+         * the shorter latency (36 us against 60 us for one tile): short lists -- small volumes, the tail of a solve -- are a
+         * single tile deep per launch and go to the workgroup form.  Both forms keep the same state in HBM. */
+        else if ((h->wave_kernels & 1) && h->est_phase_tiles >= h->wave_min_tiles) { hipLaunchKernelGGL(k_discharge_w, dim3(h->wave_grid_dis), dim3(MGCW_LANES), 0, h->stream, h->L, lst, phase, sweeps, (h->wave_kernels & 4) ? MGCW_BFS : 0, h->tk_dis, zero_idx); h->tk_dis ^= 1; }
+        else hipLaunchKernelGGL(k_discharge, dim3(grid(h->L.ntiles)), dim3(MGC_TV), 0, h->stream, h->L, lst, phase,
+                                (h->wave_kernels & 1) && !(h->wave_kernels & 4) ? -1 : cycles, sweeps, zero_idx); /* same labelling policy as the wave form */
         check(hipGetLastError());
         time_end(id);
         discharge_launches++;
@@ -2349,6 +2381,7 @@ int mgc_set_param(mgc_handle h, const char* name, int64_t value)
     else if (!strcmp(name, "incremental_relabel")) h->params.incremental_relabel = value != 0;
     else if (!strcmp(name, "use_filters")) h->use_filters = (int)value;
     else if (!strcmp(name, "wave_kernels")) h->wave_kernels = (int)value;
+    else if (!strcmp(name, "wave_min_tiles") && value >= 0) h->wave_min_tiles = (int)value;
     else if (!strcmp(name, "wave_grid_dis") && value > 0) h->wave_grid_dis = (int)value;
     else if (!strcmp(name, "wave_grid_rel") && value > 0) h->wave_grid_rel = (int)value;
     else if (!strcmp(name, "kernel_timing")) h->timing = value != 0;

@@ -388,14 +388,25 @@ MGC_HD void mgc_discharge_tile(X& x, const MgcLattice& L, int tile, uint32_t pha
 
     bool active = false;
     int sweep_id = 0;
+    /* max_cycles < 0: no exact in-tile labelling -- the stored labels are valid lower bounds (distances only grow) and the
+     * local relabel at the end of every sweep raises the voxels that are stuck (what the one-wave-per-tile form does) */
+    const bool stored_labels = max_cycles < 0;
+    if (stored_labels) max_cycles = 1;
     for (int cyc = 0; cyc < max_cycles; ++cyc) {
-        /* exact labels given the frozen halo */
-        x.tile_labels([&](int t) {
-            int m = snk[t] > 0.0 ? MGC_MASK_SINK : 0;
-            for (int d = 0; d < 6; ++d) m |= (x.S.r[d][t] > 0.0) ? (1 << d) : 0;
-            msk[t] = m;
-            return m;
-        }, hme);
+        if (stored_labels) {
+            x.par([&](int t) {
+                hme[t] = t_height[(unsigned)t];
+                x.S.hs[mgc_hs_index(t >> 6, (t >> 3) & 7, t & 7)] = hme[t];
+            });
+        } else {
+            /* exact labels given the frozen halo */
+            x.tile_labels([&](int t) {
+                int m = snk[t] > 0.0 ? MGC_MASK_SINK : 0;
+                for (int d = 0; d < 6; ++d) m |= (x.S.r[d][t] > 0.0) ? (1 << d) : 0;
+                msk[t] = m;
+                return m;
+            }, hme);
+        }
         active = x.any([&](int t) -> bool { return e[t] > 0.0 && hme[t] < MGC_HINF; });
         x.mark(L, 1); /* in-tile labels */
         if (!active) break;

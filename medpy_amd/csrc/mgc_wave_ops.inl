@@ -39,7 +39,8 @@
  *                         64 + 70 state accesses of a discharge need ONE address register instead of a 64-bit pair each
  *   w.fresh()             the lane id becomes opaque to the optimiser again (GPU): addresses derived from it before this
  *                         point are recomputed afterwards instead of being kept alive (or spilled) across the sweeps
- *   w.mark(id)            work-profile hook (counts sections in the simulator; nothing on the GPU)
+ *   w.mark(id)            work-profile hook: counts sections in the simulator; on the GPU nothing, or (development build
+ *                         -DMGCW_PROFILE) the cycles since the previous mark, accumulated per section
  */
 #ifndef MGC_WAVE_OPS_INL
 #define MGC_WAVE_OPS_INL
@@ -318,6 +319,7 @@ MGC_HD void mgcw_discharge_impl(W& w, const MgcLattice& L, int tile, uint32_t ph
         return e(l, K) > 0.0 && r[D](l, K) > 0.0 && hnb == h(l, K) - 1;
     };
 
+    w.mark(0); /* load + absorb + label set-up */
     uint32_t am = slot_mask();
     for (int sw = 0; sw < max_sweeps && am; ++sw) {
         /* ---- per active slot: sink, then the four in-plane directions as lane shifts.  ONE vote per (slot, direction):
@@ -434,6 +436,7 @@ MGC_HD void mgcw_discharge_impl(W& w, const MgcLattice& L, int tile, uint32_t ph
         w.mark(2); /* one push sweep */
     }
     const bool active = am != 0; /* sweep budget exhausted with work left: run again in the next phase of this colour */
+    w.mark(1); /* (whatever followed the last counted sweep: the vote that ended the loop) */
 
     /* ---- tail: votes, outbox staged through LDS (face order: the neighbours read 64 consecutive doubles per face) ---- */
     bool has_sink = false, has_exc = false;
@@ -513,6 +516,7 @@ MGC_HD void mgcw_discharge_impl(W& w, const MgcLattice& L, int tile, uint32_t ph
         /* DIRTY only if a residual arc disappeared: otherwise no distance in the tile (or through it) can have changed */
         if (l == 7) L.status[tile] = (L.status[tile] & ~(MGC_ST_SINK | MGC_ST_EXCESS)) | (has_sink ? MGC_ST_SINK : 0u) | (saturated ? MGC_ST_DIRTY : 0u) | (has_exc ? MGC_ST_EXCESS : 0u);
     });
+    w.mark(3); /* tail votes + stores */
 }
 
 template <class W>
