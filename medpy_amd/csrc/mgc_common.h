@@ -77,6 +77,8 @@ struct MgcLattice {
     uint32_t* status;         /* [ntiles] bit1 (2): the tile holds a residual arc to the sink; bit2 (4): DIRTY = discharged
                                  since the last global relabel; bit3 (8): SUSPECT (labels must be recomputed);
                                  bits 8..13: faces through which the tile's labels are supported by a neighbour */
+    int32_t*  hshadow[2];     /* slabs, 6-neighbourhood: [gy*gx][64] labels of the owned border layer (lower / upper) as the neighbour
+                                 slab last received them -- a border tile only travels when it differs from this (or holds flow) */
     unsigned long long* prof; /* optional [16] cycle accumulators of the discharge sections (development aid) or NULL */
 };
 

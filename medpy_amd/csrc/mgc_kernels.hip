@@ -536,7 +536,10 @@ __global__ __launch_bounds__(MGC_TV) void k_reset_suspect(MgcLattice L, uint32_t
         const int n = nsel;
         /* same effect as mgc_reset_suspect_tile per selected tile, without a barrier per tile: all lanes stream INF over the
          * selected tiles' labels, then one lane per tile retires the flags and queues the tile */
-        for (int i = 0; i < n; ++i) L.height[(int64_t)sel[i] * MGC_TV + threadIdx.x] = MGC_HINF;
+        for (int i = 0; i < n; ++i) {
+            L.height[(int64_t)sel[i] * MGC_TV + threadIdx.x] = MGC_HINF;
+            if (threadIdx.x < MGC_TF) mgc_shadow_reset(L, sel[i], (int)threadIdx.x);
+        }
         if ((int)threadIdx.x < n) {
             const int tile = sel[threadIdx.x];
             L.status[tile] = (L.status[tile] & ~(MGC_ST_SUSPECT | MGC_ST_DIRTY | (63u << MGC_ST_DEP_SHIFT))) | MGC_ST_ALLINF;
@@ -1297,7 +1300,13 @@ struct HipDevT {
     std::vector<Span> spans;
     void check(hipError_t e) { if (e != hipSuccess && first_error == hipSuccess) first_error = e; }
     int grid(int64_t n) const { return (int)(n < 1 ? 1 : (n < h->grid_cap ? n : h->grid_cap)); }
-    void fill_heights_inf() { flush_zero(); check(hipMemsetAsync(h->L.height, 0x3f, (size_t)h->L.ntiles * MGC_TV * sizeof(int32_t), h->stream)); }
+    void fill_heights_inf()
+    {
+        flush_zero();
+        check(hipMemsetAsync(h->L.height, 0x3f, (size_t)h->L.ntiles * MGC_TV * sizeof(int32_t), h->stream));
+        for (int sd = 0; sd < 2; ++sd) /* the neighbour slabs fill their ghost layers too: the shadows of what they hold follow */
+            if (h->L.hshadow[sd]) check(hipMemsetAsync(h->L.hshadow[sd], 0x3f, (size_t)h->L.gy * h->L.gx * MGC_TF * sizeof(int32_t), h->stream));
+    }
     void flush_zero()
     {
         if (h->pending_zero >= 0) check(hipMemsetAsync(h->L.count + h->pending_zero, 0, sizeof(int32_t), h->stream));
@@ -1580,6 +1589,12 @@ static int mgc_create_impl(int ndim, const int64_t* shape, int connectivity, int
         if ((rc = mgc_alloc(h, &L.rmask32, nv))) return rc;
     }
     if ((rc = mgc_alloc(h, &L.oflags, nt))) return rc;
+    if (slab && L.ndir == 6) { /* labels of the border layers as the neighbour slabs last received them */
+        for (int sd = 0; sd < 2; ++sd) {
+            if ((rc = mgc_alloc(h, &L.hshadow[sd], (int64_t)L.gy * L.gx * MGC_TF))) return rc;
+            MGC_HIP(h, hipMemsetAsync(L.hshadow[sd], 0x3f, (size_t)L.gy * L.gx * MGC_TF * sizeof(int32_t), h->stream));
+        }
+    }
     for (int i = 0; i < (L.ndir == 6 ? 8 : 18); ++i)
         if ((rc = mgc_alloc(h, &L.list[i], nt))) return rc;
     if ((rc = mgc_alloc(h, &L.count, (int64_t)MGC_NCOUNT))) return rc;
@@ -1684,10 +1699,24 @@ int mgc_halo_pack(mgc_handle h, int side, int kind, void* buf, int buf_on_device
         dst = h->d_halo;
     }
     const int T = h->L.gy * h->L.gx;
-    if (h->L.ndir == MGC26_NDIR && kind == 1) MGC_HIP(h, hipMemsetAsync((char*)dst + mgc26_halo_off_count(h->L), 0, 4, h->stream));
+    const bool compact = mgc_halo_compact_nd(h->L, kind);
+    if (compact) MGC_HIP(h, hipMemsetAsync((char*)dst + mgc_halo_off_count_nd(h->L), 0, 4, h->stream));
     hipLaunchKernelGGL(k_halo_pack, dim3(T < 2048 ? T : 2048), dim3(MGC_TV), 0, h->stream, h->L, side, kind, dst);
     MGC_HIP(h, hipGetLastError());
-    if (!buf_on_device) MGC_HIP(h, hipMemcpyAsync(buf, dst, (size_t)bytes, hipMemcpyDeviceToHost, h->stream));
+    if (!buf_on_device) {
+        int64_t used = bytes;
+        if (compact) { /* header first, then only the records that were filled */
+            const int64_t off = mgc_halo_off_rec_nd(h->L);
+            MGC_HIP(h, hipMemcpyAsync(buf, dst, (size_t)off, hipMemcpyDeviceToHost, h->stream));
+            MGC_HIP(h, hipStreamSynchronize(h->stream));
+            int32_t cnt = 0;
+            memcpy(&cnt, (const char*)buf + mgc_halo_off_count_nd(h->L), 4);
+            used = (int64_t)cnt * mgc_halo_rec_bytes_nd(h->L, kind);
+            if (used) MGC_HIP(h, hipMemcpyAsync((char*)buf + off, (const char*)dst + off, (size_t)used, hipMemcpyDeviceToHost, h->stream));
+        } else {
+            MGC_HIP(h, hipMemcpyAsync(buf, dst, (size_t)used, hipMemcpyDeviceToHost, h->stream));
+        }
+    }
     MGC_HIP(h, hipStreamSynchronize(h->stream)); /* the transport runs on the caller's stream / thread */
     return MGC_OK;
 }
@@ -1704,7 +1733,14 @@ int mgc_halo_unpack(mgc_handle h, int side, int kind, const void* buf, int buf_o
     if (!buf_on_device) {
         const int rc = mgc_halo_staging(h, bytes);
         if (rc) return rc;
-        MGC_HIP(h, hipMemcpyAsync(h->d_halo, buf, (size_t)bytes, hipMemcpyHostToDevice, h->stream));
+        int64_t used = bytes;
+        if (mgc_halo_compact_nd(h->L, kind)) { /* the header says how many records follow it */
+            int32_t cnt = 0;
+            memcpy(&cnt, (const char*)buf + mgc_halo_off_count_nd(h->L), 4);
+            if (cnt < 0 || cnt > h->L.gy * h->L.gx) return mgc_fail(h, MGC_ERR_INVALID, "mgc_halo_unpack: record count %d out of range", (int)cnt);
+            used = mgc_halo_off_rec_nd(h->L) + (int64_t)cnt * mgc_halo_rec_bytes_nd(h->L, kind);
+        }
+        MGC_HIP(h, hipMemcpyAsync(h->d_halo, buf, (size_t)used, hipMemcpyHostToDevice, h->stream));
         src = h->d_halo;
     }
     const int T = h->L.gy * h->L.gx;
@@ -1812,7 +1848,8 @@ int mgc_halo_exchange(mgc_handle h, int kind, uint32_t epoch, int list)
     MGC_HIP(h, hipSetDevice(h->device));
     if (kind < 0 || kind > 2) return mgc_fail(h, MGC_ERR_INVALID, "mgc_halo_exchange: kind must be 0, 1 or 2");
     if (kind == 2 && h->L.ndir != 6) return mgc_fail(h, MGC_ERR_UNSUPPORTED, "halo kind 2 (suspect flags) exists for the 2*ndim neighbourhood only");
-    const int64_t bytes = mgc_halo_bytes_nd(h->L, 1); /* size for the larger kind; reused for both */
+    int64_t bytes = mgc_halo_bytes_nd(h->L, 1); /* capacity of the largest kind; reused for all */
+    if (mgc_halo_bytes_nd(h->L, 0) > bytes) bytes = mgc_halo_bytes_nd(h->L, 0);
     if (h->xchg_cap < bytes) {
         for (int i = 0; i < 4; ++i) {
             if (h->d_xchg[i]) (void)hipFree(h->d_xchg[i]);
@@ -1821,15 +1858,15 @@ int mgc_halo_exchange(mgc_handle h, int kind, uint32_t epoch, int list)
         }
         h->xchg_cap = bytes;
     }
-    /* 26-neighbourhood phases: fixed header first, then only the records that were filled (mgc26_halo_pack_tile) */
-    const bool compact = h->L.ndir == MGC26_NDIR && kind == 1;
-    const int64_t nb = compact ? mgc26_halo_off_rec(h->L) : mgc_halo_bytes_nd(h->L, kind);
+    /* compacted kinds: fixed header first, then only the records that were filled (mgc_halo_pack_tile, mgc26_halo_pack_tile) */
+    const bool compact = mgc_halo_compact_nd(h->L, kind);
+    const int64_t nb = compact ? mgc_halo_off_rec_nd(h->L) : mgc_halo_bytes_nd(h->L, kind);
     const bool has[2] = {h->L.tz_own_lo > 0, h->L.tz_own_hi < h->L.gz};
     const int peer[2] = {h->rank - 1, h->rank + 1};
     const int T = h->L.gy * h->L.gx, grid = T < 2048 ? T : 2048;
     for (int side = 0; side < 2; ++side)
         if (has[side]) {
-            if (compact) MGC_HIP(h, hipMemsetAsync((char*)h->d_xchg[2 * side] + mgc26_halo_off_count(h->L), 0, 4, h->stream));
+            if (compact) MGC_HIP(h, hipMemsetAsync((char*)h->d_xchg[2 * side] + mgc_halo_off_count_nd(h->L), 0, 4, h->stream));
             hipLaunchKernelGGL(k_halo_pack, dim3(grid), dim3(MGC_TV), 0, h->stream, h->L, side, kind, h->d_xchg[2 * side]);
             MGC_HIP(h, hipGetLastError());
         }
@@ -1844,9 +1881,9 @@ int mgc_halo_exchange(mgc_handle h, int kind, uint32_t epoch, int list)
         /* how many records each direction carries: mine (packed above) and the neighbour's (just received) */
         int32_t* hc = h->h_count; /* pinned scratch, 4 of MGC_NCOUNT slots */
         for (int i = 0; i < 4; ++i)
-            if (has[i >> 1]) MGC_HIP(h, hipMemcpyAsync(hc + i, (char*)h->d_xchg[i] + mgc26_halo_off_count(h->L), 4, hipMemcpyDeviceToHost, h->stream));
+            if (has[i >> 1]) MGC_HIP(h, hipMemcpyAsync(hc + i, (char*)h->d_xchg[i] + mgc_halo_off_count_nd(h->L), 4, hipMemcpyDeviceToHost, h->stream));
         MGC_HIP(h, hipStreamSynchronize(h->stream));
-        const int64_t off = mgc26_halo_off_rec(h->L), rb = (int64_t)MGC26_REC * 8;
+        const int64_t off = mgc_halo_off_rec_nd(h->L), rb = mgc_halo_rec_bytes_nd(h->L, kind);
         bool any = false;
         for (int i = 0; i < 4; ++i) any |= has[i >> 1] && hc[i] > 0;
         if (any) {
@@ -1877,7 +1914,7 @@ int mgc_destroy(mgc_handle h)
     void* ptrs[] = {L.rcap, L.cap0, L.excess, L.sink, L.height, L.rmask, L.rmask32, L.obox, L.oflags, L.list[0], L.list[1], L.list[2],
                     L.list[3], L.list[4], L.list[5], L.list[6], L.list[7], L.list[8], L.list[9], L.list[10], L.list[11], L.list[12],
                     L.list[13], L.list[14], L.list[15], L.list[16], L.list[17], L.count, L.stamp, L.rstamp, L.status, h->d_tr0, h->d_part, h->d_part2, h->d_scalar,
-                    h->d_labels, h->d_image, h->d_prob, h->d_fg, h->d_bg, h->d_tr_in, h->d_eslot, h->d_eval, h->d_erun, h->d_halo, h->d_xchg[0], h->d_xchg[1], h->d_xchg[2], h->d_xchg[3], h->d_cnt64};
+                    h->d_labels, h->d_image, h->d_prob, h->d_fg, h->d_bg, h->d_tr_in, h->d_eslot, h->d_eval, h->d_erun, L.hshadow[0], L.hshadow[1], h->d_halo, h->d_xchg[0], h->d_xchg[1], h->d_xchg[2], h->d_xchg[3], h->d_cnt64};
     for (void* p : ptrs)
         if (p) (void)hipFree(p);
     if (h->h_count) (void)hipHostFree(h->h_count);

@@ -585,6 +585,16 @@ MGC_HD bool mgc_suspect_tile(const MgcLattice& L, int tile)
     return sus;
 }
 
+/* A suspect tile is reset on BOTH sides of a slab border (the ghost mirrors the owner's flags): the ghost's labels are INF
+ * from then on, so the owner's shadow of "what the neighbour holds" must say INF too -- otherwise a tile whose labels are
+ * recomputed to their old values would never travel again and the neighbour would keep INF.  k = 0..63. */
+MGC_HD void mgc_shadow_reset(const MgcLattice& L, int tile, int k)
+{
+    const int T = L.gy * L.gx, layer = tile / T, i = tile % T;
+    if (L.hshadow[0] && L.tz_own_lo > 0 && layer == L.tz_own_lo) L.hshadow[0][(int64_t)i * MGC_TF + k] = MGC_HINF;
+    if (L.hshadow[1] && L.tz_own_hi < L.gz && layer == L.tz_own_hi - 1) L.hshadow[1][(int64_t)i * MGC_TF + k] = MGC_HINF;
+}
+
 /* suspect tiles: labels := INF, queued for the first relabel pass; flags retired */
 template <class X>
 MGC_HD void mgc_reset_suspect_tile(X& x, const MgcLattice& L, int tile, uint32_t epoch, int list)
@@ -593,6 +603,7 @@ MGC_HD void mgc_reset_suspect_tile(X& x, const MgcLattice& L, int tile, uint32_t
     if (st & MGC_ST_SUSPECT) {
         x.par([&](int t) {
             L.height[(int64_t)tile * MGC_TV + t] = MGC_HINF;
+            if (t < MGC_TF) mgc_shadow_reset(L, tile, t);
             if (t == 0) {
                 L.status[tile] = (st & ~(MGC_ST_SUSPECT | MGC_ST_DIRTY | (63u << MGC_ST_DEP_SHIFT))) | MGC_ST_ALLINF;
                 mgc_enqueue(x, L, list, L.rstamp, epoch, tile);
@@ -603,18 +614,30 @@ MGC_HD void mgc_reset_suspect_tile(X& x, const MgcLattice& L, int tile, uint32_t
 
 /* ---------------------------------------------------------------------------------------
  * Z-slab halo exchange (multi-GPU).  A slab boundary is an ordinary tile face whose
- * neighbour lives on another GPU: the sender packs, per border tile, the labels of its 64 face
- * voxels, its outbox across that face and the outbox flag; the receiver unpacks them into the
- * GHOST tile that mirrors the sender's tile.  "side" 0 = lower slab boundary (face 4, -z),
- * 1 = upper (face 5, +z).  Buffer layout for T = gy*gx tiles per layer:
- *     double flow[T][64] ; int32 label[T][64] ; int32 flag[T]          (kind 1: discharge phases)
- *     int32 label[T][64]                                              (kind 0: relabel passes)
- *     int32 status[T]  (DIRTY | SUSPECT bits of the border tile)      (kind 2: suspect closure of an incremental relabel)
+ * neighbour lives on another GPU: per border tile the sender ships the labels of its 64 face voxels
+ * (+ its outbox across that face and the outbox flag in a discharge phase); the receiver unpacks them
+ * into the GHOST tile that mirrors the sender's tile.  "side" 0 = lower slab boundary (face 4, -z),
+ * 1 = upper (face 5, +z).
+ *
+ * Messages are COMPACTED: a 1024 x 1024 cross-section has 16 384 border tiles, and in a colour phase or a
+ * relabel pass a few per cent of them change.  The sender keeps a shadow of the labels the neighbour last
+ * received (L.hshadow); a tile only travels when its face labels differ from the shadow or its outbox
+ * holds flow.  Layout for T = gy*gx tiles per layer:
+ *     int32 slot1[T]  (0 = unchanged, else 1 + record index) ; int32 count ; pad to 16 B ; record[count]
+ *     kind 0 (relabel passes):   record = int32 label[64]                                   (256 B)
+ *     kind 1 (discharge phases): record = double flow[64] ; int32 label[64] ; int32 flag ; pad (784 B)
+ *     kind 2 (suspect closure of an incremental relabel): int32 status[T]  (DIRTY | SUSPECT bits; dense, 4 B per tile)
+ * The transport moves the header, then `count` records (mgc_halo_exchange).  The sender zeroes `count`
+ * before packing.  (Dense, every exchange moved 772 B per border tile: 12.6 MB per side at 1024 x 1024.)
  * ------------------------------------------------------------------------------------- */
+MGC_HD int64_t mgc_halo_off_count(const MgcLattice& L) { return (int64_t)L.gy * L.gx * 4; }
+MGC_HD int64_t mgc_halo_off_rec(const MgcLattice& L) { return (mgc_halo_off_count(L) + 4 + 15) / 16 * 16; }
+MGC_HD int64_t mgc_halo_rec_bytes(int kind) { return kind ? MGC_TF * 8 + MGC_TF * 4 + 16 : MGC_TF * 4; }
+
 MGC_HD int64_t mgc_halo_bytes(const MgcLattice& L, int kind)
 {
     const int64_t T = (int64_t)L.gy * L.gx;
-    return kind == 2 ? T * 4 : (kind ? T * (MGC_TF * 8 + MGC_TF * 4 + 4) : T * MGC_TF * 4);
+    return kind == 2 ? T * 4 : mgc_halo_off_rec(L) + T * mgc_halo_rec_bytes(kind); /* capacity: every tile changed */
 }
 
 /* i = tile index inside the layer; packs the OWNED border tile of `side` */
@@ -625,27 +648,44 @@ MGC_HD void mgc_halo_pack_tile(X& x, const MgcLattice& L, int side, int kind, in
     const int layer = side ? L.tz_own_hi - 1 : L.tz_own_lo;
     const int tile = layer * (int)T + i;
     const int f = side ? 5 : 4;
-    double* flow = (double*)buf;
-    int32_t* lab = kind ? (int32_t*)((char*)buf + T * MGC_TF * 8) : (int32_t*)buf;
-    int32_t* flg = (int32_t*)((char*)buf + T * MGC_TF * 12);
     if (kind == 2) {
         x.par([&](int t) {
             if (t == 0) ((int32_t*)buf)[i] = (int32_t)(L.status[tile] & (MGC_ST_DIRTY | MGC_ST_SUSPECT));
         });
         return;
     }
+    int32_t* slot1 = (int32_t*)buf;
+    int32_t* count = (int32_t*)((char*)buf + mgc_halo_off_count(L));
+    char* recs = (char*)buf + mgc_halo_off_rec(L);
+    int32_t* shadow = L.hshadow[side] + (int64_t)i * MGC_TF;
+    const uint32_t fl = kind ? ((L.oflags[tile] >> f) & 1u) : 0u; /* the outbox across the border holds flow */
+    const bool changed = x.any([&](int t) -> bool {
+        return fl || (t < MGC_TF && L.height[(int64_t)tile * MGC_TV + mgc_face_voxel(f, t)] != shadow[t]);
+    });
     x.par([&](int t) {
+        if (t == 0) {
+            const int sl = changed ? x.atomic_add(count, 1) : -1;
+            x.S.flag[0] = sl;
+            slot1[i] = sl + 1;
+        }
+    });
+    if (!changed) return;
+    x.par([&](int t) {
+        char* rec = recs + (int64_t)x.S.flag[0] * mgc_halo_rec_bytes(kind);
+        double* flow = (double*)rec;
+        int32_t* lab = kind ? (int32_t*)(rec + MGC_TF * 8) : (int32_t*)rec;
         if (t < MGC_TF) {
-            lab[(int64_t)i * MGC_TF + t] = L.height[(int64_t)tile * MGC_TV + mgc_face_voxel(f, t)];
+            const int32_t hcur = L.height[(int64_t)tile * MGC_TV + mgc_face_voxel(f, t)];
+            lab[t] = hcur;
+            shadow[t] = hcur; /* what the neighbour holds from now on */
             if (kind) {
                 double* slot = &L.obox[((int64_t)tile * 6 + f) * MGC_TF + t];
-                flow[(int64_t)i * MGC_TF + t] = *slot;
+                flow[t] = *slot;
                 *slot = 0.0; /* the flow now travels in the message */
             }
         }
         if (kind && t == MGC_TF) {
-            const uint32_t fl = (L.oflags[tile] >> f) & 1u;
-            flg[i] = (int32_t)fl;
+            lab[MGC_TF] = (int32_t)fl;
             if (fl) x.atomic_and(&L.oflags[tile], ~(1u << f));
         }
     });
@@ -662,9 +702,6 @@ MGC_HD void mgc_halo_unpack_tile(X& x, const MgcLattice& L, int side, int kind, 
     const int own_layer = side ? L.tz_own_hi - 1 : L.tz_own_lo;
     const int ghost = ghost_layer * (int)T + i, own = own_layer * (int)T + i;
     const int f = side ? 4 : 5; /* the face of the SENDER's tile that touches us */
-    const double* flow = (const double*)buf;
-    const int32_t* lab = kind ? (const int32_t*)((const char*)buf + T * MGC_TF * 8) : (const int32_t*)buf;
-    const int32_t* flg = (const int32_t*)((const char*)buf + T * MGC_TF * 12);
     if (kind == 2) { /* the ghost mirrors the owner's flags; a ghost that turns suspect keeps the closure going */
         x.par([&](int t) {
             if (t != 0) return;
@@ -674,15 +711,20 @@ MGC_HD void mgc_halo_unpack_tile(X& x, const MgcLattice& L, int side, int kind, 
         });
         return;
     }
+    const int sl = ((const int32_t*)buf)[i] - 1;
+    if (sl < 0) return; /* the sender's tile is as the ghost already has it */
+    const char* rec = (const char*)buf + mgc_halo_off_rec(L) + (int64_t)sl * mgc_halo_rec_bytes(kind);
+    const double* flow = (const double*)rec;
+    const int32_t* lab = kind ? (const int32_t*)(rec + MGC_TF * 8) : (const int32_t*)rec;
     const bool lowered = x.any([&](int t) -> bool {
         bool low = false;
         if (t < MGC_TF) {
             int32_t* hp = &L.height[(int64_t)ghost * MGC_TV + mgc_face_voxel(f, t)];
-            const int32_t hn = lab[(int64_t)i * MGC_TF + t];
+            const int32_t hn = lab[t];
             low = hn < *hp;
             *hp = hn;
             if (kind) {
-                const double d = flow[(int64_t)i * MGC_TF + t];
+                const double d = flow[t];
                 if (d != 0.0) L.obox[((int64_t)ghost * 6 + f) * MGC_TF + t] += d;
             }
         }
@@ -691,7 +733,7 @@ MGC_HD void mgc_halo_unpack_tile(X& x, const MgcLattice& L, int side, int kind, 
     x.par([&](int t) {
         if (t != 0) return;
         if (kind) {
-            if (flg[i]) {
+            if (lab[MGC_TF]) {
                 x.atomic_or(&L.oflags[ghost], 1u << f);
                 mgc_enqueue(x, L, (int)((epoch + 1) & 3u), L.stamp, epoch + 1, own);
             }

@@ -455,6 +455,11 @@ MGC_HD void mgc26_halo_unpack_tile(X& x, const MgcLattice& L, int side, int kind
 
 /* neighbourhood-agnostic entry points used by the kernels / the host simulator */
 MGC_HD int64_t mgc_halo_bytes_nd(const MgcLattice& L, int kind) { return L.ndir == MGC26_NDIR ? mgc26_halo_bytes(L, kind) : mgc_halo_bytes(L, kind); }
+/* compacted messages (header, then `count` records): which kinds, where the count sits, how long a record is */
+MGC_HD bool mgc_halo_compact_nd(const MgcLattice& L, int kind) { return L.ndir == MGC26_NDIR ? kind == 1 : kind != 2; }
+MGC_HD int64_t mgc_halo_off_count_nd(const MgcLattice& L) { return L.ndir == MGC26_NDIR ? mgc26_halo_off_count(L) : mgc_halo_off_count(L); }
+MGC_HD int64_t mgc_halo_off_rec_nd(const MgcLattice& L) { return L.ndir == MGC26_NDIR ? mgc26_halo_off_rec(L) : mgc_halo_off_rec(L); }
+MGC_HD int64_t mgc_halo_rec_bytes_nd(const MgcLattice& L, int kind) { return L.ndir == MGC26_NDIR ? (int64_t)MGC26_REC * 8 : mgc_halo_rec_bytes(kind); }
 
 template <class X>
 MGC_HD void mgc_halo_pack_nd(X& x, const MgcLattice& L, int side, int kind, int i, void* buf)

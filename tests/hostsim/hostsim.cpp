@@ -17,6 +17,7 @@
 #include <stdlib.h>
 #include <string.h>
 
+#include <algorithm>
 #include <vector>
 
 #include "../../medpy_amd/csrc/mgc_tile_ops.inl"
@@ -153,8 +154,13 @@ struct HostDev {
     std::vector<int32_t> height, lists, count;
     std::vector<uint8_t> rmask;
     std::vector<uint32_t> oflags, stamp, rstamp, status;
+    std::vector<int32_t> hshadow[2];
 
-    void fill_heights_inf() { for (int64_t i = 0; i < (int64_t)L.ntiles * MGC_TV; ++i) L.height[i] = MGC_HINF; }
+    void fill_heights_inf()
+    {
+        for (int64_t i = 0; i < (int64_t)L.ntiles * MGC_TV; ++i) L.height[i] = MGC_HINF;
+        for (int sd = 0; sd < 2; ++sd) std::fill(hshadow[sd].begin(), hshadow[sd].end(), (int32_t)MGC_HINF); /* what the neighbours hold now */
+    }
     void zero_count(int i) { L.count[i] = 0; }
     void read_counts(int* out) { memcpy(out, L.count, MGC_NCOUNT * sizeof(int)); }
     void absorb_all() { HostBlock x(S); for (int t = 0; t < L.ntiles; ++t) mgc_absorb_tile(x, L, t); }
@@ -228,6 +234,10 @@ struct HostDev {
         L.rmask = rmask.data(); L.obox = obox.data(); L.oflags = oflags.data();
         for (int i = 0; i < 8; ++i) L.list[i] = lists.data() + i * nt;
         L.count = count.data(); L.stamp = stamp.data(); L.rstamp = rstamp.data(); L.status = status.data();
+        for (int sd = 0; sd < 2; ++sd) {
+            hshadow[sd].assign((size_t)L.gy * L.gx * MGC_TF, (int32_t)MGC_HINF);
+            L.hshadow[sd] = hshadow[sd].data();
+        }
     }
 
     /* w[a] = forward n-link capacities along array axis a of the LOCAL volume in the oracle's per-axis layout
@@ -343,6 +353,7 @@ int hostsim_halo_pack(void* h, int side, int kind, void* buf, int on_device)
     HostDev* d = (HostDev*)h;
     HostBlock x(d->S);
     const int T = d->L.gy * d->L.gx;
+    if (kind != 2) memset((char*)buf + mgc_halo_off_count(d->L), 0, 4);
     for (int i = 0; i < T; ++i) mgc_halo_pack_tile(x, d->L, side, kind, i, buf);
     return 0;
 }
