@@ -20,10 +20,10 @@ def main():
     elif mode == "json":
         # python tools/rocpd_summary.py json <fetch.db> <write.db> > profiles/pmc_discharge.json
         import json
-        out = {}
+        out = {"kernel": "k_discharge_w"}
         for key, db in (("fetch_kib_per_launch", sys.argv[2]), ("write_kib_per_launch", sys.argv[3])):
             c = sqlite3.connect(db).cursor()
-            n, v = c.execute("select count(*), avg(value) from counters_collection where kernel_name like 'k_discharge%'").fetchone()
+            n, v = c.execute("select count(*), avg(value) from counters_collection where kernel_name like 'k_discharge_w%'").fetchone()
             out[key] = v
             out[key.replace("kib_per_launch", "launches")] = n
         import hashlib, os
