@@ -35,3 +35,18 @@ def test_large_volume_labels_hash(name):
     assert hashlib.sha256(np.packbits(labels.astype(np.uint8).ravel()).tobytes()).hexdigest() == c["sha256_packed_labels"]
     assert flow == pytest.approx(c["flow"], rel=1e-9)
     print(name, "flow", flow, "stats", g.stats())
+
+
+@pytest.mark.skipif(not os.environ.get("MEDPY_BIG_IDS"), reason="needs ~215 GB of HBM and a minute: set MEDPY_BIG_IDS=1 (result of the run on MI355X: "
+                                                                  "profiles/r2_big_ids_2415919104_voxels.txt)")
+def test_more_than_2_31_voxels_on_one_gpu():
+    """2304 x 1024 x 1024 = 2.4e9 voxels, ids beyond the reference's 32-bit node ids (graph.h:57-62):
+    three identical walled-in blocks must give three identical cuts (the third lies entirely above id 2^31), the device-side
+    invariants hold over the whole volume, what_segment() beyond 2^31 agrees with the bulk labels (tools/gpu_big_ids.py)."""
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    res = subprocess.run([sys.executable, os.path.join(root, "tools", "gpu_big_ids.py")], capture_output=True, text=True, timeout=1200)
+    assert res.returncode == 0, (res.stdout[-2000:], res.stderr[-2000:])
+    out = json.loads([ln for ln in res.stdout.splitlines() if ln.startswith("{")][-1])
+    assert out["voxels"] > 2 ** 31 and out["three_blocks_identical"] and out["what_segment_beyond_2_31_matches_labels"]
