@@ -35,6 +35,8 @@ struct MgcSolveParams {
     int relabel_batch;      /* BFS passes launched between two counter read-backs         */
     int check_rounds;       /* colour rounds launched between two counter read-backs      */
     int incremental_relabel;/* 1: later global relabels touch suspect tiles only          */
+    int adaptive_rounds;    /* 1: the number of rounds between two relabels doubles (up to 4x) while a relabel visits more
+                               than three times as many tiles as the discharges of the cycle before it did               */
 };
 
 struct MgcSolveStats {
@@ -76,6 +78,7 @@ static inline MgcSolveParams mgc_default_params(int ndir = 6)
     p.relabel_batch = 8;
     p.check_rounds = 4;
     p.incremental_relabel = 1;
+    p.adaptive_rounds = ndir == 6;
     return p;
 }
 
@@ -85,6 +88,8 @@ int mgc_solve(Dev& dev, const MgcLattice& L, const MgcSolveParams& P, MgcSolveSt
     uint32_t phase = 4; /* stamps start at 0 */
     uint32_t rep = 2;   /* relabel epoch     */
     int cnt[MGC_NCOUNT];
+    int rounds = P.rounds_per_relabel;
+    int64_t prev_dis = 0, prev_rel = 0;
     st = MgcSolveStats();
     dev.zero_count(lay.cnt_dis);
     dev.zero_count(lay.cnt_rel);
@@ -151,13 +156,23 @@ int mgc_solve(Dev& dev, const MgcLattice& L, const MgcSolveParams& P, MgcSolveSt
         st.last_active = cnt[lay.cnt_active];
         st.discharge_tiles = cnt[lay.cnt_dis];
         st.relabel_tiles = cnt[lay.cnt_rel];
+        /* A relabel that costs several times what the discharges between two relabels cost is paid too often (weak
+         * contrast, tie-heavy inputs: nearly every tile is suspect every time): let the discharges run longer.  Any schedule
+         * reaches the same cut; measured at 512^3: `hard` 110 -> 95 ms at 16 rounds, the headline volume is best at 8. */
+        {
+            const int64_t d_dis = (int64_t)cnt[lay.cnt_dis] - prev_dis; /* discharges since the relabel before this one */
+            const int64_t d_rel = (int64_t)cnt[lay.cnt_rel] - prev_rel; /* tile visits of the relabel that just ended  */
+            if (P.adaptive_rounds && outer > 0 && d_rel > 3 * d_dis && rounds < 4 * P.rounds_per_relabel) rounds *= 2;
+            prev_dis = cnt[lay.cnt_dis];
+            prev_rel = cnt[lay.cnt_rel];
+        }
         if (cnt[lay.cnt_active] == 0) {
             st.converged = 1;
             return 0;
         }
 
         /* ---- colour phases ---- */
-        for (int r = 0; r < P.rounds_per_relabel; ++r) {
+        for (int r = 0; r < rounds; ++r) {
             for (int c = 0; c < lay.ncolours; ++c) {
                 const int lst = (int)(phase & (uint32_t)lay.list_mask);
                 dev.discharge(lst, phase, P.max_cycles, P.max_sweeps);
@@ -165,7 +180,7 @@ int mgc_solve(Dev& dev, const MgcLattice& L, const MgcSolveParams& P, MgcSolveSt
                 st.phases++;
                 phase++;
             }
-            if ((r + 1) % P.check_rounds == 0 && r + 1 < P.rounds_per_relabel) {
+            if ((r + 1) % P.check_rounds == 0 && r + 1 < rounds) {
                 dev.read_counts(cnt);
                 st.readbacks++;
                 int pending = 0;

@@ -1,6 +1,6 @@
 """A/B of the kernel forms and schedule knobs on the GPU (development aid).
 
-    python tools/gpu_wave_ab.py [n] [workload] [variant ...]     variant = wave:sweeps:rounds  (0 = default)
+    python tools/gpu_wave_ab.py [n] [workload] [variant ...]     variant = wave:sweeps:rounds:grid:adaptive  (0 = default; adaptive 1 = off, 2 = on)
 
 Every variant must return the labels of the first one; prints one JSON line per variant."""
 import sys, os, time, json
@@ -17,12 +17,14 @@ g._set_boundary("difference_exponential", s["image"], s["sigma"], False)
 g._set_markers(s["fg"], s["bg"])
 ref = None
 for v in variants:
-    f = [int(x) for x in v.split(":")] + [0, 0, 0, 0]
+    f = [int(x) for x in v.split(":")] + [0, 0, 0, 0, 0]
     g.set_param("wave_kernels", f[0])
     g.set_param("max_sweeps", f[1] or 12)
     g.set_param("rounds_per_relabel", f[2] or 8)
     if f[3]:
         g.set_param("wave_grid_dis", f[3])
+    if f[4]:
+        g.set_param("adaptive_rounds", f[4] - 1)
     best, bst = 1e9, None
     for rep in range(3):
         t0 = time.perf_counter(); g._build(); fl = g.maxflow(); dt = time.perf_counter() - t0
