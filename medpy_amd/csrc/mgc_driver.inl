@@ -63,7 +63,7 @@ struct MgcLayout {
 };
 
 static inline MgcLayout mgc_layout6() { MgcLayout l = {2, 3, 4, 6, 8, 9, 1, 7}; return l; }
-static inline MgcLayout mgc_layout26() { MgcLayout l = {8, 15, 16, 18, 19, 20, 0, -1}; return l; }
+static inline MgcLayout mgc_layout26() { MgcLayout l = {8, 15, 16, 18, 19, 20, 1, -1}; return l; }
 
 static inline MgcSolveParams mgc_default_params(int ndir = 6)
 {

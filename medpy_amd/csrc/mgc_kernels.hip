@@ -430,11 +430,13 @@ __global__ __launch_bounds__(MGC_TV) void k26_activate(MgcLattice L, uint32_t ph
 {
     __shared__ MgcTileShared26 S;
     GpuBlock26 x(S);
+    int nact = 0;
     for (int tile = blockIdx.x; tile < L.ntiles; tile += gridDim.x) {
         x.new_tile();
-        mgc26_activate_tile(x, L, tile, phase);
+        nact += mgc26_activate_tile(x, L, tile, phase) ? 1 : 0;
         __syncthreads();
     }
+    if (threadIdx.x == 0 && nact) atomicAdd(&L.count[MGC26_CNT_ACTIVE], nact);
 }
 
 #ifndef MGC26_DISCHARGE_WAVES
@@ -495,10 +497,17 @@ __global__ __launch_bounds__(MGC_TV) void k_relabel_list(MgcLattice L, int lst, 
     }
 }
 
+__global__ void k_status_or(MgcLattice L, uint32_t bits)
+{
+    const int tile = blockIdx.x * blockDim.x + threadIdx.x;
+    if (tile < L.ntiles) L.status[tile] |= bits;
+}
+
 /* incremental global relabel: tile-level suspect closure (one thread per tile) and reset of the suspect tiles.
  * A workgroup owns a BRICK of 8x8x8 tiles and iterates the closure inside it to a fixpoint before it leaves (the flags
  * only ever get set, so racing with the neighbour bricks is benign: what they add is picked up by the next pass).  The
  * closure then advances a brick per launch instead of a tile per launch: ~30 launches per 512^3 step instead of 200. */
+template <bool FULL> /* FULL: 26 supporting neighbour tiles (mgc26_suspect_tile) */
 __global__ __launch_bounds__(MGC_TV) void k_suspect_pass(MgcLattice L)
 {
     const int bxn = (L.gx + 7) / 8, byn = (L.gy + 7) / 8, bzn = (L.gz + 7) / 8;
@@ -510,7 +519,7 @@ __global__ __launch_bounds__(MGC_TV) void k_suspect_pass(MgcLattice L)
         const bool in = tz < L.gz && ty < L.gy && tx < L.gx;
         const int tile = in ? mgc_tile_id(L, tz, ty, tx) : 0;
         for (int it = 0; it < 24; ++it) { /* a brick is at most 22 steps across */
-            const bool ch = in && mgc_suspect_tile(L, tile);
+            const bool ch = in && (FULL ? mgc26_suspect_tile(L, tile) : mgc_suspect_tile(L, tile));
             any |= ch;
             __threadfence_block();
             if (!__syncthreads_or(ch)) break;
@@ -519,6 +528,7 @@ __global__ __launch_bounds__(MGC_TV) void k_suspect_pass(MgcLattice L)
     if (any) L.count[MGC_CNT_CHANGED] = 1;
 }
 
+template <bool FULL>
 __global__ __launch_bounds__(MGC_TV) void k_reset_suspect(MgcLattice L, uint32_t epoch, int list)
 {
     /* a workgroup scans the status words of 512 consecutive tiles (one per lane), then resets the few that are suspect:
@@ -542,7 +552,7 @@ __global__ __launch_bounds__(MGC_TV) void k_reset_suspect(MgcLattice L, uint32_t
         }
         if ((int)threadIdx.x < n) {
             const int tile = sel[threadIdx.x];
-            L.status[tile] = (L.status[tile] & ~(MGC_ST_SUSPECT | MGC_ST_DIRTY | (63u << MGC_ST_DEP_SHIFT))) | MGC_ST_ALLINF;
+            L.status[tile] = (L.status[tile] & ~(MGC_ST_SUSPECT | MGC_ST_DIRTY | (FULL ? MGC26_ST_DEP_MASK : (63u << MGC_ST_DEP_SHIFT)))) | MGC_ST_ALLINF;
             mgc_enqueue(x, L, list, L.rstamp, epoch, tile);
         }
         __syncthreads();
@@ -1304,6 +1314,7 @@ struct HipDevT {
     {
         flush_zero();
         check(hipMemsetAsync(h->L.height, 0x3f, (size_t)h->L.ntiles * MGC_TV * sizeof(int32_t), h->stream));
+        hipLaunchKernelGGL(k_status_or, dim3((h->L.ntiles + 255) / 256), dim3(256), 0, h->stream, h->L, (uint32_t)MGC_ST_ALLINF); /* until a relabel lowers a label */
         for (int sd = 0; sd < 2; ++sd) /* the neighbour slabs fill their ghost layers too: the shadows of what they hold follow */
             if (h->L.hshadow[sd]) check(hipMemsetAsync(h->L.hshadow[sd], 0x3f, (size_t)h->L.gy * h->L.gx * MGC_TF * sizeof(int32_t), h->stream));
     }
@@ -1377,29 +1388,23 @@ struct HipDevT {
     void suspect_pass()
     {
         flush_zero();
-        if constexpr (!FULL) {
-            const int nb = ((h->L.gx + 7) / 8) * ((h->L.gy + 7) / 8) * ((h->L.gz + 7) / 8);
-            hipLaunchKernelGGL(k_suspect_pass, dim3(nb < 4096 ? nb : 4096), dim3(MGC_TV), 0, h->stream, h->L);
-            check(hipGetLastError());
-        }
+        const int nb = ((h->L.gx + 7) / 8) * ((h->L.gy + 7) / 8) * ((h->L.gz + 7) / 8);
+        hipLaunchKernelGGL(k_suspect_pass<FULL>, dim3(nb < 4096 ? nb : 4096), dim3(MGC_TV), 0, h->stream, h->L);
+        check(hipGetLastError());
     }
     void reset_suspect(uint32_t epoch, int list)
     {
         flush_zero();
-        if constexpr (!FULL) {
-            const int id = time_begin(1);
-            if (!(h->use_filters & 4)) hipLaunchKernelGGL(k_reset_suspect, dim3(grid((h->L.ntiles + MGC_TV - 1) / MGC_TV)), dim3(MGC_TV), 0, h->stream, h->L, epoch, list);
-            else {
+        const int id = time_begin(1);
+        if (FULL || !(h->use_filters & 4)) hipLaunchKernelGGL(k_reset_suspect<FULL>, dim3(grid((h->L.ntiles + MGC_TV - 1) / MGC_TV)), dim3(MGC_TV), 0, h->stream, h->L, epoch, list);
+        else {
             zero_count(11);
-            if (getenv("MGC_DEBUG_SUSPECT")) { hipLaunchKernelGGL(k_count_status, dim3(256), dim3(256), 0, h->stream, h->L, (uint32_t)MGC_ST_SUSPECT, 13); }
             hipLaunchKernelGGL(k_filter, dim3(filter_grid()), dim3(256), 0, h->stream, h->L, 2, 6, 11);
             hipLaunchKernelGGL(k_reset_suspect_list, dim3(grid(h->L.ntiles)), dim3(MGC_TV), 0, h->stream, h->L, 6, 11, epoch, list);
-            if (getenv("MGC_DEBUG_SUSPECT")) { hipLaunchKernelGGL(k_count_status, dim3(256), dim3(256), 0, h->stream, h->L, (uint32_t)MGC_ST_SUSPECT, 14); }
-            }
-            check(hipGetLastError());
-            time_end(id);
-            relabel_launches++;
         }
+        check(hipGetLastError());
+        time_end(id);
+        relabel_launches++;
     }
     void activate_all(uint32_t phase)
     {

@@ -38,8 +38,16 @@ struct MgcTileShared26 {
     double  out[2][MGC_TV];
     int32_t nbr[27];      /* neighbour tile ids, index = (dz+1)*9 + (dy+1)*3 + (dx+1); 13 = self */
     int32_t nbrflag[27];
+    int32_t depflag[27];  /* relabel: some label of the tile is supported by a voxel of that neighbour tile */
     int32_t flag[2];
+    int32_t satflag;      /* discharge: some arc (or sink link) of the tile was saturated               */
 };
+
+/* status word of a tile, full neighbourhood: bits 0..5 as in mgc_common.h (SINK, DIRTY, SUSPECT, EXCESS, ALLINF), bits 6..31 =
+ * the 26 neighbour tiles that support a label of this tile (incremental global relabel, see mgc_suspect_tile) */
+#define MGC26_ST_DEP_SHIFT 6
+#define MGC26_ST_DEP_MASK (~0u << MGC26_ST_DEP_SHIFT)
+MGC_HD int mgc26_dep_bit(int ni) { return MGC26_ST_DEP_SHIFT + (ni < 13 ? ni : ni - 1); } /* ni = 0..26 without 13 */
 
 /* LDS of the discharge kernel: half of the 26 residuals of every voxel live here (directions 13..25), the other half in
  * registers.  All 26 in registers need 256 VGPRs (2 waves/SIMD, one workgroup per CU, and still spill); 13 + 13 fits
@@ -76,8 +84,10 @@ MGC_HD void mgc26_load_nbrs(X& x, const MgcLattice& L, int tile, int t)
         const int nz = tz + t / 9 - 1, ny = ty + (t / 3) % 3 - 1, nx = tx + t % 3 - 1;
         x.S.nbr[t] = (nz >= 0 && nz < L.gz && ny >= 0 && ny < L.gy && nx >= 0 && nx < L.gx) ? mgc_tile_id(L, nz, ny, nx) : -1;
         x.S.nbrflag[t] = 0;
+        x.S.depflag[t] = 0;
     }
     if (t < 2) x.S.flag[t] = 0;
+    if (t == 2) x.S.satflag = 0;
 }
 
 /* the 488 halo cells of the 10x10x10 label block come from up to 26 neighbour tiles */
@@ -138,30 +148,83 @@ MGC_HD void mgc26_relabel_tile(X& x, const MgcLattice& L, int tile, uint32_t nex
     mgc26_tile_bfs(x, [&](int t) { return m[t]; });
     x.par([&](int t) {
         const int z = t >> 6, y = (t >> 3) & 7, xx = t & 7;
-        const int h = x.S.hs[mgc_hs_index(z, y, xx)];
-        if (h < h0[t]) {
+        const int me = mgc_hs_index(z, y, xx);
+        const int h = x.S.hs[me];
+        const bool border = z == 0 || z == 7 || y == 0 || y == 7 || xx == 0 || xx == 7;
+        const bool lowered = h < h0[t];
+        if (lowered) {
             L.height[base + t] = h;
-            /* wake a neighbour tile only if one of its voxels next to this one could improve (see mgc_relabel_tile) */
-            const int me = mgc_hs_index(z, y, xx);
+            x.S.flag[0] = 1; /* not "all INF" (any more) */
+        }
+        if (!border || h >= MGC_HINF) return;
 #pragma unroll
-            for (int d = 0; d < MGC26_NDIR; ++d) {
-                int dz, dy, dx;
-                mgc26_offset(d, dz, dy, dx);
-                const int vz = z + dz, vy = y + dy, vx = xx + dx;
-                const int oz = vz < 0 ? -1 : (vz > 7 ? 1 : 0), oy = vy < 0 ? -1 : (vy > 7 ? 1 : 0), ox = vx < 0 ? -1 : (vx > 7 ? 1 : 0);
-                if ((oz || oy || ox) && h + 1 < x.S.hs[me + mgc26_hs_step(d)]) x.S.nbrflag[(oz + 1) * 9 + (oy + 1) * 3 + (ox + 1)] = 1;
-            }
+        for (int d = 0; d < MGC26_NDIR; ++d) {
+            int dz, dy, dx;
+            mgc26_offset(d, dz, dy, dx);
+            const int vz = z + dz, vy = y + dy, vx = xx + dx;
+            const int oz = vz < 0 ? -1 : (vz > 7 ? 1 : 0), oy = vy < 0 ? -1 : (vy > 7 ? 1 : 0), ox = vx < 0 ? -1 : (vx > 7 ? 1 : 0);
+            if (!(oz || oy || ox)) continue;
+            const int ni = (oz + 1) * 9 + (oy + 1) * 3 + (ox + 1), hv = x.S.hs[me + mgc26_hs_step(d)];
+            /* which neighbour tiles support a label of this tile (incremental relabel) */
+            if (((m[t] >> d) & 1u) && hv + 1 == h) x.S.depflag[ni] = 1;
+            /* wake a neighbour tile only if one of its voxels next to this one could improve (see mgc_relabel_tile) */
+            if (lowered && h + 1 < hv) x.S.nbrflag[ni] = 1;
         }
     });
     x.par([&](int t) {
         if (t < 27 && t != 13 && x.S.nbrflag[t] && x.S.nbr[t] >= 0) mgc_enqueue(x, L, next_list, L.rstamp, next_epoch, x.S.nbr[t]);
+        if (t == 27) {
+            uint32_t dep = 0;
+            for (int ni = 0; ni < 27; ++ni)
+                if (ni != 13 && x.S.depflag[ni]) dep |= 1u << mgc26_dep_bit(ni);
+            L.status[tile] = (L.status[tile] & ~(MGC26_ST_DEP_MASK | (x.S.flag[0] ? MGC_ST_ALLINF : 0u))) | dep;
+        }
     });
 }
 
-template <class X>
-MGC_HD void mgc26_activate_tile(X& x, const MgcLattice& L, int tile, uint32_t phase)
+/* incremental global relabel, tile-level closure (see mgc_suspect_tile): 26 supporting neighbours instead of 6 */
+MGC_HD bool mgc26_suspect_tile(const MgcLattice& L, int tile)
 {
-    if (!mgc_owned(L, tile)) return; /* a ghost tile's excess / rcap only accumulate what was pushed into it */
+    const uint32_t st = L.status[tile];
+    if (st & MGC_ST_SUSPECT) return false;
+    bool sus = (st & MGC_ST_DIRTY) != 0;
+    if (!sus && (st & MGC26_ST_DEP_MASK)) {
+        int tz, ty, tx;
+        mgc_tile_coords(L, tile, tz, ty, tx);
+        for (int ni = 0; ni < 27 && !sus; ++ni) {
+            if (ni == 13 || !((st >> mgc26_dep_bit(ni)) & 1u)) continue;
+            const int nz = tz + ni / 9 - 1, ny = ty + (ni / 3) % 3 - 1, nx = tx + ni % 3 - 1;
+            if (nz < 0 || nz >= L.gz || ny < 0 || ny >= L.gy || nx < 0 || nx >= L.gx) continue;
+            sus = (L.status[mgc_tile_id(L, nz, ny, nx)] & MGC_ST_SUSPECT) != 0;
+        }
+    }
+    if (sus) L.status[tile] = st | MGC_ST_SUSPECT;
+    return sus;
+}
+
+/* suspect tiles: labels := INF, queued for the first relabel pass; flags retired */
+template <class X>
+MGC_HD void mgc26_reset_suspect_tile(X& x, const MgcLattice& L, int tile, uint32_t epoch, int list)
+{
+    const uint32_t st = L.status[tile];
+    if (st & MGC_ST_SUSPECT) {
+        x.par([&](int t) {
+            L.height[(int64_t)tile * MGC_TV + t] = MGC_HINF;
+            if (t == 0) {
+                L.status[tile] = (st & ~(MGC_ST_SUSPECT | MGC_ST_DIRTY | MGC26_ST_DEP_MASK)) | MGC_ST_ALLINF;
+                mgc_enqueue(x, L, list, L.rstamp, epoch, tile);
+            }
+        });
+    }
+}
+
+/* returns whether the tile was queued; the CALLER counts the active tiles (one atomic per workgroup on the counter instead of one
+ * per tile: with a regional term every tile is active after the first relabel, and 262 144 atomics on one address took 3 ms) */
+template <class X>
+MGC_HD bool mgc26_activate_tile(X& x, const MgcLattice& L, int tile, uint32_t phase)
+{
+    if (!mgc_owned(L, tile)) return false; /* a ghost tile's excess / rcap only accumulate what was pushed into it */
+    if (L.status[tile] & MGC_ST_ALLINF) return false; /* no label of the tile is finite: nothing can flow */
     const int64_t base = (int64_t)tile * MGC_TV;
     const bool act = x.any([&](int t) -> bool { return L.excess[base + t] > 0.0 && L.height[base + t] < MGC_HINF; });
     x.par([&](int t) {
@@ -170,9 +233,9 @@ MGC_HD void mgc26_activate_tile(X& x, const MgcLattice& L, int tile, uint32_t ph
             mgc_tile_coords(L, tile, tz, ty, tx);
             const uint32_t target = phase + (((uint32_t)mgc26_colour(L, tz, ty, tx) - phase) & 7u);
             mgc_enqueue(x, L, (int)(target & 15u), L.stamp, target, tile);
-            x.atomic_add(&L.count[MGC26_CNT_ACTIVE], 1);
         }
     });
+    return act;
 }
 
 /* region discharge of one tile in colour phase `phase` (all 26 neighbour tiles are idle).
@@ -237,6 +300,7 @@ MGC_HD void mgc26_discharge_tile(X& x, const MgcLattice& L, int tile, uint32_t p
                             e[t] -= delta;
                             snk[t] -= delta;
                             x.S.flag[fl] = 1;
+                            if (snk[t] == 0.0) x.S.satflag = 1;
                         }
                     } else {
                         if (s == 1 && t == 0) x.S.flag[fl ^ 1] = 0;
@@ -266,6 +330,7 @@ MGC_HD void mgc26_discharge_tile(X& x, const MgcLattice& L, int tile, uint32_t p
                                 e[t] -= delta;
                                 R(d, t) -= delta;
                                 x.S.flag[fl] = 1;
+                                if (R(d, t) == 0.0) x.S.satflag = 1;
                             }
                         }
                         if (inside) {
@@ -338,7 +403,8 @@ MGC_HD void mgc26_discharge_tile(X& x, const MgcLattice& L, int tile, uint32_t p
             if (!mgc_owned(L, x.S.nbr[t])) x.atomic_or(&L.oflags[x.S.nbr[t]], 1u); /* ghost: the halo exchange ships what it received */
         }
         if (t == 27 && active) mgc_enqueue(x, L, (int)((phase + 8) & 15u), L.stamp, phase + 8, tile);
-        if (t == 28) L.status[tile] = (L.status[tile] & ~2u) | (has_sink ? 2u : 0u);
+        /* DIRTY only if a residual arc disappeared: otherwise no distance in the tile (or through it) can have changed */
+        if (t == 28) L.status[tile] = (L.status[tile] & ~MGC_ST_SINK) | (has_sink ? MGC_ST_SINK : 0u) | (x.S.satflag ? MGC_ST_DIRTY : 0u);
     });
 }
 

@@ -159,6 +159,7 @@ struct HostDev {
     void fill_heights_inf()
     {
         for (int64_t i = 0; i < (int64_t)L.ntiles * MGC_TV; ++i) L.height[i] = MGC_HINF;
+        for (int t = 0; t < L.ntiles; ++t) L.status[t] |= MGC_ST_ALLINF; /* until a relabel lowers a label */
         for (int sd = 0; sd < 2; ++sd) std::fill(hshadow[sd].begin(), hshadow[sd].end(), (int32_t)MGC_HINF); /* what the neighbours hold now */
     }
     void zero_count(int i) { L.count[i] = 0; }
@@ -404,13 +405,25 @@ struct HostDev26 {
     std::vector<double> rcap, excess, sink;
     std::vector<int32_t> height, lists, count;
     std::vector<uint32_t> rmask32, stamp, rstamp, status;
-    void fill_heights_inf() { for (int64_t i = 0; i < (int64_t)L.ntiles * MGC_TV; ++i) L.height[i] = MGC_HINF; }
+    void fill_heights_inf()
+    {
+        for (int64_t i = 0; i < (int64_t)L.ntiles * MGC_TV; ++i) L.height[i] = MGC_HINF;
+        for (int t = 0; t < L.ntiles; ++t) L.status[t] |= MGC_ST_ALLINF; /* until a relabel lowers a label */
+    }
     void zero_count(int i) { L.count[i] = 0; }
     void read_counts(int* out) { memcpy(out, L.count, MGC_NCOUNT * sizeof(int)); }
     void absorb_all() {}
-    int suspect_batch() const { return 1; }
-    void suspect_pass() {}
-    void reset_suspect(uint32_t, int) {}
+    int suspect_batch() const { return 8; }
+    void suspect_pass()
+    {
+        for (int t = 0; t < L.ntiles; ++t)
+            if (mgc26_suspect_tile(L, t)) L.count[MGC_CNT_CHANGED] = 1;
+    }
+    void reset_suspect(uint32_t epoch, int list)
+    {
+        HostBlock26 x(S);
+        for (int t = 0; t < L.ntiles; ++t) mgc26_reset_suspect_tile(x, L, t, epoch, list);
+    }
     void relabel_all(uint32_t epoch, int next)
     {
         HostBlock26 x(S);
@@ -426,7 +439,12 @@ struct HostDev26 {
         L.count[MGC26_CNT_REL] += n;
         for (int i = 0; i < n; ++i) mgc26_relabel_tile(x, L, L.list[lst][i], epoch, next, false);
     }
-    void activate_all(uint32_t phase) { HostBlock26 x(S); for (int t = 0; t < L.ntiles; ++t) mgc26_activate_tile(x, L, t, phase); }
+    void activate_all(uint32_t phase)
+    {
+        HostBlock26 x(S);
+        for (int t = 0; t < L.ntiles; ++t)
+            if (mgc26_activate_tile(x, L, t, phase)) L.count[MGC26_CNT_ACTIVE]++;
+    }
     void discharge(int lst, uint32_t phase, int cycles, int sweeps)
     {
         HostBlock26D x(S);

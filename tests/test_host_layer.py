@@ -165,6 +165,25 @@ def test_hostsim_full_neighbourhood_matches_bk(gen, shape):
     np.testing.assert_array_equal(lab, g.labels().reshape(shape))
 
 
+@pytest.mark.parametrize("gen,shape", [("hard", (32, 32, 32)), ("ties", (24, 24, 24)), ("sphere", (24, 40, 17))])
+@pytest.mark.parametrize("rounds,cycles,sweeps", [(1, -1, 2), (1, 1, 1), (2, -1, 4)])
+def test_hostsim_full_neighbourhood_incremental_relabel(gen, shape, rounds, cycles, sweeps):
+    """Short colour rounds force many global relabels; all but the first recompute only the SUSPECT tiles (26 supporting
+    neighbour tiles in the status word, mgc26_suspect_tile).  Labels must still be the BK oracle's."""
+    import sim
+    from medpy_amd import synthetic
+    from oracle import energy_numpy, pipeline
+    s = getattr(synthetic, gen)(shape)
+    offs = energy_numpy.forward_offsets(3, 26)
+    w = energy_numpy.boundary_weights_offsets(s["term"], s["image"], offs, s["sigma"])
+    g = pipeline.build_graph(s["fg"], s["bg"], weights=w, connectivity=26)
+    tr = np.array([g.get_trcap(i) for i in range(s["fg"].size)])
+    g.maxflow()
+    lab, st = sim.solve26(shape, w, tr, rounds=rounds, cycles=cycles, sweeps=sweeps)
+    assert st["converged"] == 1 and st["outer"] >= 5
+    np.testing.assert_array_equal(lab, g.labels().reshape(shape))
+
+
 def test_dimacs_writer_text_equals_the_reference_layout():
     """reference medpy/graphcut/write.py:29-76 on the dict Graph (graph.py:31-264); expected text written out by hand from
     the reference's format strings"""
