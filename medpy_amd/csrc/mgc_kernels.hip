@@ -108,6 +108,8 @@ struct GpuBlockT {
     __device__ __forceinline__ int atomic_add(int32_t* p, int v) { return atomicAdd(p, v); }
     __device__ __forceinline__ uint32_t atomic_exch(uint32_t* p, uint32_t v) { return atomicExch(p, v); }
     __device__ __forceinline__ void atomic_or(uint32_t* p, uint32_t v) { atomicOr(p, v); }
+    /* a value every lane of the workgroup holds alike (read from LDS after a barrier): scalar for the branches on it */
+    __device__ __forceinline__ uint32_t uniform(uint32_t v) const { return (uint32_t)__builtin_amdgcn_readfirstlane((int)v); }
     __device__ __forceinline__ void atomic_and(uint32_t* p, uint32_t v) { atomicAnd(p, v); }
     /* ---- exact in-tile labels (executor primitive, see mgc_tile_ops.inl) ----
      * Chaotic relaxation in LDS (mgc_tile_bfs).  A bit-parallel level-synchronous BFS (lane = (y,x) column, bit z of
@@ -212,6 +214,8 @@ struct GpuWave {
     __device__ __forceinline__ int atomic_add(int32_t* p, int v) { return atomicAdd(p, v); }
     __device__ __forceinline__ uint32_t atomic_exch(uint32_t* p, uint32_t v) { return atomicExch(p, v); }
     __device__ __forceinline__ void atomic_or(uint32_t* p, uint32_t v) { atomicOr(p, v); }
+    /* a value every lane of the workgroup holds alike (read from LDS after a barrier): scalar for the branches on it */
+    __device__ __forceinline__ uint32_t uniform(uint32_t v) const { return (uint32_t)__builtin_amdgcn_readfirstlane((int)v); }
     __device__ __forceinline__ void atomic_and(uint32_t* p, uint32_t v) { atomicAnd(p, v); }
 #if defined(MGCW_PROFILE) /* development build (tools/gpu_sections.py): cycles per section of a tile discharge, per wave */
     unsigned long long last = 0, acc[4] = {0, 0, 0, 0};
@@ -353,7 +357,10 @@ struct GpuBlockV {
     }
     __device__ __forceinline__ int atomic_add(int32_t* p, int v) { return atomicAdd(p, v); }
     __device__ __forceinline__ uint32_t atomic_exch(uint32_t* p, uint32_t v) { return atomicExch(p, v); }
+    __device__ __forceinline__ void mark(const MgcLattice&, int) {}
     __device__ __forceinline__ void atomic_or(uint32_t* p, uint32_t v) { atomicOr(p, v); }
+    /* a value every lane of the workgroup holds alike (read from LDS after a barrier): scalar for the branches on it */
+    __device__ __forceinline__ uint32_t uniform(uint32_t v) const { return (uint32_t)__builtin_amdgcn_readfirstlane((int)v); }
     __device__ __forceinline__ void atomic_and(uint32_t* p, uint32_t v) { atomicAnd(p, v); }
 };
 
@@ -451,9 +458,11 @@ __global__ __launch_bounds__(MGC_TV, MGC26_DISCHARGE_WAVES) void k26_discharge(M
     if (blockIdx.x == 0 && threadIdx.x == 0 && n) atomicAdd(&L.count[MGC26_CNT_DIS], n);
     for (int i = blockIdx.x; i < n; i += gridDim.x) {
         x.new_tile();
+        if (L.prof && threadIdx.x == 0) x.last = clock64();
         mgc26_discharge_tile(x, L, L.list[lst][i], phase, cycles, sweeps);
         __syncthreads();
     }
+    x.flush_marks(L);
 }
 
 __global__ __launch_bounds__(MGC_TV) void k_absorb(MgcLattice L)

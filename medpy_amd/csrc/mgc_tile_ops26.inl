@@ -25,6 +25,10 @@
 #include "mgc_tile_ops.inl"
 
 #define MGC26_NDIR 26
+#define MGC26_INL __attribute__((always_inline))
+#ifndef MGC26_COUNT_STEPS
+#define MGC26_COUNT_STEPS(mask) /* host simulator: statistics of the direction masks */
+#endif
 #define MGC26_MASK_SINK (1u << 26)
 /* counter / list layout of the 26-neighbourhood solver */
 #define MGC26_NLIST 16        /* discharge lists 0..15 (target phase & 15)   */
@@ -35,12 +39,13 @@
 
 struct MgcTileShared26 {
     int32_t hs[1000];
-    double  out[2][MGC_TV];
+    double  out[4][MGC_TV];  /* push hand-off: two directions per step, double buffered */
     int32_t nbr[27];      /* neighbour tile ids, index = (dz+1)*9 + (dy+1)*3 + (dx+1); 13 = self */
     int32_t nbrflag[27];
     int32_t depflag[27];  /* relabel: some label of the tile is supported by a voxel of that neighbour tile */
     int32_t flag[2];
     int32_t satflag;      /* discharge: some arc (or sink link) of the tile was saturated               */
+    uint32_t dirmask[2];  /* discharge: directions along which some active voxel can push in this sweep  */
 };
 
 /* status word of a tile, full neighbourhood: bits 0..5 as in mgc_common.h (SINK, DIRTY, SUSPECT, EXCESS, ALLINF), bits 6..31 =
@@ -88,6 +93,7 @@ MGC_HD void mgc26_load_nbrs(X& x, const MgcLattice& L, int tile, int t)
     }
     if (t < 2) x.S.flag[t] = 0;
     if (t == 2) x.S.satflag = 0;
+    if (t == 3) x.S.dirmask[0] = x.S.dirmask[1] = 0;
 }
 
 /* the 488 halo cells of the 10x10x10 label block come from up to 26 neighbour tiles */
@@ -262,6 +268,7 @@ MGC_HD void mgc26_discharge_tile(X& x, const MgcLattice& L, int tile, uint32_t p
         for (int d = 0; d < MGC26_NDIR; ++d) R(d, t) = L.rcap[((int64_t)tile * MGC26_NDIR + d) * MGC_TV + t];
         mgc26_load_halo(x, L, t);
     });
+    x.mark(L, 0); /* load */
 
     bool active = false;
     int sweep_id = 0;
@@ -286,15 +293,95 @@ MGC_HD void mgc26_discharge_tile(X& x, const MgcLattice& L, int tile, uint32_t p
             return e[t] > 0.0 && hme[t] < MGC_HINF;
         });
         if (!active) break;
+        x.mark(L, 1); /* labels */
 
         for (int sw = 0; sw < max_sweeps; ++sw, ++sweep_id) {
             const int fl = sweep_id & 1;
-            /* 27 steps: step s pushes along direction s (s < 26) after receiving direction s-1 */
-            auto step = [&](auto sc) {
-                constexpr int s = decltype(sc)::value;
+            /* Along which directions can a voxel that holds excess NOW push?  Only those steps run: a step costs a barrier and
+             * two LDS exchanges for all 512 voxels, and late sweeps move the excess of a few voxels along a few directions.
+             * (A voxel that receives excess during the sweep pushes on in the steps that run; its other directions wait for
+             * the next sweep -- any order of admissible pushes is a valid discharge.) */
+            x.par([&](int t) {
+                if (e[t] > 0.0 && hme[t] < MGC_HINF) {
+                    const int me = mgc_hs_index(t >> 6, (t >> 3) & 7, t & 7);
+                    uint32_t m = 0;
+#pragma unroll
+                    for (int d = 0; d < MGC26_NDIR; ++d)
+                        m |= (R(d, t) > 0.0 && x.S.hs[me + mgc26_hs_step(d)] == hme[t] - 1) ? (1u << d) : 0u;
+                    if (m) x.atomic_or(&x.S.dirmask[fl], m);
+                }
+            });
+#ifdef MGC26_ALL_STEPS /* A/B: every step runs */
+            const uint32_t M = 0x3ffffffu;
+#else
+            const uint32_t M = x.uniform(x.S.dirmask[fl]);
+#endif
+            MGC26_COUNT_STEPS(M);
+            /* 14 steps: step p pushes along the OPPOSITE directions p and 25 - p (p < 13) after receiving what step p - 1
+             * pushed.  Two directions share a barrier, and their LDS round trips overlap.  Opposite directions, because
+             * pushes over the tile boundary update the idle neighbour tile in place, one writer per voxel and step: two
+             * voxels of this tile reach the same outside voxel only along offsets that agree in the sign of the axis it lies
+             * beyond, and o and -o agree in none.  (Nor can u push to v along o while v pushes to u along -o: a push goes
+             * one label down.) */
+            auto receive = [&](int t, auto dc, int buf) MGC26_INL {
+                constexpr int d = decltype(dc)::value;
+                int dz, dy, dx;
+                mgc26_offset(d, dz, dy, dx);
+                const int sz = (t >> 6) - dz, sy = ((t >> 3) & 7) - dy, sx = (t & 7) - dx; /* the voxel that pushed towards me */
+                if (sz >= 0 && sz < 8 && sy >= 0 && sy < 8 && sx >= 0 && sx < 8) {
+                    const double din = x.S.out[buf][mgc_local(sz, sy, sx)];
+                    if (din != 0.0) {
+                        e[t] += din;
+                        R(25 - d, t) += din;
+                    }
+                }
+            };
+            auto push = [&](int t, auto dc, int buf) MGC26_INL {
+                constexpr int d = decltype(dc)::value;
+                const int z = t >> 6, y = (t >> 3) & 7, xx = t & 7;
+                int dz, dy, dx;
+                mgc26_offset(d, dz, dy, dx);
+                const int vz = z + dz, vy = y + dy, vx = xx + dx;
+                const bool inside = vz >= 0 && vz < 8 && vy >= 0 && vy < 8 && vx >= 0 && vx < 8;
+                double delta = 0.0;
+                if (e[t] > 0.0 && R(d, t) > 0.0 && hme[t] < MGC_HINF) {
+                    const int hv = x.S.hs[mgc_hs_index(z, y, xx) + mgc26_hs_step(d)];
+                    if (hv == hme[t] - 1) {
+                        delta = e[t] < R(d, t) ? e[t] : R(d, t);
+                        e[t] -= delta;
+                        R(d, t) -= delta;
+                        x.S.flag[fl] = 1;
+                        if (R(d, t) == 0.0) x.S.satflag = 1;
+                    }
+                }
+                if (inside) {
+                    x.S.out[buf][t] = delta;
+                } else if (delta != 0.0) {
+                    /* the target voxel lives in an idle neighbour tile and nobody else writes it in this step: update its
+                     * excess and reverse residual in place */
+                    const int ni = ((vz < 0 ? -1 : (vz > 7 ? 1 : 0)) + 1) * 9 + ((vy < 0 ? -1 : (vy > 7 ? 1 : 0)) + 1) * 3 +
+                                   ((vx < 0 ? -1 : (vx > 7 ? 1 : 0)) + 1);
+                    const int nt = x.S.nbr[ni];
+                    const int lv = mgc_local(vz & 7, vy & 7, vx & 7);
+                    L.excess[(int64_t)nt * MGC_TV + lv] += delta;
+                    L.rcap[((int64_t)nt * MGC26_NDIR + (25 - d)) * MGC_TV + lv] += delta;
+                    L.rmask32[(int64_t)nt * MGC_TV + lv] |= 1u << (25 - d);
+                    x.S.nbrflag[ni] = 1;
+                }
+            };
+            auto step = [&](auto pc) {
+                constexpr int p = decltype(pc)::value;            /* 0..13 */
+                constexpr int q = p > 0 ? p - 1 : 0;              /* the pair received in this step */
+                constexpr int pp = p < 13 ? p : 0;                /* the pair pushed in this step   */
+                constexpr uint32_t recv_bits = p > 0 ? ((1u << q) | (1u << (25 - q))) : 0u;
+                constexpr uint32_t push_bits = p < 13 ? ((1u << pp) | (1u << (25 - pp))) : 0u;
+                if (p > 0 && !(M & (recv_bits | push_bits))) return; /* nothing to receive, nobody pushes: no barrier either */
                 x.par([&](int t) {
-                    const int z = t >> 6, y = (t >> 3) & 7, xx = t & 7;
-                    if (s == 0) {
+                    if (p == 0) {
+                        if (t == 0) { /* the other buffers are free: their last readers are behind the barrier of the mask pass */
+                            x.S.flag[fl ^ 1] = 0;
+                            x.S.dirmask[fl ^ 1] = 0;
+                        }
                         if (e[t] > 0.0 && snk[t] > 0.0) {
                             const double delta = e[t] < snk[t] ? e[t] : snk[t];
                             e[t] -= delta;
@@ -303,58 +390,18 @@ MGC_HD void mgc26_discharge_tile(X& x, const MgcLattice& L, int tile, uint32_t p
                             if (snk[t] == 0.0) x.S.satflag = 1;
                         }
                     } else {
-                        if (s == 1 && t == 0) x.S.flag[fl ^ 1] = 0;
-                        constexpr int dp = s > 0 ? s - 1 : 0;
-                        int dz, dy, dx;
-                        mgc26_offset(dp, dz, dy, dx);
-                        const int sz = z - dz, sy = y - dy, sx = xx - dx; /* the voxel that pushed towards me */
-                        if (sz >= 0 && sz < 8 && sy >= 0 && sy < 8 && sx >= 0 && sx < 8) {
-                            const double din = x.S.out[dp & 1][mgc_local(sz, sy, sx)];
-                            if (din != 0.0) {
-                                e[t] += din;
-                                R(25 - dp, t) += din;
-                            }
-                        }
+                        if ((M >> q) & 1u) receive(t, std::integral_constant<int, q>{}, (q & 1) * 2);
+                        if ((M >> (25 - q)) & 1u) receive(t, std::integral_constant<int, 25 - q>{}, (q & 1) * 2 + 1);
                     }
-                    if (s < MGC26_NDIR) {
-                        constexpr int d = s < MGC26_NDIR ? s : 0;
-                        int dz, dy, dx;
-                        mgc26_offset(d, dz, dy, dx);
-                        const int vz = z + dz, vy = y + dy, vx = xx + dx;
-                        const bool inside = vz >= 0 && vz < 8 && vy >= 0 && vy < 8 && vx >= 0 && vx < 8;
-                        double delta = 0.0;
-                        if (e[t] > 0.0 && R(d, t) > 0.0 && hme[t] < MGC_HINF) {
-                            const int hv = x.S.hs[mgc_hs_index(z, y, xx) + mgc26_hs_step(d)];
-                            if (hv == hme[t] - 1) {
-                                delta = e[t] < R(d, t) ? e[t] : R(d, t);
-                                e[t] -= delta;
-                                R(d, t) -= delta;
-                                x.S.flag[fl] = 1;
-                                if (R(d, t) == 0.0) x.S.satflag = 1;
-                            }
-                        }
-                        if (inside) {
-                            x.S.out[d & 1][t] = delta;
-                        } else if (delta != 0.0) {
-                            /* the target voxel lives in an idle neighbour tile and nobody else writes it in
-                             * this step: update its excess and reverse residual in place */
-                            const int ni = ((vz < 0 ? -1 : (vz > 7 ? 1 : 0)) + 1) * 9 + ((vy < 0 ? -1 : (vy > 7 ? 1 : 0)) + 1) * 3 +
-                                           ((vx < 0 ? -1 : (vx > 7 ? 1 : 0)) + 1);
-                            const int nt = x.S.nbr[ni];
-                            const int lv = mgc_local(vz & 7, vy & 7, vx & 7);
-                            L.excess[(int64_t)nt * MGC_TV + lv] += delta;
-                            L.rcap[((int64_t)nt * MGC26_NDIR + (25 - d)) * MGC_TV + lv] += delta;
-                            L.rmask32[(int64_t)nt * MGC_TV + lv] |= 1u << (25 - d);
-                            x.S.nbrflag[ni] = 1;
-                        }
+                    if (p < 13) {
+                        if ((M >> pp) & 1u) push(t, std::integral_constant<int, pp>{}, (pp & 1) * 2);
+                        if ((M >> (25 - pp)) & 1u) push(t, std::integral_constant<int, 25 - pp>{}, (pp & 1) * 2 + 1);
                     }
                 });
             };
 #define MGC26_STEP(n) step(std::integral_constant<int, n>{});
             MGC26_STEP(0) MGC26_STEP(1) MGC26_STEP(2) MGC26_STEP(3) MGC26_STEP(4) MGC26_STEP(5) MGC26_STEP(6) MGC26_STEP(7) MGC26_STEP(8)
-            MGC26_STEP(9) MGC26_STEP(10) MGC26_STEP(11) MGC26_STEP(12) MGC26_STEP(13) MGC26_STEP(14) MGC26_STEP(15) MGC26_STEP(16)
-            MGC26_STEP(17) MGC26_STEP(18) MGC26_STEP(19) MGC26_STEP(20) MGC26_STEP(21) MGC26_STEP(22) MGC26_STEP(23) MGC26_STEP(24)
-            MGC26_STEP(25) MGC26_STEP(26)
+            MGC26_STEP(9) MGC26_STEP(10) MGC26_STEP(11) MGC26_STEP(12) MGC26_STEP(13)
 #undef MGC26_STEP
             /* local relabel of stuck active voxels (see mgc_discharge_tile): labels stay valid lower bounds */
             x.par([&](int t) {
@@ -374,6 +421,7 @@ MGC_HD void mgc26_discharge_tile(X& x, const MgcLattice& L, int tile, uint32_t p
                     }
                 }
             });
+            x.mark(L, 2); /* one sweep */
             if (!x.S.flag[fl]) break;
         }
     }
@@ -406,6 +454,7 @@ MGC_HD void mgc26_discharge_tile(X& x, const MgcLattice& L, int tile, uint32_t p
         /* DIRTY only if a residual arc disappeared: otherwise no distance in the tile (or through it) can have changed */
         if (t == 28) L.status[tile] = (L.status[tile] & ~MGC_ST_SINK) | (has_sink ? MGC_ST_SINK : 0u) | (x.S.satflag ? MGC_ST_DIRTY : 0u);
     });
+    x.mark(L, 3); /* store */
 }
 
 /* ---------------------------------------------------------------------------------------

@@ -21,9 +21,12 @@
 #include <vector>
 
 #include "../../medpy_amd/csrc/mgc_tile_ops.inl"
+static long long g26_sweeps, g26_dirs; /* direction masks of the 26-neighbourhood discharge: sweeps, directions that ran */
+#define MGC26_COUNT_STEPS(mask) (g26_sweeps++, g26_dirs += __builtin_popcount(mask))
 #include "../../medpy_amd/csrc/mgc_tile_ops26.inl"
 #include "../../medpy_amd/csrc/mgc_wave_ops.inl"
 #include "../../medpy_amd/csrc/mgc_driver.inl"
+#include <cstdio>
 
 /* work-profile counters (development aid, read with hostsim_prof): [id] = number of mark(id) calls (0 load, 1 labels, 2 sweep,
  * 3 store, ...); [16]/[17] = waves that voted "active" / waves asked; [18] relaxation rounds of mgc_tile_bfs (par calls inside) */
@@ -79,6 +82,7 @@ struct HostBlockT {
     int atomic_add(int32_t* p, int v) { int o = *p; *p += v; return o; }
     uint32_t atomic_exch(uint32_t* p, uint32_t v) { uint32_t o = *p; *p = v; return o; }
     void atomic_or(uint32_t* p, uint32_t v) { *p |= v; }
+    uint32_t uniform(uint32_t v) const { return v; }
     void atomic_and(uint32_t* p, uint32_t v) { *p &= v; }
     void mark(const MgcLattice&, int id) { g_prof[id & 15]++; }
     void wave_fence() {}
@@ -131,6 +135,7 @@ struct HostWave {
     int atomic_add(int32_t* p, int v) { int o = *p; *p += v; return o; }
     uint32_t atomic_exch(uint32_t* p, uint32_t v) { uint32_t o = *p; *p = v; return o; }
     void atomic_or(uint32_t* p, uint32_t v) { *p |= v; }
+    uint32_t uniform(uint32_t v) const { return v; }
     void atomic_and(uint32_t* p, uint32_t v) { *p &= v; }
     void mark(int id) { g_prof[id & 15]++; }
     template <class T> T ld(const T* p, int l) { return p[l]; }
@@ -526,6 +531,8 @@ int hostsim_solve26(const int64_t* shape, const double* w, const double* trcap, 
     memcpy(stats_out, &st, sizeof(st));
     d->labels(labels_out);
     delete d;
+    if (getenv("HOSTSIM_PROF26")) fprintf(stderr, "26-neighbourhood discharge: %lld sweeps, %.2f of 26 directions per sweep\n", g26_sweeps, g26_sweeps ? (double)g26_dirs / g26_sweeps : 0.0);
+    g26_sweeps = g26_dirs = 0;
     return rc;
 }
 
