@@ -72,13 +72,13 @@ static inline MgcSolveParams mgc_default_params(int ndir = 6)
      * One exact in-tile labelling per discharge, then sweeps with local relabels: 83 ms vs 100 ms for (3 cycles x 4
      * sweeps) at 512^3; a sweep of the 26-neighbourhood costs four times as much, so fewer of them pay there. */
     p.rounds_per_relabel = ndir == 26 ? 6 : 8;
-    p.max_cycles = 1;
+    p.max_cycles = ndir == 26 ? -1 : 1; /* < 0: the stored labels (valid lower bounds) instead of an exact in-tile labelling */
     p.max_sweeps = ndir == 26 ? 3 : 12;
     p.max_outer = 100000;
     p.relabel_batch = 8;
     p.check_rounds = 4;
     p.incremental_relabel = 1;
-    p.adaptive_rounds = ndir == 6;
+    p.adaptive_rounds = 1;
     return p;
 }
 

@@ -57,9 +57,11 @@ MGC_HD int mgc26_dep_bit(int ni) { return MGC26_ST_DEP_SHIFT + (ni < 13 ? ni : n
 /* LDS of the discharge kernel: half of the 26 residuals of every voxel live here (directions 13..25), the other half in
  * registers.  All 26 in registers need 256 VGPRs (2 waves/SIMD, one workgroup per CU, and still spill); 13 + 13 fits
  * 128 VGPRs and 66 KiB of LDS, i.e. two workgroups per CU. */
+#ifndef MGC26_NREG
 #define MGC26_NREG 13
+#endif
 struct MgcTileShared26D : MgcTileShared26 {
-    alignas(16) double rl[MGC26_NDIR - MGC26_NREG][MGC_TV];
+    alignas(16) double rl[MGC26_NDIR - MGC26_NREG > 0 ? MGC26_NDIR - MGC26_NREG : 1][MGC_TV];
 };
 
 MGC_HD void mgc26_offset(int d, int& dz, int& dy, int& dx)

@@ -180,7 +180,7 @@ def sync_image_range(slabs, ex):
         s.set_image_range(-g[0], g[1], g[2])
 
 
-def solve_slabs(slabs, ex, rounds_per_relabel=8, max_cycles=1, max_sweeps=None, max_outer=100000, check_rounds=4, relabel_batch=8,
+def solve_slabs(slabs, ex, rounds_per_relabel=8, max_cycles=None, max_sweeps=None, max_outer=100000, check_rounds=4, relabel_batch=8,
                 incremental_relabel=True):
     """Drives the local slabs to a maximum preflow.  Returns a stats dict (global numbers).
 
@@ -195,10 +195,12 @@ def solve_slabs(slabs, ex, rounds_per_relabel=8, max_cycles=1, max_sweeps=None, 
     if getattr(slabs[0], "ndir", 6) == 26:
         ncol, lmask, rl, c_act, c_dis, c_rel = 8, 15, 16, 18, 19, 20
         max_sweeps = max_sweeps or 3  # mgc_default_params(26)
-        incremental_relabel = False  # the full-neighbourhood kernels keep no support faces
+        max_cycles = max_cycles or -1  # stored labels, mgc_default_params(26)
+        incremental_relabel = False  # the DIRTY / SUSPECT flags of full-neighbourhood border tiles do not travel (no halo kind 2)
     else:
         ncol, lmask, rl, c_act, c_dis, c_rel = 2, 3, 4, 6, 8, 9
         max_sweeps = max_sweeps or 12  # mgc_default_params(6)
+        max_cycles = max_cycles or 1
     phase, rep = 2 * (lmask + 1), 2
     for s in slabs:
         s.op(OP_ZERO_COUNT, c_dis)

@@ -4,11 +4,13 @@ sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 from medpy_amd import synthetic
 from medpy_amd.graphcut.graph import VoxelGraph
 n = int(sys.argv[1]) if len(sys.argv) > 1 else 256
+regional = os.environ.get("REGIONAL", "1") == "1"
 s = synthetic.sphere((n, n, n)); r = synthetic.regional((n, n, n))
 g = VoxelGraph((n, n, n), connectivity=26)
 g._set_boundary("difference_exponential", s["image"], s["sigma"], False)
 g._set_markers(s["fg"], s["bg"])
-g._set_regional(r["prob"], r["alpha"])
+if regional:
+    g._set_regional(r["prob"], r["alpha"])
 ref = None
 for c, w, rr in [tuple(int(v) for v in a.split(":")) for a in sys.argv[2:]] or [(1, 3, 6), (-1, 3, 6), (-1, 6, 6), (1, 6, 6)]:
     g.set_param("max_cycles", c); g.set_param("max_sweeps", w); g.set_param("rounds_per_relabel", rr)
