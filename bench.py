@@ -298,7 +298,9 @@ def main():
         value = nvox / (elapsed / args.steps) / 1e6
         b_alg = B_ALG[conn] + (4.0 if regional else 0.0)
         out = {
-            "metric": "Mvoxels/s graph-cut (build+solve), 512^3 6-conn; fraction of HBM roofline",
+            # BASELINE.json's metric, quoted on config 2 (512^3, 6-conn); other configs name their own shape and neighbourhood
+            "metric": "Mvoxels/s graph-cut (build+solve), %s %d-conn; fraction of HBM roofline" % (
+                "512^3" if tuple(gshape) == (512, 512, 512) else "x".join(str(v) for v in gshape), conn),
             "value": round(value, 3), "unit": "Mvoxels/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": round(ms_per_step, 3), "higher_is_better": True, "scaling": "strong" if args.strong else "weak",
             "vs_baseline": None, "dtype": "f64", "data": "synthetic",
