@@ -825,25 +825,30 @@ __device__ __forceinline__ void k_build_tiles(const MgcLattice& L, const MgcBuil
                 if (w > 0.0) m |= 1u << d; /* NaN (0/0 of the linear terms on a constant image) is not residual */
             }
         } else {
-            /* full neighbourhood: same g(.) on all 26 offsets (oracle/energy_numpy.py:boundary_weights_offsets) */
-            for (int d = 0; d < MGC26_NDIR; ++d) {
-                int dz, dy, dx;
-                mgc26_offset(d, dz, dy, dx);
-                const int64_t nz = gz + dz, ny = gy + dy, nx = gx + dx;
-                const bool has = valid && nz >= 0 && nz < L.dz && ny >= 0 && ny < L.dy && nx >= 0 && nx < L.dx;
+            /* full neighbourhood: same g(.) on all 26 offsets (oracle/energy_numpy.py:boundary_weights_offsets).  Unrolled: the
+             * offsets, the LDS steps and the plane offsets of the stores are constants, and "is there a neighbour" is three bits
+             * of a per-lane mask instead of six 64-bit comparisons per direction (this kernel is bound by instruction issue). */
+            const uint32_t nb = (gz > 0 ? 1u : 0u) | (gz + 1 < L.dz ? 2u : 0u) | (gy > 0 ? 4u : 0u) | (gy + 1 < L.dy ? 8u : 0u) |
+                                (gx > 0 ? 16u : 0u) | (gx + 1 < L.dx ? 32u : 0u);
+            double* const plane0 = L.rcap + ((int64_t)tile * MGC26_NDIR) * MGC_TV + t;
+            const double mine = TERM != MGC_TERM_NONE ? img[me] : 0.0;
+            mgcw_static_for<MGC26_NDIR>([&](auto dc) __attribute__((always_inline)) {
+                constexpr int d = decltype(dc)::value;
+                constexpr int c = d < 13 ? d : d + 1;
+                constexpr int dz = c / 9 - 1, dy = (c / 3) % 3 - 1, dx = c % 3 - 1;
+                constexpr uint32_t need = (dz < 0 ? 1u : (dz > 0 ? 2u : 0u)) | (dy < 0 ? 4u : (dy > 0 ? 8u : 0u)) | (dx < 0 ? 16u : (dx > 0 ? 32u : 0u));
+                const bool has = valid && (nb & need) == need;
                 double w = 0.0;
                 if (has && TERM != MGC_TERM_NONE) {
-                    const bool fwd = d >= 13;
-                    const double a = fwd ? img[me] : img[me + mgc26_hs_step(d)];
-                    const double b = fwd ? img[me + mgc26_hs_step(d)] : img[me];
-                    w = mgc_boundary_g(TERM, a, b, A.p0);
+                    const double other = img[me + dz * 100 + dy * 10 + dx];
+                    w = d >= 13 ? mgc_boundary_g(TERM, mine, other, A.p0) : mgc_boundary_g(TERM, other, mine, A.p0); /* g(lower, upper) */
                     if (A.has_spacing) w = w / A.div26[d];
                 }
-                const int64_t o = ((int64_t)tile * MGC26_NDIR + d) * MGC_TV + t;
-                L.rcap[o] = w;
-                if (L.cap0) L.cap0[o] = w;
+                plane0[(int64_t)d * MGC_TV] = w;
+                if (L.cap0) L.cap0[((int64_t)tile * MGC26_NDIR + d) * MGC_TV + t] = w;
                 if (w > 0.0) m |= 1u << d;
-            }
+                if (d % 4 == 3) asm volatile("" ::: "memory"); /* four weights in flight, not 26: 26 keep 151 VGPRs alive (one workgroup per CU) */
+            });
         }
         /* t-links: regional term, then fg marker, then bg marker (generate.py:159-172) */
         double tr = 0.0, fc = 0.0;
@@ -899,22 +904,32 @@ __device__ __forceinline__ void k_build_tiles(const MgcLattice& L, const MgcBuil
     }
 }
 
-template <bool FULL> /* FULL: 26-neighbourhood */
+/* One kernel per (neighbourhood, boundary term): g(.) is straight-line code, and every instance gets the registers ITS term
+ * needs (one kernel with a switch is allocated for the power terms: 151 VGPRs, one workgroup per CU for all nine). */
+template <bool FULL, int TERM> /* FULL: 26-neighbourhood */
 __global__ __launch_bounds__(MGC_TV, FULL ? 2 : 4) void k_build(MgcLattice L, MgcBuildArgs A)
 {
     __shared__ double img[1000]; /* 10x10x10: tile + one-voxel halo, already |.|'d for the maximum terms */
     __shared__ double scratch[MGC_TV];
     __shared__ double wf[FULL ? 1 : 3 * 576]; /* 6-neighbourhood: the forward n-link weights of the tile and its lower faces */
-    switch (A.term) { /* one dispatch per kernel, not one per weight */
-    case MGC_TERM_NONE: k_build_tiles<FULL, MGC_TERM_NONE>(L, A, img, scratch, wf); break;
-    case MGC_TERM_DIFFERENCE_LINEAR: k_build_tiles<FULL, MGC_TERM_DIFFERENCE_LINEAR>(L, A, img, scratch, wf); break;
-    case MGC_TERM_DIFFERENCE_EXPONENTIAL: k_build_tiles<FULL, MGC_TERM_DIFFERENCE_EXPONENTIAL>(L, A, img, scratch, wf); break;
-    case MGC_TERM_DIFFERENCE_DIVISION: k_build_tiles<FULL, MGC_TERM_DIFFERENCE_DIVISION>(L, A, img, scratch, wf); break;
-    case MGC_TERM_DIFFERENCE_POWER: k_build_tiles<FULL, MGC_TERM_DIFFERENCE_POWER>(L, A, img, scratch, wf); break;
-    case MGC_TERM_MAXIMUM_LINEAR: k_build_tiles<FULL, MGC_TERM_MAXIMUM_LINEAR>(L, A, img, scratch, wf); break;
-    case MGC_TERM_MAXIMUM_EXPONENTIAL: k_build_tiles<FULL, MGC_TERM_MAXIMUM_EXPONENTIAL>(L, A, img, scratch, wf); break;
-    case MGC_TERM_MAXIMUM_DIVISION: k_build_tiles<FULL, MGC_TERM_MAXIMUM_DIVISION>(L, A, img, scratch, wf); break;
-    default: k_build_tiles<FULL, MGC_TERM_MAXIMUM_POWER>(L, A, img, scratch, wf); break;
+    k_build_tiles<FULL, TERM>(L, A, img, scratch, wf);
+}
+
+template <bool FULL>
+static void mgc_launch_build(int term, int grid, hipStream_t stream, const MgcLattice& L, const MgcBuildArgs& A)
+{
+    switch (term) {
+#define MGC_BUILD_CASE(T) case T: hipLaunchKernelGGL((k_build<FULL, T>), dim3(grid), dim3(MGC_TV), 0, stream, L, A); break;
+    MGC_BUILD_CASE(MGC_TERM_NONE)
+    MGC_BUILD_CASE(MGC_TERM_DIFFERENCE_LINEAR)
+    MGC_BUILD_CASE(MGC_TERM_DIFFERENCE_EXPONENTIAL)
+    MGC_BUILD_CASE(MGC_TERM_DIFFERENCE_DIVISION)
+    MGC_BUILD_CASE(MGC_TERM_DIFFERENCE_POWER)
+    MGC_BUILD_CASE(MGC_TERM_MAXIMUM_LINEAR)
+    MGC_BUILD_CASE(MGC_TERM_MAXIMUM_EXPONENTIAL)
+    MGC_BUILD_CASE(MGC_TERM_MAXIMUM_DIVISION)
+    default: hipLaunchKernelGGL((k_build<FULL, MGC_TERM_MAXIMUM_POWER>), dim3(grid), dim3(MGC_TV), 0, stream, L, A); break;
+#undef MGC_BUILD_CASE
     }
 }
 
@@ -2183,8 +2198,8 @@ int mgc_build(mgc_handle h)
     h->build_args = A;
     const int grid = L.ntiles < h->grid_cap * 4 ? L.ntiles : h->grid_cap * 4;
     const int bgrid = grid >= 8 ? grid / 8 * 8 : grid; /* k_build deals tiles to XCDs: multiple of 8 */
-    if (L.ndir == 6) hipLaunchKernelGGL(k_build<false>, dim3(bgrid), dim3(MGC_TV), 0, h->stream, L, A);
-    else hipLaunchKernelGGL(k_build<true>, dim3(bgrid), dim3(MGC_TV), 0, h->stream, L, A);
+    if (L.ndir == 6) mgc_launch_build<false>(A.term, bgrid, h->stream, L, A);
+    else mgc_launch_build<true>(A.term, bgrid, h->stream, L, A);
     MGC_HIP(h, hipGetLastError());
     mgc_sum_partials(h, (int64_t)L.ntiles, h->d_scalar);
     MGC_HIP(h, hipGetLastError());
