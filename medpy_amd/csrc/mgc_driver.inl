@@ -35,8 +35,8 @@ struct MgcSolveParams {
     int relabel_batch;      /* BFS passes launched between two counter read-backs         */
     int check_rounds;       /* colour rounds launched between two counter read-backs      */
     int incremental_relabel;/* 1: later global relabels touch suspect tiles only          */
-    int adaptive_rounds;    /* 1: the number of rounds between two relabels doubles (up to 4x) while a relabel visits more
-                               than three times as many tiles as the discharges of the cycle before it did               */
+    int adaptive_rounds;    /* k > 0: the number of rounds between two relabels doubles (up to 4x) while a relabel visits more
+                               than k times as many tiles as the discharges of the cycle before it did                   */
 };
 
 struct MgcSolveStats {
@@ -78,7 +78,7 @@ static inline MgcSolveParams mgc_default_params(int ndir = 6)
     p.relabel_batch = 8;
     p.check_rounds = 4;
     p.incremental_relabel = 1;
-    p.adaptive_rounds = 1;
+    p.adaptive_rounds = ndir == 26 ? 9 : 3; /* a tile visit of a relabel costs 1/3 of a discharge (9 vs 27 ns), 1/9 in the full neighbourhood (20 vs 175 ns) */
     return p;
 }
 
@@ -162,7 +162,7 @@ int mgc_solve(Dev& dev, const MgcLattice& L, const MgcSolveParams& P, MgcSolveSt
         {
             const int64_t d_dis = (int64_t)cnt[lay.cnt_dis] - prev_dis; /* discharges since the relabel before this one */
             const int64_t d_rel = (int64_t)cnt[lay.cnt_rel] - prev_rel; /* tile visits of the relabel that just ended  */
-            if (P.adaptive_rounds && outer > 0 && d_rel > 3 * d_dis && rounds < 4 * P.rounds_per_relabel) rounds *= 2;
+            if (P.adaptive_rounds > 0 && outer > 0 && d_rel > (int64_t)P.adaptive_rounds * d_dis && rounds < 4 * P.rounds_per_relabel) rounds *= 2;
             prev_dis = cnt[lay.cnt_dis];
             prev_rel = cnt[lay.cnt_rel];
         }

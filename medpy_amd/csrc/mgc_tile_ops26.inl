@@ -46,6 +46,7 @@ struct MgcTileShared26 {
     int32_t flag[2];
     int32_t satflag;      /* discharge: some arc (or sink link) of the tile was saturated               */
     uint32_t dirmask[2];  /* discharge: directions along which some active voxel can push in this sweep  */
+    uint32_t pushmask;    /* discharge: directions along which a voxel of the tile DID push               */
 };
 
 /* status word of a tile, full neighbourhood: bits 0..5 as in mgc_common.h (SINK, DIRTY, SUSPECT, EXCESS, ALLINF), bits 6..31 =
@@ -96,6 +97,7 @@ MGC_HD void mgc26_load_nbrs(X& x, const MgcLattice& L, int tile, int t)
     if (t < 2) x.S.flag[t] = 0;
     if (t == 2) x.S.satflag = 0;
     if (t == 3) x.S.dirmask[0] = x.S.dirmask[1] = 0;
+    if (t == 4) x.S.pushmask = 0;
 }
 
 /* the 488 halo cells of the 10x10x10 label block come from up to 26 neighbour tiles */
@@ -260,10 +262,12 @@ MGC_HD void mgc26_discharge_tile(X& x, const MgcLattice& L, int tile, uint32_t p
      * constant wherever this is used (unrolled loops), so the choice folds away */
     auto R = [&](int d, int t) -> double& { return d < NREG ? rr[d < NREG ? d : 0][t] : x.S.rl[d >= NREG ? d - NREG : 0][t]; };
     typename X::template Reg<int> hme;
+    typename X::template Reg<uint32_t> pushed; /* directions this voxel pushed along */
     const int64_t base = (int64_t)tile * MGC_TV;
 
     x.par([&](int t) { mgc26_load_nbrs(x, L, tile, t); });
     x.par([&](int t) {
+        pushed[t] = 0;
         e[t] = L.excess[base + t];
         snk[t] = L.sink[base + t];
 #pragma unroll
@@ -354,6 +358,10 @@ MGC_HD void mgc26_discharge_tile(X& x, const MgcLattice& L, int tile, uint32_t p
                         R(d, t) -= delta;
                         x.S.flag[fl] = 1;
                         if (R(d, t) == 0.0) x.S.satflag = 1;
+                        if (!((pushed[t] >> d) & 1u)) { /* (the lane's own copy spares the atomic on every further push) */
+                            pushed[t] |= 1u << d;
+                            x.atomic_or(&x.S.pushmask, 1u << d);
+                        }
                     }
                 }
                 if (inside) {
@@ -430,13 +438,16 @@ MGC_HD void mgc26_discharge_tile(X& x, const MgcLattice& L, int tile, uint32_t p
     if (active) active = x.any([&](int t) -> bool { return e[t] > 0.0 && hme[t] < MGC_HINF; });
     const bool has_sink = x.any([&](int t) -> bool { return snk[t] > 0.0; });
 
+    /* a residual plane changed iff somebody pushed along it or along its opposite (the receiver's reverse arc): the others --
+     * typically 10 of 26 -- are not written back */
+    const uint32_t PM = x.uniform(x.S.pushmask);
     x.par([&](int t) {
         L.excess[base + t] = e[t];
         L.sink[base + t] = snk[t];
         uint32_t m = snk[t] > 0.0 ? MGC26_MASK_SINK : 0u;
 #pragma unroll
         for (int d = 0; d < MGC26_NDIR; ++d) {
-            L.rcap[((int64_t)tile * MGC26_NDIR + d) * MGC_TV + t] = R(d, t);
+            if (((PM >> d) | (PM >> (25 - d))) & 1u) L.rcap[((int64_t)tile * MGC26_NDIR + d) * MGC_TV + t] = R(d, t);
             m |= (R(d, t) > 0.0) ? (1u << d) : 0u;
         }
         L.rmask32[base + t] = m;

@@ -1,6 +1,6 @@
 """A/B of the kernel forms and schedule knobs on the GPU (development aid).
 
-    python tools/gpu_wave_ab.py [n] [workload] [variant ...]     variant = wave:sweeps:rounds:grid:adaptive  (0 = default; adaptive 1 = off, 2 = on)
+    python tools/gpu_wave_ab.py [n] [workload] [variant ...]     variant = wave:sweeps:rounds:grid:adaptive  (0 = default; adaptive 1 = off, k + 1 = threshold k (default 3))
 
 Every variant must return the labels of the first one; prints one JSON line per variant."""
 import sys, os, time, json
