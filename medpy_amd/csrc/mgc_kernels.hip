@@ -406,7 +406,10 @@ void k26_discharge_v(MgcLattice L, int lst, uint32_t phase, int cycles, int swee
     }
 }
 
-__global__ __launch_bounds__(MGC_TV) void k26_relabel_all(MgcLattice L, uint32_t epoch, int next_list)
+#ifndef MGC26_RELABEL_WAVES
+#define MGC26_RELABEL_WAVES 8 /* 64 VGPRs, no scratch: four workgroups per CU hide the barrier per relaxation round (config 3: relabel 16.2 -> 11.6 ms; 6 waves: 13.0) */
+#endif
+__global__ __launch_bounds__(MGC_TV, MGC26_RELABEL_WAVES) void k26_relabel_all(MgcLattice L, uint32_t epoch, int next_list)
 {
     __shared__ MgcTileShared26 S;
     GpuBlock26 x(S);
@@ -420,7 +423,7 @@ __global__ __launch_bounds__(MGC_TV) void k26_relabel_all(MgcLattice L, uint32_t
     if (threadIdx.x == 0 && visited) atomicAdd(&L.count[MGC26_CNT_REL], visited);
 }
 
-__global__ __launch_bounds__(MGC_TV) void k26_relabel_list(MgcLattice L, int lst, uint32_t epoch, int next_list)
+__global__ __launch_bounds__(MGC_TV, MGC26_RELABEL_WAVES) void k26_relabel_list(MgcLattice L, int lst, uint32_t epoch, int next_list)
 {
     __shared__ MgcTileShared26 S;
     GpuBlock26 x(S);
@@ -906,8 +909,11 @@ __device__ __forceinline__ void k_build_tiles(const MgcLattice& L, const MgcBuil
 
 /* One kernel per (neighbourhood, boundary term): g(.) is straight-line code, and every instance gets the registers ITS term
  * needs (one kernel with a switch is allocated for the power terms: 151 VGPRs, one workgroup per CU for all nine). */
+#ifndef MGC_BUILD_WAVES6
+#define MGC_BUILD_WAVES6 6 /* three workgroups per CU: 80 VGPRs and 32 B of scratch for the exponential term; measured 3.74 ms vs 4.28 ms at 4 (and 4.35 at 5) for 512^3 */
+#endif
 template <bool FULL, int TERM> /* FULL: 26-neighbourhood */
-__global__ __launch_bounds__(MGC_TV, FULL ? 2 : 4) void k_build(MgcLattice L, MgcBuildArgs A)
+__global__ __launch_bounds__(MGC_TV, FULL ? 2 : MGC_BUILD_WAVES6) void k_build(MgcLattice L, MgcBuildArgs A)
 {
     __shared__ double img[1000]; /* 10x10x10: tile + one-voxel halo, already |.|'d for the maximum terms */
     __shared__ double scratch[MGC_TV];
