@@ -1277,6 +1277,7 @@ struct mgc_graph {
     double flow_const = 0.0, flow = 0.0;
     MgcSolveParams params = mgc_default_params();
     int grid_cap = 4096;
+    int grid26_dis = 16384;        /* workgroups of a k26_discharge launch (0: grid_cap): two tiles per workgroup at 512^3, 62.0 ms of discharges per config-3 step vs 63.0 at 4096 and 65.7 at 512 */
     int wave_kernels = 9;  /* bit0: region discharge, bit1: global-relabel passes run one wave per tile (mgc_wave_ops.inl);
                               bit2: the wave discharge starts from exact in-tile labels (MGCW_BFS); bit3: relabel passes with
                               MGC_RELABEL_V voxels per thread (k_relabel_v) instead of one (k_relabel_list) */
@@ -1466,7 +1467,7 @@ struct HipDevT {
              * 6; markers only 494 ms at 3, 431 at 8. */
             if (h->sweeps_sparse26 > 0 && (int64_t)h->est_phase_tiles * 40 < h->L.ntiles) sweeps = h->sweeps_sparse26;
             if (h->wave_kernels & 16) hipLaunchKernelGGL(k26_discharge_v, dim3(grid(h->L.ntiles)), dim3(MGC_TV / 2), 0, h->stream, h->L, lst, phase, cycles, sweeps);
-            else hipLaunchKernelGGL(k26_discharge, dim3(grid(h->L.ntiles)), dim3(MGC_TV), 0, h->stream, h->L, lst, phase, cycles, sweeps);
+            else hipLaunchKernelGGL(k26_discharge, dim3(h->grid26_dis > 0 ? (h->grid26_dis < h->L.ntiles ? h->grid26_dis : h->L.ntiles) : grid(h->L.ntiles)), dim3(MGC_TV), 0, h->stream, h->L, lst, phase, cycles, sweeps);
         }
         /* one wave per tile has the higher throughput (2 048 tiles in flight, fewer instructions per tile), eight waves per tile
          * the shorter latency (36 us against 60 us for one tile): short lists -- small volumes, the tail of a solve -- are a
@@ -2458,6 +2459,7 @@ int mgc_set_param(mgc_handle h, const char* name, int64_t value)
     else if (!strcmp(name, "max_sweeps") && value > 0) h->params.max_sweeps = (int)value;
     else if (!strcmp(name, "max_outer") && value > 0) h->params.max_outer = (int)value;
     else if (!strcmp(name, "grid_cap") && value > 0) h->grid_cap = (int)value;
+    else if (!strcmp(name, "grid26_dis") && value >= 0) h->grid26_dis = (int)value;
     else if (!strcmp(name, "relabel_batch") && value > 0) h->params.relabel_batch = (int)value;
     else if (!strcmp(name, "check_rounds") && value > 0) h->params.check_rounds = (int)value;
     else if (!strcmp(name, "incremental_relabel")) h->params.incremental_relabel = value != 0;

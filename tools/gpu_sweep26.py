@@ -12,6 +12,8 @@ g._set_markers(s["fg"], s["bg"])
 if regional:
     g._set_regional(r["prob"], r["alpha"])
 ref = None
+if os.environ.get("GRID26"):
+    g.set_param("grid26_dis", int(os.environ["GRID26"]))
 for c, w, rr in [tuple(int(v) for v in a.split(":")) for a in sys.argv[2:]] or [(1, 3, 6), (-1, 3, 6), (-1, 6, 6), (1, 6, 6)]:
     g.set_param("max_cycles", c); g.set_param("max_sweeps", w); g.set_param("rounds_per_relabel", rr)
     best = 1e9
