@@ -1734,7 +1734,7 @@ int mgc_halo_pack(mgc_handle h, int side, int kind, void* buf, int buf_on_device
 {
     if (!h || !buf || side < 0 || side > 1) return MGC_ERR_INVALID;
     if (!h->built) return mgc_fail(h, MGC_ERR_STATE, "mgc_halo_pack before mgc_build");
-    if (kind < 0 || kind > 2 || (kind == 2 && h->L.ndir != 6)) return mgc_fail(h, MGC_ERR_INVALID, "mgc_halo_pack: halo kind %d not available for this neighbourhood", kind);
+    if (kind < 0 || kind > 2) return mgc_fail(h, MGC_ERR_INVALID, "mgc_halo_pack: no halo kind %d", kind);
     if (side == 0 ? h->L.tz_own_lo == 0 : h->L.tz_own_hi == h->L.gz) return mgc_fail(h, MGC_ERR_INVALID, "no neighbour slab on side %d", side);
     MGC_HIP(h, hipSetDevice(h->device));
     const int64_t bytes = mgc_halo_bytes_nd(h->L, kind);
@@ -1771,7 +1771,7 @@ int mgc_halo_unpack(mgc_handle h, int side, int kind, const void* buf, int buf_o
 {
     if (!h || !buf || side < 0 || side > 1) return MGC_ERR_INVALID;
     if (!h->built) return mgc_fail(h, MGC_ERR_STATE, "mgc_halo_unpack before mgc_build");
-    if (kind < 0 || kind > 2 || (kind == 2 && h->L.ndir != 6)) return mgc_fail(h, MGC_ERR_INVALID, "mgc_halo_unpack: halo kind %d not available for this neighbourhood", kind);
+    if (kind < 0 || kind > 2) return mgc_fail(h, MGC_ERR_INVALID, "mgc_halo_unpack: no halo kind %d", kind);
     if (side == 0 ? h->L.tz_own_lo == 0 : h->L.tz_own_hi == h->L.gz) return mgc_fail(h, MGC_ERR_INVALID, "no neighbour slab on side %d", side);
     MGC_HIP(h, hipSetDevice(h->device));
     const int64_t bytes = mgc_halo_bytes_nd(h->L, kind);
@@ -1893,7 +1893,6 @@ int mgc_halo_exchange(mgc_handle h, int kind, uint32_t epoch, int list)
     if (!h->comm) return mgc_fail(h, MGC_ERR_STATE, "mgc_halo_exchange before mgc_comm_init");
     MGC_HIP(h, hipSetDevice(h->device));
     if (kind < 0 || kind > 2) return mgc_fail(h, MGC_ERR_INVALID, "mgc_halo_exchange: kind must be 0, 1 or 2");
-    if (kind == 2 && h->L.ndir != 6) return mgc_fail(h, MGC_ERR_UNSUPPORTED, "halo kind 2 (suspect flags) exists for the 2*ndim neighbourhood only");
     int64_t bytes = mgc_halo_bytes_nd(h->L, 1); /* capacity of the largest kind; reused for all */
     if (mgc_halo_bytes_nd(h->L, 0) > bytes) bytes = mgc_halo_bytes_nd(h->L, 0);
     if (h->xchg_cap < bytes) {

@@ -492,6 +492,7 @@ MGC_HD int64_t mgc26_halo_off_rec(const MgcLattice& L) { return (mgc26_halo_off_
 MGC_HD int64_t mgc26_halo_bytes(const MgcLattice& L, int kind)
 {
     const int64_t T = (int64_t)L.gy * L.gx;
+    if (kind == 2) return T * 4; /* int32 status[T]: DIRTY | SUSPECT of the owned border tiles (suspect closure, as mgc_halo_bytes) */
     return kind == 1 ? mgc26_halo_off_rec(L) + T * MGC26_REC * 8 : T * MGC_TF * 4;
 }
 
@@ -502,6 +503,12 @@ MGC_HD void mgc26_halo_pack_tile(X& x, const MgcLattice& L, int side, int kind, 
     const int own = (side ? L.tz_own_hi - 1 : L.tz_own_lo) * (int)T + i;
     const int ghost = (side ? L.tz_own_hi : L.tz_own_lo - 1) * (int)T + i;
     const int f_own = side ? 5 : 4, f_ghost = side ? 4 : 5, dbase = side ? 0 : 17;
+    if (kind == 2) {
+        x.par([&](int t) {
+            if (t == 0) ((int32_t*)buf)[i] = (int32_t)(L.status[own] & (MGC_ST_DIRTY | MGC_ST_SUSPECT));
+        });
+        return;
+    }
     int32_t* lab = (int32_t*)buf;
     int32_t* slot1 = (int32_t*)((char*)buf + mgc26_halo_off_slot(L));
     int32_t* count = (int32_t*)((char*)buf + mgc26_halo_off_count(L));
@@ -538,6 +545,15 @@ MGC_HD void mgc26_halo_unpack_tile(X& x, const MgcLattice& L, int side, int kind
     const int own = own_layer * (int)T + i;
     const int ghost = (side ? L.tz_own_hi : L.tz_own_lo - 1) * (int)T + i;
     const int f_own = side ? 5 : 4, f_ghost = side ? 4 : 5, dbase = side ? 17 : 0; /* the sender packed ITS other side */
+    if (kind == 2) { /* the ghost mirrors the owner's flags; a ghost that turns suspect keeps the closure going */
+        x.par([&](int t) {
+            if (t != 0) return;
+            const uint32_t msg = (uint32_t)((const int32_t*)buf)[i], old = L.status[ghost];
+            L.status[ghost] = (old & ~(MGC_ST_DIRTY | MGC_ST_SUSPECT)) | msg;
+            if ((msg & MGC_ST_SUSPECT) && !(old & MGC_ST_SUSPECT)) L.count[MGC_CNT_CHANGED] = 1;
+        });
+        return;
+    }
     const int32_t* lab = (const int32_t*)buf;
     const int32_t* slot1 = (const int32_t*)((const char*)buf + mgc26_halo_off_slot(L));
     const double* rec = (const double*)((const char*)buf + mgc26_halo_off_rec(L));

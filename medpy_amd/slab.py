@@ -196,7 +196,6 @@ def solve_slabs(slabs, ex, rounds_per_relabel=8, max_cycles=None, max_sweeps=Non
         ncol, lmask, rl, c_act, c_dis, c_rel = 8, 15, 16, 18, 19, 20
         max_sweeps = max_sweeps or 3  # mgc_default_params(26)
         max_cycles = max_cycles or -1  # stored labels, mgc_default_params(26)
-        incremental_relabel = False  # the DIRTY / SUSPECT flags of full-neighbourhood border tiles do not travel (no halo kind 2)
     else:
         ncol, lmask, rl, c_act, c_dis, c_rel = 2, 3, 4, 6, 8, 9
         max_sweeps = max_sweeps or 12  # mgc_default_params(6)

@@ -178,3 +178,28 @@ def test_full_neighbourhood_slabs_match_oracle(gen, shape, nslabs):
     st = solve_slabs(slabs, LoopbackExchange(slabs), rounds_per_relabel=2)
     assert st["converged"] == 1
     np.testing.assert_array_equal(np.concatenate([sl.finish()[0] for sl in slabs], axis=0), ref)
+
+
+@pytest.mark.parametrize("incremental", [True, False])
+@pytest.mark.parametrize("gen,shape,nslabs", [("hard", (48, 24, 24), 3), ("sphere", (40, 24, 17), 2), ("ties", (32, 16, 16), 4)])
+def test_full_neighbourhood_incremental_relabel_across_slabs(gen, shape, nslabs, incremental):
+    """26-neighbourhood, many global relabels (one round each): the DIRTY / SUSPECT flags of the border tiles travel as halo
+    kind 2 (mgc26_halo_pack_tile) and the closure over the 26 supporting neighbour tiles crosses the slab borders."""
+    import sim
+    from medpy_amd import synthetic
+    from medpy_amd.slab import LoopbackExchange, solve_slabs
+    from oracle import energy_numpy, pipeline
+    s = getattr(synthetic, gen)(shape)
+    offs = energy_numpy.forward_offsets(3, 26)
+    w = energy_numpy.boundary_weights_offsets(s["term"], s["image"], offs, s["sigma"])
+    g = pipeline.build_graph(s["fg"], s["bg"], weights=w, connectivity=26)
+    tr = np.array([g.get_trcap(i) for i in range(s["fg"].size)])
+    g.maxflow()
+    ref = g.labels().reshape(shape).astype(bool)
+    w26 = sim.weights26(shape, w)
+    slabs = [sim.SimSlab26(shape, r, nslabs) for r in range(nslabs)]
+    for sl in slabs:
+        sl.load(w26, tr)
+    st = solve_slabs(slabs, LoopbackExchange(slabs), rounds_per_relabel=1, max_sweeps=2, incremental_relabel=incremental)
+    assert st["converged"] == 1 and st["outer"] >= 3
+    np.testing.assert_array_equal(np.concatenate([sl.finish()[0] for sl in slabs], axis=0), ref)
