@@ -172,7 +172,7 @@ int mgc_labels(mgc_handle h, uint8_t* out);
 int mgc_what_segment(mgc_handle h, int64_t i, int* segment); /* Graph::what_segment, graph.h:561-571 */
 
 int mgc_get_node_num(mgc_handle h, int64_t* n);
-int mgc_set_param(mgc_handle h, const char* name, int64_t value); /* solver schedule knobs, see DESIGN.md */
+int mgc_set_param(mgc_handle h, const char* name, int64_t value); /* solver schedule knobs: the table in DESIGN.md section 3 */
 int mgc_get_stats(mgc_handle h, mgc_stats* out);
 /* development aid (mgc_set_param "profile_sections" 1): out16[0..3] = shader cycles of workgroup lane 0 spent in
  * load+absorb / in-tile labels / push sweeps / store of k_discharge, out16[8..11] = how many such sections */
