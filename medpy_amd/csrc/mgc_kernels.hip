@@ -605,12 +605,6 @@ __global__ void k_filter(MgcLattice L, int mode, int list, int cnt)
     }
 }
 
-__global__ void k_count_status(MgcLattice L, uint32_t bit, int cnt)
-{
-    for (int tile = blockIdx.x * blockDim.x + threadIdx.x; tile < L.ntiles; tile += gridDim.x * blockDim.x)
-        if (L.status[tile] & bit) atomicAdd(&L.count[cnt], 1);
-}
-
 /* first pass of a from-scratch global relabel over the tiles the filter found to hold a sink arc (the only seeds) */
 __global__ __launch_bounds__(MGC_TV) void k_relabel_first_list(MgcLattice L, int list, int cnt, uint32_t epoch, int next_list)
 {
@@ -1062,9 +1056,15 @@ __global__ __launch_bounds__(MGC_TV) void k_cut_value(MgcLattice L, MgcBuildArgs
                 s += tr;
             }
         }
-        const double tot = mgc_block_sum(s, scratch);
-        if (t == 0) part[tile] = tot;
-        __syncthreads();
+        /* only tiles the cut passes through (or that hold t-links on the paying side) contribute: the others skip the ten
+         * barriers of the tree sum (the sum of zeros is the same 0.0) */
+        if (__syncthreads_or(s != 0.0)) {
+            const double tot = mgc_block_sum(s, scratch);
+            if (t == 0) part[tile] = tot;
+            __syncthreads();
+        } else if (t == 0) {
+            part[tile] = 0.0;
+        }
     }
 }
 
