@@ -192,7 +192,28 @@ struct HostDev {
             else mgc_relabel_tile(x, L, L.list[lst][i], epoch, next, false);
         }
     }
-    void activate_all(uint32_t phase) { HostBlock x(S); for (int t = 0; t < L.ntiles; ++t) mgc_activate_tile(x, L, t, phase); }
+    /* work profile: what does an incremental relabel change?  labels of the tiles it reset, before and after */
+    std::vector<std::pair<int, std::vector<int32_t> > > reset_snapshot;
+    void activate_all(uint32_t phase)
+    {
+        for (auto& sn : reset_snapshot) {
+            const int32_t* h = &L.height[(int64_t)sn.first * MGC_TV];
+            int changed = 0, face_changed = 0;
+            for (int t = 0; t < MGC_TV; ++t) {
+                if (h[t] == sn.second[t]) continue;
+                changed++;
+                const int z = t >> 6, y = (t >> 3) & 7, xx = t & 7;
+                if (z == 0 || z == 7 || y == 0 || y == 7 || xx == 0 || xx == 7) face_changed++;
+            }
+            g_prof[24]++;                       /* tiles reset                                        */
+            g_prof[25] += changed == 0;         /* ... whose labels came back as they were            */
+            g_prof[26] += face_changed == 0;    /* ... whose face voxels (what neighbours see) did    */
+            g_prof[27] += changed;              /* voxels whose label changed                          */
+        }
+        reset_snapshot.clear();
+        HostBlock x(S);
+        for (int t = 0; t < L.ntiles; ++t) mgc_activate_tile(x, L, t, phase);
+    }
     int suspect_batch() const { return 8; }
     void suspect_pass()
     {
@@ -202,7 +223,11 @@ struct HostDev {
     void reset_suspect(uint32_t epoch, int list)
     {
         HostBlock x(S);
-        for (int t = 0; t < L.ntiles; ++t) mgc_reset_suspect_tile(x, L, t, epoch, list);
+        for (int t = 0; t < L.ntiles; ++t) {
+            if (!g_tile_discharges.empty() && (L.status[t] & MGC_ST_SUSPECT) && mgc_owned(L, t))
+                reset_snapshot.emplace_back(t, std::vector<int32_t>(&L.height[(int64_t)t * MGC_TV], &L.height[(int64_t)t * MGC_TV] + MGC_TV));
+            mgc_reset_suspect_tile(x, L, t, epoch, list);
+        }
     }
     void discharge(int lst, uint32_t phase, int cycles, int sweeps)
     {

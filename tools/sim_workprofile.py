@@ -62,6 +62,9 @@ def main():
     for name, m in (("inside", inside), ("shell", shell), ("outside", outside)):
         print("  %-8s tiles %6d  discharges %8d  (%.2f per tile)" % (name, m.sum(), tiles[m].sum(), tiles[m].sum() / max(1, m.sum())))
     print("  per-voxel: discharges %.2f relabels %.2f" % (st["discharge_tiles"] / nt, st["relabel_tiles"] / nt))
+    if prof[24]:
+        print("incremental relabels reset %d tiles: %.1f%% got their labels back unchanged, %.1f%% unchanged on all six faces; "
+              "%.1f voxels changed per reset tile" % (prof[24], 100.0 * prof[25] / prof[24], 100.0 * prof[26] / prof[24], prof[27] / prof[24]))
 
 
 if __name__ == "__main__":
