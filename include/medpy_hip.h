@@ -127,15 +127,16 @@ int mgc_set_regional_probability(mgc_handle h, const void* probability_map, int 
  * graph.py:310-380): nonzero fg -> add_tweights(i, 65535, 0), nonzero bg -> add_tweights(i, 0, 65535). */
 int mgc_set_markers(mgc_handle h, const uint8_t* fg, const uint8_t* bg);
 
+/* After mgc_maxflow (or the slab driver's last step): see mgc_validation.  Also works on a graph whose solve was cut
+ * short (MGC_ERR_NOT_CONVERGED): it then reports the excess that is still active.  MGC_ERR_STATE before the first solve
+ * step of a build: the distance labels it reads do not exist yet. */
+int mgc_validate(mgc_handle h, mgc_validation* out);
+
 /* The *_linear terms divide by the intensity range of the image (energy_voxel.py:101: max |I|; 174-176:
  * |max - min| in the image's dtype).  A single handle measures it itself.  A SLAB only holds its own planes, so the
  * caller reduces the local triples {min, max, max|.|} over the ranks (min, max, max) and hands the global one back
  * before mgc_build; building a *_linear slab without it fails with MGC_ERR_STATE.  NULL forgets a range set earlier;
  * mgc_set_boundary does so too. */
-/* After mgc_maxflow (or the slab driver's last step): see mgc_validation.  Also works on a graph whose solve was cut
- * short (MGC_ERR_NOT_CONVERGED): it then reports the excess that is still active. */
-int mgc_validate(mgc_handle h, mgc_validation* out);
-
 int mgc_get_image_range(mgc_handle h, double* out3);
 int mgc_set_image_range(mgc_handle h, const double* in3);
 
@@ -196,7 +197,7 @@ enum {
     MGC_OP_RELABEL_LIST = 4, /* a0 = list, a1 = next epoch, a2 = next list  */
     MGC_OP_ACTIVATE = 5,     /* a0 = phase                                  */
     MGC_OP_DISCHARGE = 6,    /* a0 = list, a1 = phase, a2 = max cycles, a3 = max sweeps */
-    MGC_OP_SUSPECT_PASS = 7, /* one pass of the tile-level suspect closure (sets counter 10 when something changed) */
+    MGC_OP_SUSPECT_PASS = 7, /* one pass of the tile-level suspect closure (sets counter MGC_CNT_CHANGED = 21 when something changed) */
     MGC_OP_RESET_SUSPECT = 8 /* a0 = next epoch, a1 = next list: suspect tiles -> labels INF, queued for relabelling */
 };
 int mgc_create_slab(int ndim, const int64_t* global_shape, int connectivity, int device, int rank, int nranks, mgc_handle* out);

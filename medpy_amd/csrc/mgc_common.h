@@ -41,7 +41,12 @@
 #define MGC_ST_ALLINF 32u      /* every label of the tile is MGC_HINF: set when an incremental relabel resets the tile, cleared when a
                                   relabel pass lowers one of its labels (a clear bit promises nothing) */
 #define MGC_ST_DEP_SHIFT 8
-#define MGC_CNT_CHANGED 10     /* counter slot: suspect-closure pass changed something */
+/* counter slots no layout uses as a work list (6-neighbourhood: lists 0..7, totals 8 / 9; 26-neighbourhood: lists 0..17,
+ * totals 18..20; tickets of the wave kernels 24..27) */
+#define MGC_CNT_CHANGED 21     /* suspect-closure pass changed something */
+#define MGC_CNT_FILTER 22      /* length of the scratch list the tile filters fill (absorb / relabel seeding / suspect reset) */
+#define MGC_CNT_FILTER_ACT 23  /* ... of the activation filter */
+#define MGC_CNT_NOT_FULL 28    /* k_build: tiles holding an n-link inside the volume that is not residual (0: the first global relabel is a distance transform) */
 
 struct MgcLattice {
     /* logical volume */

@@ -99,6 +99,7 @@ int mgc_solve(Dev& dev, const MgcLattice& L, const MgcSolveParams& P, MgcSolveSt
         dev.absorb_all();
         dev.zero_count(lay.rl_base);
         dev.zero_count(lay.rl_base + 1);
+        if (lay.rl_third >= 0) dev.zero_count(lay.rl_third); /* (all clears of this stretch go out together, see HipDevT::flush_zero) */
         if (outer == 0 || !lay.incremental || !P.incremental_relabel) {
             dev.fill_heights_inf();
             dev.relabel_all(rep + 1, lay.rl_base + (int)((rep + 1) & 1u));
@@ -118,8 +119,7 @@ int mgc_solve(Dev& dev, const MgcLattice& L, const MgcSolveParams& P, MgcSolveSt
             /* three lists rotate: pass k consumes lists[k % 3], appends to lists[(k + 1) % 3] and clears the counter of
              * lists[(k + 2) % 3] (consumed by pass k - 1) inside the kernel */
             const int lists[3] = {lay.rl_base, lay.rl_base + 1, lay.rl_third};
-            int k = (int)((rep + 1) & 1u); /* where relabel_all / reset_suspect queued their tiles */
-            dev.zero_count(lists[(k + 1) % 3]);
+            int k = (int)((rep + 1) & 1u); /* where relabel_all / reset_suspect queued their tiles; the other two lists are empty */
             for (;;) {
                 for (int b = 0; b < P.relabel_batch; ++b, ++k) {
                     rep++;

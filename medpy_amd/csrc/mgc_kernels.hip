@@ -509,6 +509,11 @@ __global__ __launch_bounds__(MGC_TV) void k_relabel_list(MgcLattice L, int lst, 
     }
 }
 
+__global__ void k_zero_counts(int32_t* count, uint32_t mask)
+{
+    if ((mask >> threadIdx.x) & 1u) count[threadIdx.x] = 0;
+}
+
 __global__ void k_status_or(MgcLattice L, uint32_t bits)
 {
     const int tile = blockIdx.x * blockDim.x + threadIdx.x;
@@ -643,6 +648,18 @@ __global__ __launch_bounds__(MGC_TV) void k_activate_list(MgcLattice L, int list
     }
 }
 
+/* activation over the filter's list, one wave per tile (four tiles per 256-thread workgroup in flight) */
+__global__ __launch_bounds__(256) void k_activate_w(MgcLattice L, int list, int cnt, uint32_t phase)
+{
+    __shared__ MgcWaveShared S; /* (not touched: the executor wants one) */
+    GpuWave w(S);
+    const int n = L.count[cnt];
+    for (int i = (int)blockIdx.x * 4 + (int)(threadIdx.x >> 6); i < n; i += (int)gridDim.x * 4) {
+        w.new_tile();
+        mgcw_activate_tile(w, L, __builtin_amdgcn_readfirstlane(L.list[list][i]), phase);
+    }
+}
+
 __global__ __launch_bounds__(MGC_TV) void k_reset_suspect_list(MgcLattice L, int list, int cnt, uint32_t epoch, int out_list)
 {
     __shared__ MgcTileShared S;
@@ -723,6 +740,7 @@ struct MgcBuildArgs {
     const double* tr_in; /* merged explicit t-links (plug-in path) or NULL */
     double* tr0;         /* out: merged tr_cap per voxel, tile-major */
     double* fpart;       /* out: per-tile partial of the flow constant */
+    uint8_t* tflags;     /* out: per tile, bit 0: some voxel has a source link (tr0 > 0), bit 1: a sink link (tr0 < 0) -- as built */
 };
 
 /* Graph::add_tweights, graph.h:416-425 */
@@ -888,6 +906,7 @@ __device__ __forceinline__ void k_build_tiles(const MgcLattice& L, const MgcBuil
             L.stamp[tile] = 0;
             L.rstamp[tile] = 0;
             L.status[tile] = (any_sink ? MGC_ST_SINK : 0u) | (any_exc ? MGC_ST_EXCESS : 0u);
+            A.tflags[tile] = (uint8_t)((any_exc ? 1 : 0) | (any_sink ? 2 : 0));
         }
         /* flow constant: only voxels whose t-links were merged more than once contribute (regional term + marker, fg and bg
          * marker on one voxel): most tiles skip the ten barriers of the tree sum */
@@ -1068,6 +1087,92 @@ __global__ __launch_bounds__(MGC_TV) void k_cut_value(MgcLattice L, MgcBuildArgs
     }
 }
 
+/* 6-neighbourhood form: labels straight from the tile-major distance labels (own tile + the six face layers next door
+ * in LDS), so the C-order label volume is not needed, and a tile only reads what it can contribute: the merged t-links
+ * only where k_build saw one of the paying sign (A.tflags), nothing at all for a tile that lies with its six neighbours
+ * entirely on the source side.  Same additions in the same order as k_cut_value: the value is bit-identical. */
+__global__ __launch_bounds__(MGC_TV) void k_cut_value6(MgcLattice L, MgcBuildArgs A, const double* tr0, double* part)
+{
+    __shared__ double scratch[MGC_TV];
+    __shared__ int32_t hs[1000];
+    const int t = threadIdx.x;
+    for (int tile = blockIdx.x; tile < L.ntiles; tile += gridDim.x) {
+        int tz, ty, tx;
+        mgc_tile_coords(L, tile, tz, ty, tx);
+        const bool owned = mgc_owned(L, tile);
+        const uint32_t tf = A.tflags[tile];
+        bool quiet = !owned;
+        if (owned && (L.status[tile] & MGC_ST_ALLINF) && !(tf & 2u)) { /* all on the source side, no sink link to pay */
+            quiet = true;
+            for (int f = 0; f < 6; ++f) {
+                const int nt = mgc_tile_nbr(L, tz, ty, tx, f);
+                if (nt >= 0 && !(mgc_owned(L, nt) && (L.status[nt] & MGC_ST_ALLINF))) quiet = false; /* (a ghost tile's flag is not maintained) */
+            }
+        }
+        if (quiet) { /* uniform per workgroup */
+            if (t == 0) part[tile] = 0.0;
+            continue;
+        }
+        const int lz = t >> 6, ly = (t >> 3) & 7, lx = t & 7;
+        const int me = mgc_hs_index(lz, ly, lx);
+        const int32_t hme = L.height[(int64_t)tile * MGC_TV + t];
+        hs[me] = hme;
+        if (t < 6 * MGC_TF) {
+            const int f = t >> 6, k = t & 63;
+            const int nt = mgc_tile_nbr(L, tz, ty, tx, f);
+            const int mine = mgc_face_voxel(f, k);
+            hs[mgc_hs_index(mine >> 6, (mine >> 3) & 7, mine & 7) + mgc_hs_step(f)] =
+                nt < 0 ? MGC_HINF : L.height[(int64_t)nt * MGC_TV + mgc_face_voxel(f ^ 1, k)];
+        }
+        __syncthreads();
+        const int64_t gz = (int64_t)tz * 8 + lz, gy = (int64_t)ty * 8 + ly, gx = (int64_t)tx * 8 + lx;
+        double s = 0.0;
+        if (gz < L.dz && gy < L.dy && gx < L.dx) {
+            if (hme >= MGC_HINF) { /* source side: pays its sink link and every n-link into T */
+                if (tf & 2u) {
+                    const double tr = tr0[(int64_t)tile * MGC_TV + t];
+                    if (tr < 0.0) s += -tr;
+                }
+#pragma unroll
+                for (int d = 0; d < 6; ++d) {
+                    const int64_t c = (d >> 1) == 0 ? gx : ((d >> 1) == 1 ? gy : gz);
+                    const int64_t lim = (d >> 1) == 0 ? L.dx : ((d >> 1) == 1 ? L.dy : L.dz);
+                    const bool has = (d & 1) ? (c + 1 < lim) : (c > 0);
+                    if (has && hs[me + mgc_hs_step(d)] < MGC_HINF) s += mgc_built_capacity(L, A, tile, t, gz, gy, gx, d);
+                }
+            } else if (tf & 1u) { /* sink side: pays its source link */
+                const double tr = tr0[(int64_t)tile * MGC_TV + t];
+                if (tr > 0.0) s += tr;
+            }
+        }
+        if (__syncthreads_or(s != 0.0)) {
+            const double tot = mgc_block_sum(s, scratch);
+            if (t == 0) part[tile] = tot;
+            __syncthreads();
+        } else if (t == 0) {
+            part[tile] = 0.0;
+        }
+    }
+}
+
+/* label read-out for rows that are whole runs of eight voxels (D2 a multiple of 8): a thread turns the 32 bytes of one tile
+ * row into 8 label bytes */
+__global__ void k_labels8(MgcLattice L, uint8_t* out)
+{
+    const int64_t rows = L.nvox >> 3;
+    const int64_t rx = L.dx >> 3;
+    for (int64_t r = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; r < rows; r += (int64_t)gridDim.x * blockDim.x) {
+        const int64_t bx = r % rx, q = r / rx, y = q % L.dy, z = q / L.dy;
+        const int tile = mgc_tile_id(L, (int)(z >> 3), (int)(y >> 3), (int)bx);
+        const int4* hp = (const int4*)(L.height + (int64_t)tile * MGC_TV + mgc_local((int)(z & 7), (int)(y & 7), 0));
+        const int4 a = hp[0], b = hp[1];
+        const unsigned long long v = (a.x < MGC_HINF ? 0ull : 1ull) | (a.y < MGC_HINF ? 0ull : 1ull << 8) | (a.z < MGC_HINF ? 0ull : 1ull << 16) |
+                                     (a.w < MGC_HINF ? 0ull : 1ull << 24) | (b.x < MGC_HINF ? 0ull : 1ull << 32) | (b.y < MGC_HINF ? 0ull : 1ull << 40) |
+                                     (b.z < MGC_HINF ? 0ull : 1ull << 48) | (b.w < MGC_HINF ? 0ull : 1ull << 56);
+        *(unsigned long long*)(out + (r << 3)) = v;
+    }
+}
+
 
 /* ======================================================================================
  * invariants of a maximum preflow (mgc_validate; the reference's Graph::test_consistency, maxflow.cpp:610-682, in spirit)
@@ -1099,7 +1204,7 @@ __global__ __launch_bounds__(MGC_TV) void k_validate(MgcLattice L, MgcBuildArgs 
         mgc_tile_coords(L, tile, tz, ty, tx);
         const int lz = t >> 6, ly = (t >> 3) & 7, lx = t & 7;
         const int64_t gz = (int64_t)tz * 8 + lz, gy = (int64_t)ty * 8 + ly, gx = (int64_t)tx * 8 + lx;
-        double into_sink = 0.0;
+        double into_sink = 0.0, cap_used = 0.0;
         const bool owned = mgc_owned(L, tile);
         if (owned && gz < L.dz && gy < L.dy && gx < L.dx) {
             const int64_t v = (int64_t)tile * MGC_TV + t;
@@ -1110,7 +1215,7 @@ __global__ __launch_bounds__(MGC_TV) void k_validate(MgcLattice L, MgcBuildArgs 
             unsigned across = 0;
             double outflow = 0.0, scale = fmax(fmax(src0, snk0), fmax(e, 1e-300));
             into_sink = snk0 - sk;
-            if (into_sink != 0.0) atomicAdd(&out->sink_cap_used, snk0);
+            if (into_sink != 0.0) cap_used = snk0;
             for (int d = 0; d < L.ndir; ++d) {
                 int dz, dy, dx;
                 if (L.ndir == 6) {
@@ -1158,6 +1263,9 @@ __global__ __launch_bounds__(MGC_TV) void k_validate(MgcLattice L, MgcBuildArgs 
         if (L.obox && t < 6 * MGC_TF && L.obox[(int64_t)tile * 6 * MGC_TF + t] != 0.0) atomicAdd(&sc[7], 1ull);
         const double tot = mgc_block_sum(into_sink, scratch);
         if (t == 0) part[tile] = tot;
+        __syncthreads();
+        const double used = mgc_block_sum(cap_used, scratch); /* one atomic per tile, not one per voxel with a sink link */
+        if (t == 0 && used != 0.0) atomicAdd(&out->sink_cap_used, used);
         __syncthreads();
         if (t < 8 && sc[t]) atomicAdd(&out->cnt[t], sc[t]);
         if (t == 8 && smax[0]) atomicMax(&out->max_pair_bits, smax[0]);
@@ -1264,11 +1372,14 @@ struct mgc_graph {
     bool edges_applied = false; /* the stored batch went into the last build (a new mgc_add_edges replaces it) */
     std::map<const void*, size_t> buf_cap; /* capacity of the buffers mgc_upload manages, keyed by the owning field */
     /* outputs / scratch */
+    uint8_t* d_tflags = nullptr; /* per tile: which signs of t-link k_build saw (MgcBuildArgs::tflags) */
     double* d_tr0 = nullptr; double* d_part = nullptr; double* d_part2 = nullptr; double* d_scalar = nullptr; uint8_t* d_labels = nullptr;
     int32_t* h_count = nullptr; /* pinned */
     double* h_scalar = nullptr; /* pinned */
     uint8_t* h_labels = nullptr; bool labels_on_host = false;
     bool built = false, solved = false;
+    bool labels_valid = false; /* the distance labels belong to this build (set by the first label fill of a solve, cleared by mgc_build) */
+    void* d_vout = nullptr;    /* MgcValidateOut of mgc_validate */
     int rank = 0, nranks = 1;
     int64_t plane0 = 0, plane1 = 0, own0 = 0, own1 = 0; /* global plane ranges of a slab */
     void* d_halo = nullptr; int64_t halo_cap = 0;
@@ -1287,6 +1398,7 @@ struct mgc_graph {
     int sweeps_sparse26 = 8;       /* 26-neighbourhood: sweep budget of a discharge while fewer than 20 % of a colour's tiles are active */
     int wave_min_tiles = 512;      /* shorter lists are discharged by the workgroup-per-tile kernel (measured: 128^3 4.8 -> 3.4 ms, 256^3 10.8 -> 10.5 ms,
                                       512^3 unchanged; 1024 costs 512^3 8 % more discharges) */
+    uint32_t zero_mask = 0; /* counters to clear before the next launch (HipDevT::flush_zero) */
     int pending_zero = -1; /* list counter the schedule asked to clear right after a discharge: the next discharge kernel clears
                               it (it neither reads nor appends to that list), any other operation flushes it with a memset first */
     int use_filters = 3; /* bit0 absorb, bit1 activate, bit2 reset-suspect go through the tile-level filter.  Bit2 is off:
@@ -1345,21 +1457,29 @@ struct HipDevT {
     void fill_heights_inf()
     {
         flush_zero();
+        h->labels_valid = true;
         check(hipMemsetAsync(h->L.height, 0x3f, (size_t)h->L.ntiles * MGC_TV * sizeof(int32_t), h->stream));
         hipLaunchKernelGGL(k_status_or, dim3((h->L.ntiles + 255) / 256), dim3(256), 0, h->stream, h->L, (uint32_t)MGC_ST_ALLINF); /* until a relabel lowers a label */
         for (int sd = 0; sd < 2; ++sd) /* the neighbour slabs fill their ghost layers too: the shadows of what they hold follow */
             if (h->L.hshadow[sd]) check(hipMemsetAsync(h->L.hshadow[sd], 0x3f, (size_t)h->L.gy * h->L.gx * MGC_TF * sizeof(int32_t), h->stream));
     }
+    /* Counter clears are collected in a bit mask and go out as ONE one-thread kernel in front of the next launch that
+     * is not itself a clear (a 512^3 solve asked for ~160 four-byte memsets, each a fill kernel of its own). */
     void flush_zero()
     {
-        if (h->pending_zero >= 0) check(hipMemsetAsync(h->L.count + h->pending_zero, 0, sizeof(int32_t), h->stream));
+        if (h->pending_zero >= 0) h->zero_mask |= 1u << h->pending_zero;
         h->pending_zero = -1;
+        if (h->zero_mask) {
+            hipLaunchKernelGGL(k_zero_counts, dim3(1), dim3(MGC_NCOUNT), 0, h->stream, h->L.count, h->zero_mask);
+            check(hipGetLastError());
+        }
+        h->zero_mask = 0;
     }
     void zero_count(int i)
     {
-        flush_zero();
-        if (!FULL && i == last_discharged) { h->pending_zero = i; last_discharged = -1; return; }
-        check(hipMemsetAsync(h->L.count + i, 0, sizeof(int32_t), h->stream));
+        if (!FULL && i == last_discharged) { flush_zero(); h->pending_zero = i; last_discharged = -1; return; }
+        if (h->pending_zero >= 0) { h->zero_mask |= 1u << h->pending_zero; h->pending_zero = -1; }
+        h->zero_mask |= 1u << i;
     }
     void read_counts(int* out)
     {
@@ -1386,9 +1506,10 @@ struct HipDevT {
         else if (!(h->use_filters & 1)) { hipLaunchKernelGGL(k_absorb, dim3(grid(h->L.ntiles)), dim3(MGC_TV), 0, h->stream, h->L); check(hipGetLastError()); }
         else {
             /* one thread per tile finds the tiles with a pending inbox; only those get a workgroup */
-            zero_count(11);
-            hipLaunchKernelGGL(k_filter, dim3(filter_grid()), dim3(256), 0, h->stream, h->L, 0, 6, 11);
-            hipLaunchKernelGGL(k_absorb_list, dim3(grid(h->L.ntiles)), dim3(MGC_TV), 0, h->stream, h->L, 6, 11);
+            zero_count(MGC_CNT_FILTER);
+            flush_zero();
+            hipLaunchKernelGGL(k_filter, dim3(filter_grid()), dim3(256), 0, h->stream, h->L, 0, 6, MGC_CNT_FILTER);
+            hipLaunchKernelGGL(k_absorb_list, dim3(grid(h->L.ntiles)), dim3(MGC_TV), 0, h->stream, h->L, 6, MGC_CNT_FILTER);
             check(hipGetLastError());
         }
     }
@@ -1399,11 +1520,12 @@ struct HipDevT {
         if constexpr (FULL) hipLaunchKernelGGL(k26_relabel_all, dim3(grid(h->L.ntiles)), dim3(MGC_TV), 0, h->stream, h->L, epoch, next);
         else if (!(h->use_filters & 1)) hipLaunchKernelGGL(k_relabel_all, dim3(grid(h->L.ntiles)), dim3(MGC_TV), 0, h->stream, h->L, epoch, next);
         else { /* one thread per tile finds the seeds (tiles with an arc to the sink); only those get a workgroup */
-            zero_count(11);
-            hipLaunchKernelGGL(k_filter, dim3(filter_grid()), dim3(256), 0, h->stream, h->L, 3, 6, 11);
-            if (h->wave_kernels & 8) hipLaunchKernelGGL(k_relabel_v, dim3(grid(h->L.ntiles)), dim3(MGC_TV / MGC_RELABEL_V), 0, h->stream, h->L, 6, 11, epoch, next, -1, 1);
-            else if (h->wave_kernels & 2) { hipLaunchKernelGGL(k_relabel_w, dim3(h->wave_grid_rel), dim3(MGCW_LANES), 0, h->stream, h->L, 6, 11, epoch, next, -1, 1, h->tk_rel); h->tk_rel ^= 1; }
-            else hipLaunchKernelGGL(k_relabel_first_list, dim3(grid(h->L.ntiles)), dim3(MGC_TV), 0, h->stream, h->L, 6, 11, epoch, next);
+            zero_count(MGC_CNT_FILTER);
+            flush_zero();
+            hipLaunchKernelGGL(k_filter, dim3(filter_grid()), dim3(256), 0, h->stream, h->L, 3, 6, MGC_CNT_FILTER);
+            if (h->wave_kernels & 8) hipLaunchKernelGGL(k_relabel_v, dim3(grid(h->L.ntiles)), dim3(MGC_TV / MGC_RELABEL_V), 0, h->stream, h->L, 6, MGC_CNT_FILTER, epoch, next, -1, 1);
+            else if (h->wave_kernels & 2) { hipLaunchKernelGGL(k_relabel_w, dim3(h->wave_grid_rel), dim3(MGCW_LANES), 0, h->stream, h->L, 6, MGC_CNT_FILTER, epoch, next, -1, 1, h->tk_rel); h->tk_rel ^= 1; }
+            else hipLaunchKernelGGL(k_relabel_first_list, dim3(grid(h->L.ntiles)), dim3(MGC_TV), 0, h->stream, h->L, 6, MGC_CNT_FILTER, epoch, next);
         }
         check(hipGetLastError());
         time_end(id);
@@ -1434,9 +1556,10 @@ struct HipDevT {
         const int id = time_begin(1);
         if (FULL || !(h->use_filters & 4)) hipLaunchKernelGGL(k_reset_suspect<FULL>, dim3(grid((h->L.ntiles + MGC_TV - 1) / MGC_TV)), dim3(MGC_TV), 0, h->stream, h->L, epoch, list);
         else {
-            zero_count(11);
-            hipLaunchKernelGGL(k_filter, dim3(filter_grid()), dim3(256), 0, h->stream, h->L, 2, 6, 11);
-            hipLaunchKernelGGL(k_reset_suspect_list, dim3(grid(h->L.ntiles)), dim3(MGC_TV), 0, h->stream, h->L, 6, 11, epoch, list);
+            zero_count(MGC_CNT_FILTER);
+            flush_zero();
+            hipLaunchKernelGGL(k_filter, dim3(filter_grid()), dim3(256), 0, h->stream, h->L, 2, 6, MGC_CNT_FILTER);
+            hipLaunchKernelGGL(k_reset_suspect_list, dim3(grid(h->L.ntiles)), dim3(MGC_TV), 0, h->stream, h->L, 6, MGC_CNT_FILTER, epoch, list);
         }
         check(hipGetLastError());
         time_end(id);
@@ -1449,16 +1572,19 @@ struct HipDevT {
         else if (!(h->use_filters & 2)) hipLaunchKernelGGL(k_activate, dim3(grid(h->L.ntiles)), dim3(MGC_TV), 0, h->stream, h->L, phase);
         else {
             /* only tiles whose status says "holds excess" are examined voxel by voxel */
-            zero_count(12);
-            hipLaunchKernelGGL(k_filter, dim3(filter_grid()), dim3(256), 0, h->stream, h->L, 1, 7, 12);
-            hipLaunchKernelGGL(k_activate_list, dim3(grid(h->L.ntiles)), dim3(MGC_TV), 0, h->stream, h->L, 7, 12, phase);
+            zero_count(MGC_CNT_FILTER_ACT);
+            flush_zero();
+            hipLaunchKernelGGL(k_filter, dim3(filter_grid()), dim3(256), 0, h->stream, h->L, 1, 7, MGC_CNT_FILTER_ACT);
+            if (h->wave_kernels & 1) hipLaunchKernelGGL(k_activate_w, dim3(grid((h->L.ntiles + 3) / 4)), dim3(256), 0, h->stream, h->L, 7, MGC_CNT_FILTER_ACT, phase);
+            else hipLaunchKernelGGL(k_activate_list, dim3(grid(h->L.ntiles)), dim3(MGC_TV), 0, h->stream, h->L, 7, MGC_CNT_FILTER_ACT, phase);
         }
         check(hipGetLastError());
     }
     void discharge(int lst, uint32_t phase, int cycles, int sweeps)
     {
-        const int zero_idx = h->pending_zero; /* cleared inside the kernel: no memset between two colour phases */
+        const int zero_idx = h->pending_zero; /* cleared inside the kernel: nothing sits between two colour phases */
         h->pending_zero = -1;
+        flush_zero(); /* (whatever else is waiting to be cleared) */
         const int id = time_begin(0);
         if constexpr (FULL) {
             /* Busy phases (a regional term: 40 % of the tiles hold excess) are paced by their heaviest tiles, and excess cannot
@@ -1517,6 +1643,14 @@ struct HipDevT {
 typedef HipDevT<false> HipDev;
 typedef HipDevT<true> HipDev26;
 
+/* C entry points that launch kernels or read the counters outside a HipDevT: clears that are still pending go out first */
+static void mgc_flush_zero(mgc_handle h)
+{
+    HipDev dev;
+    dev.h = h;
+    dev.flush_zero();
+}
+
 /* one step of the solver schedule (mgc_solver_op), on the kernels of either neighbourhood */
 template <class Dev>
 static int mgc_solver_op_on(mgc_handle h, int op, int64_t a0, int64_t a1, int64_t a2, int64_t a3)
@@ -1558,6 +1692,24 @@ static void mgc_sum_partials(mgc_handle h, int64_t n, double* out)
     } else {
         hipLaunchKernelGGL(k_sum_partials, dim3(1), dim3(MGC_TV), 0, h->stream, (const double*)h->d_part, n, out);
     }
+}
+
+/* read-out: the label volume (C order, 0 = SINK side) and the capacity of the cut those labels define, summed into
+ * h->d_scalar[slot] */
+static int mgc_launch_readout(mgc_handle h, int slot, hipEvent_t after_labels)
+{
+    MgcLattice& L = h->L;
+    if (L.dx % 8 == 0) hipLaunchKernelGGL(k_labels8, dim3(2048), dim3(256), 0, h->stream, L, h->d_labels);
+    else hipLaunchKernelGGL(k_labels, dim3(2048), dim3(256), 0, h->stream, L, h->d_labels);
+    MGC_HIP(h, hipGetLastError());
+    if (after_labels) MGC_HIP(h, hipEventRecord(after_labels, h->stream));
+    const int grid = L.ntiles < h->grid_cap * 4 ? L.ntiles : h->grid_cap * 4;
+    if (L.ndir == 6) hipLaunchKernelGGL(k_cut_value6, dim3(grid), dim3(MGC_TV), 0, h->stream, L, h->build_args, (const double*)h->d_tr0, h->d_part);
+    else hipLaunchKernelGGL(k_cut_value, dim3(grid), dim3(MGC_TV), 0, h->stream, L, h->build_args, (const double*)h->d_tr0, (const uint8_t*)h->d_labels, h->d_part);
+    MGC_HIP(h, hipGetLastError());
+    mgc_sum_partials(h, (int64_t)L.ntiles, h->d_scalar + slot);
+    MGC_HIP(h, hipGetLastError());
+    return MGC_OK;
 }
 
 extern "C" {
@@ -1648,6 +1800,7 @@ static int mgc_create_impl(int ndim, const int64_t* shape, int connectivity, int
     if ((rc = mgc_alloc(h, &L.rstamp, nt))) return rc;
     if ((rc = mgc_alloc(h, &L.status, nt))) return rc;
     if ((rc = mgc_alloc(h, &h->d_tr0, nv))) return rc;
+    if ((rc = mgc_alloc(h, &h->d_tflags, nt))) return rc;
     if ((rc = mgc_alloc(h, &h->d_part, nt > 4096 ? nt : (int64_t)4096))) return rc;
     if ((rc = mgc_alloc(h, &h->d_part2, (int64_t)256))) return rc;
     if ((rc = mgc_alloc(h, &h->d_scalar, (int64_t)8))) return rc;
@@ -1707,6 +1860,7 @@ int mgc_read_counts(mgc_handle h, int32_t* out)
 {
     if (!h || !out) return MGC_ERR_INVALID;
     MGC_HIP(h, hipSetDevice(h->device));
+    mgc_flush_zero(h);
     MGC_HIP(h, hipMemcpyAsync(h->h_count, h->L.count, MGC_NCOUNT * sizeof(int32_t), hipMemcpyDeviceToHost, h->stream));
     MGC_HIP(h, hipStreamSynchronize(h->stream));
     memcpy(out, h->h_count, MGC_NCOUNT * sizeof(int32_t));
@@ -1737,6 +1891,7 @@ int mgc_halo_pack(mgc_handle h, int side, int kind, void* buf, int buf_on_device
     if (kind < 0 || kind > 2) return mgc_fail(h, MGC_ERR_INVALID, "mgc_halo_pack: no halo kind %d", kind);
     if (side == 0 ? h->L.tz_own_lo == 0 : h->L.tz_own_hi == h->L.gz) return mgc_fail(h, MGC_ERR_INVALID, "no neighbour slab on side %d", side);
     MGC_HIP(h, hipSetDevice(h->device));
+    mgc_flush_zero(h);
     const int64_t bytes = mgc_halo_bytes_nd(h->L, kind);
     void* dst = buf;
     if (!buf_on_device) {
@@ -1774,6 +1929,7 @@ int mgc_halo_unpack(mgc_handle h, int side, int kind, const void* buf, int buf_o
     if (kind < 0 || kind > 2) return mgc_fail(h, MGC_ERR_INVALID, "mgc_halo_unpack: no halo kind %d", kind);
     if (side == 0 ? h->L.tz_own_lo == 0 : h->L.tz_own_hi == h->L.gz) return mgc_fail(h, MGC_ERR_INVALID, "no neighbour slab on side %d", side);
     MGC_HIP(h, hipSetDevice(h->device));
+    mgc_flush_zero(h);
     const int64_t bytes = mgc_halo_bytes_nd(h->L, kind);
     const void* src = buf;
     if (!buf_on_device) {
@@ -1878,6 +2034,7 @@ int mgc_allreduce_counts(mgc_handle h, int64_t* out)
     if (!h || !out) return MGC_ERR_INVALID;
     if (!h->comm) return mgc_fail(h, MGC_ERR_STATE, "mgc_allreduce_counts before mgc_comm_init");
     MGC_HIP(h, hipSetDevice(h->device));
+    mgc_flush_zero(h);
     hipLaunchKernelGGL(k_widen_counts, dim3(1), dim3(64), 0, h->stream, (const int32_t*)h->L.count, h->d_cnt64);
     MGC_HIP(h, hipGetLastError());
     MGC_NCCL(h, g_rccl.AllReduce(h->d_cnt64, h->d_cnt64 + MGC_NCOUNT, MGC_NCOUNT, ncclInt64, ncclSum, h->comm, h->stream));
@@ -1892,6 +2049,7 @@ int mgc_halo_exchange(mgc_handle h, int kind, uint32_t epoch, int list)
     if (!h->built) return mgc_fail(h, MGC_ERR_STATE, "mgc_halo_exchange before mgc_build");
     if (!h->comm) return mgc_fail(h, MGC_ERR_STATE, "mgc_halo_exchange before mgc_comm_init");
     MGC_HIP(h, hipSetDevice(h->device));
+    mgc_flush_zero(h);
     if (kind < 0 || kind > 2) return mgc_fail(h, MGC_ERR_INVALID, "mgc_halo_exchange: kind must be 0, 1 or 2");
     int64_t bytes = mgc_halo_bytes_nd(h->L, 1); /* capacity of the largest kind; reused for all */
     if (mgc_halo_bytes_nd(h->L, 0) > bytes) bytes = mgc_halo_bytes_nd(h->L, 0);
@@ -1959,7 +2117,7 @@ int mgc_destroy(mgc_handle h)
     void* ptrs[] = {L.rcap, L.cap0, L.excess, L.sink, L.height, L.rmask, L.rmask32, L.obox, L.oflags, L.list[0], L.list[1], L.list[2],
                     L.list[3], L.list[4], L.list[5], L.list[6], L.list[7], L.list[8], L.list[9], L.list[10], L.list[11], L.list[12],
                     L.list[13], L.list[14], L.list[15], L.list[16], L.list[17], L.count, L.stamp, L.rstamp, L.status, h->d_tr0, h->d_part, h->d_part2, h->d_scalar,
-                    h->d_labels, h->d_image, h->d_prob, h->d_fg, h->d_bg, h->d_tr_in, h->d_eslot, h->d_eval, h->d_erun, L.hshadow[0], L.hshadow[1], h->d_halo, h->d_xchg[0], h->d_xchg[1], h->d_xchg[2], h->d_xchg[3], h->d_cnt64};
+                    h->d_labels, h->d_tflags, h->d_image, h->d_prob, h->d_fg, h->d_bg, h->d_tr_in, h->d_eslot, h->d_eval, h->d_erun, L.hshadow[0], L.hshadow[1], h->d_vout, h->d_halo, h->d_xchg[0], h->d_xchg[1], h->d_xchg[2], h->d_xchg[3], h->d_cnt64};
     for (void* p : ptrs)
         if (p) (void)hipFree(p);
     if (h->h_count) (void)hipHostFree(h->h_count);
@@ -2056,26 +2214,23 @@ int mgc_validate(mgc_handle h, mgc_validation* out)
     if (!h || !out) return MGC_ERR_INVALID;
     if (!h->built) return mgc_fail(h, MGC_ERR_STATE, "mgc_validate before mgc_build");
     MGC_HIP(h, hipSetDevice(h->device));
+    mgc_flush_zero(h);
     MgcLattice& L = h->L;
     memset(out, 0, sizeof(*out));
-    MgcValidateOut* d_out = nullptr;
-    MGC_HIP(h, hipMalloc((void**)&d_out, sizeof(MgcValidateOut)));
+    if (!h->labels_valid) return mgc_fail(h, MGC_ERR_STATE, "mgc_validate before a solve: the distance labels of this build were never computed");
+    if (!h->d_vout) MGC_HIP(h, hipMalloc((void**)&h->d_vout, sizeof(MgcValidateOut)));
+    MgcValidateOut* const d_out = (MgcValidateOut*)h->d_vout;
     MGC_HIP(h, hipMemsetAsync(d_out, 0, sizeof(MgcValidateOut), h->stream));
     const int grid = L.ntiles < h->grid_cap * 4 ? L.ntiles : h->grid_cap * 4;
     hipLaunchKernelGGL(k_validate, dim3(grid), dim3(MGC_TV), 0, h->stream, L, h->build_args, (const double*)h->d_tr0, h->d_part, d_out);
     MGC_HIP(h, hipGetLastError());
     mgc_sum_partials(h, (int64_t)L.ntiles, h->d_scalar + 2);
     /* the capacity of the cut the current labels define (the labels are read from the distance labels, as k_labels does) */
-    hipLaunchKernelGGL(k_labels, dim3(2048), dim3(256), 0, h->stream, L, h->d_labels);
-    hipLaunchKernelGGL(k_cut_value, dim3(grid), dim3(MGC_TV), 0, h->stream, L, h->build_args, (const double*)h->d_tr0, (const uint8_t*)h->d_labels, h->d_part);
-    MGC_HIP(h, hipGetLastError());
-    mgc_sum_partials(h, (int64_t)L.ntiles, h->d_scalar + 3);
-    MGC_HIP(h, hipGetLastError());
+    { const int rc = mgc_launch_readout(h, 3, nullptr); if (rc) return rc; }
     MgcValidateOut ho;
     MGC_HIP(h, hipMemcpyAsync(&ho, d_out, sizeof(ho), hipMemcpyDeviceToHost, h->stream));
     MGC_HIP(h, hipMemcpyAsync(h->h_scalar, h->d_scalar, 8 * sizeof(double), hipMemcpyDeviceToHost, h->stream));
     MGC_HIP(h, hipStreamSynchronize(h->stream));
-    (void)hipFree(d_out);
     h->labels_on_host = false;
     out->voxels = (int64_t)ho.cnt[0]; out->negative_values = (int64_t)ho.cnt[1]; out->active_excess = (int64_t)ho.cnt[2];
     out->residual_arcs_across = (int64_t)ho.cnt[3]; out->sink_links_across = (int64_t)ho.cnt[4];
@@ -2112,6 +2267,7 @@ int mgc_add_edges(mgc_handle h, int64_t n, const int64_t* i, const int64_t* j, c
 {
     if (!h || n < 0 || (n && (!i || !j || !cap || !rev))) return MGC_ERR_INVALID;
     if (h->n_edges && !h->edges_applied) return mgc_fail(h, MGC_ERR_UNSUPPORTED, "mgc_add_edges: one batch per build (concatenate on the host)");
+    if (h->n_edges && h->edges_applied) h->built = h->solved = false; /* the built graph still holds the batch that is dropped here */
     h->n_edges = h->n_runs = 0; /* a batch that a build already applied is replaced */
     h->edges_applied = false;
     if (n == 0) return MGC_OK;
@@ -2196,7 +2352,7 @@ int mgc_build(mgc_handle h)
     }
     A.prob = h->d_prob; A.prob_dtype = h->prob_dtype; A.alpha = h->alpha;
     A.fg = h->d_fg; A.bg = h->d_bg; A.tr_in = h->d_tr_in;
-    A.tr0 = h->d_tr0; A.fpart = h->d_part;
+    A.tr0 = h->d_tr0; A.fpart = h->d_part; A.tflags = h->d_tflags;
     if (h->n_edges && !L.cap0) { /* explicit edges change capacities that the image no longer determines */
         const int rc = mgc_alloc(h, &L.cap0, (int64_t)L.ntiles * MGC_TV * L.ndir);
         if (rc) return rc;
@@ -2227,6 +2383,8 @@ int mgc_build(mgc_handle h)
         }
     }
     MGC_HIP(h, hipMemsetAsync(L.count, 0, MGC_NCOUNT * sizeof(int32_t), h->stream));
+    h->zero_mask = 0;
+    h->pending_zero = -1;
     MGC_HIP(h, hipEventRecord(h->ev[1], h->stream));
     MGC_HIP(h, hipMemcpyAsync(h->h_scalar, h->d_scalar, 8 * sizeof(double), hipMemcpyDeviceToHost, h->stream));
     MGC_HIP(h, hipStreamSynchronize(h->stream));
@@ -2239,6 +2397,7 @@ int mgc_build(mgc_handle h)
     h->edges_applied = h->n_edges != 0;
     h->built = true;
     h->solved = false;
+    h->labels_valid = false;
     h->labels_on_host = false;
     return MGC_OK;
 }
@@ -2259,7 +2418,6 @@ int mgc_maxflow(mgc_handle h, double* flow)
         int rc;
         if (L.ndir == 6) {
             rc = mgc_solve(dev, L, h->params, st);
-            dev.flush_zero();
         } else {
             rc = mgc_solve(dev26, L, h->params, st, mgc_layout26());
             dev.first_error = dev26.first_error;
@@ -2268,6 +2426,7 @@ int mgc_maxflow(mgc_handle h, double* flow)
             dev.discharge_launches = dev26.discharge_launches; dev.relabel_launches = dev26.relabel_launches; dev.readbacks = dev26.readbacks;
             for (int k = 0; k < 2; ++k) { dev.timed[k] = dev26.timed[k]; dev.seen[k] = dev26.seen[k]; }
         }
+        mgc_flush_zero(h);
         if (dev.first_error != hipSuccess)
             return mgc_fail(h, MGC_ERR_HIP, "solver: HIP error %s", hipGetErrorString(dev.first_error));
         if (rc) { /* the work counters of the truncated run stay readable (mgc_get_stats) */
@@ -2280,15 +2439,7 @@ int mgc_maxflow(mgc_handle h, double* flow)
             return mgc_fail(h, MGC_ERR_NOT_CONVERGED, "solver did not converge within %d global relabels", h->params.max_outer);
         }
         /* read-out: labels, then the capacity of the cut they define */
-        hipLaunchKernelGGL(k_labels, dim3(2048), dim3(256), 0, h->stream, L, h->d_labels);
-        MGC_HIP(h, hipGetLastError());
-        MGC_HIP(h, hipEventRecord(h->ev[1], h->stream));
-        const int grid = L.ntiles < h->grid_cap * 4 ? L.ntiles : h->grid_cap * 4;
-        hipLaunchKernelGGL(k_cut_value, dim3(grid), dim3(MGC_TV), 0, h->stream, L, h->build_args, (const double*)h->d_tr0,
-                           (const uint8_t*)h->d_labels, h->d_part);
-        MGC_HIP(h, hipGetLastError());
-        mgc_sum_partials(h, (int64_t)L.ntiles, h->d_scalar + 1);
-        MGC_HIP(h, hipGetLastError());
+        { const int rc2 = mgc_launch_readout(h, 1, h->ev[1]); if (rc2) return rc2; }
         MGC_HIP(h, hipMemcpyAsync(h->h_scalar, h->d_scalar, 8 * sizeof(double), hipMemcpyDeviceToHost, h->stream));
         MGC_HIP(h, hipStreamSynchronize(h->stream));
         float ms = 0.f;
@@ -2317,14 +2468,9 @@ int mgc_finish(mgc_handle h, double* flow_partial)
     if (!h) return MGC_ERR_INVALID;
     if (!h->built) return mgc_fail(h, MGC_ERR_STATE, "mgc_finish before mgc_build");
     MGC_HIP(h, hipSetDevice(h->device));
+    mgc_flush_zero(h);
     MgcLattice& L = h->L;
-    hipLaunchKernelGGL(k_labels, dim3(2048), dim3(256), 0, h->stream, L, h->d_labels);
-    MGC_HIP(h, hipGetLastError());
-    const int grid = L.ntiles < h->grid_cap * 4 ? L.ntiles : h->grid_cap * 4;
-    hipLaunchKernelGGL(k_cut_value, dim3(grid), dim3(MGC_TV), 0, h->stream, L, h->build_args, (const double*)h->d_tr0, (const uint8_t*)h->d_labels, h->d_part);
-    MGC_HIP(h, hipGetLastError());
-    mgc_sum_partials(h, (int64_t)L.ntiles, h->d_scalar + 1);
-    MGC_HIP(h, hipGetLastError());
+    { const int rc = mgc_launch_readout(h, 1, nullptr); if (rc) return rc; }
     MGC_HIP(h, hipMemcpyAsync(h->h_scalar, h->d_scalar, 8 * sizeof(double), hipMemcpyDeviceToHost, h->stream));
     MGC_HIP(h, hipStreamSynchronize(h->stream));
     h->flow = h->flow_const + h->h_scalar[1];

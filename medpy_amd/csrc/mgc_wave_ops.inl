@@ -597,4 +597,43 @@ MGC_HD void mgcw_relabel_tile(W& w, const MgcLattice& L, int tile, uint32_t next
     });
 }
 
+/* ---------------------------------------------------------------------------------------
+ * After a global relabel: does the tile hold excess that can still reach the sink?  One wave per tile, no LDS, no
+ * barrier: sixteen loads per lane, one vote.  Same contract as mgc_activate_tile.
+ * ------------------------------------------------------------------------------------- */
+template <class W>
+MGC_HD void mgcw_activate_tile(W& w, const MgcLattice& L, int tile, uint32_t phase)
+{
+    if (!mgc_owned(L, tile) || (L.status[tile] & MGC_ST_ALLINF)) return; /* all labels INF: nothing can reach the sink */
+    typename W::template Reg<double, 8> e;
+    typename W::template Reg<int, 8> h;
+    const double* const t_excess = L.excess + (int64_t)tile * MGC_TV;
+    const int32_t* const t_height = L.height + (int64_t)tile * MGC_TV;
+    w.lanes([&](int l) MGCW_INL {
+        mgcw_static_for<8>([&](auto KK) MGCW_INL {
+            constexpr int K = decltype(KK)::value;
+            e(l, K) = w.ld(t_excess, K * 64 + l);
+            h(l, K) = w.ld(t_height, K * 64 + l);
+        });
+    });
+    const bool act = w.any([&](int l) MGCW_INL -> bool {
+        bool a = false;
+        mgcw_static_for<8>([&](auto KK) MGCW_INL {
+            constexpr int K = decltype(KK)::value;
+            a = a || (e(l, K) > 0.0 && h(l, K) < MGC_HINF);
+        });
+        return a;
+    });
+    if (!act) return;
+    w.lanes([&](int l) MGCW_INL {
+        if (l == 0) {
+            int tz, ty, tx;
+            mgc_tile_coords(L, tile, tz, ty, tx);
+            const uint32_t target = phase + ((mgc_tile_colour(L, tz, ty, tx) ^ (int)(phase & 1u)) & 1);
+            mgc_enqueue(w, L, (int)(target & 3u), L.stamp, target, tile);
+            w.atomic_add(&L.count[6], 1);
+        }
+    });
+}
+
 #endif /* MGC_WAVE_OPS_INL */

@@ -20,7 +20,7 @@ import numpy as np
 
 (OP_ABSORB_ALL, OP_FILL_INF, OP_ZERO_COUNT, OP_RELABEL_ALL, OP_RELABEL_LIST, OP_ACTIVATE, OP_DISCHARGE, OP_SUSPECT_PASS,
  OP_RESET_SUSPECT) = range(9)
-CNT_CHANGED = 10  # MGC_CNT_CHANGED (mgc_common.h)
+CNT_CHANGED = 21  # MGC_CNT_CHANGED (mgc_common.h)
 
 
 class LoopbackExchange(object):

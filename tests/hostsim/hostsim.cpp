@@ -212,7 +212,11 @@ struct HostDev {
         }
         reset_snapshot.clear();
         HostBlock x(S);
-        for (int t = 0; t < L.ntiles; ++t) mgc_activate_tile(x, L, t, phase);
+        HostWave w(WS);
+        for (int t = 0; t < L.ntiles; ++t) {
+            if (g_wave_mode & 1) mgcw_activate_tile(w, L, t, phase);
+            else mgc_activate_tile(x, L, t, phase);
+        }
     }
     int suspect_batch() const { return 8; }
     void suspect_pass()
