@@ -19,7 +19,7 @@
  *
  * Dev concept (every call is asynchronous on the device's stream unless it returns a value):
  *   fill_heights_inf()  zero_count(i)  read_counts(int out[MGC_NCOUNT])   absorb_all()   suspect_pass()  suspect_batch()
- *   relabel_all(epoch, next_list)  relabel_list(list, epoch, next_list)
+ *   relabel_all(epoch, next_list)  relabel_list(list, epoch, next_list)  first_relabel_dt() -> bool
  *   activate_all(phase)  discharge(list, phase, max_cycles, max_sweeps)
  */
 #ifndef MGC_DRIVER_INL
@@ -100,7 +100,9 @@ int mgc_solve(Dev& dev, const MgcLattice& L, const MgcSolveParams& P, MgcSolveSt
         dev.zero_count(lay.rl_base);
         dev.zero_count(lay.rl_base + 1);
         if (lay.rl_third >= 0) dev.zero_count(lay.rl_third); /* (all clears of this stretch go out together, see HipDevT::flush_zero) */
-        if (outer == 0 || !lay.incremental || !P.incremental_relabel) {
+        const bool by_transform = outer == 0 && dev.first_relabel_dt(); /* exact labels in six streaming scans: no passes at all */
+        if (by_transform) {
+        } else if (outer == 0 || !lay.incremental || !P.incremental_relabel) {
             dev.fill_heights_inf();
             dev.relabel_all(rep + 1, lay.rl_base + (int)((rep + 1) & 1u));
         } else {
@@ -115,7 +117,8 @@ int mgc_solve(Dev& dev, const MgcLattice& L, const MgcSolveParams& P, MgcSolveSt
             dev.reset_suspect(rep + 1, lay.rl_base + (int)((rep + 1) & 1u));
         }
         st.relabel_passes++;
-        if (lay.rl_third >= 0) {
+        if (by_transform) {
+        } else if (lay.rl_third >= 0) {
             /* three lists rotate: pass k consumes lists[k % 3], appends to lists[(k + 1) % 3] and clears the counter of
              * lists[(k + 2) % 3] (consumed by pass k - 1) inside the kernel */
             const int lists[3] = {lay.rl_base, lay.rl_base + 1, lay.rl_third};

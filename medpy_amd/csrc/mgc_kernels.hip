@@ -38,6 +38,7 @@
 #include "mgc_tile_ops.inl"
 #include "mgc_tile_ops26.inl"
 #include "mgc_wave_ops.inl"
+#include "mgc_dt_ops.inl"
 #include "mgc_terms.h"
 #include "mgc_driver.inl"
 
@@ -648,6 +649,30 @@ __global__ __launch_bounds__(MGC_TV) void k_activate_list(MgcLattice L, int list
     }
 }
 
+/* first global relabel as a distance transform (mgc_dt_ops.inl): one scan of every tile line along AXIS, one wave per line */
+template <int AXIS, bool BWD, bool SEED, bool FINAL>
+__global__ __launch_bounds__(256) void k_dt_scan(MgcLattice L, const void* in, void* out)
+{
+    __shared__ MgcWaveShared S; /* (not touched: the executor wants one) */
+    GpuWave w(S);
+    const int n = mgc_dt_lines<AXIS>(L);
+    for (int line = (int)blockIdx.x * 4 + (int)(threadIdx.x >> 6); line < n; line += (int)gridDim.x * 4) {
+        w.new_tile();
+        mgc_dt_scan_line<AXIS, BWD, SEED, FINAL>(w, L, __builtin_amdgcn_readfirstlane(line), in, out);
+    }
+}
+
+__global__ __launch_bounds__(256) void k_dt_finish(MgcLattice L)
+{
+    __shared__ MgcWaveShared S;
+    GpuWave w(S);
+    if (blockIdx.x == 0 && threadIdx.x == 0) atomicAdd(&L.count[9], L.ntiles); /* every tile was labelled once */
+    for (int tile = (int)blockIdx.x * 4 + (int)(threadIdx.x >> 6); tile < L.ntiles; tile += (int)gridDim.x * 4) {
+        w.new_tile();
+        mgc_dt_finish_tile(w, L, __builtin_amdgcn_readfirstlane(tile));
+    }
+}
+
 /* activation over the filter's list, one wave per tile (four tiles per 256-thread workgroup in flight) */
 __global__ __launch_bounds__(256) void k_activate_w(MgcLattice L, int list, int cnt, uint32_t phase)
 {
@@ -890,6 +915,10 @@ __device__ __forceinline__ void k_build_tiles(const MgcLattice& L, const MgcBuil
         L.excess[v] = tr > 0.0 ? tr : 0.0;
         L.sink[v] = tr < 0.0 ? -tr : 0.0;
         if constexpr (!FULL) {
+            /* is every n-link of the volume residual?  (then the first global relabel is a distance transform, mgc_dt_ops.inl) */
+            const uint32_t need = (gx > 0 ? 1u : 0u) | (gx + 1 < L.dx ? 2u : 0u) | (gy > 0 ? 4u : 0u) | (gy + 1 < L.dy ? 8u : 0u) |
+                                  (gz > 0 ? 16u : 0u) | (gz + 1 < L.dz ? 32u : 0u);
+            if (__ballot(valid && (m & need) != need) != 0ull && (t & 63) == 0) atomicAdd(&L.count[MGC_CNT_NOT_FULL], 1);
             if (tr < 0.0) m |= MGC_MASK_SINK;
             L.rmask[v] = (uint8_t)m;
         } else {
@@ -1380,6 +1409,9 @@ struct mgc_graph {
     bool built = false, solved = false;
     bool labels_valid = false; /* the distance labels belong to this build (set by the first label fill of a solve, cleared by mgc_build) */
     void* d_vout = nullptr;    /* MgcValidateOut of mgc_validate */
+    uint16_t* d_dt16 = nullptr; /* scratch of the distance-transform relabel (uint16 per voxel, tile-major), allocated on first use */
+    bool all_residual = false; /* k_build found every n-link inside the volume residual */
+    int use_dt = 1;            /* first global relabel as a distance transform when all_residual (parameter first_relabel_dt) */
     int rank = 0, nranks = 1;
     int64_t plane0 = 0, plane1 = 0, own0 = 0, own1 = 0; /* global plane ranges of a slab */
     void* d_halo = nullptr; int64_t halo_cap = 0;
@@ -1446,7 +1478,7 @@ template <bool FULL> /* FULL: 26-neighbourhood kernels */
 struct HipDevT {
     mgc_handle h;
     hipError_t first_error = hipSuccess;
-    float discharge_ms = 0.f, relabel_ms = 0.f;
+    float discharge_ms = 0.f, relabel_ms = 0.f, once_ms = 0.f;
     int64_t discharge_launches = 0, relabel_launches = 0, readbacks = 0;
     int last_discharged = -1; /* list consumed by the discharge launched last (see pending_zero) */
     int suspect_batch() const { return 2; } /* closure passes between two looks at the "changed" flag: a pass settles a brick */
@@ -1531,6 +1563,34 @@ struct HipDevT {
         time_end(id);
         relabel_launches++;
     }
+    /* the first global relabel of a solve as a distance transform: labels, label supports and ALLINF flags as the relabel
+     * passes would leave them (mgc_dt_ops.inl).  false: not applicable to this graph, run the passes. */
+    bool first_relabel_dt()
+    {
+        if (FULL || !h->use_dt || !h->all_residual) return false;
+        if (!h->d_dt16) {
+            if (hipMalloc((void**)&h->d_dt16, (size_t)h->L.ntiles * MGC_TV * sizeof(uint16_t)) != hipSuccess) { (void)hipGetLastError(); return false; }
+            h->device_bytes += (int64_t)h->L.ntiles * MGC_TV * (int64_t)sizeof(uint16_t);
+        }
+        flush_zero();
+        h->labels_valid = true;
+        const int id = time_begin(2);
+        const MgcLattice& L = h->L;
+        void* const T = h->d_dt16;
+        const dim3 blk(256);
+        auto g = [&](int lines) { return dim3(grid((lines + 3) / 4)); };
+        hipLaunchKernelGGL((k_dt_scan<0, false, true, false>), g(L.gz * L.gy), blk, 0, h->stream, L, (const void*)L.rmask, T);
+        hipLaunchKernelGGL((k_dt_scan<0, true, false, false>), g(L.gz * L.gy), blk, 0, h->stream, L, (const void*)T, T);
+        hipLaunchKernelGGL((k_dt_scan<1, false, false, false>), g(L.gz * L.gx), blk, 0, h->stream, L, (const void*)T, T);
+        hipLaunchKernelGGL((k_dt_scan<1, true, false, false>), g(L.gz * L.gx), blk, 0, h->stream, L, (const void*)T, T);
+        hipLaunchKernelGGL((k_dt_scan<2, false, false, false>), g(L.gy * L.gx), blk, 0, h->stream, L, (const void*)T, T);
+        hipLaunchKernelGGL((k_dt_scan<2, true, false, true>), g(L.gy * L.gx), blk, 0, h->stream, L, (const void*)T, (void*)L.height);
+        hipLaunchKernelGGL(k_dt_finish, g(L.ntiles), blk, 0, h->stream, L);
+        check(hipGetLastError());
+        time_end(id);
+        relabel_launches += 7;
+        return true;
+    }
     void relabel_list(int lst, uint32_t epoch, int next, int zero_list = -1)
     {
         flush_zero();
@@ -1613,8 +1673,10 @@ struct HipDevT {
         /* every `timing_stride`-th launch of a kind carries a pair of HIP events (an event is a barrier packet in the queue:
          * a pair around each of the ~450 solver launches of a 512^3 step costs 3 ms of its 47); the kernel time of the
          * kind is the mean of the timed launches times the number of launches.  An odd stride samples both tile colours. */
-        if ((seen[kind]++ % h->timing_stride) != 0) return -1;
-        timed[kind]++;
+        if (kind < 2) { /* (kind 2 = a one-off stretch, always timed, never extrapolated: the distance-transform relabel) */
+            if ((seen[kind]++ % h->timing_stride) != 0) return -1;
+            timed[kind]++;
+        }
         const size_t need = 2 * spans.size() + 2;
         while (h->ev_pool.size() < need) {
             hipEvent_t e;
@@ -1634,10 +1696,11 @@ struct HipDevT {
     {
         for (const Span& sp : spans) {
             float ms = 0.f;
-            if (hipEventElapsedTime(&ms, h->ev_pool[sp.a], h->ev_pool[sp.b]) == hipSuccess) (sp.kind == 0 ? discharge_ms : relabel_ms) += ms;
+            if (hipEventElapsedTime(&ms, h->ev_pool[sp.a], h->ev_pool[sp.b]) == hipSuccess) (sp.kind == 0 ? discharge_ms : (sp.kind == 1 ? relabel_ms : once_ms)) += ms;
         }
         if (timed[0]) discharge_ms *= (float)seen[0] / (float)timed[0];
         if (timed[1]) relabel_ms *= (float)seen[1] / (float)timed[1];
+        relabel_ms += once_ms;
     }
 };
 typedef HipDevT<false> HipDev;
@@ -2117,7 +2180,7 @@ int mgc_destroy(mgc_handle h)
     void* ptrs[] = {L.rcap, L.cap0, L.excess, L.sink, L.height, L.rmask, L.rmask32, L.obox, L.oflags, L.list[0], L.list[1], L.list[2],
                     L.list[3], L.list[4], L.list[5], L.list[6], L.list[7], L.list[8], L.list[9], L.list[10], L.list[11], L.list[12],
                     L.list[13], L.list[14], L.list[15], L.list[16], L.list[17], L.count, L.stamp, L.rstamp, L.status, h->d_tr0, h->d_part, h->d_part2, h->d_scalar,
-                    h->d_labels, h->d_tflags, h->d_image, h->d_prob, h->d_fg, h->d_bg, h->d_tr_in, h->d_eslot, h->d_eval, h->d_erun, L.hshadow[0], L.hshadow[1], h->d_vout, h->d_halo, h->d_xchg[0], h->d_xchg[1], h->d_xchg[2], h->d_xchg[3], h->d_cnt64};
+                    h->d_labels, h->d_tflags, h->d_image, h->d_prob, h->d_fg, h->d_bg, h->d_tr_in, h->d_eslot, h->d_eval, h->d_erun, L.hshadow[0], L.hshadow[1], h->d_vout, h->d_dt16, h->d_halo, h->d_xchg[0], h->d_xchg[1], h->d_xchg[2], h->d_xchg[3], h->d_cnt64};
     for (void* p : ptrs)
         if (p) (void)hipFree(p);
     if (h->h_count) (void)hipHostFree(h->h_count);
@@ -2360,6 +2423,9 @@ int mgc_build(mgc_handle h)
     h->build_args = A;
     const int grid = L.ntiles < h->grid_cap * 4 ? L.ntiles : h->grid_cap * 4;
     const int bgrid = grid >= 8 ? grid / 8 * 8 : grid; /* k_build deals tiles to XCDs: multiple of 8 */
+    MGC_HIP(h, hipMemsetAsync(L.count, 0, MGC_NCOUNT * sizeof(int32_t), h->stream)); /* (k_build counts in MGC_CNT_NOT_FULL) */
+    h->zero_mask = 0;
+    h->pending_zero = -1;
     if (L.ndir == 6) mgc_launch_build<false>(A.term, bgrid, h->stream, L, A);
     else mgc_launch_build<true>(A.term, bgrid, h->stream, L, A);
     MGC_HIP(h, hipGetLastError());
@@ -2382,12 +2448,14 @@ int mgc_build(mgc_handle h)
             MGC_HIP(h, hipMemsetAsync(L.rcap + t0 * MGC26_NDIR * MGC_TV, 0, (size_t)T * MGC26_NDIR * MGC_TV * sizeof(double), h->stream));
         }
     }
-    MGC_HIP(h, hipMemsetAsync(L.count, 0, MGC_NCOUNT * sizeof(int32_t), h->stream));
-    h->zero_mask = 0;
-    h->pending_zero = -1;
     MGC_HIP(h, hipEventRecord(h->ev[1], h->stream));
     MGC_HIP(h, hipMemcpyAsync(h->h_scalar, h->d_scalar, 8 * sizeof(double), hipMemcpyDeviceToHost, h->stream));
+    MGC_HIP(h, hipMemcpyAsync(h->h_count, L.count, MGC_NCOUNT * sizeof(int32_t), hipMemcpyDeviceToHost, h->stream));
     MGC_HIP(h, hipStreamSynchronize(h->stream));
+    /* every n-link of the volume residual (and nothing added on top that the mask refresh could have changed): the first
+     * global relabel of the solve is a distance transform (mgc_dt_ops.inl) */
+    h->all_residual = L.ndir == 6 && A.term != MGC_TERM_NONE && h->h_count[MGC_CNT_NOT_FULL] == 0 && !h->n_edges && h->nranks == 1 &&
+                      L.dz + L.dy + L.dx < MGC_DT_INF - 8;
     float ms = 0.f;
     MGC_HIP(h, hipEventElapsedTime(&ms, h->ev[0], h->ev[1]));
     h->stats.build_ms = ms;
@@ -2615,6 +2683,7 @@ int mgc_set_param(mgc_handle h, const char* name, int64_t value)
     else if (!strcmp(name, "sweeps_sparse26") && value >= 0) h->sweeps_sparse26 = (int)value;
     else if (!strcmp(name, "wave_grid_dis") && value > 0) h->wave_grid_dis = (int)value;
     else if (!strcmp(name, "wave_grid_rel") && value > 0) h->wave_grid_rel = (int)value;
+    else if (!strcmp(name, "first_relabel_dt")) h->use_dt = value != 0;
     else if (!strcmp(name, "kernel_timing")) h->timing = value != 0;
     else if (!strcmp(name, "timing_stride") && value > 0) h->timing_stride = (int)value;
     else if (!strcmp(name, "profile_sections")) {

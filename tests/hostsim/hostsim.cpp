@@ -25,6 +25,7 @@ static long long g26_sweeps, g26_dirs; /* direction masks of the 26-neighbourhoo
 #define MGC26_COUNT_STEPS(mask) (g26_sweeps++, g26_dirs += __builtin_popcount(mask))
 #include "../../medpy_amd/csrc/mgc_tile_ops26.inl"
 #include "../../medpy_amd/csrc/mgc_wave_ops.inl"
+#include "../../medpy_amd/csrc/mgc_dt_ops.inl"
 #include "../../medpy_amd/csrc/mgc_driver.inl"
 #include <cstdio>
 
@@ -145,6 +146,7 @@ struct HostWave {
 /* which form of the two hot tile operations the simulator runs: bit 0 = wave discharge, bit 1 = wave relabel,
  * bit 2 = the wave discharge computes exact in-tile labels first (MGCW_BFS) */
 static int g_wave_mode = 0;
+static int g_use_dt = 1; /* the first global relabel may be a distance transform (hostsim_set_dt) */
 
 typedef HostBlockT<MgcTileShared> HostBlock;
 typedef HostBlockT<MgcTileShared26> HostBlock26;
@@ -179,6 +181,33 @@ struct HostDev {
             if (g_wave_mode & 2) mgcw_relabel_tile(w, L, t, epoch, next, true);
             else mgc_relabel_tile(x, L, t, epoch, next, true);
         }
+    }
+    /* the first global relabel as a distance transform (mgc_dt_ops.inl) under the library's condition: every n-link of
+     * the volume residual, one handle (no slabs) */
+    bool first_relabel_dt()
+    {
+        if (!g_use_dt || spec.nranks > 1 || L.dz + L.dy + L.dx >= MGC_DT_INF - 8) return false;
+        for (int64_t z = 0; z < L.dz; ++z)
+            for (int64_t y = 0; y < L.dy; ++y)
+                for (int64_t x = 0; x < L.dx; ++x) {
+                    int tile, loc;
+                    mgc_node_to_tile(L, (z * L.dy + y) * L.dx + x, tile, loc);
+                    const uint32_t need = (x > 0 ? 1u : 0u) | (x + 1 < L.dx ? 2u : 0u) | (y > 0 ? 4u : 0u) | (y + 1 < L.dy ? 8u : 0u) |
+                                          (z > 0 ? 16u : 0u) | (z + 1 < L.dz ? 32u : 0u);
+                    if ((rmask[(int64_t)tile * MGC_TV + loc] & need) != need) return false;
+                }
+        std::vector<uint16_t> T((size_t)L.ntiles * MGC_TV);
+        HostWave w(WS);
+        for (int i = 0; i < L.gz * L.gy; ++i) mgc_dt_scan_line<0, false, true, false>(w, L, i, L.rmask, T.data());
+        for (int i = 0; i < L.gz * L.gy; ++i) mgc_dt_scan_line<0, true, false, false>(w, L, i, T.data(), T.data());
+        for (int i = 0; i < L.gz * L.gx; ++i) mgc_dt_scan_line<1, false, false, false>(w, L, i, T.data(), T.data());
+        for (int i = 0; i < L.gz * L.gx; ++i) mgc_dt_scan_line<1, true, false, false>(w, L, i, T.data(), T.data());
+        for (int i = 0; i < L.gy * L.gx; ++i) mgc_dt_scan_line<2, false, false, false>(w, L, i, T.data(), T.data());
+        for (int i = 0; i < L.gy * L.gx; ++i) mgc_dt_scan_line<2, true, false, true>(w, L, i, T.data(), L.height);
+        for (int t = 0; t < L.ntiles; ++t) mgc_dt_finish_tile(w, L, t);
+        L.count[9] += L.ntiles;
+        g_prof[28]++;
+        return true;
     }
     void relabel_list(int lst, uint32_t epoch, int next, int zero_list = -1)
     {
@@ -320,6 +349,7 @@ struct HostDev {
 extern "C" {
 
 void hostsim_set_wave_mode(int mode) { g_wave_mode = mode; }
+void hostsim_set_dt(int on) { g_use_dt = on; }
 
 /* work-profile read-out: copies and clears the counters; tiles != NULL with ntiles > 0 arms / returns the per-tile discharge counts */
 void hostsim_prof(int64_t* out, int32_t* tiles, int ntiles)
@@ -428,6 +458,30 @@ int hostsim_solve(const int64_t* shape, const double* w0, const double* w1, cons
     return rc;
 }
 
+/* the first global relabel of a solve alone (use_dt: as a distance transform when the graph allows it, else by relaxation
+ * passes): distance labels (tile-major) and status words out; returns 1 when the transform ran */
+int hostsim_first_relabel(const int64_t* shape, const double* w0, const double* w1, const double* w2, const double* trcap,
+                          int use_dt, int32_t* heights_out, uint32_t* status_out)
+{
+    HostDev* d = (HostDev*)hostsim_create(shape, 0, 1);
+    d->load(w0, w1, w2, trcap);
+    const int keep = g_use_dt;
+    g_use_dt = use_dt;
+    MgcSolveParams P = mgc_default_params();
+    P.max_outer = 1; /* one global relabel + the activation, then the rounds of colour phases: stop before them */
+    P.rounds_per_relabel = 0;
+    MgcSolveStats st;
+    g_prof[28] = 0;
+    (void)mgc_solve(*d, d->L, P, st);
+    const int ran = (int)g_prof[28];
+    g_prof[28] = 0;
+    g_use_dt = keep;
+    memcpy(heights_out, d->height.data(), d->height.size() * sizeof(int32_t));
+    memcpy(status_out, d->status.data(), d->status.size() * sizeof(uint32_t));
+    delete d;
+    return ran;
+}
+
 } /* extern "C" */
 
 /* ------------------------------------------------------------------------------------------
@@ -439,6 +493,7 @@ struct HostDev26 {
     std::vector<double> rcap, excess, sink;
     std::vector<int32_t> height, lists, count;
     std::vector<uint32_t> rmask32, stamp, rstamp, status;
+    bool first_relabel_dt() { return false; } /* (an L-infinity distance is not separable) */
     void fill_heights_inf()
     {
         for (int64_t i = 0; i < (int64_t)L.ntiles * MGC_TV; ++i) L.height[i] = MGC_HINF;

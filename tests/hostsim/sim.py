@@ -13,7 +13,7 @@ _lib = None
 def build():
     src = os.path.join(_HERE, "hostsim.cpp")
     deps = [src] + [os.path.join(_HERE, "..", "..", "medpy_amd", "csrc", f) for f in
-                    ("mgc_tile_ops.inl", "mgc_tile_ops26.inl", "mgc_wave_ops.inl", "mgc_driver.inl", "mgc_common.h")]
+                    ("mgc_tile_ops.inl", "mgc_tile_ops26.inl", "mgc_wave_ops.inl", "mgc_dt_ops.inl", "mgc_driver.inl", "mgc_common.h")]
     if os.path.exists(_SO) and all(os.path.getmtime(_SO) >= os.path.getmtime(d) for d in deps):
         return
     subprocess.check_call(["g++", "-O2", "-std=c++17", "-Wno-unknown-pragmas", "-fPIC", "-shared", "-o", _SO, src])
@@ -67,6 +67,23 @@ def solve(shape, weights, trcap, rounds=0, cycles=0, sweeps=0, max_outer=0, wave
     st = dict(zip(STAT_NAMES, stats.tolist()))
     st["rc"] = rc
     return labels.reshape(tuple(shape)), st
+
+
+def first_relabel(shape, weights, trcap, use_dt):
+    """the first global relabel alone: (ran_as_distance_transform, labels[tiles, 512] int32, status[tiles] uint32)"""
+    shape = np.asarray(shape, dtype=np.int64)
+    ws = [np.ascontiguousarray(w, dtype=np.float64).ravel() for w in weights]
+    ws = [w if w.size else np.zeros(1) for w in ws]
+    tr = np.ascontiguousarray(trcap, dtype=np.float64).ravel()
+    nt = int(np.prod((shape + 7) // 8))
+    h, st = np.zeros((nt, 512), np.int32), np.zeros(nt, np.uint32)
+    L = lib()
+    pf = np.ctypeslib.ndpointer(np.float64, flags="C_CONTIGUOUS")
+    L.hostsim_first_relabel.restype = C.c_int
+    L.hostsim_first_relabel.argtypes = [np.ctypeslib.ndpointer(np.int64), pf, pf, pf, pf, C.c_int,
+                                        np.ctypeslib.ndpointer(np.int32), np.ctypeslib.ndpointer(np.uint32)]
+    ran = L.hostsim_first_relabel(shape, ws[0], ws[1], ws[2], tr, int(bool(use_dt)), h, st)
+    return bool(ran), h, st
 
 
 # ------------------------------------------------------------------------------------------

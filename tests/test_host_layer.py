@@ -248,3 +248,42 @@ def test_relabel_first_appearance_order():
     lab = np.asarray([[7, 7, 3], [9, 3, 7], [2, 2, 9]])
     np.testing.assert_array_equal(relabel(lab), [[1, 1, 2], [3, 2, 1], [4, 4, 3]])
     np.testing.assert_array_equal(relabel(lab, start=5), np.asarray([[1, 1, 2], [3, 2, 1], [4, 4, 3]]) + 4)
+
+
+@pytest.mark.parametrize("gen,shape", [("sphere", (16, 16, 16)), ("sphere", (40, 24, 33)), ("hard", (9, 21, 35)), ("sphere", (5, 8, 64)),
+                                       ("ties", (24, 16, 16)), ("sphere", (1, 30, 30))])
+def test_first_relabel_as_distance_transform(gen, shape):
+    """mgc_dt_ops.inl (same source as k_dt_scan / k_dt_finish): when every n-link of the volume is residual, six axis scans
+    leave exactly the labels, the label-support bits and the ALLINF flags the relaxation passes of the first global relabel
+    converge to; and the solve that starts from them reaches the reference labels."""
+    import sim
+    from medpy_amd import synthetic
+    from oracle import energy_numpy, pipeline
+    s = getattr(synthetic, gen)(shape)
+    w = energy_numpy.boundary_weights(s["term"], s["image"], s["sigma"])
+    g = pipeline.build_graph(s["fg"], s["bg"], weights=w)
+    tr = np.array([g.get_trcap(i) for i in range(s["fg"].size)])
+    ran, h_dt, st_dt = sim.first_relabel(shape, w, tr, True)
+    ran0, h_rx, st_rx = sim.first_relabel(shape, w, tr, False)
+    assert ran and not ran0
+    np.testing.assert_array_equal(h_dt, h_rx)
+    keep = ~np.uint32(4 | 8)  # (DIRTY / SUSPECT are not the relabel's to set)
+    np.testing.assert_array_equal(st_dt & keep, st_rx & keep)
+    lab, ref, st = _sim_case(gen, shape)
+    assert st["converged"] == 1
+    if gen != "ties":
+        np.testing.assert_array_equal(lab, ref)
+
+
+def test_distance_transform_is_refused_when_an_arc_is_missing():
+    """a saturated (zero) n-link inside the volume: the residual graph is not the full lattice, the passes must run"""
+    import sim
+    shape = (16, 16, 16)
+    w = [np.ones((15, 16, 16)), np.ones((16, 15, 16)), np.ones((16, 16, 15))]
+    w[1][3, 4, 5] = 0.0
+    tr = np.zeros(shape)
+    tr[0] = -1.0
+    tr[8, 8, 8] = 5.0
+    ran, h, st = sim.first_relabel(shape, w, tr, True)
+    assert not ran
+    assert int(h.reshape(2, 2, 2, 8, 8, 8)[1, 1, 1, 0, 0, 0]) == 9  # voxel (8, 8, 8): eight steps to plane 0, one into the sink
