@@ -182,6 +182,16 @@ def check(handle, rc):
         raise MedpyHipError(rc, (msg or b"").decode("utf-8", "replace"))
 
 
+def apply_env_params(handle):
+    """MEDPY_HIP_PARAMS="name=value,name=value": schedule / kernel-form knobs (mgc_set_param) applied to every lattice handle at
+    creation.  How the test suite sends all its golden vectors through the kernel forms a large volume uses (the wave
+    kernels only take over from 512 active tiles per phase on) without touching the tests themselves."""
+    spec = os.environ.get("MEDPY_HIP_PARAMS", "")
+    for kv in filter(None, (p.strip() for p in spec.split(","))):
+        name, _, value = kv.partition("=")
+        check(handle, load().mgc_set_param(handle, name.strip().encode(), int(value)))
+
+
 def check_sparse(handle, rc):
     if rc != OK:
         msg = load().msg_last_error(handle)

@@ -37,7 +37,7 @@
 #define MGC_ST_SINK 2u
 #define MGC_ST_DIRTY 4u
 #define MGC_ST_SUSPECT 8u
-#define MGC_ST_EXCESS 16u      /* some voxel of the tile holds excess (maintained by build / absorb / discharge) */
+#define MGC_ST_EXCESS 16u      /* some voxel of the tile holds excess under a finite label, as of build / absorb / its last discharge */
 #define MGC_ST_ALLINF 32u      /* every label of the tile is MGC_HINF: set when an incremental relabel resets the tile, cleared when a
                                   relabel pass lowers one of its labels (a clear bit promises nothing) */
 #define MGC_ST_DEP_SHIFT 8

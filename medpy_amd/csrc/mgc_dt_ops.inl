@@ -110,21 +110,24 @@ MGC_HD void mgc_dt_finish_tile(W& w, const MgcLattice& L, int tile)
     int tz, ty, tx;
     mgc_tile_coords(L, tile, tz, ty, tx);
     const int32_t* const t_height = L.height + (int64_t)tile * MGC_TV;
-    uint32_t dep = 0;
-    bool finite = false;
-#pragma unroll
-    for (int f = 0; f < 6; ++f) {
-        const int nt = mgc_tile_nbr(L, tz, ty, tx, f);
-        const int32_t* const n_height = L.height + (int64_t)(nt < 0 ? tile : nt) * MGC_TV;
-        const bool sup = w.any([&](int l) MGCW_INL -> bool {
-            const int32_t own = w.ld(t_height, mgc_face_voxel(f, l));
-            const int32_t oth = nt < 0 ? MGC_HINF : w.ld(n_height, mgc_face_voxel(f ^ 1, l));
-            return own < MGC_HINF && oth + 1 == own;
+    /* one trip to HBM: per face the lane's own face voxel and the voxel it touches next door */
+    typename W::template Reg<int, 6> own, oth;
+    w.lanes([&](int l) MGCW_INL {
+        mgcw_static_for<6>([&](auto FF) MGCW_INL {
+            constexpr int F = decltype(FF)::value;
+            const int nt = mgc_tile_nbr(L, tz, ty, tx, F);
+            own(l, F) = w.ld(t_height, mgc_face_voxel(F, l));
+            oth(l, F) = MGC_HINF;
+            if (nt >= 0) oth(l, F) = w.ld(L.height + (int64_t)nt * MGC_TV, mgc_face_voxel(F ^ 1, l));
         });
-        if (sup) dep |= 1u << f;
-        if (f == 0 || f == 2 || f == 4) /* the voxel (0, 0, 0) of a tile is always inside the volume, and it lies on these faces */
-            finite = finite || w.any([&](int l) MGCW_INL -> bool { return w.ld(t_height, mgc_face_voxel(f, l)) < MGC_HINF; });
-    }
+    });
+    uint32_t dep = 0;
+    mgcw_static_for<6>([&](auto FF) MGCW_INL {
+        constexpr int F = decltype(FF)::value;
+        if (w.any([&](int l) MGCW_INL -> bool { return own(l, F) < MGC_HINF && oth(l, F) + 1 == own(l, F); })) dep |= 1u << F;
+    });
+    /* the voxel (0, 0, 0) of a tile is always inside the volume; it lies on face 0 */
+    const bool finite = w.any([&](int l) MGCW_INL -> bool { return own(l, 0) < MGC_HINF; });
     w.lanes([&](int l) MGCW_INL {
         if (l == 0) L.status[tile] = (L.status[tile] & ~((63u << MGC_ST_DEP_SHIFT) | MGC_ST_ALLINF)) | (dep << MGC_ST_DEP_SHIFT) | (finite ? 0u : MGC_ST_ALLINF);
     });

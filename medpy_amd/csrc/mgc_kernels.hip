@@ -44,6 +44,13 @@
 
 #define MGC_MARKER_MAX 65535.0              /* GCGraph.MAX, graph.py:288-291 */
 
+#ifndef MGCW_DPP
+#define MGCW_DPP 1      /* +-x hand-offs of the wave discharge as DPP row shifts (0: ds_bpermute like +-y) */
+#endif
+#ifndef MGCW_PREFETCH
+#define MGCW_PREFETCH 0 /* 1: a discharging wave requests the excess / labels / masks of its next tile while it sweeps; 2: the residual planes too */
+#endif
+
 /* ======================================================================================
  * block executor for the single-source tile operations
  * ==================================================================================== */
@@ -212,6 +219,62 @@ struct GpuWave {
         const double v = __shfl(src.v[0], from & 63, 64);
         dst.v[0] = (from >= 0 && from < 64) ? v : 0.0;
     }
+    /* delta = +-1, src 0.0 wherever the source lane lies in another row of eight: a DPP shift inside the 16-lane rows of the
+     * wave (row_shl / row_shr, zero fill at the row ends) moves both halves of the double in two VALU instructions; what
+     * crosses from one row of eight into the other inside a 16-lane row is one of those zeros */
+    __device__ __forceinline__ void shift_x(Reg<double, 1>& dst, Reg<double, 1>& src, int delta)
+    {
+#if MGCW_DPP
+        const int lo = __double2loint(src.v[0]), hi = __double2hiint(src.v[0]);
+        int rlo, rhi;
+        if (delta > 0) { /* dst(l) = src(l + 1): row_shl:1 */
+            rlo = __builtin_amdgcn_update_dpp(0, lo, 0x101, 0xf, 0xf, true);
+            rhi = __builtin_amdgcn_update_dpp(0, hi, 0x101, 0xf, 0xf, true);
+        } else { /* dst(l) = src(l - 1): row_shr:1 */
+            rlo = __builtin_amdgcn_update_dpp(0, lo, 0x111, 0xf, 0xf, true);
+            rhi = __builtin_amdgcn_update_dpp(0, hi, 0x111, 0xf, 0xf, true);
+        }
+        dst.v[0] = __hiloint2double(rhi, rlo);
+#else
+        shift(dst, src, delta);
+#endif
+    }
+    /* ---- running ahead of the tile loop (mgc_wave_ops.inl: W::kPrefetch) ---- */
+    static constexpr int kPrefetch = MGCW_PREFETCH;
+    int32_t* pf = nullptr;          /* 1 KiB of LDS the prefetch DMA lands in (never read) */
+    const int32_t* nlist = nullptr; /* the list being consumed, its length */
+    int nn = 0;
+    int tkv = 0, lsv = -1;          /* in flight: the ticket just drawn (lane 0), the list entry it points at */
+    __device__ __forceinline__ void ticket_issue(const MgcLattice& L, int tk)
+    {
+        tkv = 0;
+        if (threadIdx.x == 0) tkv = atomicAdd(&L.count[tk], 1);
+    }
+    __device__ __forceinline__ void hint_begin()
+    {
+        const int i = (int)gridDim.x + __builtin_amdgcn_readfirstlane(tkv);
+        lsv = -1;
+        if (i < nn) lsv = nlist[i];
+    }
+    int nst = 0; /* in flight: the status word of that tile */
+    int next_tile = -1;
+    __device__ __forceinline__ int hint_end(const MgcLattice& L)
+    {
+        next_tile = __builtin_amdgcn_readfirstlane(lsv);
+        nst = 0;
+        if (next_tile >= 0) nst = (int)L.status[next_tile];
+        return next_tile;
+    }
+    /* [p, p + bytes) -> L2 / Infinity Cache by way of LDS-DMA loads that nobody waits for (bytes a multiple of 256) */
+    __device__ __forceinline__ void prefetch(const void* p, int bytes)
+    {
+        const char* g = (const char*)p;
+        int c = 0;
+        for (; c + 1024 <= bytes; c += 1024)
+            __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(g + c + lane * 16), (__attribute__((address_space(3))) void*)pf, 16, 0, 0);
+        for (; c + 256 <= bytes; c += 256)
+            __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(g + c + lane * 4), (__attribute__((address_space(3))) void*)pf, 4, 0, 0);
+    }
     __device__ __forceinline__ int atomic_add(int32_t* p, int v) { return atomicAdd(p, v); }
     __device__ __forceinline__ uint32_t atomic_exch(uint32_t* p, uint32_t v) { return atomicExch(p, v); }
     __device__ __forceinline__ void atomic_or(uint32_t* p, uint32_t v) { atomicOr(p, v); }
@@ -264,7 +327,7 @@ __device__ __forceinline__ int mgcw_next_ticket(const MgcLattice& L, int tk)
                                   4 -> 57 ms */
 #endif
 __global__ __launch_bounds__(MGCW_LANES) __attribute__((amdgpu_waves_per_eu(MGCW_DISCHARGE_WAVES, MGCW_DISCHARGE_WAVES)))
-void k_discharge_w(MgcLattice L, int lst, uint32_t phase, int sweeps, int flags, int tk, int zero_idx)
+void k_discharge_w(MgcLattice L, int lst, uint32_t phase, int sweeps, int flags, int tk, int zero_idx, int stagger)
 {
     __shared__ MgcWaveShared S;
     GpuWave w(S);
@@ -274,12 +337,33 @@ void k_discharge_w(MgcLattice L, int lst, uint32_t phase, int sweeps, int flags,
         L.count[tk ^ 1] = 0;
         if (zero_idx >= 0) L.count[zero_idx] = 0; /* the list the previous phase consumed */
     }
-    for (int i = (int)blockIdx.x; i < n; i = mgcw_next_ticket(L, tk)) {
-        w.new_tile();
-        w.mark(1); /* between two tiles: the ticket, the list entry */
-        /* the tile id is wave-uniform: keep it (and every base address derived from it) in SGPRs */
-        mgcw_discharge_tile(w, L, __builtin_amdgcn_readfirstlane(L.list[lst][i]), phase, sweeps, flags);
+    /* development knob: the second half of the grid (the second wave of every SIMD) starts late, so that the two waves of a
+     * SIMD do not sit in their load / store phases at the same moments (units of ~8 000 shader cycles) */
+    if (stagger > 0 && blockIdx.x >= gridDim.x / 2 && (int)blockIdx.x < n)
+        for (int k = 0; k < stagger; ++k) __builtin_amdgcn_s_sleep(127);
+    /* The wave runs one tile ahead of itself: the ticket for its NEXT tile is drawn when a visit starts and resolved in the
+     * middle of it (hint_begin / hint_end inside mgcw_discharge_impl), together with that tile's status word -- a returning
+     * atomic or a load issued behind the ~70 stores that end a visit would wait until they have all retired. */
+    __shared__ int32_t pf[256];
+    w.pf = pf;
+    w.nlist = L.list[lst];
+    w.nn = n;
+    int tile = -1, st = 0;
+    if ((int)blockIdx.x < n) {
+        tile = __builtin_amdgcn_readfirstlane(L.list[lst][blockIdx.x]);
+        st = (int)L.status[tile];
     }
+    while (tile >= 0) {
+        w.new_tile();
+        w.mark(1); /* between two tiles */
+        w.ticket_issue(L, tk);
+        /* the tile id is wave-uniform: keep it (and every base address derived from it) in SGPRs */
+        if (__builtin_amdgcn_readfirstlane(st) & (int)MGC_ST_SINK) mgcw_discharge_impl<true>(w, L, tile, phase, sweeps, flags);
+        else mgcw_discharge_impl<false>(w, L, tile, phase, sweeps, flags);
+        tile = w.next_tile;
+        st = w.nst;
+    }
+    if (MGCW_PREFETCH) asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); /* (nothing may still be on its way into this wave's LDS when it ends) */
     w.flush_marks(L);
 }
 
@@ -674,14 +758,15 @@ __global__ __launch_bounds__(256) void k_dt_finish(MgcLattice L)
 }
 
 /* activation over the filter's list, one wave per tile (four tiles per 256-thread workgroup in flight) */
-__global__ __launch_bounds__(256) void k_activate_w(MgcLattice L, int list, int cnt, uint32_t phase)
+__global__ __launch_bounds__(256) void k_activate_w(MgcLattice L, int list, int cnt, uint32_t phase, int exact_max)
 {
     __shared__ MgcWaveShared S; /* (not touched: the executor wants one) */
     GpuWave w(S);
     const int n = L.count[cnt];
+    const bool exact = n <= exact_max; /* many candidates: their status words decide (mgcw_activate_tile) */
     for (int i = (int)blockIdx.x * 4 + (int)(threadIdx.x >> 6); i < n; i += (int)gridDim.x * 4) {
         w.new_tile();
-        mgcw_activate_tile(w, L, __builtin_amdgcn_readfirstlane(L.list[list][i]), phase);
+        mgcw_activate_tile(w, L, __builtin_amdgcn_readfirstlane(L.list[list][i]), phase, exact);
     }
 }
 
@@ -1118,9 +1203,9 @@ __global__ __launch_bounds__(MGC_TV) void k_cut_value(MgcLattice L, MgcBuildArgs
 
 /* 6-neighbourhood form: labels straight from the tile-major distance labels (own tile + the six face layers next door
  * in LDS), so the C-order label volume is not needed, and a tile only reads what it can contribute: the merged t-links
- * only where k_build saw one of the paying sign (A.tflags), nothing at all for a tile that lies with its six neighbours
- * entirely on the source side.  Same additions in the same order as k_cut_value: the value is bit-identical. */
-__global__ __launch_bounds__(MGC_TV) void k_cut_value6(MgcLattice L, MgcBuildArgs A, const double* tr0, double* part)
+ * only where k_build saw one of the paying sign (A.tflags), nothing at all for a tile that lies entirely on the sink side,
+ * or with its six neighbours entirely on the source side (tsum: the per-tile summaries of k_labels8, or NULL).  Same additions in the same order as k_cut_value: the value is bit-identical. */
+__global__ __launch_bounds__(MGC_TV) void k_cut_value6(MgcLattice L, MgcBuildArgs A, const double* tr0, const uint8_t* tsum, double* part)
 {
     __shared__ double scratch[MGC_TV];
     __shared__ int32_t hs[1000];
@@ -1131,11 +1216,15 @@ __global__ __launch_bounds__(MGC_TV) void k_cut_value6(MgcLattice L, MgcBuildArg
         const bool owned = mgc_owned(L, tile);
         const uint32_t tf = A.tflags[tile];
         bool quiet = !owned;
-        if (owned && (L.status[tile] & MGC_ST_ALLINF) && !(tf & 2u)) { /* all on the source side, no sink link to pay */
-            quiet = true;
-            for (int f = 0; f < 6; ++f) {
-                const int nt = mgc_tile_nbr(L, tz, ty, tx, f);
-                if (nt >= 0 && !(mgc_owned(L, nt) && (L.status[nt] & MGC_ST_ALLINF))) quiet = false; /* (a ghost tile's flag is not maintained) */
+        if (owned && tsum) { /* the label summaries k_labels8 left: most tiles lie on one side of the cut and pay nothing */
+            const uint32_t sm = tsum[tile];
+            if (sm == 0) quiet = !(tf & 1u); /* all on the sink side: only source links are paid */
+            else if (sm == 1 && !(tf & 2u)) { /* all on the source side, no sink link: pays n-links into a neighbour tile at most */
+                quiet = true;
+                for (int f = 0; f < 6; ++f) {
+                    const int nt = mgc_tile_nbr(L, tz, ty, tx, f);
+                    if (nt >= 0 && !(mgc_owned(L, nt) && tsum[nt] == 1)) quiet = false; /* (a ghost tile only mirrors one voxel layer) */
+                }
             }
         }
         if (quiet) { /* uniform per workgroup */
@@ -1184,24 +1273,27 @@ __global__ __launch_bounds__(MGC_TV) void k_cut_value6(MgcLattice L, MgcBuildArg
     }
 }
 
-/* label read-out for rows that are whole runs of eight voxels (D2 a multiple of 8): a thread turns the 32 bytes of one tile
- * row into 8 label bytes */
-__global__ void k_labels8(MgcLattice L, uint8_t* out)
+/* label read-out for rows that are whole runs of eight voxels (D2 a multiple of 8), one wave per tile: lane (z, y) turns the
+ * 32 bytes of its tile row into 8 label bytes, and the wave leaves a one-byte summary of the tile for k_cut_value6
+ * (0: every voxel on the sink side, 1: every voxel on the source side, 2: both) */
+__global__ __launch_bounds__(256) void k_labels8(MgcLattice L, uint8_t* out, uint8_t* tsum)
 {
-    const int64_t rows = L.nvox >> 3;
-    const int64_t rx = L.dx >> 3;
-    for (int64_t r = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; r < rows; r += (int64_t)gridDim.x * blockDim.x) {
-        const int64_t bx = r % rx, q = r / rx, y = q % L.dy, z = q / L.dy;
-        const int tile = mgc_tile_id(L, (int)(z >> 3), (int)(y >> 3), (int)bx);
-        const int4* hp = (const int4*)(L.height + (int64_t)tile * MGC_TV + mgc_local((int)(z & 7), (int)(y & 7), 0));
+    const int lane = threadIdx.x & 63;
+    for (int tile = (int)blockIdx.x * 4 + (int)(threadIdx.x >> 6); tile < L.ntiles; tile += (int)gridDim.x * 4) {
+        int tz, ty, tx;
+        mgc_tile_coords(L, tile, tz, ty, tx);
+        const int4* hp = (const int4*)(L.height + (int64_t)tile * MGC_TV + lane * 8);
         const int4 a = hp[0], b = hp[1];
         const unsigned long long v = (a.x < MGC_HINF ? 0ull : 1ull) | (a.y < MGC_HINF ? 0ull : 1ull << 8) | (a.z < MGC_HINF ? 0ull : 1ull << 16) |
                                      (a.w < MGC_HINF ? 0ull : 1ull << 24) | (b.x < MGC_HINF ? 0ull : 1ull << 32) | (b.y < MGC_HINF ? 0ull : 1ull << 40) |
                                      (b.z < MGC_HINF ? 0ull : 1ull << 48) | (b.w < MGC_HINF ? 0ull : 1ull << 56);
-        *(unsigned long long*)(out + (r << 3)) = v;
+        const int64_t z = (int64_t)tz * 8 + (lane >> 3), y = (int64_t)ty * 8 + (lane & 7);
+        const bool inside = z < L.dz && y < L.dy; /* (rows are whole: x never leaves the volume) */
+        if (inside) *(unsigned long long*)(out + (z * L.dy + y) * L.dx + (int64_t)tx * 8) = v;
+        const bool any1 = __ballot(inside && v != 0ull) != 0ull, any0 = __ballot(inside && v != 0x0101010101010101ull) != 0ull;
+        if (lane == 0) tsum[tile] = (uint8_t)(any1 ? (any0 ? 2 : 1) : 0);
     }
 }
-
 
 /* ======================================================================================
  * invariants of a maximum preflow (mgc_validate; the reference's Graph::test_consistency, maxflow.cpp:610-682, in spirit)
@@ -1401,6 +1493,7 @@ struct mgc_graph {
     bool edges_applied = false; /* the stored batch went into the last build (a new mgc_add_edges replaces it) */
     std::map<const void*, size_t> buf_cap; /* capacity of the buffers mgc_upload manages, keyed by the owning field */
     /* outputs / scratch */
+    uint8_t* d_tsum = nullptr;   /* per tile: on which side of the cut its voxels lie (k_labels8) */
     uint8_t* d_tflags = nullptr; /* per tile: which signs of t-link k_build saw (MgcBuildArgs::tflags) */
     double* d_tr0 = nullptr; double* d_part = nullptr; double* d_part2 = nullptr; double* d_scalar = nullptr; uint8_t* d_labels = nullptr;
     int32_t* h_count = nullptr; /* pinned */
@@ -1428,6 +1521,8 @@ struct mgc_graph {
     int tk_dis = MGC_CNT_TICKET_DIS, tk_rel = MGC_CNT_TICKET_REL; /* ticket slot of the next wave launch (alternates) */
     int est_phase_tiles = 1 << 30; /* length of the discharge lists at the last counter read-back */
     int sweeps_sparse26 = 8;       /* 26-neighbourhood: sweep budget of a discharge while fewer than 20 % of a colour's tiles are active */
+    int activate_exact_max = 4096; /* activation looks at the voxels of its candidate tiles only when there are at most this many (mgcw_activate_tile) */
+    int wave_stagger = 0;          /* development knob of k_discharge_w (see there) */
     int wave_min_tiles = 512;      /* shorter lists are discharged by the workgroup-per-tile kernel (measured: 128^3 4.8 -> 3.4 ms, 256^3 10.8 -> 10.5 ms,
                                       512^3 unchanged; 1024 costs 512^3 8 % more discharges) */
     uint32_t zero_mask = 0; /* counters to clear before the next launch (HipDevT::flush_zero) */
@@ -1635,7 +1730,7 @@ struct HipDevT {
             zero_count(MGC_CNT_FILTER_ACT);
             flush_zero();
             hipLaunchKernelGGL(k_filter, dim3(filter_grid()), dim3(256), 0, h->stream, h->L, 1, 7, MGC_CNT_FILTER_ACT);
-            if (h->wave_kernels & 1) hipLaunchKernelGGL(k_activate_w, dim3(grid((h->L.ntiles + 3) / 4)), dim3(256), 0, h->stream, h->L, 7, MGC_CNT_FILTER_ACT, phase);
+            if (h->wave_kernels & 1) hipLaunchKernelGGL(k_activate_w, dim3(grid((h->L.ntiles + 3) / 4)), dim3(256), 0, h->stream, h->L, 7, MGC_CNT_FILTER_ACT, phase, h->activate_exact_max);
             else hipLaunchKernelGGL(k_activate_list, dim3(grid(h->L.ntiles)), dim3(MGC_TV), 0, h->stream, h->L, 7, MGC_CNT_FILTER_ACT, phase);
         }
         check(hipGetLastError());
@@ -1658,7 +1753,7 @@ struct HipDevT {
         /* one wave per tile has the higher throughput (2 048 tiles in flight, fewer instructions per tile), eight waves per tile
          * the shorter latency (36 us against 60 us for one tile): short lists -- small volumes, the tail of a solve -- are a
          * single tile deep per launch and go to the workgroup form.  Both forms keep the same state in HBM. */
-        else if ((h->wave_kernels & 1) && h->est_phase_tiles >= h->wave_min_tiles) { hipLaunchKernelGGL(k_discharge_w, dim3(h->wave_grid_dis), dim3(MGCW_LANES), 0, h->stream, h->L, lst, phase, sweeps, (h->wave_kernels & 4) ? MGCW_BFS : 0, h->tk_dis, zero_idx); h->tk_dis ^= 1; }
+        else if ((h->wave_kernels & 1) && h->est_phase_tiles >= h->wave_min_tiles) { hipLaunchKernelGGL(k_discharge_w, dim3(h->wave_grid_dis), dim3(MGCW_LANES), 0, h->stream, h->L, lst, phase, sweeps, (h->wave_kernels & 4) ? MGCW_BFS : 0, h->tk_dis, zero_idx, h->wave_stagger); h->tk_dis ^= 1; }
         else hipLaunchKernelGGL(k_discharge, dim3(grid(h->L.ntiles)), dim3(MGC_TV), 0, h->stream, h->L, lst, phase,
                                 (h->wave_kernels & 1) && !(h->wave_kernels & 4) ? -1 : cycles, sweeps, zero_idx); /* same labelling policy as the wave form */
         check(hipGetLastError());
@@ -1762,12 +1857,13 @@ static void mgc_sum_partials(mgc_handle h, int64_t n, double* out)
 static int mgc_launch_readout(mgc_handle h, int slot, hipEvent_t after_labels)
 {
     MgcLattice& L = h->L;
-    if (L.dx % 8 == 0) hipLaunchKernelGGL(k_labels8, dim3(2048), dim3(256), 0, h->stream, L, h->d_labels);
+    const bool rows8 = L.dx % 8 == 0;
+    if (rows8) hipLaunchKernelGGL(k_labels8, dim3(2048), dim3(256), 0, h->stream, L, h->d_labels, h->d_tsum);
     else hipLaunchKernelGGL(k_labels, dim3(2048), dim3(256), 0, h->stream, L, h->d_labels);
     MGC_HIP(h, hipGetLastError());
     if (after_labels) MGC_HIP(h, hipEventRecord(after_labels, h->stream));
     const int grid = L.ntiles < h->grid_cap * 4 ? L.ntiles : h->grid_cap * 4;
-    if (L.ndir == 6) hipLaunchKernelGGL(k_cut_value6, dim3(grid), dim3(MGC_TV), 0, h->stream, L, h->build_args, (const double*)h->d_tr0, h->d_part);
+    if (L.ndir == 6) hipLaunchKernelGGL(k_cut_value6, dim3(grid), dim3(MGC_TV), 0, h->stream, L, h->build_args, (const double*)h->d_tr0, rows8 ? (const uint8_t*)h->d_tsum : (const uint8_t*)nullptr, h->d_part);
     else hipLaunchKernelGGL(k_cut_value, dim3(grid), dim3(MGC_TV), 0, h->stream, L, h->build_args, (const double*)h->d_tr0, (const uint8_t*)h->d_labels, h->d_part);
     MGC_HIP(h, hipGetLastError());
     mgc_sum_partials(h, (int64_t)L.ntiles, h->d_scalar + slot);
@@ -1864,6 +1960,7 @@ static int mgc_create_impl(int ndim, const int64_t* shape, int connectivity, int
     if ((rc = mgc_alloc(h, &L.status, nt))) return rc;
     if ((rc = mgc_alloc(h, &h->d_tr0, nv))) return rc;
     if ((rc = mgc_alloc(h, &h->d_tflags, nt))) return rc;
+    if ((rc = mgc_alloc(h, &h->d_tsum, nt))) return rc;
     if ((rc = mgc_alloc(h, &h->d_part, nt > 4096 ? nt : (int64_t)4096))) return rc;
     if ((rc = mgc_alloc(h, &h->d_part2, (int64_t)256))) return rc;
     if ((rc = mgc_alloc(h, &h->d_scalar, (int64_t)8))) return rc;
@@ -2180,7 +2277,7 @@ int mgc_destroy(mgc_handle h)
     void* ptrs[] = {L.rcap, L.cap0, L.excess, L.sink, L.height, L.rmask, L.rmask32, L.obox, L.oflags, L.list[0], L.list[1], L.list[2],
                     L.list[3], L.list[4], L.list[5], L.list[6], L.list[7], L.list[8], L.list[9], L.list[10], L.list[11], L.list[12],
                     L.list[13], L.list[14], L.list[15], L.list[16], L.list[17], L.count, L.stamp, L.rstamp, L.status, h->d_tr0, h->d_part, h->d_part2, h->d_scalar,
-                    h->d_labels, h->d_tflags, h->d_image, h->d_prob, h->d_fg, h->d_bg, h->d_tr_in, h->d_eslot, h->d_eval, h->d_erun, L.hshadow[0], L.hshadow[1], h->d_vout, h->d_dt16, h->d_halo, h->d_xchg[0], h->d_xchg[1], h->d_xchg[2], h->d_xchg[3], h->d_cnt64};
+                    h->d_labels, h->d_tflags, h->d_tsum, h->d_image, h->d_prob, h->d_fg, h->d_bg, h->d_tr_in, h->d_eslot, h->d_eval, h->d_erun, L.hshadow[0], L.hshadow[1], h->d_vout, h->d_dt16, h->d_halo, h->d_xchg[0], h->d_xchg[1], h->d_xchg[2], h->d_xchg[3], h->d_cnt64};
     for (void* p : ptrs)
         if (p) (void)hipFree(p);
     if (h->h_count) (void)hipHostFree(h->h_count);
@@ -2684,6 +2781,8 @@ int mgc_set_param(mgc_handle h, const char* name, int64_t value)
     else if (!strcmp(name, "wave_grid_dis") && value > 0) h->wave_grid_dis = (int)value;
     else if (!strcmp(name, "wave_grid_rel") && value > 0) h->wave_grid_rel = (int)value;
     else if (!strcmp(name, "first_relabel_dt")) h->use_dt = value != 0;
+    else if (!strcmp(name, "wave_stagger") && value >= 0) h->wave_stagger = (int)value;
+    else if (!strcmp(name, "activate_exact_max") && value >= 0) h->activate_exact_max = (int)value;
     else if (!strcmp(name, "kernel_timing")) h->timing = value != 0;
     else if (!strcmp(name, "timing_stride") && value > 0) h->timing_stride = (int)value;
     else if (!strcmp(name, "profile_sections")) {

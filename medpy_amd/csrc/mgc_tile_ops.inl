@@ -525,7 +525,7 @@ MGC_HD void mgc_discharge_tile(X& x, const MgcLattice& L, int tile, uint32_t pha
         if (ob0[t] != 0.0) x.S.faceflag[xx == 0 ? 0 : 1] = 1;
         if (ob1[t] != 0.0) x.S.faceflag[y == 0 ? 2 : 3] = 1;
         if (ob2[t] != 0.0) x.S.faceflag[z == 0 ? 4 : 5] = 1;
-        if (e[t] > 0.0) x.S.excflag = 1;
+        if (e[t] > 0.0 && x.S.hs[mgc_hs_index(z, y, xx)] < MGC_HINF) x.S.excflag = 1; /* (excess under an INF label is dead for good) */
     });
     x.mark(L, 5); /* face flags */
     /* ... then ONE block of global stores: state, masks, labels, outbox, wake-ups */

@@ -39,6 +39,13 @@
  *                         64 + 70 state accesses of a discharge need ONE address register instead of a 64-bit pair each
  *   w.fresh()             the lane id becomes opaque to the optimiser again (GPU): addresses derived from it before this
  *                         point are recomputed afterwards instead of being kept alive (or spilled) across the sweeps
+ *   w.shift_x(dst, src, k) the same for k = +-1 when src is 0.0 on every lane whose source would lie in another row of eight
+ *                         (the x-row of a tile layer): two DPP row shifts on the GPU instead of two LDS-crossbar permutes
+ *   W::kPrefetch          >= 0: the executor runs ahead of the tile loop -- w.hint_begin() / w.hint_end(L) yield the tile this
+ *                         wave will discharge NEXT (or -1) while the current one is being swept, so that no ticket or
+ *                         list entry is waited for behind the stores of a visit; > 0: w.prefetch(p, bytes) also starts
+ *                         moving [p, p + bytes) of that tile towards the caches without a register or a wait
+ *                         (1: excess / labels / masks; 2: the residual planes too).  -1 (host): none of this exists
  *   w.mark(id)            work-profile hook: counts sections in the simulator; on the GPU nothing, or (development build
  *                         -DMGCW_PROFILE) the cycles since the previous mark, accumulated per section
  */
@@ -164,6 +171,18 @@ MGC_HD void mgcw_relax(W& w, RegI& h, ArcFn arc)
     }
 }
 
+/* start moving the state of the tile this wave discharges next: a wave spends half of a visit waiting for its own loads and
+ * stores (profiles/README.md), and all resident waves of a launch do so at the same moments; the next tile's lines are
+ * requested while this one is being swept, so that its load phase finds them in the L2 / Infinity Cache */
+template <class W>
+MGC_HD void mgcw_prefetch_tile(W& w, const MgcLattice& L, int tile)
+{
+    w.prefetch(L.excess + (int64_t)tile * MGC_TV, MGC_TV * (int)sizeof(double));
+    w.prefetch(L.height + (int64_t)tile * MGC_TV, MGC_TV * (int)sizeof(int32_t));
+    w.prefetch(L.rmask + (int64_t)tile * MGC_TV, MGC_TV);
+    if (W::kPrefetch >= 2) w.prefetch(L.rcap + (int64_t)tile * 6 * MGC_TV, 6 * MGC_TV * (int)sizeof(double));
+}
+
 /* ---------------------------------------------------------------------------------------
  * Region discharge of one tile by one wave (colour phase `phase`; the six face neighbours are idle).
  *   load -> absorb inbox -> labels -> sweeps { per slot: sink, -x, +x, -y, +y ; -z down the column ; +z up the
@@ -234,6 +253,7 @@ MGC_HD void mgcw_discharge_impl(W& w, const MgcLattice& L, int tile, uint32_t ph
             if constexpr (K == 7) { const double d = w.S.inbox[5][l]; e(l, K) += d; r[5](l, K) += d; }
         });
     });
+    if constexpr (W::kPrefetch >= 0) w.hint_begin(); /* (the own loads have landed: ask for the next list entry) */
     /* residual planes this discharge changes (bit D): a plane nobody pushed along, received along or absorbed into goes
      * back to HBM as it came -- so it does not go back at all (a discharge typically moves flow along one or two axes) */
     uint32_t dirty = 0;
@@ -319,6 +339,10 @@ MGC_HD void mgcw_discharge_impl(W& w, const MgcLattice& L, int tile, uint32_t ph
         return e(l, K) > 0.0 && r[D](l, K) > 0.0 && hnb == h(l, K) - 1;
     };
 
+    if constexpr (W::kPrefetch >= 0) {
+        const int coming = w.hint_end(L); /* the tile this wave discharges next: known a whole visit ahead */
+        if (W::kPrefetch > 0 && coming >= 0) mgcw_prefetch_tile(w, L, coming);
+    }
     w.mark(0); /* load + absorb + label set-up */
     uint32_t am = slot_mask();
     for (int sw = 0; sw < max_sweeps && am; ++sw) {
@@ -357,7 +381,10 @@ MGC_HD void mgcw_discharge_impl(W& w, const MgcLattice& L, int tile, uint32_t ph
                     if constexpr (D < 2) obx(l, K) += delta - stay; /* what leaves the tile across face D: delta or 0.0, exactly */
                     else oby(l, K) += delta - stay;
                 });
-                w.shift(din, dl, D == 0 ? 1 : (D == 1 ? -1 : (D == 2 ? 8 : -8))); /* -x: from the lane at x + 1, ... */
+                /* -x: from the lane at x + 1, ...; dl is 0.0 on the lanes whose push left the tile, which are exactly the lanes
+                 * at the end of an x-row: the x shifts never carry anything from one row of eight into the next */
+                if constexpr (D < 2) w.shift_x(din, dl, D == 0 ? 1 : -1);
+                else w.shift(din, dl, D == 2 ? 8 : -8);
                 w.lanes([&](int l) MGCW_INL { /* what the neighbour pushed in direction D arrives: reverse residual grows */
                     e(l, K) += din(l, 0);
                     r[D ^ 1](l, K) += din(l, 0);
@@ -443,7 +470,7 @@ MGC_HD void mgcw_discharge_impl(W& w, const MgcLattice& L, int tile, uint32_t ph
     mgcw_static_for<8>([&](auto KK) MGCW_INL {
         constexpr int K = decltype(KK)::value;
         if constexpr (SINK) has_sink = has_sink || w.any([&](int l) MGCW_INL -> bool { return w.S.snk[K * 64 + l] > 0.0; });
-        has_exc = has_exc || w.any([&](int l) MGCW_INL -> bool { return e(l, K) > 0.0; });
+        has_exc = has_exc || w.any([&](int l) MGCW_INL -> bool { return e(l, K) > 0.0 && h(l, K) < MGC_HINF; }); /* (excess under an INF label is dead for good) */
     });
     const bool saturated = w.any([&](int l) MGCW_INL -> bool { return sat(l, 0) != 0; });
     w.lanes([&](int l) MGCW_INL {
@@ -463,8 +490,20 @@ MGC_HD void mgcw_discharge_impl(W& w, const MgcLattice& L, int tile, uint32_t ph
     for (int f = 0; f < 6; ++f)
         if (w.any([&](int l) MGCW_INL -> bool { return w.S.inbox[f][l] != 0.0; })) face |= 1u << f;
 
-    /* ---- ONE block of global stores: state, masks, labels, outbox, wake-ups ---- */
+    /* ---- wake-ups and flags FIRST: their atomics return a value, and the memory counter of a wave retires in issue order --
+     * behind the ~70 stores below, the first of them would wait until the whole tile has been written back (that wait was
+     * most of the "tail" section of the round-2 profile).  Nothing in this launch reads what they publish. ---- */
     w.fresh();
+    w.lanes([&](int l) MGCW_INL {
+        if (l < 6 && ((face >> l) & 1u)) {
+            w.atomic_or(&L.oflags[tile], 1u << l);
+            mgc_enqueue(w, L, (int)((phase + 1) & 3u), L.stamp, phase + 1, mgc_tile_nbr(L, tz, ty, tx, l));
+        }
+        if (l == 6 && active) mgc_enqueue(w, L, (int)((phase + 2) & 3u), L.stamp, phase + 2, tile);
+        /* DIRTY only if a residual arc disappeared: otherwise no distance in the tile (or through it) can have changed */
+        if (l == 7) L.status[tile] = (L.status[tile] & ~(MGC_ST_SINK | MGC_ST_EXCESS)) | (has_sink ? MGC_ST_SINK : 0u) | (saturated ? MGC_ST_DIRTY : 0u) | (has_exc ? MGC_ST_EXCESS : 0u);
+    });
+    /* ---- then ONE block of global stores nobody waits for: state, masks, labels, outbox ---- */
     w.lanes([&](int l) MGCW_INL {
         mgcw_static_for<8>([&](auto KK) MGCW_INL {
             constexpr int K = decltype(KK)::value;
@@ -508,13 +547,6 @@ MGC_HD void mgcw_discharge_impl(W& w, const MgcLattice& L, int tile, uint32_t ph
             const double ob = w.S.inbox[f][l];
             if (ob != 0.0) w.st(t_obox + f * MGC_TF, l, ob);
         }
-        if (l < 6 && ((face >> l) & 1u)) {
-            w.atomic_or(&L.oflags[tile], 1u << l);
-            mgc_enqueue(w, L, (int)((phase + 1) & 3u), L.stamp, phase + 1, mgc_tile_nbr(L, tz, ty, tx, l));
-        }
-        if (l == 6 && active) mgc_enqueue(w, L, (int)((phase + 2) & 3u), L.stamp, phase + 2, tile);
-        /* DIRTY only if a residual arc disappeared: otherwise no distance in the tile (or through it) can have changed */
-        if (l == 7) L.status[tile] = (L.status[tile] & ~(MGC_ST_SINK | MGC_ST_EXCESS)) | (has_sink ? MGC_ST_SINK : 0u) | (saturated ? MGC_ST_DIRTY : 0u) | (has_exc ? MGC_ST_EXCESS : 0u);
     });
     w.mark(3); /* tail votes + stores */
 }
@@ -602,9 +634,26 @@ MGC_HD void mgcw_relabel_tile(W& w, const MgcLattice& L, int tile, uint32_t next
  * barrier: sixteen loads per lane, one vote.  Same contract as mgc_activate_tile.
  * ------------------------------------------------------------------------------------- */
 template <class W>
-MGC_HD void mgcw_activate_tile(W& w, const MgcLattice& L, int tile, uint32_t phase)
+MGC_HD void mgcw_activate_tile(W& w, const MgcLattice& L, int tile, uint32_t phase, bool exact)
 {
     if (!mgc_owned(L, tile) || (L.status[tile] & MGC_ST_ALLINF)) return; /* all labels INF: nothing can reach the sink */
+    /* !exact: the status word alone decides.  MGC_ST_EXCESS says "at its last visit some voxel held excess under a finite
+     * label"; a finite label can still turn INF at a later global relabel (never the other way round), so the word can only
+     * err towards a visit too many -- which finds nothing to push, clears the bit, and is not repeated.  The voxel-level
+     * test below reads 6 KiB per candidate tile; it runs when the candidates are few, i.e. near the end of a solve, where
+     * a wrong "still active" would cost a whole extra round of relabel + phases. */
+    if (!exact) {
+        w.lanes([&](int l) MGCW_INL {
+            if (l == 0) {
+                int tz, ty, tx;
+                mgc_tile_coords(L, tile, tz, ty, tx);
+                const uint32_t target = phase + ((mgc_tile_colour(L, tz, ty, tx) ^ (int)(phase & 1u)) & 1);
+                mgc_enqueue(w, L, (int)(target & 3u), L.stamp, target, tile);
+                w.atomic_add(&L.count[6], 1);
+            }
+        });
+        return;
+    }
     typename W::template Reg<double, 8> e;
     typename W::template Reg<int, 8> h;
     const double* const t_excess = L.excess + (int64_t)tile * MGC_TV;

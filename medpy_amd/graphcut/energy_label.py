@@ -11,6 +11,8 @@ import sys
 
 import numpy
 
+from .generate import _consecutive_region_ids
+
 __all__ = ["boundary_difference_of_means", "boundary_stawiaski", "boundary_stawiaski_directed", "regional_atlas"]
 
 
@@ -22,19 +24,11 @@ def _axis_pairs(arr, axis):
     return arr[tuple(a)], arr[tuple(b)]
 
 
-def __check_label_image(label_image):
-    """labels have to be 1..n without gaps (energy_label.py:451-461)"""
-    encountered_indices = numpy.unique(label_image)
-    expected_indices = numpy.arange(1, label_image.max() + 1)
-    if not encountered_indices.size == expected_indices.size or not (encountered_indices == expected_indices).all():
-        raise AttributeError("The supplied label image does either not contain any regions or they are not labeled consecutively starting from 1.")
-
-
 def _prepare(label_image):
     label_image = numpy.asarray(label_image)
     if label_image.flags["F_CONTIGUOUS"]:
         label_image = numpy.ascontiguousarray(label_image)
-    __check_label_image(label_image)
+    _consecutive_region_ids(label_image)  # 1..n without gaps, or AttributeError (energy_label.py:451-461)
     return label_image
 
 
@@ -121,7 +115,7 @@ def regional_atlas(graph, label_image, xxx_todo_changeme1):
     (probability_map, alpha) = xxx_todo_changeme1
     label_image = numpy.asarray(label_image)
     probability_map = numpy.asarray(probability_map)
-    __check_label_image(label_image)
+    _consecutive_region_ids(label_image)  # 1..n without gaps, or AttributeError (energy_label.py:451-461)
     nregions = int(label_image.max())
     if hasattr(graph, "merge_tweights"):
         from .graph import region_sums

@@ -38,42 +38,48 @@ def graph_from_voxels(
     neighbourhood; ``3**ndim - 1`` (8 in 2-D, 26 in 3-D) = full neighbourhood, the built-in boundary
     terms then apply the same g(.) to every neighbour offset (spacing: Euclidean offset length).
     """
-    fg_markers = numpy.asarray(fg_markers)
-    bg_markers = numpy.asarray(bg_markers)
-    logger.debug("Assuming %d nodes and %d edges for image of shape %s", fg_markers.size,
-                 __voxel_4conectedness(fg_markers.shape), fg_markers.shape)
-    graph = GCGraph(fg_markers.size, __voxel_4conectedness(fg_markers.shape), shape=fg_markers.shape, connectivity=connectivity)
+    fg_mask = numpy.asarray(fg_markers, dtype=numpy.bool_)
+    bg_mask = numpy.asarray(bg_markers, dtype=numpy.bool_)
+    shape = fg_mask.shape
 
-    logger.info("Performing attribute tests...")
-    fg_markers = numpy.asarray(fg_markers, dtype=numpy.bool_)
-    bg_markers = numpy.asarray(bg_markers, dtype=numpy.bool_)
+    # the two plug-ins, each called as term(graph, args); an absent one records nothing
+    regional = _checked_plugin(regional_term, "regional_term", 2)
+    boundary = _checked_plugin(boundary_term, "boundary_term", 2)
 
-    if not regional_term:
-        regional_term = __regional_term_voxel
-    if not boundary_term:
-        boundary_term = __boundary_term_voxel
+    # one node per voxel (C-order flat index); the edge count only mirrors the reference's estimate, the lattice is implicit
+    n_edges = _lattice_edge_count(shape)
+    logger.debug("graph_from_voxels: shape %s -> %d nodes, %d n-links; %d source / %d sink markers",
+                 shape, fg_mask.size, n_edges, numpy.count_nonzero(fg_mask), numpy.count_nonzero(bg_mask))
+    graph = GCGraph(fg_mask.size, n_edges, shape=shape, connectivity=connectivity)
 
-    if not hasattr(regional_term, "__call__") or not 2 == len(inspect.getfullargspec(regional_term)[0]):
-        raise AttributeError("regional_term has to be a callable object which takes two parameter.")
-    if not hasattr(boundary_term, "__call__") or not 2 == len(inspect.getfullargspec(boundary_term)[0]):
-        raise AttributeError("boundary_term has to be a callable object which takes two parameters.")
-
-    logger.debug("#nodes=%d, #hardwired-nodes source/sink=%d/%d", fg_markers.size,
-                 numpy.count_nonzero(fg_markers), numpy.count_nonzero(bg_markers))
-
-    logger.info("Computing and adding terminal edge weights...")
-    regional_term(graph, regional_term_args)
-
-    logger.info("Computing and adding inter-node edge weights...")
-    boundary_term(graph, boundary_term_args)
-
-    logger.info("Setting terminal weights for the markers...")
-    if not 0 == numpy.count_nonzero(fg_markers):
-        graph.set_source_nodes(fg_markers.ravel().nonzero()[0])
-    if not 0 == numpy.count_nonzero(bg_markers):
-        graph.set_sink_nodes(bg_markers.ravel().nonzero()[0])
-
+    # order matters for the merged t-links (graph.h:416-425): regional term, boundary term, then the hard constraints
+    regional(graph, regional_term_args)
+    boundary(graph, boundary_term_args)
+    for mask, wire in ((fg_mask, graph.set_source_nodes), (bg_mask, graph.set_sink_nodes)):
+        ids = numpy.flatnonzero(mask)
+        if ids.size:  # (an empty id list makes set_*_nodes raise, as the reference's does: graph.py:330, generate.py:169-172)
+            wire(ids)
     return graph.get_graph()
+
+
+def _checked_plugin(term, name, nparams):
+    """A term is optional (any false value); when given it must be callable with exactly ``nparams`` positional parameters --
+    the reference's protocol (generate.py:135-146, 280-291), which raises AttributeError otherwise."""
+    if not term:
+        return (lambda graph, args: None) if nparams == 2 else (lambda graph, label_image, args: None)
+    if not callable(term) or len(inspect.getfullargspec(term).args) != nparams:
+        raise AttributeError("%s must be a callable taking exactly %d parameters" % (name, nparams))
+    return term
+
+
+def _lattice_edge_count(shape):
+    """Edges of the 2*ndim lattice: along every axis of extent s > 1 each of the prod(shape) / s lines holds s - 1 of them.
+    (The reference arrives at the same number through floating point, generate.py:363-383; it only sizes its allocation.)"""
+    extents = [int(s) for s in shape]
+    total = 1
+    for s in extents:
+        total *= s
+    return sum(total // s * (s - 1) for s in extents if s > 1)
 
 
 def graph_from_labels(
@@ -95,63 +101,28 @@ def graph_from_labels(
     graph is assembled and solved in MI355X HBM; the returned object is the stand-in for ``maxflow.GraphDouble``.
 
     Raises ``AttributeError`` for a malformed label image or terms that do not take three parameters."""
-    label_image = numpy.asarray(label_image)
-    fg_markers = numpy.asarray(fg_markers, dtype=numpy.bool_)
-    bg_markers = numpy.asarray(bg_markers, dtype=numpy.bool_)
-    __check_label_image(label_image)
+    regions = numpy.asarray(label_image)
+    fg_mask = numpy.asarray(fg_markers, dtype=numpy.bool_)
+    bg_mask = numpy.asarray(bg_markers, dtype=numpy.bool_)
+    region_ids = _consecutive_region_ids(regions)
 
-    if not regional_term:
-        regional_term = __regional_term_label
-    if not boundary_term:
-        boundary_term = __boundary_term_label
-    if not hasattr(regional_term, "__call__") or not 3 == len(inspect.getfullargspec(regional_term)[0]):
-        raise AttributeError("regional_term has to be a callable object which takes three parameters.")
-    if not hasattr(boundary_term, "__call__") or not 3 == len(inspect.getfullargspec(boundary_term)[0]):
-        raise AttributeError("boundary_term has to be a callable object which takes three parameters.")
+    regional = _checked_plugin(regional_term, "regional_term", 3)
+    boundary = _checked_plugin(boundary_term, "boundary_term", 3)
 
-    nodes = len(numpy.unique(label_image))
-    edges = 10 * nodes  # the reference's guess (generate.py:296-300); sizes nothing here
-    graph = GCGraph(nodes, edges)
-
-    regional_term(graph, label_image, regional_term_args)
-    boundary_term(graph, label_image, boundary_term_args)
-
-    graph.set_source_nodes(numpy.unique(label_image[fg_markers] - 1))  # node ids start at 0
-    graph.set_sink_nodes(numpy.unique(label_image[bg_markers] - 1))
+    # node r - 1 stands for region r; the edge count is the reference's guess (generate.py:296-300) and sizes nothing here
+    graph = GCGraph(region_ids.size, 10 * region_ids.size)
+    regional(graph, regions, regional_term_args)
+    boundary(graph, regions, boundary_term_args)
+    graph.set_source_nodes(numpy.unique(regions[fg_mask]) - 1)
+    graph.set_sink_nodes(numpy.unique(regions[bg_mask]) - 1)
     return graph.get_graph()
 
 
-def __check_label_image(label_image):
-    """labels have to be 1..n without gaps (reference generate.py:352-360 / energy_label.py:451-461)"""
-    encountered_indices = numpy.unique(label_image)
-    expected_indices = numpy.arange(1, label_image.max() + 1)
-    if not encountered_indices.size == expected_indices.size or not (encountered_indices == expected_indices).all():
-        raise AttributeError("The supplied label image does either not contain any regions or they are not labeled consecutively starting from 1.")
-
-
-def __regional_term_label(graph, label_image, regional_term_args):
-    """Fake regional_term function with the appropriate signature."""
-    return {}
-
-
-def __boundary_term_label(graph, label_image, boundary_term_args):
-    """Fake boundary_term function with the appropriate signature."""
-    return {}
-
-
-def __regional_term_voxel(graph, regional_term_args):
-    """Fake regional_term function with the appropriate signature (generate.py:341-343)."""
-    return {}
-
-
-def __boundary_term_voxel(graph, boundary_term_args):
-    """Fake boundary_term function with the appropriate signature (generate.py:351-354)."""
-    return {}
-
-
-def __voxel_4conectedness(shape):
-    """Number of edges for the 2*ndim neighbourhood (generate.py:363-383)."""
-    shape = list(shape)
-    while 1 in shape:
-        shape.remove(1)
-    return int(round(sum([(dim - 1) / float(dim) for dim in shape]) * numpy.prod(shape)))
+def _consecutive_region_ids(label_image):
+    """The region ids of a label image, which must be exactly 1..n (reference generate.py:352-360, energy_label.py:451-461:
+    AttributeError otherwise)."""
+    ids = numpy.unique(label_image)
+    if ids.size == 0 or ids[0] != 1 or ids[-1] != ids.size:
+        raise AttributeError("the label image must hold the region ids 1..n without gaps (found %d distinct ids between %s and %s)"
+                             % (ids.size, ids[0] if ids.size else "-", ids[-1] if ids.size else "-"))
+    return ids

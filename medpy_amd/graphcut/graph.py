@@ -49,6 +49,7 @@ class VoxelGraph(object):
             raise _lib.MedpyHipError(rc, msg)
         self._nodes = int(numpy.prod(self._shape))
         self._labels = None
+        _lib.apply_env_params(self._h)
 
     # -- life cycle
     def close(self):

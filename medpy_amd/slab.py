@@ -307,6 +307,7 @@ class HipSlab(object):
         self.has_lo, self.has_hi = bool(info[4]), bool(info[5])
         self.local_shape = (self.plane1 - self.plane0, int(global_shape[1]), int(global_shape[2]))
         self.rank, self.nranks = rank, nranks
+        _lib.apply_env_params(self._h)
 
     def close(self):
         if getattr(self, "_h", None):

@@ -89,6 +89,21 @@ def lattice_edges(shape, weights):
     return np.concatenate(ii), np.concatenate(jj), np.concatenate(ww)
 
 
+TIGHT_TOL = 64 * 2.220446049250313e-16  # 64 ulp of the local capacity: what a handful of additions can lose
+
+
+def _record(entry):
+    """one JSON line per comparison that needed the relaxation (MEDPY_PARITY_LOG names the file; the test run on the GPU
+    box writes it under gpurun_out/, the round's summary is committed as profiles/r3_parity_relaxations.json)"""
+    path = os.environ.get("MEDPY_PARITY_LOG")
+    if not path:
+        return
+    import json
+    entry = dict(entry, test=os.environ.get("PYTEST_CURRENT_TEST", "").split(" ")[0], params=os.environ.get("MEDPY_HIP_PARAMS", ""))
+    with open(path, "a") as f:
+        f.write(json.dumps(entry) + "\n")
+
+
 def assert_labels_equivalent(labels, ref_cut, max_differing=None, exact=None, tol=1e-12):
     """``labels``: bool array, True = source side (the CLI's 1), as the HIP path returns them; ``ref_cut``: an
     oracle/pipeline.py:Cut (solved).  Passes when the labels are identical, or when (a) every differing voxel lies in
@@ -105,11 +120,24 @@ def assert_labels_equivalent(labels, ref_cut, max_differing=None, exact=None, to
     if nbad == 0:
         return 0
     assert max_differing is None or nbad <= max_differing, "%d voxels differ from the reference (bound %d)" % (nbad, max_differing)
-    fs, ts, amb = ambiguity(ref_cut.graph, tol)
+    # the ambiguity set at the tight granularity first (TIGHT_TOL); the wider one (`tol`, 1e-12 by default: ~4 500 ulp, the
+    # drift of a residual that hundreds of pushes went through) only when a differing voxel is not covered, and says so
+    fs, ts, amb = ambiguity(ref_cut.graph, min(tol, TIGHT_TOL))
+    level, n_tight = "64ulp", int(amb.sum())
     outside = diff & ~amb
+    if outside.any() and tol > TIGHT_TOL:
+        fs, ts, amb = ambiguity(ref_cut.graph, tol)
+        level, outside = "%g" % tol, diff & ~amb
+    entry = {"differing": nbad, "voxels": int(diff.size), "granularity": level, "ambiguous_at_64ulp": n_tight, "ambiguous_used": int(amb.sum())}
+    if outside.any():
+        _record(dict(entry, verdict="FAIL: differing voxel outside the ambiguity set"))
     assert not outside.any(), "%d differing voxels are NOT ambiguous (reachable from the source: %d, can reach the sink: %d)" % (
         int(outside.sum()), int((outside & fs).sum()), int((outside & ts).sum()))
     if exact is not None:
         a, b = exact_cut_value(labels, *exact), exact_cut_value(ref, *exact)
+        entry["cut_capacity_exact_equal"] = float(a) == float(b)
+        if float(a) != float(b):
+            _record(dict(entry, verdict="FAIL: cut capacities differ"))
         assert float(a) == float(b), "cut capacities differ: %r vs %r (by %r)" % (float(a), float(b), float(a - b))
+    _record(dict(entry, verdict="equivalent"))
     return nbad

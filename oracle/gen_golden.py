@@ -259,6 +259,13 @@ def main_large():
         "sphere_128_26": dict(gen="sphere", shape=(128, 128, 128), conn=26, regional=False),
         "sphere_256_26": dict(gen="sphere", shape=(256, 256, 256), conn=26, regional=False),
         "config3_256_26_regional": dict(gen="sphere", shape=(256, 256, 256), conn=26, regional=True),
+        # discriminating cases (round-2 review: the three 256^3 sphere cuts above are all the geometric ball): weak contrast, so
+        # the cut depends on the neighbourhood and on the regional term
+        "hard_128_26": dict(gen="hard", shape=(128, 128, 128), conn=26, regional=False),
+        "hard_192_26": dict(gen="hard", shape=(192, 192, 192), conn=26, regional=False),
+        "hard_192_6": dict(gen="hard", shape=(192, 192, 192), conn=6, regional=False),
+        "config3_hard_192_26_alpha005": dict(gen="hard", shape=(192, 192, 192), conn=26, regional=True, alpha=0.05),
+        "config3_hard_256_26_alpha005": dict(gen="hard", shape=(256, 256, 256), conn=26, regional=True, alpha=0.05),
     }
     path = os.path.join(OUT, "reference_large.json")
     store = json.load(open(path)) if os.path.exists(path) else {}
@@ -268,12 +275,12 @@ def main_large():
         kw = {}
         if c["regional"]:
             r = synthetic.regional(c["shape"])
-            kw = dict(prob=r["prob"], alpha=r["alpha"])
+            kw = dict(prob=r["prob"], alpha=c.get("alpha", r["alpha"]))
         t0 = time.time()
         cut = pipeline.graphcut_voxel(s["fg"], s["bg"], term=s["term"], image=s["image"], sigma=s["sigma"], kind="ref",
                                       connectivity=c["conn"] if c["conn"] != 6 else None, **kw)
         lab = np.packbits(cut.labels.astype(np.uint8).ravel())
-        store[name] = {"gen": c["gen"], "shape": list(c["shape"]), "connectivity": c["conn"], "regional": c["regional"],
+        store[name] = {"gen": c["gen"], "shape": list(c["shape"]), "connectivity": c["conn"], "regional": c["regional"], "alpha": kw.get("alpha"),
                        "sha256_packed_labels": hashlib.sha256(lab.tobytes()).hexdigest(), "flow": cut.flow,
                        "foreground_voxels": int(cut.labels.sum()), "oracle_seconds": round(time.time() - t0, 1)}
         print(name, store[name], flush=True)

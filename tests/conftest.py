@@ -62,3 +62,34 @@ def golden_synth():
 def _build_oracle():
     from oracle import bk
     bk.build()
+
+
+# ---- the golden vectors a second time through the kernel forms a LARGE volume uses ------------------------------------
+# k_discharge_w (the kernel the bench times) only takes over from 512 active tiles per colour phase on, and the activation
+# only trusts the tiles' status words when there are more than 4096 candidates: a 64^3 fixture never gets there.  Every test
+# of these modules therefore runs twice on the GPU: as shipped, and with the thresholds at zero (MEDPY_HIP_PARAMS is applied to
+# every lattice handle at creation, medpy_amd/_lib.py:apply_env_params) plus the two-voxels-per-thread 26-neighbourhood
+# discharge (wave_kernels bit 4).
+_FORMS_MODULES = ("test_gpu_parity", "test_gpu_edge_cases", "test_gpu_slabs", "test_gpu_full_neighbourhood")
+LARGE_VOLUME_FORMS = "wave_min_tiles=0,activate_exact_max=0,wave_kernels=25"
+
+
+def pytest_generate_tests(metafunc):
+    if metafunc.module.__name__.rsplit(".", 1)[-1] in _FORMS_MODULES and "kernel_forms" in metafunc.fixturenames:
+        metafunc.parametrize("kernel_forms", ["as_shipped", "large_volume_forms"], indirect=True)
+
+
+@pytest.fixture(autouse=True)
+def kernel_forms(request, monkeypatch):
+    mode = getattr(request, "param", "as_shipped")
+    if mode == "large_volume_forms":
+        monkeypatch.setenv("MEDPY_HIP_PARAMS", LARGE_VOLUME_FORMS)
+    return mode
+
+
+@pytest.fixture(autouse=True, scope="session")
+def _parity_log():
+    """where oracle/cutcheck.py records every comparison that needed the tie relaxation (GPU box: under gpurun_out/)"""
+    if "MEDPY_PARITY_LOG" not in os.environ and os.path.isdir(os.path.join(ROOT, "gpurun_out")):
+        os.environ["MEDPY_PARITY_LOG"] = os.path.join(ROOT, "gpurun_out", "parity_relaxations.jsonl")
+    yield

@@ -133,6 +133,21 @@ struct HostWave {
             dst(l, 0) = (from >= 0 && from < MGCW_LANES) ? src(from, 0) : 0.0;
         }
     }
+    /* the x-row contract of shift_x is checked here: nothing may arrive from another row of eight */
+    void shift_x(Reg<double, 1>& dst, Reg<double, 1>& src, int delta)
+    {
+        g_prof[22]++;
+        for (int l = 0; l < MGCW_LANES; ++l) {
+            const int from = l + delta;
+            const bool same_row = from >= 0 && from < MGCW_LANES && (from >> 3) == (l >> 3);
+            if (!same_row && from >= 0 && from < MGCW_LANES && src(from, 0) != 0.0) abort();
+            dst(l, 0) = same_row ? src(from, 0) : 0.0;
+        }
+    }
+    static constexpr int kPrefetch = -1;
+    void hint_begin() {}
+    int hint_end(const MgcLattice&) { return -1; }
+    void prefetch(const void*, int) {}
     int atomic_add(int32_t* p, int v) { int o = *p; *p += v; return o; }
     uint32_t atomic_exch(uint32_t* p, uint32_t v) { uint32_t o = *p; *p = v; return o; }
     void atomic_or(uint32_t* p, uint32_t v) { *p |= v; }
@@ -146,6 +161,7 @@ struct HostWave {
 /* which form of the two hot tile operations the simulator runs: bit 0 = wave discharge, bit 1 = wave relabel,
  * bit 2 = the wave discharge computes exact in-tile labels first (MGCW_BFS) */
 static int g_wave_mode = 0;
+static int g_act_exact_max = 4096; /* hostsim_set_act_exact: see mgcw_activate_tile */
 static int g_use_dt = 1; /* the first global relabel may be a distance transform (hostsim_set_dt) */
 
 typedef HostBlockT<MgcTileShared> HostBlock;
@@ -242,9 +258,16 @@ struct HostDev {
         reset_snapshot.clear();
         HostBlock x(S);
         HostWave w(WS);
+        int candidates = 0; /* what the library's tile filter would list */
+        for (int t = 0; t < L.ntiles; ++t)
+            candidates += mgc_owned(L, t) && (L.status[t] & (MGC_ST_EXCESS | MGC_ST_ALLINF)) == MGC_ST_EXCESS;
+        const bool exact = candidates <= g_act_exact_max;
         for (int t = 0; t < L.ntiles; ++t) {
-            if (g_wave_mode & 1) mgcw_activate_tile(w, L, t, phase);
-            else mgc_activate_tile(x, L, t, phase);
+            if (g_wave_mode & 1) {
+                if ((L.status[t] & (MGC_ST_EXCESS | MGC_ST_ALLINF)) == MGC_ST_EXCESS) mgcw_activate_tile(w, L, t, phase, exact);
+            } else {
+                mgc_activate_tile(x, L, t, phase);
+            }
         }
     }
     int suspect_batch() const { return 8; }
@@ -350,6 +373,7 @@ extern "C" {
 
 void hostsim_set_wave_mode(int mode) { g_wave_mode = mode; }
 void hostsim_set_dt(int on) { g_use_dt = on; }
+void hostsim_set_act_exact(int n) { g_act_exact_max = n; }
 
 /* work-profile read-out: copies and clears the counters; tiles != NULL with ntiles > 0 arms / returns the per-tile discharge counts */
 void hostsim_prof(int64_t* out, int32_t* tiles, int ntiles)

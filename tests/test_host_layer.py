@@ -287,3 +287,18 @@ def test_distance_transform_is_refused_when_an_arc_is_missing():
     ran, h, st = sim.first_relabel(shape, w, tr, True)
     assert not ran
     assert int(h.reshape(2, 2, 2, 8, 8, 8)[1, 1, 1, 0, 0, 0]) == 9  # voxel (8, 8, 8): eight steps to plane 0, one into the sink
+
+
+@pytest.mark.parametrize("gen,shape", [("sphere", (40, 40, 40)), ("hard", (32, 32, 32)), ("sphere", (9, 21, 35))])
+def test_activation_by_status_word_reaches_the_same_cut(gen, shape):
+    """mgcw_activate_tile(exact=false): with many candidate tiles the activation after a global relabel trusts the tiles' status
+    words (excess under a finite label at the last visit) instead of reading their voxels; a stale word costs one empty visit
+    and is cleared by it.  Forced for every activation here: same labels, and the solve still terminates."""
+    import sim
+    sim.lib().hostsim_set_act_exact(-1)
+    try:
+        lab, ref, st = _sim_case(gen, shape, wave_mode=1)
+    finally:
+        sim.lib().hostsim_set_act_exact(4096)
+    assert st["converged"] == 1
+    np.testing.assert_array_equal(lab, ref)

@@ -42,14 +42,24 @@ def block():
 
 def main():
     t0 = time.time()
-    img, fg, bg = (np.concatenate([a] * REP, axis=0) for a in block())
+    try:
+        img, fg, bg = (np.concatenate([a] * REP, axis=0) for a in block())
+    except MemoryError:
+        print("out of host memory for the input arrays", flush=True)
+        sys.exit(77)
     shape = img.shape
     nvox = int(np.prod(shape))
     assert nvox > 2 ** 31
     print("volume %s = %d voxels (2^31 = %d), host arrays ready after %.0f s" % (shape, nvox, 2 ** 31, time.time() - t0), flush=True)
-    g = VoxelGraph(shape)
-    g._set_boundary("difference_exponential", img, 15.0, False)
-    g._set_markers(fg, bg)
+    try:
+        g = VoxelGraph(shape)
+        g._set_boundary("difference_exponential", img, 15.0, False)
+        g._set_markers(fg, bg)
+    except _lib.MedpyHipError as e:
+        if e.code == _lib.ERR_OOM:
+            print("out of device memory for %d voxels: %s" % (nvox, e), flush=True)
+            sys.exit(77)
+        raise
     t1 = time.perf_counter()
     g._build()
     flow = g.maxflow()
