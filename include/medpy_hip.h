@@ -72,7 +72,13 @@ typedef struct mgc_stats {
     int64_t ntiles;
     int64_t nvox;
     int64_t device_bytes;      /* HBM held by the handle                                   */
-    int64_t reserved[3];
+    int64_t reserved[3];       /* [0]: counter read-backs (host syncs) of the solve         */
+    /* the dominant kernel by itself: discharge_ms / _launches / _tiles pool the one-wave-per-tile kernel (k_discharge_w) and the
+     * workgroup-per-tile kernel that takes the short lists; these three are k_discharge_w alone */
+    double  discharge_wave_ms;
+    int64_t discharge_wave_launches;
+    int64_t discharge_wave_tiles;
+    int64_t timing_stride;     /* every n-th solver launch of a kind carries a HIP event pair; the _ms are their mean x launches */
 } mgc_stats;
 
 /* Invariants of a maximum preflow, checked on the device (mgc_validate).  The reference has the same idea as a debugging

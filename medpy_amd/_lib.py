@@ -31,6 +31,8 @@ class Stats(C.Structure):
         ("discharge_launches", C.c_int64), ("relabel_launches", C.c_int64), ("discharge_tiles", C.c_int64),
         ("relabel_tiles", C.c_int64), ("global_relabels", C.c_int64), ("phases", C.c_int64), ("ntiles", C.c_int64),
         ("nvox", C.c_int64), ("device_bytes", C.c_int64), ("reserved", C.c_int64 * 3),
+        ("discharge_wave_ms", C.c_double), ("discharge_wave_launches", C.c_int64), ("discharge_wave_tiles", C.c_int64),
+        ("timing_stride", C.c_int64),
     ]
 
     def as_dict(self):

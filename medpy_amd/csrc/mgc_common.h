@@ -46,6 +46,7 @@
 #define MGC_CNT_CHANGED 21     /* suspect-closure pass changed something */
 #define MGC_CNT_FILTER 22      /* length of the scratch list the tile filters fill (absorb / relabel seeding / suspect reset) */
 #define MGC_CNT_FILTER_ACT 23  /* ... of the activation filter */
+#define MGC_CNT_WAVE_TILES 29  /* running total of the tiles k_discharge_w visited (count[8] pools both discharge kernels) */
 #define MGC_CNT_NOT_FULL 28    /* k_build: tiles holding an n-link inside the volume that is not residual (0: the first global relabel is a distance transform) */
 
 struct MgcLattice {
@@ -74,9 +75,20 @@ struct MgcLattice {
     uint32_t* oflags;         /* [ntiles] bit f: obox[f] holds something            */
     /* work lists: [0],[1] = discharge lists of colour 0 / 1 being consumed; [2],[3] = being produced;
        [4],[5] = relabel list consumed / produced */
-    int32_t*  list[20];       /* 26-neighbourhood: [0..15] discharge lists (target phase & 15), [16],[17] relabel */
+    int32_t*  list[20];       /* 26-neighbourhood: [0..15] discharge lists (target phase & 15), [16],[17] relabel.  Every list is
+                                 cut into `nshard` regions of `shard_cap` entries (see scount) */
     int32_t*  count;          /* [MGC_NCOUNT] device resident: [0..5] list lengths, [6] active tiles found by the last
                                  activation, [8]/[9] running totals of tiles discharged / relabelled            */
+    /* SHARDED list lengths.  A list counter is the hottest word of the solver: every tile visit appends a few neighbours,
+       a relabel pass appends ~9 000 tiles in 30 us, and one address takes ~88 returning atomics per microsecond
+       (MI355X_MICROARCH.md, "dequeue") -- the resident waves of a launch finish their tiles in bursts and then queue up on
+       it.  So the length of list / counter slot c is the SUM of nshard words scount[c * nshard + s]; an appender uses the
+       shard its workgroup id selects (spread over the XCDs) and writes into region s of the list,
+       list[l][s * shard_cap + pos].  Consumers read the nshard words once (MgcListView) and walk the regions as one
+       sequence.  The host simulator runs with nshard = 1 and scount = count: the plain layout. */
+    int32_t*  scount;         /* [MGC_NCOUNT][nshard] */
+    int       nshard;         /* 1 or MGC_NSHARD */
+    int       shard_cap;      /* entries per region = ntiles (a list holds a tile at most once) */
     uint32_t* stamp;          /* [ntiles] de-duplication stamp for list appends (discharge) */
     uint32_t* rstamp;         /* [ntiles] same for the relabel lists                */
     uint32_t* status;         /* [ntiles] bit1 (2): the tile holds a residual arc to the sink; bit2 (4): DIRTY = discharged
@@ -86,6 +98,42 @@ struct MgcLattice {
                                  slab last received them -- a border tile only travels when it differs from this (or holds flow) */
     unsigned long long* prof; /* optional [16] cycle accumulators of the discharge sections (development aid) or NULL */
 };
+
+#define MGC_NSHARD 16
+
+MGC_HD int32_t* mgc_counter(const MgcLattice& L, int c, int shard) { return L.scount + c * L.nshard + shard; }
+
+/* the regions of one list as one sequence: pre[s] = entries in the regions before s (pre[k] = n for k >= nshard) */
+struct MgcListView {
+    int n;
+    int pre[MGC_NSHARD + 1];
+};
+
+MGC_HD int mgc_list_view(const MgcLattice& L, int c, MgcListView& v)
+{
+    int acc = 0;
+#if defined(__HIP_DEVICE_COMPILE__)
+#pragma unroll
+#endif
+    for (int s = 0; s < MGC_NSHARD; ++s) {
+        v.pre[s] = acc;
+        if (s < L.nshard) acc += L.scount[c * L.nshard + s];
+    }
+    v.pre[MGC_NSHARD] = acc;
+    return v.n = acc;
+}
+
+/* entry i (0 <= i < v.n) of list l whose length lives in the counter slot the view was taken from */
+MGC_HD int mgc_list_at(const MgcLattice& L, int l, const MgcListView& v, int i)
+{
+    int s = 0, base = 0;
+#if defined(__HIP_DEVICE_COMPILE__)
+#pragma unroll
+#endif
+    for (int k = 1; k < MGC_NSHARD; ++k)
+        if (i >= v.pre[k] && v.pre[k + 1] > v.pre[k]) { s = k; base = v.pre[k]; }
+    return L.list[l][(int64_t)s * L.shard_cap + (i - base)];
+}
 
 MGC_HD int mgc_tile_id(const MgcLattice& L, int tz, int ty, int tx) { return (tz * L.gy + ty) * L.gx + tx; }
 

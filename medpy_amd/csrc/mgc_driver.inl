@@ -20,7 +20,7 @@
  * Dev concept (every call is asynchronous on the device's stream unless it returns a value):
  *   fill_heights_inf()  zero_count(i)  read_counts(int out[MGC_NCOUNT])   absorb_all()   suspect_pass()  suspect_batch()
  *   relabel_all(epoch, next_list)  relabel_list(list, epoch, next_list)  first_relabel_dt() -> bool
- *   activate_all(phase)  discharge(list, phase, max_cycles, max_sweeps)
+ *   activate_all(phase)  discharge(list, phase, max_cycles, max_sweeps)  range_push(name) / range_pop() (tracing ranges)
  */
 #ifndef MGC_DRIVER_INL
 #define MGC_DRIVER_INL
@@ -96,6 +96,7 @@ int mgc_solve(Dev& dev, const MgcLattice& L, const MgcSolveParams& P, MgcSolveSt
 
     for (int outer = 0; outer < P.max_outer; ++outer) {
         /* ---- global relabel ---- */
+        dev.range_push("global relabel");
         dev.absorb_all();
         dev.zero_count(lay.rl_base);
         dev.zero_count(lay.rl_base + 1);
@@ -148,8 +149,10 @@ int mgc_solve(Dev& dev, const MgcLattice& L, const MgcSolveParams& P, MgcSolveSt
             }
         }
         st.outer++;
+        dev.range_pop();
 
         /* ---- who can still push towards the sink? ---- */
+        dev.range_push("activation");
         phase += 2 * (uint32_t)(lay.list_mask + 1); /* fresh stamps: anything queued before the relabel is void */
         for (int i = 0; i <= lay.list_mask; ++i) dev.zero_count(i);
         dev.zero_count(lay.cnt_active);
@@ -169,12 +172,14 @@ int mgc_solve(Dev& dev, const MgcLattice& L, const MgcSolveParams& P, MgcSolveSt
             prev_dis = cnt[lay.cnt_dis];
             prev_rel = cnt[lay.cnt_rel];
         }
+        dev.range_pop();
         if (cnt[lay.cnt_active] == 0) {
             st.converged = 1;
             return 0;
         }
 
         /* ---- colour phases ---- */
+        dev.range_push("colour phases");
         for (int r = 0; r < rounds; ++r) {
             for (int c = 0; c < lay.ncolours; ++c) {
                 const int lst = (int)(phase & (uint32_t)lay.list_mask);
@@ -191,6 +196,7 @@ int mgc_solve(Dev& dev, const MgcLattice& L, const MgcSolveParams& P, MgcSolveSt
                 if (pending == 0) break;
             }
         }
+        dev.range_pop();
     }
     {   /* not converged within max_outer: leave the work counters of the truncated run */
         dev.read_counts(cnt);

@@ -116,6 +116,8 @@ struct GpuBlockT {
     __device__ __forceinline__ int atomic_add(int32_t* p, int v) { return atomicAdd(p, v); }
     __device__ __forceinline__ uint32_t atomic_exch(uint32_t* p, uint32_t v) { return atomicExch(p, v); }
     __device__ __forceinline__ void atomic_or(uint32_t* p, uint32_t v) { atomicOr(p, v); }
+    /* the region of a work list this workgroup appends to (MgcLattice::scount): workgroup ids go round the XCDs */
+    __device__ __forceinline__ int shard(const MgcLattice& L) const { return (int)(blockIdx.x & (unsigned)(L.nshard - 1)); }
     /* a value every lane of the workgroup holds alike (read from LDS after a barrier): scalar for the branches on it */
     __device__ __forceinline__ uint32_t uniform(uint32_t v) const { return (uint32_t)__builtin_amdgcn_readfirstlane((int)v); }
     __device__ __forceinline__ void atomic_and(uint32_t* p, uint32_t v) { atomicAnd(p, v); }
@@ -242,19 +244,35 @@ struct GpuWave {
     /* ---- running ahead of the tile loop (mgc_wave_ops.inl: W::kPrefetch) ---- */
     static constexpr int kPrefetch = MGCW_PREFETCH;
     int32_t* pf = nullptr;          /* 1 KiB of LDS the prefetch DMA lands in (never read) */
-    const int32_t* nlist = nullptr; /* the list being consumed, its length */
-    int nn = 0;
+    const int32_t* nlist = nullptr; /* the list being consumed */
     int tkv = 0, lsv = -1;          /* in flight: the ticket just drawn (lane 0), the list entry it points at */
-    __device__ __forceinline__ void ticket_issue(const MgcLattice& L, int tk)
+    /* Tickets are sharded like the lists: region s of the list being consumed has its own ticket word, drawn from by the
+     * waves whose home it is (workgroup id & (nshard - 1), `per` of them, which took its first `per` entries without a
+     * ticket) and by waves that ran out of work at home and moved on.  A wave visits the regions in ring order from its
+     * home and is done when it is back there. */
+    const MgcLattice* lat = nullptr;
+    int tk = 0, lc = 0, home = 0, cur = 0, curlen = 0; /* ticket slot, length slot of the list, home / current region and its length */
+    /* waves whose home region `sh` is: they took its first entries without a ticket, so its tickets start there */
+    __device__ __forceinline__ int per_of(int sh) const { return (int)(gridDim.x + (unsigned)(lat->nshard - 1 - sh)) / lat->nshard; }
+    __device__ __forceinline__ void ticket_issue(const MgcLattice& L, int)
     {
         tkv = 0;
-        if (threadIdx.x == 0) tkv = atomicAdd(&L.count[tk], 1);
+        if (cur >= 0 && threadIdx.x == 0) tkv = atomicAdd(mgc_counter(L, tk, cur), 1);
     }
     __device__ __forceinline__ void hint_begin()
     {
-        const int i = (int)gridDim.x + __builtin_amdgcn_readfirstlane(tkv);
         lsv = -1;
-        if (i < nn) lsv = nlist[i];
+        if (cur < 0) return;
+        int t = per_of(cur) + __builtin_amdgcn_readfirstlane(tkv);
+        while (t >= curlen) { /* this region is exhausted: on to the next one (rare: a few times per wave and launch) */
+            cur = (cur + 1) & (lat->nshard - 1);
+            if (cur == home) { cur = -1; return; }
+            curlen = __builtin_amdgcn_readfirstlane(*mgc_counter(*lat, lc, cur)); /* (nobody appends to the list being consumed) */
+            int v = 0;
+            if (threadIdx.x == 0) v = atomicAdd(mgc_counter(*lat, tk, cur), 1);
+            t = per_of(cur) + __builtin_amdgcn_readfirstlane(v);
+        }
+        lsv = nlist[(int64_t)cur * lat->shard_cap + t];
     }
     int nst = 0; /* in flight: the status word of that tile */
     int next_tile = -1;
@@ -278,6 +296,7 @@ struct GpuWave {
     __device__ __forceinline__ int atomic_add(int32_t* p, int v) { return atomicAdd(p, v); }
     __device__ __forceinline__ uint32_t atomic_exch(uint32_t* p, uint32_t v) { return atomicExch(p, v); }
     __device__ __forceinline__ void atomic_or(uint32_t* p, uint32_t v) { atomicOr(p, v); }
+    __device__ __forceinline__ int shard(const MgcLattice& L) const { return (int)(blockIdx.x & (unsigned)(L.nshard - 1)); }
     /* a value every lane of the workgroup holds alike (read from LDS after a barrier): scalar for the branches on it */
     __device__ __forceinline__ uint32_t uniform(uint32_t v) const { return (uint32_t)__builtin_amdgcn_readfirstlane((int)v); }
     __device__ __forceinline__ void atomic_and(uint32_t* p, uint32_t v) { atomicAnd(p, v); }
@@ -321,6 +340,12 @@ __device__ __forceinline__ int mgcw_next_ticket(const MgcLattice& L, int tk)
     return (int)gridDim.x + __builtin_amdgcn_readfirstlane(i);
 }
 
+/* workgroup 0 clears the words of counter slot c (a list the schedule is done with, or the next launch's tickets) */
+__device__ __forceinline__ void mgc_clear_counter(const MgcLattice& L, int c)
+{
+    if (c >= 0 && blockIdx.x == 0 && (int)threadIdx.x < L.nshard) *mgc_counter(L, c, (int)threadIdx.x) = 0;
+}
+
 #ifndef MGCW_DISCHARGE_WAVES
 #define MGCW_DISCHARGE_WAVES 2 /* waves per SIMD the register allocator leaves room for: 256 VGPRs each.  Measured on MI355X at 512^3: 2 -> 24.0 ms
                                   of discharge kernels per step, 3 (168 VGPRs, 150 of them spilled around the load / store phases) -> 31.8 ms,
@@ -331,15 +356,16 @@ void k_discharge_w(MgcLattice L, int lst, uint32_t phase, int sweeps, int flags,
 {
     __shared__ MgcWaveShared S;
     GpuWave w(S);
-    const int n = L.count[lst];
-    if (blockIdx.x == 0 && threadIdx.x == 0) {
-        if (n) atomicAdd(&L.count[8], n);
-        L.count[tk ^ 1] = 0;
-        if (zero_idx >= 0) L.count[zero_idx] = 0; /* the list the previous phase consumed */
+    if (blockIdx.x == 0) { /* running totals: tiles discharged */
+        MgcListView view;
+        const int n = mgc_list_view(L, lst, view);
+        if (threadIdx.x == 0 && n) { atomicAdd(&L.count[8], n); atomicAdd(&L.count[MGC_CNT_WAVE_TILES], n); }
     }
+    mgc_clear_counter(L, tk ^ 1);
+    mgc_clear_counter(L, zero_idx); /* the list the previous phase consumed */
     /* development knob: the second half of the grid (the second wave of every SIMD) starts late, so that the two waves of a
      * SIMD do not sit in their load / store phases at the same moments (units of ~8 000 shader cycles) */
-    if (stagger > 0 && blockIdx.x >= gridDim.x / 2 && (int)blockIdx.x < n)
+    if (stagger > 0 && blockIdx.x >= gridDim.x / 2)
         for (int k = 0; k < stagger; ++k) __builtin_amdgcn_s_sleep(127);
     /* The wave runs one tile ahead of itself: the ticket for its NEXT tile is drawn when a visit starts and resolved in the
      * middle of it (hint_begin / hint_end inside mgcw_discharge_impl), together with that tile's status word -- a returning
@@ -347,11 +373,23 @@ void k_discharge_w(MgcLattice L, int lst, uint32_t phase, int sweeps, int flags,
     __shared__ int32_t pf[256];
     w.pf = pf;
     w.nlist = L.list[lst];
-    w.nn = n;
+    w.lat = &L;
+    w.tk = tk;
+    w.lc = lst;
+    w.home = w.cur = w.shard(L);
+    w.curlen = __builtin_amdgcn_readfirstlane(*mgc_counter(L, lst, w.home));
     int tile = -1, st = 0;
-    if ((int)blockIdx.x < n) {
-        tile = __builtin_amdgcn_readfirstlane(L.list[lst][blockIdx.x]);
-        st = (int)L.status[tile];
+    {
+        const int rank = (int)blockIdx.x / L.nshard; /* first visit: entry `rank` of the home region, no ticket */
+        if (rank < w.curlen) {
+            tile = L.list[lst][(int64_t)w.home * L.shard_cap + rank];
+        } else { /* nothing left at home: a ticket there comes back beyond its end, and the search moves on */
+            w.ticket_issue(L, tk);
+            w.hint_begin();
+            tile = w.lsv;
+        }
+        tile = __builtin_amdgcn_readfirstlane(tile);
+        if (tile >= 0) st = (int)L.status[tile];
     }
     while (tile >= 0) {
         w.new_tile();
@@ -373,15 +411,16 @@ __global__ __launch_bounds__(MGCW_LANES) void k_relabel_w(MgcLattice L, int lst,
 {
     __shared__ MgcWaveShared S;
     GpuWave w(S);
-    const int n = L.count[cnt];
+    MgcListView view;
+    const int n = mgc_list_view(L, cnt, view);
     if (blockIdx.x == 0 && threadIdx.x == 0) {
         if (n) atomicAdd(&L.count[9], n);
-        if (zero_list >= 0) L.count[zero_list] = 0; /* consumed by the previous pass; the next pass appends to it */
         L.count[tk ^ 1] = 0;
     }
+    mgc_clear_counter(L, zero_list); /* consumed by the previous pass; the next pass appends to it */
     for (int i = (int)blockIdx.x; i < n; i = mgcw_next_ticket(L, tk)) {
         w.new_tile();
-        mgcw_relabel_tile(w, L, __builtin_amdgcn_readfirstlane(L.list[lst][i]), epoch, next_list, first != 0);
+        mgcw_relabel_tile(w, L, __builtin_amdgcn_readfirstlane(mgc_list_at(L, lst, view, i)), epoch, next_list, first != 0);
     }
 }
 
@@ -443,6 +482,7 @@ struct GpuBlockV {
     __device__ __forceinline__ int atomic_add(int32_t* p, int v) { return atomicAdd(p, v); }
     __device__ __forceinline__ uint32_t atomic_exch(uint32_t* p, uint32_t v) { return atomicExch(p, v); }
     __device__ __forceinline__ void mark(const MgcLattice&, int) {}
+    __device__ __forceinline__ int shard(const MgcLattice& L) const { return (int)(blockIdx.x & (unsigned)(L.nshard - 1)); }
     __device__ __forceinline__ void atomic_or(uint32_t* p, uint32_t v) { atomicOr(p, v); }
     /* a value every lane of the workgroup holds alike (read from LDS after a barrier): scalar for the branches on it */
     __device__ __forceinline__ uint32_t uniform(uint32_t v) const { return (uint32_t)__builtin_amdgcn_readfirstlane((int)v); }
@@ -460,14 +500,13 @@ __global__ __launch_bounds__(MGC_TV / MGC_RELABEL_V) void k_relabel_v(MgcLattice
 {
     __shared__ MgcTileSharedR S;
     GpuBlockR x(S);
-    const int n = L.count[cnt];
-    if (blockIdx.x == 0 && threadIdx.x == 0) {
-        if (n) atomicAdd(&L.count[9], n);
-        if (zero_list >= 0) L.count[zero_list] = 0; /* consumed by the previous pass; the next pass appends to it */
-    }
+    MgcListView view;
+    const int n = mgc_list_view(L, cnt, view);
+    if (blockIdx.x == 0 && threadIdx.x == 0 && n) atomicAdd(&L.count[9], n);
+    mgc_clear_counter(L, zero_list); /* consumed by the previous pass; the next pass appends to it */
     for (int i = blockIdx.x; i < n; i += gridDim.x) {
         x.new_tile();
-        mgc_relabel_tile(x, L, L.list[lst][i], epoch, next_list, first != 0);
+        mgc_relabel_tile(x, L, mgc_list_at(L, lst, view, i), epoch, next_list, first != 0);
         __syncthreads();
     }
 }
@@ -482,11 +521,12 @@ void k26_discharge_v(MgcLattice L, int lst, uint32_t phase, int cycles, int swee
 {
     __shared__ MgcTileShared26V S;
     GpuBlockV<2, MgcTileShared26V, true> x(S);
-    const int n = L.count[lst];
+    MgcListView view;
+    const int n = mgc_list_view(L, lst, view);
     if (blockIdx.x == 0 && threadIdx.x == 0 && n) atomicAdd(&L.count[MGC26_CNT_DIS], n);
     for (int i = blockIdx.x; i < n; i += gridDim.x) {
         x.new_tile();
-        mgc26_discharge_tile<26>(x, L, L.list[lst][i], phase, cycles, sweeps);
+        mgc26_discharge_tile<26>(x, L, mgc_list_at(L, lst, view, i), phase, cycles, sweeps);
         __syncthreads();
     }
 }
@@ -512,11 +552,12 @@ __global__ __launch_bounds__(MGC_TV, MGC26_RELABEL_WAVES) void k26_relabel_list(
 {
     __shared__ MgcTileShared26 S;
     GpuBlock26 x(S);
-    const int n = L.count[lst];
+    MgcListView view;
+    const int n = mgc_list_view(L, lst, view);
     if (blockIdx.x == 0 && threadIdx.x == 0 && n) atomicAdd(&L.count[MGC26_CNT_REL], n);
     for (int i = blockIdx.x; i < n; i += gridDim.x) {
         x.new_tile();
-        mgc26_relabel_tile(x, L, L.list[lst][i], epoch, next_list, false);
+        mgc26_relabel_tile(x, L, mgc_list_at(L, lst, view, i), epoch, next_list, false);
         __syncthreads();
     }
 }
@@ -542,12 +583,13 @@ __global__ __launch_bounds__(MGC_TV, MGC26_DISCHARGE_WAVES) void k26_discharge(M
 {
     __shared__ MgcTileShared26D S;
     GpuBlock26D x(S);
-    const int n = L.count[lst];
+    MgcListView view;
+    const int n = mgc_list_view(L, lst, view);
     if (blockIdx.x == 0 && threadIdx.x == 0 && n) atomicAdd(&L.count[MGC26_CNT_DIS], n);
     for (int i = blockIdx.x; i < n; i += gridDim.x) {
         x.new_tile();
         if (L.prof && threadIdx.x == 0) x.last = clock64();
-        mgc26_discharge_tile(x, L, L.list[lst][i], phase, cycles, sweeps);
+        mgc26_discharge_tile(x, L, mgc_list_at(L, lst, view, i), phase, cycles, sweeps);
         __syncthreads();
     }
     x.flush_marks(L);
@@ -582,21 +624,23 @@ __global__ __launch_bounds__(MGC_TV) void k_relabel_list(MgcLattice L, int lst, 
 {
     __shared__ MgcTileShared S;
     GpuBlock x(S);
-    const int n = L.count[lst];
-    if (blockIdx.x == 0 && threadIdx.x == 0) {
-        if (n) atomicAdd(&L.count[9], n);
-        if (zero_list >= 0) L.count[zero_list] = 0; /* consumed by the previous pass; the next pass appends to it */
-    }
+    MgcListView view;
+    const int n = mgc_list_view(L, lst, view);
+    if (blockIdx.x == 0 && threadIdx.x == 0 && n) atomicAdd(&L.count[9], n);
+    mgc_clear_counter(L, zero_list); /* consumed by the previous pass; the next pass appends to it */
     for (int i = blockIdx.x; i < n; i += gridDim.x) {
         x.new_tile();
-        mgc_relabel_tile(x, L, L.list[lst][i], epoch, next_list, false);
+        mgc_relabel_tile(x, L, mgc_list_at(L, lst, view, i), epoch, next_list, false);
         __syncthreads();
     }
 }
 
-__global__ void k_zero_counts(int32_t* count, uint32_t mask)
+__global__ void k_zero_counts(MgcLattice L, uint32_t mask)
 {
-    if ((mask >> threadIdx.x) & 1u) count[threadIdx.x] = 0;
+    const int c = (int)threadIdx.x / MGC_NSHARD, sh = (int)threadIdx.x % MGC_NSHARD; /* MGC_NCOUNT * MGC_NSHARD threads */
+    if (!((mask >> c) & 1u)) return;
+    if (sh == 0) L.count[c] = 0;
+    if (sh < L.nshard) *mgc_counter(L, c, sh) = 0;
 }
 
 __global__ void k_status_or(MgcLattice L, uint32_t bits)
@@ -688,9 +732,10 @@ __global__ void k_filter(MgcLattice L, int mode, int list, int cnt)
         const unsigned long long m = __ballot(take);
         if (m) {
             int pos = 0;
-            if ((threadIdx.x & 63) == 0) pos = atomicAdd(&L.count[cnt], __popcll(m));
+            const int sh = (int)(blockIdx.x & (unsigned)(L.nshard - 1));
+            if ((threadIdx.x & 63) == 0) pos = atomicAdd(mgc_counter(L, cnt, sh), __popcll(m));
             pos = __shfl(pos, 0);
-            if (take) L.list[list][pos + __popcll(m & ((1ull << (threadIdx.x & 63)) - 1ull))] = tile;
+            if (take) L.list[list][(int64_t)sh * L.shard_cap + pos + __popcll(m & ((1ull << (threadIdx.x & 63)) - 1ull))] = tile;
         }
     }
 }
@@ -700,11 +745,12 @@ __global__ __launch_bounds__(MGC_TV) void k_relabel_first_list(MgcLattice L, int
 {
     __shared__ MgcTileShared S;
     GpuBlock x(S);
-    const int n = L.count[cnt];
+    MgcListView view;
+    const int n = mgc_list_view(L, cnt, view);
     if (blockIdx.x == 0 && threadIdx.x == 0 && n) atomicAdd(&L.count[9], n);
     for (int i = blockIdx.x; i < n; i += gridDim.x) {
         x.new_tile();
-        mgc_relabel_tile(x, L, L.list[list][i], epoch, next_list, true);
+        mgc_relabel_tile(x, L, mgc_list_at(L, list, view, i), epoch, next_list, true);
         __syncthreads();
     }
 }
@@ -713,10 +759,11 @@ __global__ __launch_bounds__(MGC_TV) void k_absorb_list(MgcLattice L, int list, 
 {
     __shared__ MgcTileShared S;
     GpuBlock x(S);
-    const int n = L.count[cnt];
+    MgcListView view;
+    const int n = mgc_list_view(L, cnt, view);
     for (int i = blockIdx.x; i < n; i += gridDim.x) {
         x.new_tile();
-        mgc_absorb_tile(x, L, L.list[list][i]);
+        mgc_absorb_tile(x, L, mgc_list_at(L, list, view, i));
         __syncthreads();
     }
 }
@@ -725,10 +772,11 @@ __global__ __launch_bounds__(MGC_TV) void k_activate_list(MgcLattice L, int list
 {
     __shared__ MgcTileShared S;
     GpuBlock x(S);
-    const int n = L.count[cnt];
+    MgcListView view;
+    const int n = mgc_list_view(L, cnt, view);
     for (int i = blockIdx.x; i < n; i += gridDim.x) {
         x.new_tile();
-        mgc_activate_tile(x, L, L.list[list][i], phase);
+        mgc_activate_tile(x, L, mgc_list_at(L, list, view, i), phase);
         __syncthreads();
     }
 }
@@ -762,11 +810,38 @@ __global__ __launch_bounds__(256) void k_activate_w(MgcLattice L, int list, int 
 {
     __shared__ MgcWaveShared S; /* (not touched: the executor wants one) */
     GpuWave w(S);
-    const int n = L.count[cnt];
-    const bool exact = n <= exact_max; /* many candidates: their status words decide (mgcw_activate_tile) */
-    for (int i = (int)blockIdx.x * 4 + (int)(threadIdx.x >> 6); i < n; i += (int)gridDim.x * 4) {
-        w.new_tile();
-        mgcw_activate_tile(w, L, __builtin_amdgcn_readfirstlane(L.list[list][i]), phase, exact);
+    MgcListView view;
+    const int n = mgc_list_view(L, cnt, view);
+    if (n <= exact_max) { /* few candidates: look at their voxels (mgcw_activate_tile) */
+        for (int i = (int)blockIdx.x * 4 + (int)(threadIdx.x >> 6); i < n; i += (int)gridDim.x * 4) {
+            w.new_tile();
+            mgcw_activate_tile(w, L, __builtin_amdgcn_readfirstlane(mgc_list_at(L, list, view, i)), phase, true);
+        }
+        return;
+    }
+    /* many candidates: their status words decide (the filter checked them: owned, excess under a finite label, not ALLINF).
+     * One THREAD per candidate, one atomic per wave and colour -- one per tile on the two list words cost 140 us at 512^3. */
+    const int sh = (int)(blockIdx.x & (unsigned)(L.nshard - 1)), lane = (int)(threadIdx.x & 63);
+    for (int base = (int)blockIdx.x * 256; base < n; base += (int)gridDim.x * 256) {
+        const int i = base + (int)threadIdx.x;
+        const bool take = i < n;
+        const int tile = take ? mgc_list_at(L, list, view, i) : 0;
+        int tz, ty, tx;
+        mgc_tile_coords(L, tile, tz, ty, tx);
+        const uint32_t target = phase + ((mgc_tile_colour(L, tz, ty, tx) ^ (int)(phase & 1u)) & 1);
+        for (uint32_t tg = phase; tg <= phase + 1; ++tg) {
+            const unsigned long long m = __ballot(take && target == tg);
+            if (!m) continue;
+            int pos = 0;
+            if (lane == 0) pos = atomicAdd(mgc_counter(L, (int)(tg & 3u), sh), __popcll(m));
+            pos = __shfl(pos, 0);
+            if (take && target == tg) {
+                L.list[tg & 3u][(int64_t)sh * L.shard_cap + pos + __popcll(m & ((1ull << lane) - 1ull))] = tile;
+                L.stamp[tile] = tg; /* (each candidate is listed once: no exchange needed to keep it unique) */
+            }
+        }
+        const unsigned long long all = __ballot(take);
+        if (all && lane == 0) atomicAdd(&L.count[6], __popcll(all));
     }
 }
 
@@ -774,10 +849,11 @@ __global__ __launch_bounds__(MGC_TV) void k_reset_suspect_list(MgcLattice L, int
 {
     __shared__ MgcTileShared S;
     GpuBlock x(S);
-    const int n = L.count[cnt];
+    MgcListView view;
+    const int n = mgc_list_view(L, cnt, view);
     for (int i = blockIdx.x; i < n; i += gridDim.x) {
         x.new_tile();
-        mgc_reset_suspect_tile(x, L, L.list[list][i], epoch, out_list);
+        mgc_reset_suspect_tile(x, L, mgc_list_at(L, list, view, i), epoch, out_list);
         __syncthreads();
     }
 }
@@ -801,15 +877,14 @@ __global__ __launch_bounds__(MGC_TV, MGC_DISCHARGE_WAVES) void k_discharge(MgcLa
 {
     __shared__ MgcTileShared S;
     GpuBlock x(S);
-    const int n = L.count[lst];
-    if (blockIdx.x == 0 && threadIdx.x == 0) {
-        if (n) atomicAdd(&L.count[8], n);
-        if (zero_idx >= 0) L.count[zero_idx] = 0; /* the list the previous phase consumed */
-    }
+    MgcListView view;
+    const int n = mgc_list_view(L, lst, view);
+    if (blockIdx.x == 0 && threadIdx.x == 0 && n) atomicAdd(&L.count[8], n);
+    mgc_clear_counter(L, zero_idx); /* the list the previous phase consumed */
     for (int i = blockIdx.x; i < n; i += gridDim.x) {
         x.new_tile();
         if (L.prof && threadIdx.x == 0) x.last = clock64();
-        mgc_discharge_tile(x, L, L.list[lst][i], phase, cycles, sweeps);
+        mgc_discharge_tile(x, L, mgc_list_at(L, lst, view, i), phase, cycles, sweeps);
         __syncthreads();
     }
     x.flush_marks(L);
@@ -1467,6 +1542,42 @@ __global__ void k_untile_f64(MgcLattice L, const double* tiled, double* out)
 /* ======================================================================================
  * host side: handle, device policy, C ABI
  * ==================================================================================== */
+
+/* roctx ranges around the stretches of a solve (tracing), for rocprofv3 --marker-trace: opt-in with
+ * MEDPY_HIP_ROCTX=1, resolved lazily from the profiler's own library so that nothing is linked or loaded otherwise */
+struct MgcRoctx {
+    bool tried = false;
+    int (*push)(const char*) = nullptr;
+    int (*pop)() = nullptr;
+    void resolve()
+    {
+        tried = true;
+        const char* on = getenv("MEDPY_HIP_ROCTX");
+        if (!on || !*on || *on == '0') return;
+        for (const char* n : {"librocprofiler-sdk-roctx.so.1", "librocprofiler-sdk-roctx.so", "libroctx64.so.4", "libroctx64.so"}) {
+            void* dl = dlopen(n, RTLD_NOW | RTLD_GLOBAL);
+            if (!dl) continue;
+            *(void**)(&push) = dlsym(dl, "roctxRangePushA");
+            *(void**)(&pop) = dlsym(dl, "roctxRangePop");
+            if (push && pop) return;
+            push = nullptr; pop = nullptr;
+        }
+    }
+};
+static MgcRoctx g_roctx;
+static inline void mgc_range_push(const char* name)
+{
+    if (!g_roctx.tried) g_roctx.resolve();
+    if (g_roctx.push) (void)g_roctx.push(name);
+}
+static inline void mgc_range_pop()
+{
+    if (g_roctx.pop) (void)g_roctx.pop();
+}
+struct MgcRange { /* scope guard */
+    explicit MgcRange(const char* name) { mgc_range_push(name); }
+    ~MgcRange() { mgc_range_pop(); }
+};
 static std::string g_create_error;
 
 struct mgc_graph {
@@ -1565,6 +1676,13 @@ static int mgc_alloc(mgc_handle h, T** p, int64_t count)
     return MGC_OK;
 }
 
+/* the counter block as the host sees it: slot c = its plain word + its shard words (a slot is used one way or the other) */
+static void mgc_fold_counts(mgc_handle h)
+{
+    for (int c = 0; c < MGC_NCOUNT; ++c)
+        for (int sh = 0; sh < MGC_NSHARD; ++sh) h->h_count[c] += h->h_count[MGC_NCOUNT + c * MGC_NSHARD + sh];
+}
+
 /* device policy for mgc_solve(): one kernel launch per call, in-order on the handle's stream.
  * List lengths live on the device, so launches use a fixed persistent-style grid and never wait
  * for the host; per-kernel time comes from HIP event pairs recorded on the launch stream and
@@ -1577,6 +1695,8 @@ struct HipDevT {
     int64_t discharge_launches = 0, relabel_launches = 0, readbacks = 0;
     int last_discharged = -1; /* list consumed by the discharge launched last (see pending_zero) */
     int suspect_batch() const { return 2; } /* closure passes between two looks at the "changed" flag: a pass settles a brick */
+    void range_push(const char* name) { mgc_range_push(name); } /* roctx range around a stretch of the schedule (mgc_driver.inl) */
+    void range_pop() { mgc_range_pop(); }
     struct Span { int a, b, kind; };
     std::vector<Span> spans;
     void check(hipError_t e) { if (e != hipSuccess && first_error == hipSuccess) first_error = e; }
@@ -1597,7 +1717,7 @@ struct HipDevT {
         if (h->pending_zero >= 0) h->zero_mask |= 1u << h->pending_zero;
         h->pending_zero = -1;
         if (h->zero_mask) {
-            hipLaunchKernelGGL(k_zero_counts, dim3(1), dim3(MGC_NCOUNT), 0, h->stream, h->L.count, h->zero_mask);
+            hipLaunchKernelGGL(k_zero_counts, dim3(1), dim3(MGC_NCOUNT * MGC_NSHARD), 0, h->stream, h->L, h->zero_mask);
             check(hipGetLastError());
         }
         h->zero_mask = 0;
@@ -1611,8 +1731,9 @@ struct HipDevT {
     void read_counts(int* out)
     {
         flush_zero();
-        check(hipMemcpyAsync(h->h_count, h->L.count, MGC_NCOUNT * sizeof(int32_t), hipMemcpyDeviceToHost, h->stream));
+        check(hipMemcpyAsync(h->h_count, h->L.count, MGC_NCOUNT * (1 + MGC_NSHARD) * sizeof(int32_t), hipMemcpyDeviceToHost, h->stream));
         check(hipStreamSynchronize(h->stream));
+        mgc_fold_counts(h);
         memcpy(out, h->h_count, MGC_NCOUNT * sizeof(int32_t));
         readbacks++;
         if (!FULL) { /* how long are the discharge lists at the moment?  (picks the form of the discharge kernel) */
@@ -1740,7 +1861,8 @@ struct HipDevT {
         const int zero_idx = h->pending_zero; /* cleared inside the kernel: nothing sits between two colour phases */
         h->pending_zero = -1;
         flush_zero(); /* (whatever else is waiting to be cleared) */
-        const int id = time_begin(0);
+        const bool wave_form = !FULL && (h->wave_kernels & 1) && h->est_phase_tiles >= h->wave_min_tiles;
+        const int id = time_begin(FULL || wave_form ? 0 : 3);
         if constexpr (FULL) {
             /* Busy phases (a regional term: 40 % of the tiles hold excess) are paced by their heaviest tiles, and excess cannot
              * leave a tile before its neighbours run: three sweeps per visit.  Sparse phases (a front of active tiles) are
@@ -1753,7 +1875,7 @@ struct HipDevT {
         /* one wave per tile has the higher throughput (2 048 tiles in flight, fewer instructions per tile), eight waves per tile
          * the shorter latency (36 us against 60 us for one tile): short lists -- small volumes, the tail of a solve -- are a
          * single tile deep per launch and go to the workgroup form.  Both forms keep the same state in HBM. */
-        else if ((h->wave_kernels & 1) && h->est_phase_tiles >= h->wave_min_tiles) { hipLaunchKernelGGL(k_discharge_w, dim3(h->wave_grid_dis), dim3(MGCW_LANES), 0, h->stream, h->L, lst, phase, sweeps, (h->wave_kernels & 4) ? MGCW_BFS : 0, h->tk_dis, zero_idx, h->wave_stagger); h->tk_dis ^= 1; }
+        else if (wave_form) { hipLaunchKernelGGL(k_discharge_w, dim3(h->wave_grid_dis), dim3(MGCW_LANES), 0, h->stream, h->L, lst, phase, sweeps, (h->wave_kernels & 4) ? MGCW_BFS : 0, h->tk_dis, zero_idx, h->wave_stagger); h->tk_dis ^= 1; }
         else hipLaunchKernelGGL(k_discharge, dim3(grid(h->L.ntiles)), dim3(MGC_TV), 0, h->stream, h->L, lst, phase,
                                 (h->wave_kernels & 1) && !(h->wave_kernels & 4) ? -1 : cycles, sweeps, zero_idx); /* same labelling policy as the wave form */
         check(hipGetLastError());
@@ -1761,14 +1883,16 @@ struct HipDevT {
         discharge_launches++;
         last_discharged = lst;
     }
-    int64_t timed[2] = {0, 0}, seen[2] = {0, 0}; /* launches with an event pair / launches, per kind */
+    int64_t timed[4] = {0, 0, 0, 0}, seen[4] = {0, 0, 0, 0}; /* launches with an event pair / launches, per kind: 0 = k_discharge_w (26-neighbourhood:
+                                                                 k26_discharge), 1 = relabel passes, 2 = one-off stretches, 3 = k_discharge (short lists) */
+    float block_ms = 0.f;
     int time_begin(int kind)
     {
         if (!h->timing) return -1;
         /* every `timing_stride`-th launch of a kind carries a pair of HIP events (an event is a barrier packet in the queue:
          * a pair around each of the ~450 solver launches of a 512^3 step costs 3 ms of its 47); the kernel time of the
          * kind is the mean of the timed launches times the number of launches.  An odd stride samples both tile colours. */
-        if (kind < 2) { /* (kind 2 = a one-off stretch, always timed, never extrapolated: the distance-transform relabel) */
+        if (kind != 2) { /* (kind 2 = a one-off stretch, always timed, never extrapolated: the distance-transform relabel) */
             if ((seen[kind]++ % h->timing_stride) != 0) return -1;
             timed[kind]++;
         }
@@ -1791,10 +1915,11 @@ struct HipDevT {
     {
         for (const Span& sp : spans) {
             float ms = 0.f;
-            if (hipEventElapsedTime(&ms, h->ev_pool[sp.a], h->ev_pool[sp.b]) == hipSuccess) (sp.kind == 0 ? discharge_ms : (sp.kind == 1 ? relabel_ms : once_ms)) += ms;
+            if (hipEventElapsedTime(&ms, h->ev_pool[sp.a], h->ev_pool[sp.b]) == hipSuccess) (sp.kind == 0 ? discharge_ms : (sp.kind == 1 ? relabel_ms : (sp.kind == 2 ? once_ms : block_ms))) += ms;
         }
         if (timed[0]) discharge_ms *= (float)seen[0] / (float)timed[0];
         if (timed[1]) relabel_ms *= (float)seen[1] / (float)timed[1];
+        if (timed[3]) block_ms *= (float)seen[3] / (float)timed[3];
         relabel_ms += once_ms;
     }
 };
@@ -1856,6 +1981,7 @@ static void mgc_sum_partials(mgc_handle h, int64_t n, double* out)
  * h->d_scalar[slot] */
 static int mgc_launch_readout(mgc_handle h, int slot, hipEvent_t after_labels)
 {
+    MgcRange range_("read-out: labels + cut value");
     MgcLattice& L = h->L;
     const bool rows8 = L.dx % 8 == 0;
     if (rows8) hipLaunchKernelGGL(k_labels8, dim3(2048), dim3(256), 0, h->stream, L, h->d_labels, h->d_tsum);
@@ -1952,9 +2078,12 @@ static int mgc_create_impl(int ndim, const int64_t* shape, int connectivity, int
             MGC_HIP(h, hipMemsetAsync(L.hshadow[sd], 0x3f, (size_t)L.gy * L.gx * MGC_TF * sizeof(int32_t), h->stream));
         }
     }
+    L.nshard = MGC_NSHARD; /* sharded list lengths: MgcLattice::scount */
+    L.shard_cap = (int)nt;
     for (int i = 0; i < (L.ndir == 6 ? 8 : 18); ++i)
-        if ((rc = mgc_alloc(h, &L.list[i], nt))) return rc;
-    if ((rc = mgc_alloc(h, &L.count, (int64_t)MGC_NCOUNT))) return rc;
+        if ((rc = mgc_alloc(h, &L.list[i], nt * MGC_NSHARD))) return rc;
+    if ((rc = mgc_alloc(h, &L.count, (int64_t)MGC_NCOUNT * (1 + MGC_NSHARD)))) return rc; /* count[MGC_NCOUNT] | scount[MGC_NCOUNT][MGC_NSHARD] */
+    L.scount = L.count + MGC_NCOUNT;
     if ((rc = mgc_alloc(h, &L.stamp, nt))) return rc;
     if ((rc = mgc_alloc(h, &L.rstamp, nt))) return rc;
     if ((rc = mgc_alloc(h, &L.status, nt))) return rc;
@@ -1965,9 +2094,9 @@ static int mgc_create_impl(int ndim, const int64_t* shape, int connectivity, int
     if ((rc = mgc_alloc(h, &h->d_part2, (int64_t)256))) return rc;
     if ((rc = mgc_alloc(h, &h->d_scalar, (int64_t)8))) return rc;
     if ((rc = mgc_alloc(h, &h->d_labels, n))) return rc;
-    MGC_HIP(h, hipHostMalloc((void**)&h->h_count, MGC_NCOUNT * sizeof(int32_t), hipHostMallocDefault));
+    MGC_HIP(h, hipHostMalloc((void**)&h->h_count, MGC_NCOUNT * (1 + MGC_NSHARD) * sizeof(int32_t), hipHostMallocDefault));
     MGC_HIP(h, hipHostMalloc((void**)&h->h_scalar, 8 * sizeof(double), hipHostMallocDefault));
-    MGC_HIP(h, hipMemsetAsync(L.count, 0, MGC_NCOUNT * sizeof(int32_t), h->stream));
+    MGC_HIP(h, hipMemsetAsync(L.count, 0, MGC_NCOUNT * (1 + MGC_NSHARD) * sizeof(int32_t), h->stream));
     MGC_HIP(h, hipStreamSynchronize(h->stream));
     if (const char* wv = getenv("MEDPY_HIP_WAVE")) h->wave_kernels = atoi(wv); /* development aid: A/B the kernel forms */
     { /* persistent grids of the wave kernels: as many waves as the device keeps resident */
@@ -2021,8 +2150,9 @@ int mgc_read_counts(mgc_handle h, int32_t* out)
     if (!h || !out) return MGC_ERR_INVALID;
     MGC_HIP(h, hipSetDevice(h->device));
     mgc_flush_zero(h);
-    MGC_HIP(h, hipMemcpyAsync(h->h_count, h->L.count, MGC_NCOUNT * sizeof(int32_t), hipMemcpyDeviceToHost, h->stream));
+    MGC_HIP(h, hipMemcpyAsync(h->h_count, h->L.count, MGC_NCOUNT * (1 + MGC_NSHARD) * sizeof(int32_t), hipMemcpyDeviceToHost, h->stream));
     MGC_HIP(h, hipStreamSynchronize(h->stream));
+    mgc_fold_counts(h);
     memcpy(out, h->h_count, MGC_NCOUNT * sizeof(int32_t));
     return MGC_OK;
 }
@@ -2184,9 +2314,13 @@ int mgc_comm_init(mgc_handle h, const uint8_t* id128)
     return MGC_OK;
 }
 
-__global__ void k_widen_counts(const int32_t* c, int64_t* out)
+__global__ void k_widen_counts(MgcLattice L, int64_t* out)
 {
-    if (threadIdx.x < MGC_NCOUNT) out[threadIdx.x] = c[threadIdx.x];
+    if (threadIdx.x < MGC_NCOUNT) {
+        int64_t v = L.count[threadIdx.x];
+        for (int sh = 0; sh < L.nshard; ++sh) v += *mgc_counter(L, (int)threadIdx.x, sh);
+        out[threadIdx.x] = v;
+    }
 }
 
 int mgc_allreduce_counts(mgc_handle h, int64_t* out)
@@ -2195,7 +2329,7 @@ int mgc_allreduce_counts(mgc_handle h, int64_t* out)
     if (!h->comm) return mgc_fail(h, MGC_ERR_STATE, "mgc_allreduce_counts before mgc_comm_init");
     MGC_HIP(h, hipSetDevice(h->device));
     mgc_flush_zero(h);
-    hipLaunchKernelGGL(k_widen_counts, dim3(1), dim3(64), 0, h->stream, (const int32_t*)h->L.count, h->d_cnt64);
+    hipLaunchKernelGGL(k_widen_counts, dim3(1), dim3(64), 0, h->stream, h->L, h->d_cnt64);
     MGC_HIP(h, hipGetLastError());
     MGC_NCCL(h, g_rccl.AllReduce(h->d_cnt64, h->d_cnt64 + MGC_NCOUNT, MGC_NCOUNT, ncclInt64, ncclSum, h->comm, h->stream));
     MGC_HIP(h, hipMemcpyAsync(out, h->d_cnt64 + MGC_NCOUNT, MGC_NCOUNT * sizeof(int64_t), hipMemcpyDeviceToHost, h->stream));
@@ -2478,6 +2612,7 @@ int mgc_build(mgc_handle h)
 {
     if (!h) return MGC_ERR_INVALID;
     MGC_HIP(h, hipSetDevice(h->device));
+    MgcRange range_("mgc_build");
     MgcLattice& L = h->L;
     MgcBuildArgs A{};
     A.image = h->d_image; A.img_dtype = h->img_dtype; A.term = h->d_image ? h->term : MGC_TERM_NONE;
@@ -2520,7 +2655,7 @@ int mgc_build(mgc_handle h)
     h->build_args = A;
     const int grid = L.ntiles < h->grid_cap * 4 ? L.ntiles : h->grid_cap * 4;
     const int bgrid = grid >= 8 ? grid / 8 * 8 : grid; /* k_build deals tiles to XCDs: multiple of 8 */
-    MGC_HIP(h, hipMemsetAsync(L.count, 0, MGC_NCOUNT * sizeof(int32_t), h->stream)); /* (k_build counts in MGC_CNT_NOT_FULL) */
+    MGC_HIP(h, hipMemsetAsync(L.count, 0, MGC_NCOUNT * (1 + MGC_NSHARD) * sizeof(int32_t), h->stream)); /* (k_build counts in MGC_CNT_NOT_FULL) */
     h->zero_mask = 0;
     h->pending_zero = -1;
     if (L.ndir == 6) mgc_launch_build<false>(A.term, bgrid, h->stream, L, A);
@@ -2575,6 +2710,7 @@ int mgc_maxflow(mgc_handle h, double* flow)
     MGC_HIP(h, hipSetDevice(h->device));
     MgcLattice& L = h->L;
     if (!h->solved) {
+        MgcRange range_("mgc_maxflow");
         MgcSolveStats st;
         MGC_HIP(h, hipEventRecord(h->ev[0], h->stream));
         HipDev dev;
@@ -2589,7 +2725,7 @@ int mgc_maxflow(mgc_handle h, double* flow)
             dev.spans.clear();
             for (const auto& sp : dev26.spans) dev.spans.push_back({sp.a, sp.b, sp.kind});
             dev.discharge_launches = dev26.discharge_launches; dev.relabel_launches = dev26.relabel_launches; dev.readbacks = dev26.readbacks;
-            for (int k = 0; k < 2; ++k) { dev.timed[k] = dev26.timed[k]; dev.seen[k] = dev26.seen[k]; }
+            for (int k = 0; k < 4; ++k) { dev.timed[k] = dev26.timed[k]; dev.seen[k] = dev26.seen[k]; }
         }
         mgc_flush_zero(h);
         if (dev.first_error != hipSuccess)
@@ -2597,7 +2733,7 @@ int mgc_maxflow(mgc_handle h, double* flow)
         if (rc) { /* the work counters of the truncated run stay readable (mgc_get_stats) */
             (void)hipStreamSynchronize(h->stream);
             dev.resolve_timing();
-            h->stats.discharge_ms = dev.discharge_ms; h->stats.relabel_ms = dev.relabel_ms;
+            h->stats.discharge_ms = dev.discharge_ms + dev.block_ms; h->stats.relabel_ms = dev.relabel_ms;
             h->stats.discharge_launches = dev.discharge_launches; h->stats.relabel_launches = dev.relabel_launches;
             h->stats.discharge_tiles = st.discharge_tiles; h->stats.relabel_tiles = st.relabel_tiles;
             h->stats.global_relabels = st.outer; h->stats.phases = st.phases;
@@ -2611,12 +2747,16 @@ int mgc_maxflow(mgc_handle h, double* flow)
         MGC_HIP(h, hipEventElapsedTime(&ms, h->ev[0], h->ev[1]));
         h->stats.solve_ms = ms;
         dev.resolve_timing();
-        h->stats.discharge_ms = dev.discharge_ms;
+        h->stats.discharge_ms = dev.discharge_ms + dev.block_ms;
+        h->stats.discharge_wave_ms = dev.discharge_ms;
+        h->stats.discharge_wave_launches = dev.seen[0];
+        h->stats.timing_stride = h->timing ? h->timing_stride : 0;
         h->stats.relabel_ms = dev.relabel_ms;
         h->stats.discharge_launches = dev.discharge_launches;
         h->stats.relabel_launches = dev.relabel_launches;
         h->stats.reserved[0] = dev.readbacks;
         h->stats.discharge_tiles = st.discharge_tiles;
+        h->stats.discharge_wave_tiles = L.ndir == 6 ? h->h_count[MGC_CNT_WAVE_TILES] : st.discharge_tiles; /* (as of the solve's last counter read-back) */
         h->stats.relabel_tiles = st.relabel_tiles;
         h->stats.global_relabels = st.outer;
         h->stats.phases = st.phases;

@@ -25,6 +25,7 @@
  *                        hand-offs of a push sweep need neither an LDS slot nor a barrier
  *   x.S                  MgcTileShared& (LDS)
  *   x.atomic_add/or/and/exch   device-scope atomics on global words
+ *   x.shard(L)           which region of a work list this executor appends to (0 .. L.nshard - 1)
  *   x.async_to_lds / x.async_wait   HBM -> LDS copy without a register round trip (global_load_lds on gfx950)
  *   x.tile_labels(mask, out)   exact in-tile distance labels from scratch given the halo in x.S.hs: out[lane] and the
  *                              tile's own cells of x.S.hs (chaotic relaxation in LDS, mgc_tile_bfs below; the residual
@@ -69,8 +70,9 @@ MGC_HD void mgc_enqueue(X& x, const MgcLattice& L, int listid, uint32_t* stamps,
 {
     if (!mgc_owned(L, tile)) return; /* ghost tiles are discharged / relabelled by the slab that owns them */
     if (x.atomic_exch(&stamps[tile], epoch) != epoch) {
-        const int pos = x.atomic_add(&L.count[listid], 1);
-        L.list[listid][pos] = tile;
+        const int sh = x.shard(L); /* the appender's region of the list (MgcLattice::scount) */
+        const int pos = x.atomic_add(mgc_counter(L, listid, sh), 1);
+        L.list[listid][(int64_t)sh * L.shard_cap + pos] = tile;
     }
 }
 

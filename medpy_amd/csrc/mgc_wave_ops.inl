@@ -61,6 +61,9 @@
 /* every lambda of this file must be inlined into the kernel: a call would force the register arrays it captures into memory */
 #define MGCW_INL __attribute__((always_inline))
 #define MGCW_BFS 1            /* discharge flag: exact in-tile labels (from scratch) before the sweeps */
+#ifndef MGCW_WAKE_FIRST
+#define MGCW_WAKE_FIRST 1     /* the tail of a discharge issues its wake-up atomics before its stores (0: after them) */
+#endif
 
 struct alignas(16) MgcWaveShared {
     int32_t hs[1000];          /* 10x10x10 distance labels: the tile plus a one-voxel halo */
@@ -494,60 +497,71 @@ MGC_HD void mgcw_discharge_impl(W& w, const MgcLattice& L, int tile, uint32_t ph
      * behind the ~70 stores below, the first of them would wait until the whole tile has been written back (that wait was
      * most of the "tail" section of the round-2 profile).  Nothing in this launch reads what they publish. ---- */
     w.fresh();
-    w.lanes([&](int l) MGCW_INL {
-        if (l < 6 && ((face >> l) & 1u)) {
-            w.atomic_or(&L.oflags[tile], 1u << l);
-            mgc_enqueue(w, L, (int)((phase + 1) & 3u), L.stamp, phase + 1, mgc_tile_nbr(L, tz, ty, tx, l));
-        }
-        if (l == 6 && active) mgc_enqueue(w, L, (int)((phase + 2) & 3u), L.stamp, phase + 2, tile);
-        /* DIRTY only if a residual arc disappeared: otherwise no distance in the tile (or through it) can have changed */
-        if (l == 7) L.status[tile] = (L.status[tile] & ~(MGC_ST_SINK | MGC_ST_EXCESS)) | (has_sink ? MGC_ST_SINK : 0u) | (saturated ? MGC_ST_DIRTY : 0u) | (has_exc ? MGC_ST_EXCESS : 0u);
-    });
-    /* ---- then ONE block of global stores nobody waits for: state, masks, labels, outbox ---- */
-    w.lanes([&](int l) MGCW_INL {
-        mgcw_static_for<8>([&](auto KK) MGCW_INL {
-            constexpr int K = decltype(KK)::value;
-            w.st(t_excess, K * 64 + l, e(l, K));
-            int m = 0;
-            if constexpr (SINK) {
-                const double sk = w.S.snk[K * 64 + l];
-                w.st(t_sink, K * 64 + l, sk);
-                m = sk > 0.0 ? MGC_MASK_SINK : 0;
+    auto wake_up = [&]() MGCW_INL {
+        w.lanes([&](int l) MGCW_INL {
+            if (l < 6 && ((face >> l) & 1u)) {
+                w.atomic_or(&L.oflags[tile], 1u << l);
+                mgc_enqueue(w, L, (int)((phase + 1) & 3u), L.stamp, phase + 1, mgc_tile_nbr(L, tz, ty, tx, l));
             }
-            mgcw_static_for<6>([&](auto DD) MGCW_INL {
-                constexpr int D = decltype(DD)::value;
-                m |= (r[D](l, K) > 0.0) ? (1 << D) : 0;
-            });
-            w.st(t_rmask, K * 64 + l, (uint8_t)m);
+            if (l == 6 && active) mgc_enqueue(w, L, (int)((phase + 2) & 3u), L.stamp, phase + 2, tile);
+            /* DIRTY only if a residual arc disappeared: otherwise no distance in the tile (or through it) can have changed */
+            if (l == 7) L.status[tile] = (L.status[tile] & ~(MGC_ST_SINK | MGC_ST_EXCESS)) | (has_sink ? MGC_ST_SINK : 0u) | (saturated ? MGC_ST_DIRTY : 0u) | (has_exc ? MGC_ST_EXCESS : 0u);
         });
-    });
-    mgcw_static_for<6>([&](auto DD) MGCW_INL { /* only the residual planes that changed */
-        constexpr int D = decltype(DD)::value;
-        if (!(dirty & (1u << D))) return;
+    };
+    auto write_back = [&]() MGCW_INL {
+        /* ---- then ONE block of global stores nobody waits for: state, masks, labels, outbox ---- */
         w.lanes([&](int l) MGCW_INL {
             mgcw_static_for<8>([&](auto KK) MGCW_INL {
                 constexpr int K = decltype(KK)::value;
-                w.st(t_rcap + D * MGC_TV, K * 64 + l, r[D](l, K));
+                w.st(t_excess, K * 64 + l, e(l, K));
+                int m = 0;
+                if constexpr (SINK) {
+                    const double sk = w.S.snk[K * 64 + l];
+                    w.st(t_sink, K * 64 + l, sk);
+                    m = sk > 0.0 ? MGC_MASK_SINK : 0;
+                }
+                mgcw_static_for<6>([&](auto DD) MGCW_INL {
+                    constexpr int D = decltype(DD)::value;
+                    m |= (r[D](l, K) > 0.0) ? (1 << D) : 0;
+                });
+                w.st(t_rmask, K * 64 + l, (uint8_t)m);
             });
         });
-    });
-    if (relabelled) {
-        w.lanes([&](int l) MGCW_INL {
-            mgcw_static_for<8>([&](auto KK) MGCW_INL {
-                constexpr int K = decltype(KK)::value;
-                w.st(t_height, K * 64 + l, h(l, K));
+        mgcw_static_for<6>([&](auto DD) MGCW_INL { /* only the residual planes that changed */
+            constexpr int D = decltype(DD)::value;
+            if (!(dirty & (1u << D))) return;
+            w.lanes([&](int l) MGCW_INL {
+                mgcw_static_for<8>([&](auto KK) MGCW_INL {
+                    constexpr int K = decltype(KK)::value;
+                    w.st(t_rcap + D * MGC_TV, K * 64 + l, r[D](l, K));
+                });
             });
         });
-    }
-    w.lanes([&](int l) MGCW_INL {
-        /* outbox: plain stores -- the neighbour emptied these slots when it last absorbed, and it always runs (or
-         * absorb_all does) between two of our discharges */
-#pragma unroll
-        for (int f = 0; f < 6; ++f) {
-            const double ob = w.S.inbox[f][l];
-            if (ob != 0.0) w.st(t_obox + f * MGC_TF, l, ob);
+        if (relabelled) {
+            w.lanes([&](int l) MGCW_INL {
+                mgcw_static_for<8>([&](auto KK) MGCW_INL {
+                    constexpr int K = decltype(KK)::value;
+                    w.st(t_height, K * 64 + l, h(l, K));
+                });
+            });
         }
-    });
+        w.lanes([&](int l) MGCW_INL {
+            /* outbox: plain stores -- the neighbour emptied these slots when it last absorbed, and it always runs (or
+             * absorb_all does) between two of our discharges */
+#pragma unroll
+            for (int f = 0; f < 6; ++f) {
+                const double ob = w.S.inbox[f][l];
+                if (ob != 0.0) w.st(t_obox + f * MGC_TF, l, ob);
+            }
+        });
+    };
+#if MGCW_WAKE_FIRST
+    wake_up();
+    write_back();
+#else
+    write_back();
+    wake_up();
+#endif
     w.mark(3); /* tail votes + stores */
 }
 

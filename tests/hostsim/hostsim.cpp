@@ -80,6 +80,7 @@ struct HostBlockT {
             dst[t] = (from >= 0 && from < 64) ? src[(t & ~63) + from] : 0.0;
         }
     }
+    int shard(const MgcLattice&) const { return 0; } /* one region per list: the plain layout (MgcLattice::scount) */
     int atomic_add(int32_t* p, int v) { int o = *p; *p += v; return o; }
     uint32_t atomic_exch(uint32_t* p, uint32_t v) { uint32_t o = *p; *p = v; return o; }
     void atomic_or(uint32_t* p, uint32_t v) { *p |= v; }
@@ -148,6 +149,7 @@ struct HostWave {
     void hint_begin() {}
     int hint_end(const MgcLattice&) { return -1; }
     void prefetch(const void*, int) {}
+    int shard(const MgcLattice&) const { return 0; } /* one region per list: the plain layout (MgcLattice::scount) */
     int atomic_add(int32_t* p, int v) { int o = *p; *p += v; return o; }
     uint32_t atomic_exch(uint32_t* p, uint32_t v) { uint32_t o = *p; *p = v; return o; }
     void atomic_or(uint32_t* p, uint32_t v) { *p |= v; }
@@ -186,6 +188,8 @@ struct HostDev {
         for (int sd = 0; sd < 2; ++sd) std::fill(hshadow[sd].begin(), hshadow[sd].end(), (int32_t)MGC_HINF); /* what the neighbours hold now */
     }
     void zero_count(int i) { L.count[i] = 0; }
+    void range_push(const char*) {}
+    void range_pop() {}
     void read_counts(int* out) { memcpy(out, L.count, MGC_NCOUNT * sizeof(int)); }
     void absorb_all() { HostBlock x(S); for (int t = 0; t < L.ntiles; ++t) mgc_absorb_tile(x, L, t); }
     void relabel_all(uint32_t epoch, int next)
@@ -321,6 +325,7 @@ struct HostDev {
         L.rmask = rmask.data(); L.obox = obox.data(); L.oflags = oflags.data();
         for (int i = 0; i < 8; ++i) L.list[i] = lists.data() + i * nt;
         L.count = count.data(); L.stamp = stamp.data(); L.rstamp = rstamp.data(); L.status = status.data();
+        L.scount = L.count; L.nshard = 1; L.shard_cap = (int)nt;
         for (int sd = 0; sd < 2; ++sd) {
             hshadow[sd].assign((size_t)L.gy * L.gx * MGC_TF, (int32_t)MGC_HINF);
             L.hshadow[sd] = hshadow[sd].data();
@@ -523,6 +528,8 @@ struct HostDev26 {
         for (int64_t i = 0; i < (int64_t)L.ntiles * MGC_TV; ++i) L.height[i] = MGC_HINF;
         for (int t = 0; t < L.ntiles; ++t) L.status[t] |= MGC_ST_ALLINF; /* until a relabel lowers a label */
     }
+    void range_push(const char*) {}
+    void range_pop() {}
     void zero_count(int i) { L.count[i] = 0; }
     void read_counts(int* out) { memcpy(out, L.count, MGC_NCOUNT * sizeof(int)); }
     void absorb_all() {}
@@ -586,6 +593,7 @@ struct HostDev26 {
         L.rmask32 = rmask32.data(); L.oflags = oflags.data();
         for (int i = 0; i < 18; ++i) L.list[i] = lists.data() + i * nt;
         L.count = count.data(); L.stamp = stamp.data(); L.rstamp = rstamp.data(); L.status = status.data();
+        L.scount = L.count; L.nshard = 1; L.shard_cap = (int)nt;
     }
 
     /* w[d*N + id] = capacity of the arc from LOCAL voxel id in direction d (0..25, mgc26_offset order), 0 where there

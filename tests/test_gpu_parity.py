@@ -233,6 +233,32 @@ def test_synthetic_vs_oracle(gen, shape):
     assert flow == pytest.approx(inj.flow, rel=1e-9)
 
 
+@pytest.mark.parametrize("gen,shape", [("sphere", (128, 128, 128)), ("hard", (96, 96, 96)), ("sphere", (20, 33, 47))])
+def test_cpu_capacities_into_the_gpu_solver(gen, shape):
+    """SURVEY Appendix B "cross-inject", the direction round 2 lacked at scale: the ORACLE's capacities (NumPy energies,
+    t-links merged by the reference BK's add_tweights) go into the device solver through the plug-in path (mgc_add_edges +
+    mgc_set_tweights_merged, no boundary term on the device), so the solve runs on bit-identical inputs: labels must equal
+    the reference BK's voxel for voxel, whatever exp() the device would have used."""
+    from medpy_amd import synthetic
+    from medpy_amd.graphcut.graph import VoxelGraph
+    s = getattr(synthetic, gen)(shape)
+    w = energy_numpy.boundary_weights(s["term"], s["image"], s["sigma"])
+    ref = pipeline.graphcut_voxel(s["fg"], s["bg"], weights=w)
+    i, j, ww = cutcheck.lattice_edges(shape, w)
+    assert not (s["fg"] & s["bg"]).any()
+    tr = np.where(s["fg"], 65535.0, 0.0) - np.where(s["bg"], 65535.0, 0.0)  # add_tweights on disjoint markers, graph.h:416-425
+    g = VoxelGraph(shape)
+    g._add_edges(i, j, ww, ww)
+    g._set_tweights_merged(tr, 0.0)
+    g._build()
+    flow = g.maxflow()
+    labels = g.labels()
+    np.testing.assert_array_equal(labels, ref.labels)
+    # flow = constant folded by add_tweights (zero here: disjoint markers) + capacity of the cut
+    assert flow == pytest.approx(ref.flow, rel=1e-9)
+    print("cpu capacities -> gpu solver %s %s: flow %.15g (oracle %.15g), stats %s" % (gen, shape, flow, ref.flow, g.stats()))
+
+
 def test_regional_plus_boundary_vs_oracle():
     labels, flow, ref, inj = _oracle_vs_gpu("sphere", (48, 48, 48), regional=True)
     np.testing.assert_array_equal(labels, inj.labels)

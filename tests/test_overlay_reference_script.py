@@ -87,3 +87,52 @@ def test_overlay_module_surface():
         for k in [k for k in sys.modules if k == "medpy" or k.startswith("medpy.")]:
             del sys.modules[k]
         sys.modules.update(saved)
+
+
+SHIPPED_SCRIPT = os.path.join(ROOT, "build", "ref_bin", "medpy_graphcut_voxel.py")  # written by __graft_entry__.build()
+
+
+@pytest.mark.gpu
+@pytest.mark.skipif(not os.path.exists(SHIPPED_SCRIPT), reason="build/ref_bin/medpy_graphcut_voxel.py did not travel (run __graft_entry__.build() where /root/reference exists)")
+@pytest.mark.parametrize("flag,term", [("diff_exp", "difference_exponential"), ("diff_div", "difference_division")])
+def test_reference_voxel_script_unmodified_on_the_hip_path(tmp_path, flag, term):
+    """The reference's bin/medpy_graphcut_voxel.py, byte for byte (shipped to the GPU box as a build product), run by
+    medpy_amd.overlay over libmedpyhip.so on the reference's notebook image b0 (1024 x 1024): its argument parsing, its
+    load / split_marker / graph_from_voxels / maxflow / one-call-per-voxel what_segment loop / save
+    (bin/medpy_graphcut_voxel.py:139-187) -- and the file it writes must hold the segmentation the reference pipeline wrote
+    for the same command (tests/golden/reference_b0.npz), up to the voxels the reference's own residual graph leaves open."""
+    from conftest import GOLDEN
+    from medpy_amd import io, overlay
+    from oracle import cutcheck, energy_numpy, pipeline
+    saved = {k: v for k, v in sys.modules.items() if k == "medpy" or k.startswith("medpy.")}
+    for k in saved:
+        del sys.modules[k]
+    try:
+        z = np.load(os.path.join(GOLDEN, "reference_b0.npz"))
+        img = z["image"].astype(np.dtype(str(z["image_dtype"])))
+        markers = z["markers"]
+        sigma = float(z[term + "/sigma"])
+        hdr = io.Header((1.0, 1.0))
+        io.save(img, str(tmp_path / "b0.nii.gz"), hdr, True)
+        io.save(markers, str(tmp_path / "b0markers.nii.gz"), hdr, True)
+        out = str(tmp_path / "seg.nii.gz")
+        overlay.run(SHIPPED_SCRIPT, [str(sigma), str(tmp_path / "b0.nii.gz"), str(tmp_path / "b0markers.nii.gz"), out, "--boundary", flag, "-f"])
+        import medpy.graphcut
+        import medpy_amd.graphcut
+        assert medpy.graphcut is medpy_amd.graphcut  # the script's `from medpy import graphcut` got this package
+        seg, _ = io.load(out)
+        ref = np.unpackbits(z[term + "/labels"])[: img.size].reshape(img.shape)
+        assert seg.shape == img.shape and seg.dtype == np.uint8
+        nbad = int((seg != ref).sum())
+        print(term, "voxels differing from the reference's output:", nbad)
+        if nbad:
+            fg, bg = markers == 1, markers == 2
+            cut = pipeline.graphcut_voxel(fg, bg, term=term, image=img, sigma=sigma)
+            np.testing.assert_array_equal(cut.labels, ref.astype(bool))
+            i, j, ww = cutcheck.lattice_edges(img.shape, energy_numpy.boundary_weights(term, img, sigma))
+            tr = np.where(fg, 65535.0, 0.0) - np.where(bg, 65535.0, 0.0)
+            cutcheck.assert_labels_equivalent(seg.astype(bool), cut, exact=(i, j, ww, ww, tr))
+    finally:
+        for k in [k for k in sys.modules if k == "medpy" or k.startswith("medpy.")]:
+            del sys.modules[k]
+        sys.modules.update(saved)
