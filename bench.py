@@ -68,12 +68,46 @@ def pmc_traffic_per_launch():
     return int((2.0 * d["fetch_kib_per_launch"] + d["write_kib_per_launch"]) * 1024), info
 
 
-def cpu_baseline(sample_n, full):
-    """Reference BK (oracle/_ref, or the C restatement when it did not travel) on a bounded sample, plus the committed
-    timing of the as-shipped Python path (BASELINE config 1) from the container that holds the reference."""
+def host_memory_gb():
+    try:
+        for ln in open("/proc/meminfo"):
+            if ln.startswith("MemAvailable:"):
+                return int(ln.split()[1]) / 1048576.0
+    except OSError:
+        pass
+    return 0.0
+
+
+def cpu_baseline_in_run(sample_n, want_full):
+    """The CPU leg of the line.  The whole 512^3 workload on the reference's own solver needs ~40 GB and ~5 minutes of one core: it
+    runs (in a child process, so that a box without the memory or the time cannot take the GPU numbers down with it) when the
+    host has >= 48 GB available, else the largest cube that fits -- 384^3 from 20 GB -- else the bounded sample."""
+    import subprocess
+    avail = host_memory_gb()
+    n = BLOCK if (want_full and avail >= 48.0) else (384 if (want_full and avail >= 20.0) else sample_n)
+    if n != sample_n:
+        try:
+            res = subprocess.run([sys.executable, os.path.abspath(__file__), "--cpu-only", str(n)], capture_output=True, text=True,
+                                 timeout=float(os.environ.get("MEDPY_CPU_BASELINE_TIMEOUT", "900")))
+            lines = [ln for ln in res.stdout.splitlines() if ln.startswith("{")]
+            if res.returncode == 0 and lines:
+                out = json.loads(lines[-1])
+                out["host_memory_available_gb"] = round(avail, 1)
+                return out
+            sys.stderr.write("[bench] CPU baseline at %d^3 failed (rc %d): %s\n" % (n, res.returncode, res.stderr[-300:]))
+        except subprocess.TimeoutExpired:
+            sys.stderr.write("[bench] CPU baseline at %d^3 timed out; falling back to the %d^3 sample\n" % (n, sample_n))
+    return cpu_baseline(sample_n)
+
+
+def cpu_baseline(n):
+    """Reference BK (oracle/_ref, or the C restatement when it did not travel) on an n^3 sphere volume: t_build = the
+    reference's NumPy energies + the bulk sum_edge / add_tweights construction, t_solve = maxflow(); no label read-out, no
+    hashing.  Plus the committed timing of the as-shipped Python path (BASELINE config 1) from the container
+    that holds the reference."""
     from medpy_amd import synthetic
     from oracle import bk, energy_numpy, pipeline
-    n = BLOCK if full else sample_n
+    full = n == BLOCK
     s = synthetic.sphere((n,) * 3)
     kind = bk.best_kind()
     t0 = time.perf_counter()
@@ -92,6 +126,7 @@ def cpu_baseline(sample_n, full):
     out = {
         "value": round(n ** 3 / (best[0] + tw) / 1e6, 4), "unit": "Mvoxels/s", "cores": 1,
         "kind": "reference" if kind == "ref" else "port",
+        "t_build_s": round(tw + best[1], 3), "t_solve_s": round(best[2], 3), "voxels": n ** 3,
         "sample": "%d^3 sphere volume (%s), 6-conn, diff_exp sigma 15; NumPy weights %.2fs + bulk sum_edge build %.2fs + BK maxflow %.2fs, "
                   "single thread (the reference is single-threaded), host has %d cores" % (
                       n, "the full workload" if full else "bounded sample of the 512^3 workload", tw, best[1], best[2], os.cpu_count()),
@@ -101,7 +136,7 @@ def cpu_baseline(sample_n, full):
         out["python_path"] = json.load(open(p))
     p = os.path.join(ROOT, "profiles", "cpu_reference_512.json")
     if os.path.exists(p) and not full:
-        out["full_workload"] = json.load(open(p))
+        out["full_workload_elsewhere"] = json.load(open(p))  # (measured in the build container, incl. read-out: for scale only)
     return out
 
 
@@ -144,9 +179,14 @@ def main():
     ap.add_argument("--planes", type=int, default=256, help="planes per GPU of the multi-GPU volume")
     ap.add_argument("--block", type=int, default=BLOCK, help="edge of one sphere block of the multi-GPU volume")
     ap.add_argument("--cpu-sample", type=int, default=320)
-    ap.add_argument("--cpu-full", action="store_true")
+    ap.add_argument("--cpu-full", action="store_true", help="(default when the host has the memory) the CPU leg runs the whole 512^3")
+    ap.add_argument("--cpu-sample-only", action="store_true", help="CPU leg on the bounded sample whatever the host")
     ap.add_argument("--no-cpu", action="store_true")
+    ap.add_argument("--cpu-only", type=int, default=0, help=argparse.SUPPRESS)  # child process of cpu_baseline_in_run
     args = ap.parse_args()
+    if args.cpu_only:
+        print(json.dumps(cpu_baseline(args.cpu_only)))
+        return
 
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
@@ -172,7 +212,8 @@ def main():
         raise SystemExit("bench.py: --config 4 is 1024^3 on 4 GPUs (launch with --gpus 4)")
 
     acc = {"build_ms": 0.0, "solve_ms": 0.0, "discharge_ms": 0.0, "relabel_ms": 0.0, "discharge_launches": 0,
-           "relabel_launches": 0, "discharge_tiles": 0, "relabel_tiles": 0, "global_relabels": 0, "phases": 0}
+           "relabel_launches": 0, "discharge_tiles": 0, "relabel_tiles": 0, "global_relabels": 0, "phases": 0,
+           "discharge_wave_ms": 0.0, "discharge_wave_launches": 0, "discharge_wave_tiles": 0}
     flow = 0.0
     slab_stats = validation = None
     transport = None
@@ -315,9 +356,11 @@ def main():
         }
         if slab_stats is None:
             # dominant kernel: k_discharge_w (region discharge, one wave per tile).  Units per launch = voxels of the tiles it visits.
-            launches = max(acc["discharge_launches"], 1)
-            avg_ms = acc["discharge_ms"] / launches
-            vox_per_launch = acc["discharge_tiles"] * 512.0 / launches
+            # (the short lists of a solve go to the workgroup-per-tile kernel k_discharge: its launches, time and tiles are NOT in here)
+            wave = conn == 6 and acc["discharge_wave_launches"] > 0
+            launches = max(acc["discharge_wave_launches"] if wave else acc["discharge_launches"], 1)
+            avg_ms = (acc["discharge_wave_ms"] if wave else acc["discharge_ms"]) / launches
+            vox_per_launch = (acc["discharge_wave_tiles"] if wave else acc["discharge_tiles"]) * 512.0 / launches
             achieved = (b_alg * vox_per_launch) / (avg_ms * 1e-3) / 1e9 if avg_ms > 0 else 0.0
             traffic, traffic_info = pmc_traffic_per_launch() if conn == 6 and not args.config else (None, None)
             out["phases_ms"] = {"build": round(acc["build_ms"] / args.steps, 3), "solve": round(acc["solve_ms"] / args.steps, 3),
@@ -328,12 +371,14 @@ def main():
             out["roofline"] = {"bound": "hbm", "kernel": "k_discharge_w" if conn == 6 else "k26_discharge", "achieved": round(achieved, 2),
                                "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBS, 5), "traffic": traffic,
                                "traffic_source": traffic_info, "avg_launch_ms": round(avg_ms, 4), "launches_per_step": launches / args.steps,
-                               "voxels_per_launch": round(vox_per_launch, 1), "bytes_per_voxel": b_alg}
+                               "voxels_per_launch": round(vox_per_launch, 1), "bytes_per_voxel": b_alg,
+                               "timing": "HIP event pairs on the launch stream around every %d-th launch of the kernel, mean x launches" % max(int(st.get("timing_stride", 1)), 1),
+                               "other_discharge_launches_per_step": (acc["discharge_launches"] - launches) / args.steps if wave else 0.0}
         else:
             out["slab_schedule"] = slab_stats
             out["roofline"] = None  # per-kernel event timing is a single-handle measurement (the N = 1 line)
         if not args.no_cpu and world == 1 and not args.config and not args.strong:
-            out["cpu_baseline"] = cpu_baseline(args.cpu_sample, args.cpu_full)
+            out["cpu_baseline"] = cpu_baseline_in_run(args.cpu_sample, not args.cpu_sample_only)
         else:
             out["cpu_baseline"] = None
         print(json.dumps(out))

@@ -246,33 +246,43 @@ struct GpuWave {
     int32_t* pf = nullptr;          /* 1 KiB of LDS the prefetch DMA lands in (never read) */
     const int32_t* nlist = nullptr; /* the list being consumed */
     int tkv = 0, lsv = -1;          /* in flight: the ticket just drawn (lane 0), the list entry it points at */
-    /* Tickets are sharded like the lists: region s of the list being consumed has its own ticket word, drawn from by the
-     * waves whose home it is (workgroup id & (nshard - 1), `per` of them, which took its first `per` entries without a
-     * ticket) and by waves that ran out of work at home and moved on.  A wave visits the regions in ring order from its
-     * home and is done when it is back there. */
+    /* The list being consumed is cut into regions (MgcLattice::scount); a ticket is an index into their concatenation.  The
+     * region lengths sit in lanes 0 .. nshard - 1 of one register for the whole launch (nobody appends to a list while it is
+     * consumed).  The ticket word itself stays ONE word: its atomic is issued when a visit starts and its value is only
+     * needed in the middle of the visit, so the queueing on it is hidden; what had to be spread out are the appends. */
     const MgcLattice* lat = nullptr;
-    int tk = 0, lc = 0, home = 0, cur = 0, curlen = 0; /* ticket slot, length slot of the list, home / current region and its length */
-    /* waves whose home region `sh` is: they took its first entries without a ticket, so its tickets start there */
-    __device__ __forceinline__ int per_of(int sh) const { return (int)(gridDim.x + (unsigned)(lat->nshard - 1 - sh)) / lat->nshard; }
-    __device__ __forceinline__ void ticket_issue(const MgcLattice& L, int)
+    int lens = 0;
+    __device__ __forceinline__ void list_begin(const MgcLattice& L, int lst)
+    {
+        lat = &L;
+        nlist = L.list[lst];
+        lens = 0;
+        if ((int)threadIdx.x < L.nshard) lens = *mgc_counter(L, lst, (int)threadIdx.x);
+    }
+    /* entry i of the concatenated regions, or -1 beyond the end */
+    __device__ __forceinline__ int entry_load(int i) const
+    {
+        int sh = 0, off = i, found = 0;
+#pragma unroll
+        for (int k = 0; k < MGC_NSHARD; ++k) {
+            const int len = __builtin_amdgcn_readlane(lens, k);
+            if (!found) {
+                if (off < len) { sh = k; found = 1; }
+                else off -= len;
+            }
+        }
+        int v = -1;
+        if (found) v = nlist[(int64_t)sh * lat->shard_cap + off];
+        return v;
+    }
+    __device__ __forceinline__ void ticket_issue(const MgcLattice& L, int tk)
     {
         tkv = 0;
-        if (cur >= 0 && threadIdx.x == 0) tkv = atomicAdd(mgc_counter(L, tk, cur), 1);
+        if (threadIdx.x == 0) tkv = atomicAdd(&L.count[tk], 1);
     }
     __device__ __forceinline__ void hint_begin()
     {
-        lsv = -1;
-        if (cur < 0) return;
-        int t = per_of(cur) + __builtin_amdgcn_readfirstlane(tkv);
-        while (t >= curlen) { /* this region is exhausted: on to the next one (rare: a few times per wave and launch) */
-            cur = (cur + 1) & (lat->nshard - 1);
-            if (cur == home) { cur = -1; return; }
-            curlen = __builtin_amdgcn_readfirstlane(*mgc_counter(*lat, lc, cur)); /* (nobody appends to the list being consumed) */
-            int v = 0;
-            if (threadIdx.x == 0) v = atomicAdd(mgc_counter(*lat, tk, cur), 1);
-            t = per_of(cur) + __builtin_amdgcn_readfirstlane(v);
-        }
-        lsv = nlist[(int64_t)cur * lat->shard_cap + t];
+        lsv = entry_load((int)gridDim.x + __builtin_amdgcn_readfirstlane(tkv));
     }
     int nst = 0; /* in flight: the status word of that tile */
     int next_tile = -1;
@@ -361,7 +371,7 @@ void k_discharge_w(MgcLattice L, int lst, uint32_t phase, int sweeps, int flags,
         const int n = mgc_list_view(L, lst, view);
         if (threadIdx.x == 0 && n) { atomicAdd(&L.count[8], n); atomicAdd(&L.count[MGC_CNT_WAVE_TILES], n); }
     }
-    mgc_clear_counter(L, tk ^ 1);
+    if (blockIdx.x == 0 && threadIdx.x == 0) L.count[tk ^ 1] = 0; /* the next launch's ticket word */
     mgc_clear_counter(L, zero_idx); /* the list the previous phase consumed */
     /* development knob: the second half of the grid (the second wave of every SIMD) starts late, so that the two waves of a
      * SIMD do not sit in their load / store phases at the same moments (units of ~8 000 shader cycles) */
@@ -372,25 +382,9 @@ void k_discharge_w(MgcLattice L, int lst, uint32_t phase, int sweeps, int flags,
      * atomic or a load issued behind the ~70 stores that end a visit would wait until they have all retired. */
     __shared__ int32_t pf[256];
     w.pf = pf;
-    w.nlist = L.list[lst];
-    w.lat = &L;
-    w.tk = tk;
-    w.lc = lst;
-    w.home = w.cur = w.shard(L);
-    w.curlen = __builtin_amdgcn_readfirstlane(*mgc_counter(L, lst, w.home));
-    int tile = -1, st = 0;
-    {
-        const int rank = (int)blockIdx.x / L.nshard; /* first visit: entry `rank` of the home region, no ticket */
-        if (rank < w.curlen) {
-            tile = L.list[lst][(int64_t)w.home * L.shard_cap + rank];
-        } else { /* nothing left at home: a ticket there comes back beyond its end, and the search moves on */
-            w.ticket_issue(L, tk);
-            w.hint_begin();
-            tile = w.lsv;
-        }
-        tile = __builtin_amdgcn_readfirstlane(tile);
-        if (tile >= 0) st = (int)L.status[tile];
-    }
+    w.list_begin(L, lst);
+    int tile = __builtin_amdgcn_readfirstlane(w.entry_load((int)blockIdx.x)), st = 0; /* first visit: no ticket */
+    if (tile >= 0) st = (int)L.status[tile];
     while (tile >= 0) {
         w.new_tile();
         w.mark(1); /* between two tiles */
@@ -1276,36 +1270,58 @@ __global__ __launch_bounds__(MGC_TV) void k_cut_value(MgcLattice L, MgcBuildArgs
     }
 }
 
-/* 6-neighbourhood form: labels straight from the tile-major distance labels (own tile + the six face layers next door
- * in LDS), so the C-order label volume is not needed, and a tile only reads what it can contribute: the merged t-links
- * only where k_build saw one of the paying sign (A.tflags), nothing at all for a tile that lies entirely on the sink side,
- * or with its six neighbours entirely on the source side (tsum: the per-tile summaries of k_labels8, or NULL).  Same additions in the same order as k_cut_value: the value is bit-identical. */
-__global__ __launch_bounds__(MGC_TV) void k_cut_value6(MgcLattice L, MgcBuildArgs A, const double* tr0, const uint8_t* tsum, double* part)
+/* 6-neighbourhood form, two kernels.  k_cut_filter: one THREAD per tile decides from the label summaries k_labels8 left
+ * (tsum; NULL: no summaries, every owned tile is looked at) and from the signs of t-link k_build saw (A.tflags) whether the
+ * tile can contribute to the cut at all; the few that can (the tiles the cut passes through, the marker tiles) go to a
+ * list, the others get their zero here.  k_cut_value6: per listed tile, labels straight from the tile-major distance
+ * labels (own tile + the six face layers next door in LDS), the merged t-links only where a paying sign exists.  Same
+ * additions in the same order as k_cut_value: the value is bit-identical. */
+__global__ void k_cut_filter(MgcLattice L, MgcBuildArgs A, const uint8_t* tsum, double* part, int list, int cnt)
+{
+    for (int base = blockIdx.x * blockDim.x; base < L.ntiles; base += gridDim.x * blockDim.x) { /* uniform per block */
+        const int tile = base + (int)threadIdx.x;
+        bool take = false;
+        if (tile < L.ntiles) {
+            const bool owned = mgc_owned(L, tile);
+            take = owned;
+            if (owned && tsum) {
+                const uint32_t tf = A.tflags[tile], sm = tsum[tile];
+                if (sm == 0) take = (tf & 1u) != 0; /* all on the sink side: only source links are paid */
+                else if (sm == 1 && !(tf & 2u)) {  /* all on the source side, no sink link: pays n-links into a neighbour tile at most */
+                    int tz, ty, tx;
+                    mgc_tile_coords(L, tile, tz, ty, tx);
+                    take = false;
+                    for (int f = 0; f < 6; ++f) {
+                        const int nt = mgc_tile_nbr(L, tz, ty, tx, f);
+                        if (nt >= 0 && !(mgc_owned(L, nt) && tsum[nt] == 1)) take = true; /* (a ghost tile only mirrors one voxel layer) */
+                    }
+                }
+            }
+            if (!take) part[tile] = 0.0;
+        }
+        const unsigned long long m = __ballot(take);
+        if (m) {
+            const int sh = (int)(blockIdx.x & (unsigned)(L.nshard - 1));
+            int pos = 0;
+            if ((threadIdx.x & 63) == 0) pos = atomicAdd(mgc_counter(L, cnt, sh), __popcll(m));
+            pos = __shfl(pos, 0);
+            if (take) L.list[list][(int64_t)sh * L.shard_cap + pos + __popcll(m & ((1ull << (threadIdx.x & 63)) - 1ull))] = tile;
+        }
+    }
+}
+
+__global__ __launch_bounds__(MGC_TV) void k_cut_value6(MgcLattice L, MgcBuildArgs A, const double* tr0, int list, int cnt, double* part)
 {
     __shared__ double scratch[MGC_TV];
     __shared__ int32_t hs[1000];
     const int t = threadIdx.x;
-    for (int tile = blockIdx.x; tile < L.ntiles; tile += gridDim.x) {
+    MgcListView view;
+    const int n = mgc_list_view(L, cnt, view);
+    for (int i = blockIdx.x; i < n; i += gridDim.x) {
+        const int tile = mgc_list_at(L, list, view, i);
         int tz, ty, tx;
         mgc_tile_coords(L, tile, tz, ty, tx);
-        const bool owned = mgc_owned(L, tile);
         const uint32_t tf = A.tflags[tile];
-        bool quiet = !owned;
-        if (owned && tsum) { /* the label summaries k_labels8 left: most tiles lie on one side of the cut and pay nothing */
-            const uint32_t sm = tsum[tile];
-            if (sm == 0) quiet = !(tf & 1u); /* all on the sink side: only source links are paid */
-            else if (sm == 1 && !(tf & 2u)) { /* all on the source side, no sink link: pays n-links into a neighbour tile at most */
-                quiet = true;
-                for (int f = 0; f < 6; ++f) {
-                    const int nt = mgc_tile_nbr(L, tz, ty, tx, f);
-                    if (nt >= 0 && !(mgc_owned(L, nt) && tsum[nt] == 1)) quiet = false; /* (a ghost tile only mirrors one voxel layer) */
-                }
-            }
-        }
-        if (quiet) { /* uniform per workgroup */
-            if (t == 0) part[tile] = 0.0;
-            continue;
-        }
         const int lz = t >> 6, ly = (t >> 3) & 7, lx = t & 7;
         const int me = mgc_hs_index(lz, ly, lx);
         const int32_t hme = L.height[(int64_t)tile * MGC_TV + t];
@@ -1348,25 +1364,38 @@ __global__ __launch_bounds__(MGC_TV) void k_cut_value6(MgcLattice L, MgcBuildArg
     }
 }
 
-/* label read-out for rows that are whole runs of eight voxels (D2 a multiple of 8), one wave per tile: lane (z, y) turns the
- * 32 bytes of its tile row into 8 label bytes, and the wave leaves a one-byte summary of the tile for k_cut_value6
- * (0: every voxel on the sink side, 1: every voxel on the source side, 2: both) */
+/* label read-out for rows that are whole runs of eight voxels (D2 a multiple of 8).  One wave per GROUP of eight tiles along x:
+ * lane (z, y) turns the 32 bytes of its row in each of the eight tiles into 8 label bytes -- 64 consecutive bytes of the
+ * C-order output, written as whole lines -- and the wave leaves a one-byte summary per tile for k_cut_filter
+ * (0: every voxel on the sink side, 1: every voxel on the source side, 2: both). */
 __global__ __launch_bounds__(256) void k_labels8(MgcLattice L, uint8_t* out, uint8_t* tsum)
 {
     const int lane = threadIdx.x & 63;
-    for (int tile = (int)blockIdx.x * 4 + (int)(threadIdx.x >> 6); tile < L.ntiles; tile += (int)gridDim.x * 4) {
-        int tz, ty, tx;
-        mgc_tile_coords(L, tile, tz, ty, tx);
-        const int4* hp = (const int4*)(L.height + (int64_t)tile * MGC_TV + lane * 8);
-        const int4 a = hp[0], b = hp[1];
-        const unsigned long long v = (a.x < MGC_HINF ? 0ull : 1ull) | (a.y < MGC_HINF ? 0ull : 1ull << 8) | (a.z < MGC_HINF ? 0ull : 1ull << 16) |
-                                     (a.w < MGC_HINF ? 0ull : 1ull << 24) | (b.x < MGC_HINF ? 0ull : 1ull << 32) | (b.y < MGC_HINF ? 0ull : 1ull << 40) |
-                                     (b.z < MGC_HINF ? 0ull : 1ull << 48) | (b.w < MGC_HINF ? 0ull : 1ull << 56);
+    const int gxg = (L.gx + 7) / 8, ngroups = L.gz * L.gy * gxg;
+    for (int g = (int)blockIdx.x * 4 + (int)(threadIdx.x >> 6); g < ngroups; g += (int)gridDim.x * 4) {
+        const int tx0 = (g % gxg) * 8, ty = (g / gxg) % L.gy, tz = g / (gxg * L.gy);
         const int64_t z = (int64_t)tz * 8 + (lane >> 3), y = (int64_t)ty * 8 + (lane & 7);
         const bool inside = z < L.dz && y < L.dy; /* (rows are whole: x never leaves the volume) */
-        if (inside) *(unsigned long long*)(out + (z * L.dy + y) * L.dx + (int64_t)tx * 8) = v;
-        const bool any1 = __ballot(inside && v != 0ull) != 0ull, any0 = __ballot(inside && v != 0x0101010101010101ull) != 0ull;
-        if (lane == 0) tsum[tile] = (uint8_t)(any1 ? (any0 ? 2 : 1) : 0);
+        unsigned long long v[8];
+#pragma unroll
+        for (int k = 0; k < 8; ++k) {
+            v[k] = 0ull;
+            if (tx0 + k < L.gx) {
+                const int4* hp = (const int4*)(L.height + (int64_t)mgc_tile_id(L, tz, ty, tx0 + k) * MGC_TV + lane * 8);
+                const int4 a = hp[0], b = hp[1];
+                v[k] = (a.x < MGC_HINF ? 0ull : 1ull) | (a.y < MGC_HINF ? 0ull : 1ull << 8) | (a.z < MGC_HINF ? 0ull : 1ull << 16) |
+                       (a.w < MGC_HINF ? 0ull : 1ull << 24) | (b.x < MGC_HINF ? 0ull : 1ull << 32) | (b.y < MGC_HINF ? 0ull : 1ull << 40) |
+                       (b.z < MGC_HINF ? 0ull : 1ull << 48) | (b.w < MGC_HINF ? 0ull : 1ull << 56);
+            }
+        }
+        unsigned long long* const row = (unsigned long long*)(out + (z * L.dy + y) * L.dx + (int64_t)tx0 * 8);
+#pragma unroll
+        for (int k = 0; k < 8; ++k) {
+            if (tx0 + k >= L.gx) break; /* uniform */
+            if (inside) row[k] = v[k];
+            const bool any1 = __ballot(inside && v[k] != 0ull) != 0ull, any0 = __ballot(inside && v[k] != 0x0101010101010101ull) != 0ull;
+            if (lane == 0) tsum[mgc_tile_id(L, tz, ty, tx0 + k)] = (uint8_t)(any1 ? (any0 ? 2 : 1) : 0);
+        }
     }
 }
 
@@ -1989,7 +2018,15 @@ static int mgc_launch_readout(mgc_handle h, int slot, hipEvent_t after_labels)
     MGC_HIP(h, hipGetLastError());
     if (after_labels) MGC_HIP(h, hipEventRecord(after_labels, h->stream));
     const int grid = L.ntiles < h->grid_cap * 4 ? L.ntiles : h->grid_cap * 4;
-    if (L.ndir == 6) hipLaunchKernelGGL(k_cut_value6, dim3(grid), dim3(MGC_TV), 0, h->stream, L, h->build_args, (const double*)h->d_tr0, rows8 ? (const uint8_t*)h->d_tsum : (const uint8_t*)nullptr, h->d_part);
+    if (L.ndir == 6) {
+        const int fg = (L.ntiles + 255) / 256;
+        HipDev dev;
+        dev.h = h;
+        dev.zero_count(MGC_CNT_FILTER);
+        dev.flush_zero();
+        hipLaunchKernelGGL(k_cut_filter, dim3(fg < 1024 ? fg : 1024), dim3(256), 0, h->stream, L, h->build_args, rows8 ? (const uint8_t*)h->d_tsum : (const uint8_t*)nullptr, h->d_part, 6, MGC_CNT_FILTER);
+        hipLaunchKernelGGL(k_cut_value6, dim3(grid), dim3(MGC_TV), 0, h->stream, L, h->build_args, (const double*)h->d_tr0, 6, MGC_CNT_FILTER, h->d_part);
+    }
     else hipLaunchKernelGGL(k_cut_value, dim3(grid), dim3(MGC_TV), 0, h->stream, L, h->build_args, (const double*)h->d_tr0, (const uint8_t*)h->d_labels, h->d_part);
     MGC_HIP(h, hipGetLastError());
     mgc_sum_partials(h, (int64_t)L.ntiles, h->d_scalar + slot);
