@@ -330,6 +330,9 @@ struct GpuWave {
     __device__ __forceinline__ void flush_marks(const MgcLattice&) {}
 #endif
     __device__ __forceinline__ void fresh() { asm volatile("" : "+v"(lane)); lane &= 63; }
+    /* v unchanged, but nothing computed from it may move above this point, nor may memory operations cross it: pins the
+     * FIRST USE of a value still on its way back from memory (and with it the wait for it) to where the code says */
+    __device__ __forceinline__ int use_here(int v) { asm volatile("" : "+v"(v) : : "memory"); return v; }
     /* p[l], p wave-uniform: SGPR base + zero-extended 32-bit byte offset, the addressing mode of global_load / global_store */
     template <class T>
     __device__ __forceinline__ T ld(const T* p, int l) { return *(const T*)((const char*)p + (unsigned)(l * (int)sizeof(T))); }

@@ -46,6 +46,8 @@
  *                         list entry is waited for behind the stores of a visit; > 0: w.prefetch(p, bytes) also starts
  *                         moving [p, p + bytes) of that tile towards the caches without a register or a wait
  *                         (1: excess / labels / masks; 2: the residual planes too).  -1 (host): none of this exists
+ *   w.use_here(v)         v; on the GPU the first use of v -- and so the wait for it, if it is still on its way back from
+ *                         memory -- cannot be scheduled above this point
  *   w.mark(id)            work-profile hook: counts sections in the simulator; on the GPU nothing, or (development build
  *                         -DMGCW_PROFILE) the cycles since the previous mark, accumulated per section
  */
@@ -61,9 +63,7 @@
 /* every lambda of this file must be inlined into the kernel: a call would force the register arrays it captures into memory */
 #define MGCW_INL __attribute__((always_inline))
 #define MGCW_BFS 1            /* discharge flag: exact in-tile labels (from scratch) before the sweeps */
-#ifndef MGCW_WAKE_FIRST
-#define MGCW_WAKE_FIRST 1     /* the tail of a discharge issues its wake-up atomics before its stores (0: after them) */
-#endif
+
 
 struct alignas(16) MgcWaveShared {
     int32_t hs[1000];          /* 10x10x10 distance labels: the tile plus a one-voxel halo */
@@ -111,6 +111,49 @@ MGC_HD void mgcw_load_halo(W& w, const MgcLattice& L, int tile, int l, bool with
         w.S.hs[mgc_hs_index(mine >> 6, (mine >> 3) & 7, mine & 7) + mgc_hs_step(f)] = hv;
         if (with_inbox) w.S.inbox[f][l] = din;
     }
+}
+
+/* The same in two steps, for the discharge: ISSUE all twelve loads (per face the label and the outbox slot), COMMIT them to
+ * LDS later.  In one step the "empty the slot if it held something" store of face f sits between the loads of face f and
+ * those of face f + 1, and the compiler may not move a load across a store it cannot tell apart from it: the six faces
+ * became six dependent trips to HBM, each behind the ~76 loads of the tile's own state (that chain WAS the 32 k cycles of the
+ * "load + absorb" section of the round-2 profile).  Issued first, the twelve loads come back first (a wave's loads return in
+ * issue order) and the commit overlaps with the own state still in flight. */
+template <class W, class RegI, class RegD, class RegF>
+MGC_HD void mgcw_halo_issue(W& w, const MgcLattice& L, int tile, int l, RegI& hv, RegD& din, RegF& ofl)
+{
+    int tz, ty, tx;
+    mgc_tile_coords(L, tile, tz, ty, tx);
+    mgcw_static_for<6>([&](auto FF) MGCW_INL {
+        constexpr int F = decltype(FF)::value;
+        const int nt = mgc_tile_nbr(L, tz, ty, tx, F);
+        hv(l, F) = MGC_HINF;
+        din(l, F) = 0.0;
+        if (nt >= 0) {
+            hv(l, F) = w.ld(L.height + (int64_t)nt * MGC_TV, mgc_face_voxel(F ^ 1, l));
+            din(l, F) = w.ld(L.obox + ((int64_t)nt * 6 + (F ^ 1)) * MGC_TF, l);
+        }
+    });
+    ofl(l, 0) = 0; /* lane l < 6: the outbox flags of the neighbour across face l */
+    if (l < 6) {
+        const int nt = mgc_tile_nbr(L, tz, ty, tx, l);
+        if (nt >= 0) ofl(l, 0) = (int)L.oflags[nt];
+    }
+}
+
+template <class W, class RegI, class RegD>
+MGC_HD void mgcw_halo_commit(W& w, const MgcLattice& L, int tile, int l, RegI& hv, RegD& din)
+{
+    int tz, ty, tx;
+    mgc_tile_coords(L, tile, tz, ty, tx);
+    mgcw_static_for<6>([&](auto FF) MGCW_INL {
+        constexpr int F = decltype(FF)::value;
+        const int nt = mgc_tile_nbr(L, tz, ty, tx, F);
+        const int mine = mgc_face_voxel(F, l);
+        w.S.hs[mgc_hs_index(mine >> 6, (mine >> 3) & 7, mine & 7) + mgc_hs_step(F)] = hv(l, F);
+        w.S.inbox[F][l] = din(l, F);
+        if (nt >= 0 && din(l, F) != 0.0) w.st(L.obox + ((int64_t)nt * 6 + (F ^ 1)) * MGC_TF, l, 0.0); /* the slot is emptied */
+    });
 }
 
 /* label of the neighbour of (lane l, slot K) in direction d: in-plane neighbours and the tile halo from LDS, the
@@ -219,8 +262,14 @@ MGC_HD void mgcw_discharge_impl(W& w, const MgcLattice& L, int tile, uint32_t ph
     int tz, ty, tx;
     mgc_tile_coords(L, tile, tz, ty, tx);
 
-    /* ---- one trip to HBM: own state, label halo, inbox ---- */
+    /* ---- one trip to HBM: label halo + inbox (issued first, see mgcw_halo_issue), own state ---- */
+    typename W::template Reg<int, 6> hv;
+    typename W::template Reg<double, 6> dnb;
+    typename W::template Reg<int, 1> st0; /* the tile's status word (nobody else writes it during this launch) */
+    typename W::template Reg<int, 1> ofl;
     w.lanes([&](int l) MGCW_INL {
+        mgcw_halo_issue(w, L, tile, l, hv, dnb, ofl);
+        st0(l, 0) = (int)L.status[tile];
         mgcw_static_for<8>([&](auto KK) MGCW_INL {
             constexpr int K = decltype(KK)::value;
             e(l, K) = w.ld(t_excess, K * 64 + l);
@@ -231,12 +280,14 @@ MGC_HD void mgcw_discharge_impl(W& w, const MgcLattice& L, int tile, uint32_t ph
             });
             h(l, K) = w.ld(t_height, K * 64 + l); /* (overwritten when the exact labelling runs) */
         });
-        mgcw_load_halo(w, L, tile, l, true);
+        mgcw_halo_commit(w, L, tile, l, hv, dnb);
         if (l < 6) { /* retire the outbox flags of the slots just emptied */
             const int nt = mgc_tile_nbr(L, tz, ty, tx, l);
-            if (nt >= 0 && ((L.oflags[nt] >> (l ^ 1)) & 1u)) w.atomic_and(&L.oflags[nt], ~(1u << (l ^ 1)));
+            if (nt >= 0 && (((uint32_t)ofl(l, 0) >> (l ^ 1)) & 1u)) w.atomic_and(&L.oflags[nt], ~(1u << (l ^ 1)));
         }
     });
+    if constexpr (W::kPrefetch >= 0) w.hint_begin(); /* the ticket drawn when the visit began is back (it was issued first): ask for the
+                                                        list entry it names right behind the tile's own loads */
     /* ---- absorb the staged inbox: e += delta, reverse residual += delta, fixed face order ---- */
     w.lanes([&](int l) MGCW_INL {
         const int y = l >> 3, x = l & 7;
@@ -256,7 +307,6 @@ MGC_HD void mgcw_discharge_impl(W& w, const MgcLattice& L, int tile, uint32_t ph
             if constexpr (K == 7) { const double d = w.S.inbox[5][l]; e(l, K) += d; r[5](l, K) += d; }
         });
     });
-    if constexpr (W::kPrefetch >= 0) w.hint_begin(); /* (the own loads have landed: ask for the next list entry) */
     /* residual planes this discharge changes (bit D): a plane nobody pushed along, received along or absorbed into goes
      * back to HBM as it came -- so it does not go back at all (a discharge typically moves flow along one or two axes) */
     uint32_t dirty = 0;
@@ -468,7 +518,50 @@ MGC_HD void mgcw_discharge_impl(W& w, const MgcLattice& L, int tile, uint32_t ph
     const bool active = am != 0; /* sweep budget exhausted with work left: run again in the next phase of this colour */
     w.mark(1); /* (whatever followed the last counted sweep: the vote that ended the loop) */
 
-    /* ---- tail: votes, outbox staged through LDS (face order: the neighbours read 64 consecutive doubles per face) ---- */
+    /* ---- tail.  Order matters for time, not for the result: a wave's memory operations retire in issue order, and the wake-ups
+     * are two dependent returning atomics per woken tile (claim its stamp, then draw a list position).  They frame the
+     * tail: the claims go out first, the votes and the staging of the outbox run while they are in flight, the positions
+     * are drawn next, then the ~70 stores of the write-back are issued -- nobody waits for those -- and the list entries
+     * (which need the positions) go out last.  (Round 2 issued the claims after the stores: every visit ended by waiting
+     * for its whole write-back to retire, twice.) ---- */
+    uint32_t face = 0; /* bit f: flow left the tile across face f */
+    {
+        typename W::template Reg<int, 1> nz; /* bit 0 / 1 / 2: this lane pushed something across an x / y / z face */
+        w.lanes([&](int l) MGCW_INL {
+            int m = 0;
+            mgcw_static_for<8>([&](auto KK) MGCW_INL {
+                constexpr int K = decltype(KK)::value;
+                m |= (obx(l, K) != 0.0 ? 1 : 0) | (oby(l, K) != 0.0 ? 2 : 0);
+            });
+            nz(l, 0) = m | (obz(l, 0) != 0.0 ? 4 : 0) | (obz(l, 1) != 0.0 ? 8 : 0);
+        });
+        if (w.any([&](int l) MGCW_INL -> bool { return (nz(l, 0) & 1) && (l & 7) == 0; })) face |= 1u;
+        if (w.any([&](int l) MGCW_INL -> bool { return (nz(l, 0) & 1) && (l & 7) == 7; })) face |= 2u;
+        if (w.any([&](int l) MGCW_INL -> bool { return (nz(l, 0) & 2) && (l >> 3) == 0; })) face |= 4u;
+        if (w.any([&](int l) MGCW_INL -> bool { return (nz(l, 0) & 2) && (l >> 3) == 7; })) face |= 8u;
+        if (w.any([&](int l) MGCW_INL -> bool { return (nz(l, 0) & 4) != 0; })) face |= 16u;
+        if (w.any([&](int l) MGCW_INL -> bool { return (nz(l, 0) & 8) != 0; })) face |= 32u;
+    }
+    /* lane l < 6 wakes the neighbour across face l, lane 6 this tile itself (budget exhausted with work left) */
+    typename W::template Reg<int, 4> wk; /* tile to wake (-1: none), its list, claimed?, position */
+    int32_t* const list_nbr = L.list[(phase + 1) & 3u];
+    int32_t* const list_self = L.list[(phase + 2) & 3u];
+    w.fresh();
+    w.lanes([&](int l) MGCW_INL {
+        int target = -1, lst = 0;
+        uint32_t ep = 0;
+        if (l < 6 && ((face >> l) & 1u)) { target = mgc_tile_nbr(L, tz, ty, tx, l); ep = phase + 1; }
+        if (l == 6 && active) { target = tile; ep = phase + 2; }
+        lst = (int)(ep & 3u);
+        if (target >= 0 && !mgc_owned(L, target)) target = -1; /* a ghost tile is discharged by the slab that owns it */
+        wk(l, 0) = target;
+        wk(l, 1) = lst;
+        wk(l, 2) = (int)ep;
+        if (l < 6 && ((face >> l) & 1u)) w.atomic_or(&L.oflags[tile], 1u << l);
+        /* claim: whoever finds another stamp there is the first to queue the tile for that phase.  (What comes back is only
+         * looked at further down: the wait for it sits behind the votes and the staging below.) */
+        if (target >= 0) wk(l, 2) = (int)w.atomic_exch(&L.stamp[target], ep);
+    });
     bool has_sink = false, has_exc = false;
     mgcw_static_for<8>([&](auto KK) MGCW_INL {
         constexpr int K = decltype(KK)::value;
@@ -476,7 +569,7 @@ MGC_HD void mgcw_discharge_impl(W& w, const MgcLattice& L, int tile, uint32_t ph
         has_exc = has_exc || w.any([&](int l) MGCW_INL -> bool { return e(l, K) > 0.0 && h(l, K) < MGC_HINF; }); /* (excess under an INF label is dead for good) */
     });
     const bool saturated = w.any([&](int l) MGCW_INL -> bool { return sat(l, 0) != 0; });
-    w.lanes([&](int l) MGCW_INL {
+    w.lanes([&](int l) MGCW_INL { /* outbox staged through LDS (face order: the neighbours read 64 consecutive doubles per face) */
         const int y = l >> 3, x = l & 7;
         mgcw_static_for<8>([&](auto KK) MGCW_INL {
             constexpr int K = decltype(KK)::value;
@@ -488,80 +581,62 @@ MGC_HD void mgcw_discharge_impl(W& w, const MgcLattice& L, int tile, uint32_t ph
         w.S.inbox[4][l] = obz(l, 0);
         w.S.inbox[5][l] = obz(l, 1);
     });
-    uint32_t face = 0; /* bit f: flow left the tile across face f */
-#pragma unroll
-    for (int f = 0; f < 6; ++f)
-        if (w.any([&](int l) MGCW_INL -> bool { return w.S.inbox[f][l] != 0.0; })) face |= 1u << f;
-
-    /* ---- wake-ups and flags FIRST: their atomics return a value, and the memory counter of a wave retires in issue order --
-     * behind the ~70 stores below, the first of them would wait until the whole tile has been written back (that wait was
-     * most of the "tail" section of the round-2 profile).  Nothing in this launch reads what they publish. ---- */
-    w.fresh();
-    auto wake_up = [&]() MGCW_INL {
-        w.lanes([&](int l) MGCW_INL {
-            if (l < 6 && ((face >> l) & 1u)) {
-                w.atomic_or(&L.oflags[tile], 1u << l);
-                mgc_enqueue(w, L, (int)((phase + 1) & 3u), L.stamp, phase + 1, mgc_tile_nbr(L, tz, ty, tx, l));
+    w.lanes([&](int l) MGCW_INL { /* positions in the lists (region of this workgroup, MgcLattice::scount) */
+        const uint32_t ep = l == 6 ? phase + 2 : phase + 1;
+        wk(l, 2) = (wk(l, 0) >= 0 && (uint32_t)wk(l, 2) != ep) ? 1 : 0;
+        wk(l, 3) = 0;
+        if (wk(l, 2)) wk(l, 3) = w.atomic_add(mgc_counter(L, wk(l, 1), w.shard(L)), 1);
+    });
+    /* ---- ONE block of global stores nobody waits for: state, masks, labels, outbox ---- */
+    w.lanes([&](int l) MGCW_INL {
+        mgcw_static_for<8>([&](auto KK) MGCW_INL {
+            constexpr int K = decltype(KK)::value;
+            w.st(t_excess, K * 64 + l, e(l, K));
+            int m = 0;
+            if constexpr (SINK) {
+                const double sk = w.S.snk[K * 64 + l];
+                w.st(t_sink, K * 64 + l, sk);
+                m = sk > 0.0 ? MGC_MASK_SINK : 0;
             }
-            if (l == 6 && active) mgc_enqueue(w, L, (int)((phase + 2) & 3u), L.stamp, phase + 2, tile);
-            /* DIRTY only if a residual arc disappeared: otherwise no distance in the tile (or through it) can have changed */
-            if (l == 7) L.status[tile] = (L.status[tile] & ~(MGC_ST_SINK | MGC_ST_EXCESS)) | (has_sink ? MGC_ST_SINK : 0u) | (saturated ? MGC_ST_DIRTY : 0u) | (has_exc ? MGC_ST_EXCESS : 0u);
+            mgcw_static_for<6>([&](auto DD) MGCW_INL {
+                constexpr int D = decltype(DD)::value;
+                m |= (r[D](l, K) > 0.0) ? (1 << D) : 0;
+            });
+            w.st(t_rmask, K * 64 + l, (uint8_t)m);
         });
-    };
-    auto write_back = [&]() MGCW_INL {
-        /* ---- then ONE block of global stores nobody waits for: state, masks, labels, outbox ---- */
+    });
+    mgcw_static_for<6>([&](auto DD) MGCW_INL { /* only the residual planes that changed */
+        constexpr int D = decltype(DD)::value;
+        if (!(dirty & (1u << D))) return;
         w.lanes([&](int l) MGCW_INL {
             mgcw_static_for<8>([&](auto KK) MGCW_INL {
                 constexpr int K = decltype(KK)::value;
-                w.st(t_excess, K * 64 + l, e(l, K));
-                int m = 0;
-                if constexpr (SINK) {
-                    const double sk = w.S.snk[K * 64 + l];
-                    w.st(t_sink, K * 64 + l, sk);
-                    m = sk > 0.0 ? MGC_MASK_SINK : 0;
-                }
-                mgcw_static_for<6>([&](auto DD) MGCW_INL {
-                    constexpr int D = decltype(DD)::value;
-                    m |= (r[D](l, K) > 0.0) ? (1 << D) : 0;
-                });
-                w.st(t_rmask, K * 64 + l, (uint8_t)m);
+                w.st(t_rcap + D * MGC_TV, K * 64 + l, r[D](l, K));
             });
         });
-        mgcw_static_for<6>([&](auto DD) MGCW_INL { /* only the residual planes that changed */
-            constexpr int D = decltype(DD)::value;
-            if (!(dirty & (1u << D))) return;
-            w.lanes([&](int l) MGCW_INL {
-                mgcw_static_for<8>([&](auto KK) MGCW_INL {
-                    constexpr int K = decltype(KK)::value;
-                    w.st(t_rcap + D * MGC_TV, K * 64 + l, r[D](l, K));
-                });
-            });
-        });
-        if (relabelled) {
-            w.lanes([&](int l) MGCW_INL {
-                mgcw_static_for<8>([&](auto KK) MGCW_INL {
-                    constexpr int K = decltype(KK)::value;
-                    w.st(t_height, K * 64 + l, h(l, K));
-                });
-            });
-        }
+    });
+    if (relabelled) {
         w.lanes([&](int l) MGCW_INL {
-            /* outbox: plain stores -- the neighbour emptied these slots when it last absorbed, and it always runs (or
-             * absorb_all does) between two of our discharges */
-#pragma unroll
-            for (int f = 0; f < 6; ++f) {
-                const double ob = w.S.inbox[f][l];
-                if (ob != 0.0) w.st(t_obox + f * MGC_TF, l, ob);
-            }
+            mgcw_static_for<8>([&](auto KK) MGCW_INL {
+                constexpr int K = decltype(KK)::value;
+                w.st(t_height, K * 64 + l, h(l, K));
+            });
         });
-    };
-#if MGCW_WAKE_FIRST
-    wake_up();
-    write_back();
-#else
-    write_back();
-    wake_up();
-#endif
+    }
+    w.lanes([&](int l) MGCW_INL {
+        /* outbox: plain stores -- the neighbour emptied these slots when it last absorbed, and it always runs (or
+         * absorb_all does) between two of our discharges */
+#pragma unroll
+        for (int f = 0; f < 6; ++f) {
+            const double ob = w.S.inbox[f][l];
+            if (ob != 0.0) w.st(t_obox + f * MGC_TF, l, ob);
+        }
+        /* (the two lists as wave-uniform pointers selected per lane: indexing L.list[] with a per-lane list id would be a LOAD of
+         * the pointer, and waiting for it would wait for every store above) */
+        if (wk(l, 2)) (l == 6 ? list_self : list_nbr)[(int64_t)w.shard(L) * L.shard_cap + w.use_here(wk(l, 3))] = wk(l, 0);
+        /* DIRTY only if a residual arc disappeared: otherwise no distance in the tile (or through it) can have changed */
+        if (l == 7) L.status[tile] = ((uint32_t)st0(l, 0) & ~(MGC_ST_SINK | MGC_ST_EXCESS)) | (has_sink ? MGC_ST_SINK : 0u) | (saturated ? MGC_ST_DIRTY : 0u) | (has_exc ? MGC_ST_EXCESS : 0u);
+    });
     w.mark(3); /* tail votes + stores */
 }
 

@@ -159,6 +159,7 @@ struct HostWave {
     template <class T> T ld(const T* p, int l) { return p[l]; }
     template <class T> void st(T* p, int l, T v) { p[l] = v; }
     void fresh() {}
+    int use_here(int v) { return v; }
 };
 /* which form of the two hot tile operations the simulator runs: bit 0 = wave discharge, bit 1 = wave relabel,
  * bit 2 = the wave discharge computes exact in-tile labels first (MGCW_BFS) */
