@@ -275,7 +275,8 @@ struct GpuWave {
         if (found) v = nlist[(int64_t)sh * lat->shard_cap + off];
         return v;
     }
-    __device__ __forceinline__ void ticket_issue(const MgcLattice& L, int tk)
+    int tk = 0; /* ticket word of this launch */
+    __device__ __forceinline__ void ticket_issue(const MgcLattice& L)
     {
         tkv = 0;
         if (threadIdx.x == 0) tkv = atomicAdd(&L.count[tk], 1);
@@ -386,12 +387,12 @@ void k_discharge_w(MgcLattice L, int lst, uint32_t phase, int sweeps, int flags,
     __shared__ int32_t pf[256];
     w.pf = pf;
     w.list_begin(L, lst);
+    w.tk = tk;
     int tile = __builtin_amdgcn_readfirstlane(w.entry_load((int)blockIdx.x)), st = 0; /* first visit: no ticket */
     if (tile >= 0) st = (int)L.status[tile];
     while (tile >= 0) {
         w.new_tile();
         w.mark(1); /* between two tiles */
-        w.ticket_issue(L, tk);
         /* the tile id is wave-uniform: keep it (and every base address derived from it) in SGPRs */
         if (__builtin_amdgcn_readfirstlane(st) & (int)MGC_ST_SINK) mgcw_discharge_impl<true>(w, L, tile, phase, sweeps, flags);
         else mgcw_discharge_impl<false>(w, L, tile, phase, sweeps, flags);

@@ -223,11 +223,12 @@ MGC_HD void mgc_relabel_tile(X& x, const MgcLattice& L, int tile, uint32_t next_
 {
     /* first pass of a global relabel: every label is INF, so only tiles holding a sink arc can seed anything */
     if (first_pass && (!(L.status[tile] & 2u) || !mgc_owned(L, tile))) return;
-    typename X::template Reg<int> m, h0;
+    typename X::template Reg<int> m, h0, stw;
     const int64_t base = (int64_t)tile * MGC_TV;
-    x.par([&](int t) { /* one trip to HBM: masks, own labels, label halo */
+    x.par([&](int t) { /* one trip to HBM: masks, own labels, label halo, the status word */
         const int z = t >> 6, y = (t >> 3) & 7, xx = t & 7;
         mgc_load_nbrs(x, L, tile, t);
+        if (t == 6) stw[t] = (int)L.status[tile]; /* (rewritten below: fetched here, with everything else) */
         m[t] = L.rmask[base + t];
         h0[t] = L.height[base + t];
         x.S.hs[mgc_hs_index(z, y, xx)] = h0[t];
@@ -262,14 +263,26 @@ MGC_HD void mgc_relabel_tile(X& x, const MgcLattice& L, int tile, uint32_t next_
                 if (!mgc_inside(d, z, y, xx) && hm + 1 < x.S.hs[me + mgc_hs_step(d)]) x.S.faceflag[d] = 1;
         }
     });
-    x.par([&](int t) { /* one block of global traffic: labels + wake-ups */
+    x.par([&](int t) { /* one block of global traffic: wake-ups + labels.  The claim of a neighbour (a returning atomic) is issued
+                          BEFORE the label stores: a thread's memory operations retire in issue order, behind the stores it would
+                          wait for them to drain first */
         const int h = x.S.hs[mgc_hs_index(t >> 6, (t >> 3) & 7, t & 7)];
+        int wake = -1;
+        bool won = false;
+        if (t < 6 && x.S.faceflag[t] && x.S.nbr[t] >= 0 && mgc_owned(L, x.S.nbr[t])) {
+            wake = x.S.nbr[t];
+            won = x.atomic_exch(&L.rstamp[wake], next_epoch) != next_epoch;
+        }
         if (h < h0[t]) L.height[base + t] = h;
-        if (t < 6 && x.S.faceflag[t] && x.S.nbr[t] >= 0) mgc_enqueue(x, L, next_list, L.rstamp, next_epoch, x.S.nbr[t]);
         if (t == 6) {
             uint32_t dep = 0;
             for (int f = 0; f < 6; ++f) dep |= x.S.depflag[f] ? (1u << f) : 0u;
-            L.status[tile] = (L.status[tile] & ~((63u << MGC_ST_DEP_SHIFT) | (x.S.flag[0] ? MGC_ST_ALLINF : 0u))) | (dep << MGC_ST_DEP_SHIFT);
+            L.status[tile] = ((uint32_t)stw[t] & ~((63u << MGC_ST_DEP_SHIFT) | (x.S.flag[0] ? MGC_ST_ALLINF : 0u))) | (dep << MGC_ST_DEP_SHIFT);
+        }
+        if (won) { /* first to queue it for the next pass (what mgc_enqueue does after its claim) */
+            const int sh = x.shard(L);
+            const int pos = x.atomic_add(mgc_counter(L, next_list, sh), 1);
+            L.list[next_list][(int64_t)sh * L.shard_cap + pos] = wake;
         }
     });
 }

@@ -280,14 +280,15 @@ MGC_HD void mgcw_discharge_impl(W& w, const MgcLattice& L, int tile, uint32_t ph
             });
             h(l, K) = w.ld(t_height, K * 64 + l); /* (overwritten when the exact labelling runs) */
         });
+        /* the ticket for the tile AFTER this one goes out behind the loads: a wave's memory operations retire in issue order, and
+         * the ticket word is the one address every wave of the launch hits (ahead of the loads it would hold them all up) */
+        if constexpr (W::kPrefetch >= 0) w.ticket_issue(L);
         mgcw_halo_commit(w, L, tile, l, hv, dnb);
         if (l < 6) { /* retire the outbox flags of the slots just emptied */
             const int nt = mgc_tile_nbr(L, tz, ty, tx, l);
             if (nt >= 0 && (((uint32_t)ofl(l, 0) >> (l ^ 1)) & 1u)) w.atomic_and(&L.oflags[nt], ~(1u << (l ^ 1)));
         }
     });
-    if constexpr (W::kPrefetch >= 0) w.hint_begin(); /* the ticket drawn when the visit began is back (it was issued first): ask for the
-                                                        list entry it names right behind the tile's own loads */
     /* ---- absorb the staged inbox: e += delta, reverse residual += delta, fixed face order ---- */
     w.lanes([&](int l) MGCW_INL {
         const int y = l >> 3, x = l & 7;
@@ -392,11 +393,20 @@ MGC_HD void mgcw_discharge_impl(W& w, const MgcLattice& L, int tile, uint32_t ph
         return e(l, K) > 0.0 && r[D](l, K) > 0.0 && hnb == h(l, K) - 1;
     };
 
-    if constexpr (W::kPrefetch >= 0) {
-        const int coming = w.hint_end(L); /* the tile this wave discharges next: known a whole visit ahead */
-        if (W::kPrefetch > 0 && coming >= 0) mgcw_prefetch_tile(w, L, coming);
-    }
     w.mark(0); /* load + absorb + label set-up */
+    /* the ticket is looked at after the first sweep, the list entry it names after the second (or right after the loop): by
+     * then both have long arrived, however many waves queued up on the ticket word */
+    int hint_stage = 0;
+    auto hint_step = [&]() MGCW_INL {
+        if constexpr (W::kPrefetch >= 0) {
+            if (hint_stage == 0) w.hint_begin();
+            else if (hint_stage == 1) {
+                const int coming = w.hint_end(L); /* the tile this wave discharges next */
+                if (W::kPrefetch > 0 && coming >= 0) mgcw_prefetch_tile(w, L, coming);
+            }
+            hint_stage++;
+        }
+    };
     uint32_t am = slot_mask();
     for (int sw = 0; sw < max_sweeps && am; ++sw) {
         /* ---- per active slot: sink, then the four in-plane directions as lane shifts.  ONE vote per (slot, direction):
@@ -513,8 +523,11 @@ MGC_HD void mgcw_discharge_impl(W& w, const MgcLattice& L, int tile, uint32_t ph
             });
         });
         am = slot_mask();
+        hint_step();
         w.mark(2); /* one push sweep */
     }
+    hint_step(); /* (a visit of fewer than two sweeps) */
+    hint_step();
     const bool active = am != 0; /* sweep budget exhausted with work left: run again in the next phase of this colour */
     w.mark(1); /* (whatever followed the last counted sweep: the vote that ended the loop) */
 

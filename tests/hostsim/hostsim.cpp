@@ -147,6 +147,7 @@ struct HostWave {
     }
     static constexpr int kPrefetch = -1;
     void hint_begin() {}
+    void ticket_issue(const MgcLattice&) {}
     int hint_end(const MgcLattice&) { return -1; }
     void prefetch(const void*, int) {}
     int shard(const MgcLattice&) const { return 0; } /* one region per list: the plain layout (MgcLattice::scount) */
