@@ -47,8 +47,15 @@
 #ifndef MGCW_DPP
 #define MGCW_DPP 1      /* +-x hand-offs of the wave discharge as DPP row shifts (0: ds_bpermute like +-y) */
 #endif
+#ifndef MGCW_RUNAHEAD
+#define MGCW_RUNAHEAD 0 /* 1: a discharging wave draws the ticket for its NEXT tile while it still works on the current one (and may
+                           prefetch it, MGCW_PREFETCH).  Measured on MI355X at 512^3: hides three dependent memory trips per visit
+                           (ticket, list entry, status word) but every wave then sits on two tiles, and with ~3 visits per wave
+                           and launch the last tiles of a phase start a whole visit late: 197 us per launch instead of 165.  Off. */
+#endif
 #ifndef MGCW_PREFETCH
-#define MGCW_PREFETCH 0 /* 1: a discharging wave requests the excess / labels / masks of its next tile while it sweeps; 2: the residual planes too */
+#define MGCW_PREFETCH 0 /* (with MGCW_RUNAHEAD) 1: the wave requests the excess / labels / masks of its next tile while it sweeps; 2: the
+                           residual planes too.  Measured: no gain -- a visit is bound by dependent trips, not by bytes */
 #endif
 
 /* ======================================================================================
@@ -242,7 +249,7 @@ struct GpuWave {
 #endif
     }
     /* ---- running ahead of the tile loop (mgc_wave_ops.inl: W::kPrefetch) ---- */
-    static constexpr int kPrefetch = MGCW_PREFETCH;
+    static constexpr int kPrefetch = MGCW_RUNAHEAD ? MGCW_PREFETCH : -1;
     int32_t* pf = nullptr;          /* 1 KiB of LDS the prefetch DMA lands in (never read) */
     const int32_t* nlist = nullptr; /* the list being consumed */
     int tkv = 0, lsv = -1;          /* in flight: the ticket just drawn (lane 0), the list entry it points at */
@@ -312,18 +319,18 @@ struct GpuWave {
     __device__ __forceinline__ uint32_t uniform(uint32_t v) const { return (uint32_t)__builtin_amdgcn_readfirstlane((int)v); }
     __device__ __forceinline__ void atomic_and(uint32_t* p, uint32_t v) { atomicAnd(p, v); }
 #if defined(MGCW_PROFILE) /* development build (tools/gpu_sections.py): cycles per section of a tile discharge, per wave */
-    unsigned long long last = 0, acc[4] = {0, 0, 0, 0};
-    unsigned int cnt[4] = {0, 0, 0, 0};
+    unsigned long long last = 0, acc[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+    unsigned int cnt[8] = {0, 0, 0, 0, 0, 0, 0, 0};
     __device__ __forceinline__ void mark(int id)
     {
         const unsigned long long now = __builtin_readcyclecounter();
-        if (last) { acc[id & 3] += now - last; cnt[id & 3]++; }
+        if (last) { acc[id & 7] += now - last; cnt[id & 7]++; }
         last = now;
     }
     __device__ __forceinline__ void flush_marks(const MgcLattice& L)
     {
         if (L.prof && threadIdx.x == 0)
-            for (int i = 0; i < 4; ++i)
+            for (int i = 0; i < 8; ++i)
                 if (cnt[i]) { atomicAdd(&L.prof[i], acc[i]); atomicAdd(&L.prof[i + 8], (unsigned long long)cnt[i]); }
     }
 #else
@@ -381,9 +388,6 @@ void k_discharge_w(MgcLattice L, int lst, uint32_t phase, int sweeps, int flags,
      * SIMD do not sit in their load / store phases at the same moments (units of ~8 000 shader cycles) */
     if (stagger > 0 && blockIdx.x >= gridDim.x / 2)
         for (int k = 0; k < stagger; ++k) __builtin_amdgcn_s_sleep(127);
-    /* The wave runs one tile ahead of itself: the ticket for its NEXT tile is drawn when a visit starts and resolved in the
-     * middle of it (hint_begin / hint_end inside mgcw_discharge_impl), together with that tile's status word -- a returning
-     * atomic or a load issued behind the ~70 stores that end a visit would wait until they have all retired. */
     __shared__ int32_t pf[256];
     w.pf = pf;
     w.list_begin(L, lst);
@@ -396,10 +400,17 @@ void k_discharge_w(MgcLattice L, int lst, uint32_t phase, int sweeps, int flags,
         /* the tile id is wave-uniform: keep it (and every base address derived from it) in SGPRs */
         if (__builtin_amdgcn_readfirstlane(st) & (int)MGC_ST_SINK) mgcw_discharge_impl<true>(w, L, tile, phase, sweeps, flags);
         else mgcw_discharge_impl<false>(w, L, tile, phase, sweeps, flags);
-        tile = w.next_tile;
+#if MGCW_RUNAHEAD
+        tile = w.next_tile; /* resolved inside the visit (hint_begin / hint_end in mgcw_discharge_impl) */
         st = w.nst;
+#else
+        w.ticket_issue(L); /* a free wave takes the next unclaimed tile: ticket -> list entry -> status word */
+        w.hint_begin();
+        tile = w.hint_end(L);
+        st = w.nst;
+#endif
     }
-    if (MGCW_PREFETCH) asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); /* (nothing may still be on its way into this wave's LDS when it ends) */
+    if (MGCW_RUNAHEAD && MGCW_PREFETCH) asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); /* (nothing may still be on its way into this wave's LDS when it ends) */
     w.flush_marks(L);
 }
 

@@ -289,6 +289,7 @@ MGC_HD void mgcw_discharge_impl(W& w, const MgcLattice& L, int tile, uint32_t ph
             if (nt >= 0 && (((uint32_t)ofl(l, 0) >> (l ^ 1)) & 1u)) w.atomic_and(&L.oflags[nt], ~(1u << (l ^ 1)));
         }
     });
+    w.mark(4); /* loads issued, halo + inbox back and staged */
     /* ---- absorb the staged inbox: e += delta, reverse residual += delta, fixed face order ---- */
     w.lanes([&](int l) MGCW_INL {
         const int y = l >> 3, x = l & 7;
@@ -308,6 +309,7 @@ MGC_HD void mgcw_discharge_impl(W& w, const MgcLattice& L, int tile, uint32_t ph
             if constexpr (K == 7) { const double d = w.S.inbox[5][l]; e(l, K) += d; r[5](l, K) += d; }
         });
     });
+    w.mark(5); /* own state back, inbox absorbed */
     /* residual planes this discharge changes (bit D): a plane nobody pushed along, received along or absorbed into goes
      * back to HBM as it came -- so it does not go back at all (a discharge typically moves flow along one or two axes) */
     uint32_t dirty = 0;
@@ -594,6 +596,7 @@ MGC_HD void mgcw_discharge_impl(W& w, const MgcLattice& L, int tile, uint32_t ph
         w.S.inbox[4][l] = obz(l, 0);
         w.S.inbox[5][l] = obz(l, 1);
     });
+    w.mark(6); /* face votes, claims issued, tail votes, outbox staged */
     w.lanes([&](int l) MGCW_INL { /* positions in the lists (region of this workgroup, MgcLattice::scount) */
         const uint32_t ep = l == 6 ? phase + 2 : phase + 1;
         wk(l, 2) = (wk(l, 0) >= 0 && (uint32_t)wk(l, 2) != ep) ? 1 : 0;
@@ -636,6 +639,7 @@ MGC_HD void mgcw_discharge_impl(W& w, const MgcLattice& L, int tile, uint32_t ph
             });
         });
     }
+    w.mark(7); /* claims back, positions drawn, state / planes / labels stored */
     w.lanes([&](int l) MGCW_INL {
         /* outbox: plain stores -- the neighbour emptied these slots when it last absorbed, and it always runs (or
          * absorb_all does) between two of our discharges */

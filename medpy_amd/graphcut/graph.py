@@ -175,7 +175,7 @@ class VoxelGraph(object):
     def profile(self):
         out = numpy.zeros(16, dtype=numpy.uint64)
         self._call("mgc_get_profile", _lib.ptr(out))
-        names = ("load", "labels", "sweep", "store", "votes", "faceflags")
+        names = ("load", "labels", "sweep", "store", "votes", "faceflags", "s6", "s7")
         return {n: {"cycles": int(out[i]), "count": int(out[i + 8])} for i, n in enumerate(names)}
 
     def stats(self):

@@ -13,10 +13,17 @@ g._build(); g.maxflow()
 g.set_param("profile_sections", 1)
 g._build(); t0 = time.perf_counter(); g.maxflow(); dt = time.perf_counter() - t0
 st = g.stats(); pr = g.profile()
-names = {"load": "load + absorb + label set-up", "labels": "between tiles / after the last sweep", "sweep": "one sweep", "store": "tail votes + stores"}
+names = {"labels": "loop top: ticket, list entry, status word   (mark 1)",
+         "votes": "loads issued; halo + inbox back, staged     (mark 4)",
+         "faceflags": "own state back, inbox absorbed              (mark 5)",
+         "load": "dirty votes, labels to LDS, register set-up (mark 0)",
+         "sweep": "one sweep                                   (mark 2)",
+         "s6": "face votes, claims out, tail votes, staging (mark 6)",
+         "s7": "claims back, positions, write-back issued   (mark 7)",
+         "store": "positions back, outbox + list entries out   (mark 3)"}
 tot = sum(pr[k]["cycles"] for k in names)
 print(json.dumps({"n": n, "solve_ms": dt * 1e3, "discharge_tiles": st["discharge_tiles"]}))
 for k, label in names.items():
     v = pr[k]
-    print("%-40s cycles %16d (%5.1f%%)  count %9d  avg %8.0f cycles" % (label, v["cycles"], 100.0 * v["cycles"] / max(tot, 1), v["count"], v["cycles"] / max(v["count"], 1)))
-print("per tile discharge: %.0f cycles (s_memtime, 100 MHz? see ratio); sweeps per discharge %.2f" % (tot / max(st["discharge_tiles"], 1), pr["sweep"]["count"] / max(st["discharge_tiles"], 1)))
+    print("%-58s cycles %16d (%5.1f%%)  count %9d  avg %8.0f cycles" % (label, v["cycles"], 100.0 * v["cycles"] / max(tot, 1), v["count"], v["cycles"] / max(v["count"], 1)))
+print("per tile discharge: %.0f cycles; sweeps per discharge %.2f" % (tot / max(st["discharge_tiles"], 1), pr["sweep"]["count"] / max(st["discharge_tiles"], 1)))
