@@ -46,6 +46,10 @@
 #define MGC_CNT_CHANGED 21     /* suspect-closure pass changed something */
 #define MGC_CNT_FILTER 22      /* length of the scratch list the tile filters fill (absorb / relabel seeding / suspect reset) */
 #define MGC_CNT_FILTER_ACT 23  /* ... of the activation filter */
+/* the filters alternate between two slots each: the kernel that consumes one list clears the slot the next filter will count
+ * into (no launch in between just to clear a word) */
+#define MGC_CNT_FILTER_B 30
+#define MGC_CNT_FILTER_ACT_B 31
 #define MGC_CNT_WAVE_TILES 29  /* running total of the tiles k_discharge_w visited (count[8] pools both discharge kernels) */
 #define MGC_CNT_NOT_FULL 28    /* k_build: tiles holding an n-link inside the volume that is not residual (0: the first global relabel is a distance transform) */
 

@@ -89,7 +89,7 @@ int mgc_solve(Dev& dev, const MgcLattice& L, const MgcSolveParams& P, MgcSolveSt
     uint32_t rep = 2;   /* relabel epoch     */
     int cnt[MGC_NCOUNT];
     int rounds = P.rounds_per_relabel;
-    int64_t prev_dis = 0, prev_rel = 0;
+    int64_t prev_dis = 0, prev_rel = 0, last_passes = 0;
     st = MgcSolveStats();
     dev.zero_count(lay.cnt_dis);
     dev.zero_count(lay.cnt_rel);
@@ -124,16 +124,24 @@ int mgc_solve(Dev& dev, const MgcLattice& L, const MgcSolveParams& P, MgcSolveSt
              * lists[(k + 2) % 3] (consumed by pass k - 1) inside the kernel */
             const int lists[3] = {lay.rl_base, lay.rl_base + 1, lay.rl_third};
             int k = (int)((rep + 1) & 1u); /* where relabel_all / reset_suspect queued their tiles; the other two lists are empty */
+            /* passes between two looks at the list length: the label wave of one global relabel needs about as many passes as
+             * that of the relabel before it, so most of them go out in one stretch (a pass over an empty list costs ~4 us,
+             * a look at the counters a stream drain) */
+            int batch = outer > 0 && last_passes > 2 * P.relabel_batch ? (int)(last_passes - last_passes / 4) : P.relabel_batch;
+            int64_t passes_now = 0;
             for (;;) {
-                for (int b = 0; b < P.relabel_batch; ++b, ++k) {
+                for (int b = 0; b < batch; ++b, ++k) {
                     rep++;
                     dev.relabel_list(lists[k % 3], rep + 1, lists[(k + 1) % 3], lists[(k + 2) % 3]);
                     st.relabel_passes++;
+                    passes_now++;
                 }
                 dev.read_counts(cnt);
                 st.readbacks++;
                 if (cnt[lists[k % 3]] == 0) break; /* the last pass woke nobody: fixpoint */
+                batch = P.relabel_batch;
             }
+            last_passes = passes_now;
         } else {
             for (;;) {
                 for (int b = 0; b < P.relabel_batch; ++b) {

@@ -764,8 +764,23 @@ __global__ __launch_bounds__(MGC_TV) void k_relabel_first_list(MgcLattice L, int
     }
 }
 
-__global__ __launch_bounds__(MGC_TV) void k_absorb_list(MgcLattice L, int list, int cnt)
+/* the same, one wave per tile (four tiles per workgroup in flight) */
+__global__ __launch_bounds__(256) void k_absorb_w(MgcLattice L, int list, int cnt, int clear_cnt)
 {
+    __shared__ MgcWaveShared S; /* (not touched: the executor wants one) */
+    GpuWave w(S);
+    mgc_clear_counter(L, clear_cnt); /* the slot the next tile filter counts into (HipDevT::fslot) */
+    MgcListView view;
+    const int n = mgc_list_view(L, cnt, view);
+    for (int i = (int)blockIdx.x * 4 + (int)(threadIdx.x >> 6); i < n; i += (int)gridDim.x * 4) {
+        w.new_tile();
+        mgcw_absorb_tile(w, L, __builtin_amdgcn_readfirstlane(mgc_list_at(L, list, view, i)));
+    }
+}
+
+__global__ __launch_bounds__(MGC_TV) void k_absorb_list(MgcLattice L, int list, int cnt, int clear_cnt)
+{
+    mgc_clear_counter(L, clear_cnt); /* the slot the next tile filter counts into (HipDevT::fslot) */
     __shared__ MgcTileShared S;
     GpuBlock x(S);
     MgcListView view;
@@ -815,8 +830,9 @@ __global__ __launch_bounds__(256) void k_dt_finish(MgcLattice L)
 }
 
 /* activation over the filter's list, one wave per tile (four tiles per 256-thread workgroup in flight) */
-__global__ __launch_bounds__(256) void k_activate_w(MgcLattice L, int list, int cnt, uint32_t phase, int exact_max)
+__global__ __launch_bounds__(256) void k_activate_w(MgcLattice L, int list, int cnt, uint32_t phase, int exact_max, int clear_cnt)
 {
+    mgc_clear_counter(L, clear_cnt); /* the slot the next activation filter counts into (HipDevT::fslot) */
     __shared__ MgcWaveShared S; /* (not touched: the executor wants one) */
     GpuWave w(S);
     MgcListView view;
@@ -1325,8 +1341,9 @@ __global__ void k_cut_filter(MgcLattice L, MgcBuildArgs A, const uint8_t* tsum, 
     }
 }
 
-__global__ __launch_bounds__(MGC_TV) void k_cut_value6(MgcLattice L, MgcBuildArgs A, const double* tr0, int list, int cnt, double* part)
+__global__ __launch_bounds__(MGC_TV) void k_cut_value6(MgcLattice L, MgcBuildArgs A, const double* tr0, int list, int cnt, double* part, int clear_cnt)
 {
+    mgc_clear_counter(L, clear_cnt); /* the slot the next tile filter counts into (HipDevT::fslot) */
     __shared__ double scratch[MGC_TV];
     __shared__ int32_t hs[1000];
     const int t = threadIdx.x;
@@ -1681,6 +1698,7 @@ struct mgc_graph {
     int wave_min_tiles = 512;      /* shorter lists are discharged by the workgroup-per-tile kernel (measured: 128^3 4.8 -> 3.4 ms, 256^3 10.8 -> 10.5 ms,
                                       512^3 unchanged; 1024 costs 512^3 8 % more discharges) */
     uint32_t zero_mask = 0; /* counters to clear before the next launch (HipDevT::flush_zero) */
+    int filt[2] = {0, 0};   /* which slot of a filter's pair is in use next (HipDevT::fslot) */
     int pending_zero = -1; /* list counter the schedule asked to clear right after a discharge: the next discharge kernel clears
                               it (it neither reads nor appends to that list), any other operation flushes it with a memset first */
     int use_filters = 3; /* bit0 absorb, bit1 activate, bit2 reset-suspect go through the tile-level filter.  Bit2 is off:
@@ -1791,6 +1809,15 @@ struct HipDevT {
         }
     }
     int filter_grid() const { const int g = (h->L.ntiles + 255) / 256; return g < 1024 ? g : 1024; }
+    /* the counter slot a tile filter counts into now / next time (which = 0: absorb, relabel seeding, suspect reset, cut value;
+     * 1: activation).  The slot is clear: the consumer of the filter's previous list cleared it (or filter_done did). */
+    int fslot(int which) const { return which == 0 ? (h->filt[0] ? MGC_CNT_FILTER_B : MGC_CNT_FILTER) : (h->filt[1] ? MGC_CNT_FILTER_ACT_B : MGC_CNT_FILTER_ACT); }
+    int fnext(int which) const { return which == 0 ? (h->filt[0] ? MGC_CNT_FILTER : MGC_CNT_FILTER_B) : (h->filt[1] ? MGC_CNT_FILTER_ACT : MGC_CNT_FILTER_ACT_B); }
+    void filter_done(int which, bool consumer_cleared_next)
+    {
+        if (!consumer_cleared_next) zero_count(fnext(which));
+        h->filt[which] ^= 1;
+    }
     void absorb_all()
     {
         flush_zero();
@@ -1798,10 +1825,11 @@ struct HipDevT {
         else if (!(h->use_filters & 1)) { hipLaunchKernelGGL(k_absorb, dim3(grid(h->L.ntiles)), dim3(MGC_TV), 0, h->stream, h->L); check(hipGetLastError()); }
         else {
             /* one thread per tile finds the tiles with a pending inbox; only those get a workgroup */
-            zero_count(MGC_CNT_FILTER);
             flush_zero();
-            hipLaunchKernelGGL(k_filter, dim3(filter_grid()), dim3(256), 0, h->stream, h->L, 0, 6, MGC_CNT_FILTER);
-            hipLaunchKernelGGL(k_absorb_list, dim3(grid(h->L.ntiles)), dim3(MGC_TV), 0, h->stream, h->L, 6, MGC_CNT_FILTER);
+            hipLaunchKernelGGL(k_filter, dim3(filter_grid()), dim3(256), 0, h->stream, h->L, 0, 6, fslot(0));
+            if (h->wave_kernels & 1) hipLaunchKernelGGL(k_absorb_w, dim3(grid((h->L.ntiles + 3) / 4)), dim3(256), 0, h->stream, h->L, 6, fslot(0), fnext(0));
+            else hipLaunchKernelGGL(k_absorb_list, dim3(grid(h->L.ntiles)), dim3(MGC_TV), 0, h->stream, h->L, 6, fslot(0), fnext(0));
+            filter_done(0, true);
             check(hipGetLastError());
         }
     }
@@ -1812,12 +1840,11 @@ struct HipDevT {
         if constexpr (FULL) hipLaunchKernelGGL(k26_relabel_all, dim3(grid(h->L.ntiles)), dim3(MGC_TV), 0, h->stream, h->L, epoch, next);
         else if (!(h->use_filters & 1)) hipLaunchKernelGGL(k_relabel_all, dim3(grid(h->L.ntiles)), dim3(MGC_TV), 0, h->stream, h->L, epoch, next);
         else { /* one thread per tile finds the seeds (tiles with an arc to the sink); only those get a workgroup */
-            zero_count(MGC_CNT_FILTER);
             flush_zero();
-            hipLaunchKernelGGL(k_filter, dim3(filter_grid()), dim3(256), 0, h->stream, h->L, 3, 6, MGC_CNT_FILTER);
-            if (h->wave_kernels & 8) hipLaunchKernelGGL(k_relabel_v, dim3(grid(h->L.ntiles)), dim3(MGC_TV / MGC_RELABEL_V), 0, h->stream, h->L, 6, MGC_CNT_FILTER, epoch, next, -1, 1);
-            else if (h->wave_kernels & 2) { hipLaunchKernelGGL(k_relabel_w, dim3(h->wave_grid_rel), dim3(MGCW_LANES), 0, h->stream, h->L, 6, MGC_CNT_FILTER, epoch, next, -1, 1, h->tk_rel); h->tk_rel ^= 1; }
-            else hipLaunchKernelGGL(k_relabel_first_list, dim3(grid(h->L.ntiles)), dim3(MGC_TV), 0, h->stream, h->L, 6, MGC_CNT_FILTER, epoch, next);
+            hipLaunchKernelGGL(k_filter, dim3(filter_grid()), dim3(256), 0, h->stream, h->L, 3, 6, fslot(0));
+            if (h->wave_kernels & 8) { hipLaunchKernelGGL(k_relabel_v, dim3(grid(h->L.ntiles)), dim3(MGC_TV / MGC_RELABEL_V), 0, h->stream, h->L, 6, fslot(0), epoch, next, fnext(0), 1); filter_done(0, true); }
+            else if (h->wave_kernels & 2) { hipLaunchKernelGGL(k_relabel_w, dim3(h->wave_grid_rel), dim3(MGCW_LANES), 0, h->stream, h->L, 6, fslot(0), epoch, next, -1, 1, h->tk_rel); h->tk_rel ^= 1; filter_done(0, false); }
+            else { hipLaunchKernelGGL(k_relabel_first_list, dim3(grid(h->L.ntiles)), dim3(MGC_TV), 0, h->stream, h->L, 6, fslot(0), epoch, next); filter_done(0, false); }
         }
         check(hipGetLastError());
         time_end(id);
@@ -1876,10 +1903,10 @@ struct HipDevT {
         const int id = time_begin(1);
         if (FULL || !(h->use_filters & 4)) hipLaunchKernelGGL(k_reset_suspect<FULL>, dim3(grid((h->L.ntiles + MGC_TV - 1) / MGC_TV)), dim3(MGC_TV), 0, h->stream, h->L, epoch, list);
         else {
-            zero_count(MGC_CNT_FILTER);
             flush_zero();
-            hipLaunchKernelGGL(k_filter, dim3(filter_grid()), dim3(256), 0, h->stream, h->L, 2, 6, MGC_CNT_FILTER);
-            hipLaunchKernelGGL(k_reset_suspect_list, dim3(grid(h->L.ntiles)), dim3(MGC_TV), 0, h->stream, h->L, 6, MGC_CNT_FILTER, epoch, list);
+            hipLaunchKernelGGL(k_filter, dim3(filter_grid()), dim3(256), 0, h->stream, h->L, 2, 6, fslot(0));
+            hipLaunchKernelGGL(k_reset_suspect_list, dim3(grid(h->L.ntiles)), dim3(MGC_TV), 0, h->stream, h->L, 6, fslot(0), epoch, list);
+            filter_done(0, false);
         }
         check(hipGetLastError());
         time_end(id);
@@ -1892,11 +1919,10 @@ struct HipDevT {
         else if (!(h->use_filters & 2)) hipLaunchKernelGGL(k_activate, dim3(grid(h->L.ntiles)), dim3(MGC_TV), 0, h->stream, h->L, phase);
         else {
             /* only tiles whose status says "holds excess" are examined voxel by voxel */
-            zero_count(MGC_CNT_FILTER_ACT);
             flush_zero();
-            hipLaunchKernelGGL(k_filter, dim3(filter_grid()), dim3(256), 0, h->stream, h->L, 1, 7, MGC_CNT_FILTER_ACT);
-            if (h->wave_kernels & 1) hipLaunchKernelGGL(k_activate_w, dim3(grid((h->L.ntiles + 3) / 4)), dim3(256), 0, h->stream, h->L, 7, MGC_CNT_FILTER_ACT, phase, h->activate_exact_max);
-            else hipLaunchKernelGGL(k_activate_list, dim3(grid(h->L.ntiles)), dim3(MGC_TV), 0, h->stream, h->L, 7, MGC_CNT_FILTER_ACT, phase);
+            hipLaunchKernelGGL(k_filter, dim3(filter_grid()), dim3(256), 0, h->stream, h->L, 1, 7, fslot(1));
+            if (h->wave_kernels & 1) { hipLaunchKernelGGL(k_activate_w, dim3(grid((h->L.ntiles + 3) / 4)), dim3(256), 0, h->stream, h->L, 7, fslot(1), phase, h->activate_exact_max, fnext(1)); filter_done(1, true); }
+            else { hipLaunchKernelGGL(k_activate_list, dim3(grid(h->L.ntiles)), dim3(MGC_TV), 0, h->stream, h->L, 7, fslot(1), phase); filter_done(1, false); }
         }
         check(hipGetLastError());
     }
@@ -2037,10 +2063,10 @@ static int mgc_launch_readout(mgc_handle h, int slot, hipEvent_t after_labels)
         const int fg = (L.ntiles + 255) / 256;
         HipDev dev;
         dev.h = h;
-        dev.zero_count(MGC_CNT_FILTER);
         dev.flush_zero();
-        hipLaunchKernelGGL(k_cut_filter, dim3(fg < 1024 ? fg : 1024), dim3(256), 0, h->stream, L, h->build_args, rows8 ? (const uint8_t*)h->d_tsum : (const uint8_t*)nullptr, h->d_part, 6, MGC_CNT_FILTER);
-        hipLaunchKernelGGL(k_cut_value6, dim3(grid), dim3(MGC_TV), 0, h->stream, L, h->build_args, (const double*)h->d_tr0, 6, MGC_CNT_FILTER, h->d_part);
+        hipLaunchKernelGGL(k_cut_filter, dim3(fg < 1024 ? fg : 1024), dim3(256), 0, h->stream, L, h->build_args, rows8 ? (const uint8_t*)h->d_tsum : (const uint8_t*)nullptr, h->d_part, 6, dev.fslot(0));
+        hipLaunchKernelGGL(k_cut_value6, dim3(grid), dim3(MGC_TV), 0, h->stream, L, h->build_args, (const double*)h->d_tr0, 6, dev.fslot(0), h->d_part, dev.fnext(0));
+        dev.filter_done(0, true);
     }
     else hipLaunchKernelGGL(k_cut_value, dim3(grid), dim3(MGC_TV), 0, h->stream, L, h->build_args, (const double*)h->d_tr0, (const uint8_t*)h->d_labels, h->d_part);
     MGC_HIP(h, hipGetLastError());
@@ -2710,6 +2736,7 @@ int mgc_build(mgc_handle h)
     MGC_HIP(h, hipMemsetAsync(L.count, 0, MGC_NCOUNT * (1 + MGC_NSHARD) * sizeof(int32_t), h->stream)); /* (k_build counts in MGC_CNT_NOT_FULL) */
     h->zero_mask = 0;
     h->pending_zero = -1;
+    h->filt[0] = h->filt[1] = 0;
     if (L.ndir == 6) mgc_launch_build<false>(A.term, bgrid, h->stream, L, A);
     else mgc_launch_build<true>(A.term, bgrid, h->stream, L, A);
     MGC_HIP(h, hipGetLastError());
@@ -2974,6 +3001,13 @@ int mgc_set_param(mgc_handle h, const char* name, int64_t value)
     else if (!strcmp(name, "wave_grid_rel") && value > 0) h->wave_grid_rel = (int)value;
     else if (!strcmp(name, "first_relabel_dt")) h->use_dt = value != 0;
     else if (!strcmp(name, "wave_stagger") && value >= 0) h->wave_stagger = (int)value;
+    else if (!strcmp(name, "list_shards") && (value == 1 || value == MGC_NSHARD)) { /* regions per work list (MgcLattice::scount); between solves only */
+        mgc_flush_zero(h);
+        MGC_HIP(h, hipMemsetAsync(h->L.count, 0, MGC_NCOUNT * (1 + MGC_NSHARD) * sizeof(int32_t), h->stream));
+        h->L.nshard = (int)value;
+        h->filt[0] = h->filt[1] = 0;
+        h->solved = false;
+    }
     else if (!strcmp(name, "activate_exact_max") && value >= 0) h->activate_exact_max = (int)value;
     else if (!strcmp(name, "kernel_timing")) h->timing = value != 0;
     else if (!strcmp(name, "timing_stride") && value > 0) h->timing_stride = (int)value;

@@ -577,12 +577,15 @@ MGC_HD void mgcw_discharge_impl(W& w, const MgcLattice& L, int tile, uint32_t ph
          * looked at further down: the wait for it sits behind the votes and the staging below.) */
         if (target >= 0) wk(l, 2) = (int)w.atomic_exch(&L.stamp[target], ep);
     });
-    bool has_sink = false, has_exc = false;
-    mgcw_static_for<8>([&](auto KK) MGCW_INL {
-        constexpr int K = decltype(KK)::value;
-        if constexpr (SINK) has_sink = has_sink || w.any([&](int l) MGCW_INL -> bool { return w.S.snk[K * 64 + l] > 0.0; });
-        has_exc = has_exc || w.any([&](int l) MGCW_INL -> bool { return e(l, K) > 0.0 && h(l, K) < MGC_HINF; }); /* (excess under an INF label is dead for good) */
-    });
+    bool has_sink = false;
+    /* excess under a finite label (excess under an INF label is dead for good): what the slot votes that ended the sweeps said */
+    const bool has_exc = active;
+    if constexpr (SINK) {
+        mgcw_static_for<8>([&](auto KK) MGCW_INL {
+            constexpr int K = decltype(KK)::value;
+            has_sink = has_sink || w.any([&](int l) MGCW_INL -> bool { return w.S.snk[K * 64 + l] > 0.0; });
+        });
+    }
     const bool saturated = w.any([&](int l) MGCW_INL -> bool { return sat(l, 0) != 0; });
     w.lanes([&](int l) MGCW_INL { /* outbox staged through LDS (face order: the neighbours read 64 consecutive doubles per face) */
         const int y = l >> 3, x = l & 7;
@@ -789,6 +792,52 @@ MGC_HD void mgcw_activate_tile(W& w, const MgcLattice& L, int tile, uint32_t pha
             w.atomic_add(&L.count[6], 1);
         }
     });
+}
+
+/* ---------------------------------------------------------------------------------------
+ * Absorb-only visit (before a global relabel no flow may be in flight in an outbox while the residual masks are read),
+ * one wave per tile.  Lane k is face cell k: for every face across which the neighbour left flow (its outbox flag), the
+ * lane adds the slot's content to the excess and to the reverse residual of the voxel behind the cell and empties the
+ * slot -- faces in ascending order, one after the other, so a voxel on an edge or a corner receives its two or three
+ * contributions in the order (and with the roundings) of mgc_absorb_tile.  Same contract as mgc_absorb_tile.
+ * ------------------------------------------------------------------------------------- */
+template <class W>
+MGC_HD void mgcw_absorb_tile(W& w, const MgcLattice& L, int tile)
+{
+    if (!mgc_owned(L, tile)) return;
+    int tz, ty, tx;
+    mgc_tile_coords(L, tile, tz, ty, tx);
+    double* const t_excess = L.excess + (int64_t)tile * MGC_TV;
+    uint8_t* const t_rmask = L.rmask + (int64_t)tile * MGC_TV;
+    bool got = false;
+    mgcw_static_for<6>([&](auto FF) MGCW_INL {
+        constexpr int F = decltype(FF)::value;
+        const int nt = mgc_tile_nbr(L, tz, ty, tx, F);
+        if (nt < 0 || !((L.oflags[nt] >> (F ^ 1)) & 1u)) return; /* wave-uniform */
+        double* const slots = L.obox + ((int64_t)nt * 6 + (F ^ 1)) * MGC_TF;
+        double* const t_plane = L.rcap + ((int64_t)tile * 6 + F) * MGC_TV;
+        const bool any = w.any([&](int l) MGCW_INL -> bool {
+            const double d = w.ld(slots, l);
+            if (d != 0.0) {
+                const int v = mgc_face_voxel(F, l);
+                const double r = w.ld(t_plane, v) + d;
+                w.st(t_excess, v, w.ld(t_excess, v) + d);
+                w.st(t_plane, v, r);
+                if (r > 0.0) w.st(t_rmask, v, (uint8_t)(w.ld(t_rmask, v) | (1u << F)));
+                w.st(slots, l, 0.0);
+            }
+            return d != 0.0;
+        });
+        got = got || any;
+        w.lanes([&](int l) MGCW_INL {
+            if (l == 0) w.atomic_and(&L.oflags[nt], ~(1u << (F ^ 1)));
+        });
+    });
+    if (got) {
+        w.lanes([&](int l) MGCW_INL {
+            if (l == 0) L.status[tile] |= MGC_ST_EXCESS; /* flow arrived: the tile may hold excess now */
+        });
+    }
 }
 
 #endif /* MGC_WAVE_OPS_INL */

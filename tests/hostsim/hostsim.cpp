@@ -193,7 +193,15 @@ struct HostDev {
     void range_push(const char*) {}
     void range_pop() {}
     void read_counts(int* out) { memcpy(out, L.count, MGC_NCOUNT * sizeof(int)); }
-    void absorb_all() { HostBlock x(S); for (int t = 0; t < L.ntiles; ++t) mgc_absorb_tile(x, L, t); }
+    void absorb_all()
+    {
+        HostBlock x(S);
+        HostWave w(WS);
+        for (int t = 0; t < L.ntiles; ++t) {
+            if (g_wave_mode & 1) mgcw_absorb_tile(w, L, t);
+            else mgc_absorb_tile(x, L, t);
+        }
+    }
     void relabel_all(uint32_t epoch, int next)
     {
         HostBlock x(S);
