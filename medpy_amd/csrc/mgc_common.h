@@ -83,10 +83,10 @@ struct MgcLattice {
                                  cut into `nshard` regions of `shard_cap` entries (see scount) */
     int32_t*  count;          /* [MGC_NCOUNT] device resident: [0..5] list lengths, [6] active tiles found by the last
                                  activation, [8]/[9] running totals of tiles discharged / relabelled            */
-    /* SHARDED list lengths.  A list counter is the hottest word of the solver: every tile visit appends a few neighbours,
-       a relabel pass appends ~9 000 tiles in 30 us, and one address takes ~88 returning atomics per microsecond
-       (MI355X_MICROARCH.md, "dequeue") -- the resident waves of a launch finish their tiles in bursts and then queue up on
-       it.  So the length of list / counter slot c is the SUM of nshard words scount[c * nshard + s]; an appender uses the
+    /* List lengths, optionally SHARDED.  A list counter is the hottest word of the solver (every tile visit appends a few
+       neighbours, a relabel pass appends ~9 000 tiles in 30 us, and one address takes ~88 returning atomics per microsecond,
+       MI355X_MICROARCH.md "dequeue"), so the layout allows the length of list / counter slot c to be the SUM of nshard words
+       scount[c * nshard + s] -- see MGC_NSHARD for what that measured.  With several regions an appender uses the
        shard its workgroup id selects (spread over the XCDs) and writes into region s of the list,
        list[l][s * shard_cap + pos].  Consumers read the nshard words once (MgcListView) and walk the regions as one
        sequence.  The host simulator runs with nshard = 1 and scount = count: the plain layout. */
@@ -103,7 +103,13 @@ struct MgcLattice {
     unsigned long long* prof; /* optional [16] cycle accumulators of the discharge sections (development aid) or NULL */
 };
 
-#define MGC_NSHARD 16
+/* Measured on MI355X (round 3): 16 regions per list do NOT pay -- 512^3 sphere 38.6 ms with 16, 37.6 ms with 1; 26-neighbourhood
+ * 256^3 82.8 vs 76.7 ms: the appends of a launch are spread over its whole duration and over two lists, the extra trip for
+ * the region lengths costs more than the queueing it avoids.  One region is the default; the machinery stays (tests and
+ * tools can build with -DMGC_NSHARD=16 and switch with the list_shards parameter). */
+#ifndef MGC_NSHARD
+#define MGC_NSHARD 1
+#endif
 
 MGC_HD int32_t* mgc_counter(const MgcLattice& L, int c, int shard) { return L.scount + c * L.nshard + shard; }
 

@@ -127,7 +127,7 @@ int mgc_solve(Dev& dev, const MgcLattice& L, const MgcSolveParams& P, MgcSolveSt
             /* passes between two looks at the list length: the label wave of one global relabel needs about as many passes as
              * that of the relabel before it, so most of them go out in one stretch (a pass over an empty list costs ~4 us,
              * a look at the counters a stream drain) */
-            int batch = outer > 0 && last_passes > 2 * P.relabel_batch ? (int)(last_passes - last_passes / 4) : P.relabel_batch;
+            int batch = outer > 0 && last_passes > P.relabel_batch ? (int)last_passes : P.relabel_batch;
             int64_t passes_now = 0;
             for (;;) {
                 for (int b = 0; b < batch; ++b, ++k) {
@@ -138,10 +138,12 @@ int mgc_solve(Dev& dev, const MgcLattice& L, const MgcSolveParams& P, MgcSolveSt
                 }
                 dev.read_counts(cnt);
                 st.readbacks++;
-                if (cnt[lists[k % 3]] == 0) break; /* the last pass woke nobody: fixpoint */
-                batch = P.relabel_batch;
+                if (cnt[lists[k % 3]] == 0) { /* the last pass woke nobody: fixpoint */
+                    last_passes = passes_now - batch + 1; /* (the wave died somewhere inside the last stretch: what is known to have been needed) */
+                    break;
+                }
+                batch = P.relabel_batch > 4 ? P.relabel_batch / 2 : P.relabel_batch;
             }
-            last_passes = passes_now;
         } else {
             for (;;) {
                 for (int b = 0; b < P.relabel_batch; ++b) {

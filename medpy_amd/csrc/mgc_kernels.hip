@@ -1741,8 +1741,9 @@ static int mgc_alloc(mgc_handle h, T** p, int64_t count)
 /* the counter block as the host sees it: slot c = its plain word + its shard words (a slot is used one way or the other) */
 static void mgc_fold_counts(mgc_handle h)
 {
+    const int ns = h->L.nshard;
     for (int c = 0; c < MGC_NCOUNT; ++c)
-        for (int sh = 0; sh < MGC_NSHARD; ++sh) h->h_count[c] += h->h_count[MGC_NCOUNT + c * MGC_NSHARD + sh];
+        for (int sh = 0; sh < ns; ++sh) h->h_count[c] += h->h_count[MGC_NCOUNT + c * ns + sh];
 }
 
 /* device policy for mgc_solve(): one kernel launch per call, in-order on the handle's stream.
@@ -2156,7 +2157,7 @@ static int mgc_create_impl(int ndim, const int64_t* shape, int connectivity, int
             MGC_HIP(h, hipMemsetAsync(L.hshadow[sd], 0x3f, (size_t)L.gy * L.gx * MGC_TF * sizeof(int32_t), h->stream));
         }
     }
-    L.nshard = MGC_NSHARD; /* sharded list lengths: MgcLattice::scount */
+    L.nshard = 1; /* regions per work list (MgcLattice::scount): one, unless list_shards asks for MGC_NSHARD */
     L.shard_cap = (int)nt;
     for (int i = 0; i < (L.ndir == 6 ? 8 : 18); ++i)
         if ((rc = mgc_alloc(h, &L.list[i], nt * MGC_NSHARD))) return rc;
