@@ -376,7 +376,19 @@ def main():
                                "other_discharge_launches_per_step": (acc["discharge_launches"] - launches) / args.steps if wave else 0.0}
         else:
             out["slab_schedule"] = slab_stats
-            out["roofline"] = None  # per-kernel event timing is a single-handle measurement (the N = 1 line)
+            # the dominant kernel on THIS rank's slab (rank 0; the library times its own launches in the slab driver too)
+            pst = slab.stats()
+            wave = conn == 6 and pst.get("discharge_wave_launches", 0) > 0
+            launches = max(pst["discharge_wave_launches"] if wave else pst["discharge_launches"], 1)
+            avg_ms = (pst["discharge_wave_ms"] if wave else pst["discharge_ms"]) / launches
+            vox_per_launch = (pst["discharge_wave_tiles"] if wave else pst["discharge_tiles"]) * 512.0 / launches
+            achieved = (b_alg * vox_per_launch) / (avg_ms * 1e-3) / 1e9 if avg_ms > 0 else 0.0
+            out["phases_ms"] = {"solve": round(pst["solve_ms"], 3), "discharge_kernels": round(pst["discharge_ms"], 3),
+                                "relabel_kernels": round(pst["relabel_ms"], 3), "rank": 0}
+            out["roofline"] = {"bound": "hbm", "kernel": "k_discharge_w" if conn == 6 else "k26_discharge", "achieved": round(achieved, 2),
+                               "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBS, 5), "traffic": None,
+                               "avg_launch_ms": round(avg_ms, 4), "launches_per_step": launches, "voxels_per_launch": round(vox_per_launch, 1),
+                               "bytes_per_voxel": b_alg, "scope": "rank 0's slab, last step; per-GPU algorithmic GB/s of the whole job: per_gpu_algorithmic_gbs"}
         if not args.no_cpu and world == 1 and not args.config and not args.strong:
             out["cpu_baseline"] = cpu_baseline_in_run(args.cpu_sample, not args.cpu_sample_only)
         else:

@@ -229,6 +229,26 @@ int mgc_finish(mgc_handle h, double* flow_partial);
 int mgc_comm_unique_id(uint8_t* id128);
 int mgc_comm_init(mgc_handle h, const uint8_t* id128);
 int mgc_halo_exchange(mgc_handle h, int kind, uint32_t epoch, int list);
+
+/* The whole distributed solve of one slab inside the library: the schedule of medpy_amd/slab.py:solve_slabs (itself the
+ * single-GPU schedule of mgc_driver.inl with border exchanges and counter all-reduces added) driven from C++ over the
+ * native transport -- no host-language call per kernel, one grouped transfer per border exchange, the host looks at the
+ * device only where every rank has to take the same decision (all-reduced counters).  Call it on every rank after
+ * mgc_build (and mgc_comm_init when the volume has more than one slab); then mgc_finish.  Per-kernel times and counts of
+ * the run are in mgc_get_stats afterwards, as after mgc_maxflow. */
+typedef struct mgc_slab_stats {
+    int64_t outer;            /* global relabels                                            */
+    int64_t relabel_passes;
+    int64_t phases;           /* colour phases                                              */
+    int64_t exchanges;        /* border exchanges (each ONE grouped send/receive per neighbour) */
+    int64_t reductions;       /* counter all-reduces = points where the host waits for the device */
+    int64_t converged;
+    int64_t discharge_tiles;  /* global                                                     */
+    int64_t relabel_tiles;    /* global                                                     */
+    int64_t deferred_drains;  /* extra exchanges because a border message was full          */
+    int64_t reserved[7];
+} mgc_slab_stats;
+int mgc_solve_slab(mgc_handle h, mgc_slab_stats* out);
 int mgc_allreduce_counts(mgc_handle h, int64_t* out32);
 
 

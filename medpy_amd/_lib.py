@@ -74,6 +74,16 @@ def assert_valid(v, rel=1e-9):
     return diff / scale
 
 
+class SlabStats(C.Structure):
+    """mgc_slab_stats (include/medpy_hip.h): what mgc_solve_slab did"""
+    _fields_ = [("outer", C.c_int64), ("relabel_passes", C.c_int64), ("phases", C.c_int64), ("exchanges", C.c_int64),
+                ("reductions", C.c_int64), ("converged", C.c_int64), ("discharge_tiles", C.c_int64), ("relabel_tiles", C.c_int64),
+                ("deferred_drains", C.c_int64), ("reserved", C.c_int64 * 7)]
+
+    def as_dict(self):
+        return {k: int(getattr(self, k)) for k, _ in self._fields_ if k != "reserved"}
+
+
 class SparseStats(C.Structure):
     _fields_ = [("build_ms", C.c_double), ("solve_ms", C.c_double), ("rounds", C.c_int64), ("global_relabels", C.c_int64),
                 ("relabel_passes", C.c_int64), ("nodes", C.c_int64), ("arcs", C.c_int64), ("edges_added", C.c_int64),
@@ -125,6 +135,7 @@ SIGNATURES = {
     "mgc_comm_init": (_INT, [_VP, _VP]),
     "mgc_halo_exchange": (_INT, [_VP, _INT, C.c_uint32, _INT]),
     "mgc_allreduce_counts": (_INT, [_VP, _VP]),
+    "mgc_solve_slab": (_INT, [_VP, C.POINTER(SlabStats)]),
     # sparse graphs (region graph cut, n-D voxel graphs, edge-by-edge plug-ins)
     "msg_create": (_INT, [_I64, _INT, C.POINTER(_VP)]),
     "msg_destroy": (_INT, [_VP]),

@@ -50,6 +50,8 @@
  * into (no launch in between just to clear a word) */
 #define MGC_CNT_FILTER_B 30
 #define MGC_CNT_FILTER_ACT_B 31
+#define MGC_CNT_DEFERRED 28    /* (during a solve; k_build's MGC_CNT_NOT_FULL is read before it starts) border tiles a halo pack had to leave
+                                  for the next exchange because the message was full (MgcLattice::halo_max_rec) */
 #define MGC_CNT_WAVE_TILES 29  /* running total of the tiles k_discharge_w visited (count[8] pools both discharge kernels) */
 #define MGC_CNT_NOT_FULL 28    /* k_build: tiles holding an n-link inside the volume that is not residual (0: the first global relabel is a distance transform) */
 
@@ -98,6 +100,12 @@ struct MgcLattice {
     uint32_t* status;         /* [ntiles] bit1 (2): the tile holds a residual arc to the sink; bit2 (4): DIRTY = discharged
                                  since the last global relabel; bit3 (8): SUSPECT (labels must be recomputed);
                                  bits 8..13: faces through which the tile's labels are supported by a neighbour */
+    int       halo_max_rec;   /* slabs: records one compacted border message may carry.  A message is the fixed header plus this many
+                                 record slots, sent in ONE transfer whose size both sides know without asking the device; a
+                                 border tile that finds the message full keeps what it has to say (labels: the shadow stays
+                                 behind; flow: it stays in the outbox / ghost tile) and goes out with the next exchange.
+                                 MGC_CNT_DEFERRED counts those, and the schedule does not take "nothing woke up" for a
+                                 fixpoint, nor start a global relabel, while any are left (slab.py, mgc_solve_slab) */
     int32_t*  hshadow[2];     /* slabs, 6-neighbourhood: [gy*gx][64] labels of the owned border layer (lower / upper) as the neighbour
                                  slab last received them -- a border tile only travels when it differs from this (or holds flow) */
     unsigned long long* prof; /* optional [16] cycle accumulators of the discharge sections (development aid) or NULL */

@@ -2158,6 +2158,10 @@ static int mgc_create_impl(int ndim, const int64_t* shape, int connectivity, int
         }
     }
     L.nshard = 1; /* regions per work list (MgcLattice::scount): one, unless list_shards asks for MGC_NSHARD */
+    { /* record slots of a compacted border message (MgcLattice::halo_max_rec): an eighth of the border tiles, at least 64 */
+        const int64_t T = gy * gx;
+        L.halo_max_rec = (int)(T / 8 > 64 ? T / 8 : (T < 64 ? T : 64));
+    }
     L.shard_cap = (int)nt;
     for (int i = 0; i < (L.ndir == 6 ? 8 : 18); ++i)
         if ((rc = mgc_alloc(h, &L.list[i], nt * MGC_NSHARD))) return rc;
@@ -2281,6 +2285,8 @@ int mgc_halo_pack(mgc_handle h, int side, int kind, void* buf, int buf_on_device
             MGC_HIP(h, hipStreamSynchronize(h->stream));
             int32_t cnt = 0;
             memcpy(&cnt, (const char*)buf + mgc_halo_off_count_nd(h->L), 4);
+            if (cnt > h->L.halo_max_rec) cnt = h->L.halo_max_rec; /* (tiles beyond that were deferred, not packed) */
+            memcpy((char*)buf + mgc_halo_off_count_nd(h->L), &cnt, 4);
             used = (int64_t)cnt * mgc_halo_rec_bytes_nd(h->L, kind);
             if (used) MGC_HIP(h, hipMemcpyAsync((char*)buf + off, (const char*)dst + off, (size_t)used, hipMemcpyDeviceToHost, h->stream));
         } else {
@@ -2308,7 +2314,7 @@ int mgc_halo_unpack(mgc_handle h, int side, int kind, const void* buf, int buf_o
         if (mgc_halo_compact_nd(h->L, kind)) { /* the header says how many records follow it */
             int32_t cnt = 0;
             memcpy(&cnt, (const char*)buf + mgc_halo_off_count_nd(h->L), 4);
-            if (cnt < 0 || cnt > h->L.gy * h->L.gx) return mgc_fail(h, MGC_ERR_INVALID, "mgc_halo_unpack: record count %d out of range", (int)cnt);
+            if (cnt < 0 || cnt > h->L.halo_max_rec) return mgc_fail(h, MGC_ERR_INVALID, "mgc_halo_unpack: record count %d out of range (message holds %d)", (int)cnt, h->L.halo_max_rec);
             used = mgc_halo_off_rec_nd(h->L) + (int64_t)cnt * mgc_halo_rec_bytes_nd(h->L, kind);
         }
         MGC_HIP(h, hipMemcpyAsync(h->d_halo, buf, (size_t)used, hipMemcpyHostToDevice, h->stream));
@@ -2434,9 +2440,12 @@ int mgc_halo_exchange(mgc_handle h, int kind, uint32_t epoch, int list)
         }
         h->xchg_cap = bytes;
     }
-    /* compacted kinds: fixed header first, then only the records that were filled (mgc_halo_pack_tile, mgc26_halo_pack_tile) */
+    /* compacted kinds: the fixed header plus halo_max_rec record slots, in ONE grouped transfer whose size both sides know
+     * without asking the device (round 2 moved the header, read the two record counts back on the host -- a stream drain per
+     * exchange -- and then moved exactly that many records in a second group).  Tiles that found the message full were
+     * deferred by the pack kernel (MGC_CNT_DEFERRED). */
     const bool compact = mgc_halo_compact_nd(h->L, kind);
-    const int64_t nb = compact ? mgc_halo_off_rec_nd(h->L) : mgc_halo_bytes_nd(h->L, kind);
+    const int64_t nb = compact ? mgc_halo_off_rec_nd(h->L) + (int64_t)h->L.halo_max_rec * mgc_halo_rec_bytes_nd(h->L, kind) : mgc_halo_bytes_nd(h->L, kind);
     const bool has[2] = {h->L.tz_own_lo > 0, h->L.tz_own_hi < h->L.gz};
     const int peer[2] = {h->rank - 1, h->rank + 1};
     const int T = h->L.gy * h->L.gx, grid = T < 2048 ? T : 2048;
@@ -2453,31 +2462,177 @@ int mgc_halo_exchange(mgc_handle h, int kind, uint32_t epoch, int list)
             MGC_NCCL(h, g_rccl.Recv(h->d_xchg[2 * side + 1], (size_t)nb, ncclUint8, peer[side], h->comm, h->stream));
         }
     MGC_NCCL(h, g_rccl.GroupEnd());
-    if (compact) {
-        /* how many records each direction carries: mine (packed above) and the neighbour's (just received) */
-        int32_t* hc = h->h_count; /* pinned scratch, 4 of MGC_NCOUNT slots */
-        for (int i = 0; i < 4; ++i)
-            if (has[i >> 1]) MGC_HIP(h, hipMemcpyAsync(hc + i, (char*)h->d_xchg[i] + mgc_halo_off_count_nd(h->L), 4, hipMemcpyDeviceToHost, h->stream));
-        MGC_HIP(h, hipStreamSynchronize(h->stream));
-        const int64_t off = mgc_halo_off_rec_nd(h->L), rb = mgc_halo_rec_bytes_nd(h->L, kind);
-        bool any = false;
-        for (int i = 0; i < 4; ++i) any |= has[i >> 1] && hc[i] > 0;
-        if (any) {
-            MGC_NCCL(h, g_rccl.GroupStart());
-            for (int side = 0; side < 2; ++side)
-                if (has[side]) {
-                    if (hc[2 * side] > 0) MGC_NCCL(h, g_rccl.Send((char*)h->d_xchg[2 * side] + off, (size_t)(hc[2 * side] * rb), ncclUint8, peer[side], h->comm, h->stream));
-                    if (hc[2 * side + 1] > 0) MGC_NCCL(h, g_rccl.Recv((char*)h->d_xchg[2 * side + 1] + off, (size_t)(hc[2 * side + 1] * rb), ncclUint8, peer[side], h->comm, h->stream));
-                }
-            MGC_NCCL(h, g_rccl.GroupEnd());
-        }
-    }
     for (int side = 0; side < 2; ++side)
         if (has[side]) {
             hipLaunchKernelGGL(k_halo_unpack, dim3(grid), dim3(MGC_TV), 0, h->stream, h->L, side, kind, (const void*)h->d_xchg[2 * side + 1], epoch, list);
             MGC_HIP(h, hipGetLastError());
         }
     return MGC_OK;
+}
+
+} /* extern "C" */
+
+/* the schedule of medpy_amd/slab.py:solve_slabs on the device policy Dev (6- or 26-neighbourhood kernels) */
+template <class Dev>
+static int mgc_solve_slab_on(mgc_handle h, const MgcLayout lay, mgc_slab_stats* out)
+{
+    Dev dev;
+    dev.h = h;
+    const MgcSolveParams P = h->params;
+    const bool multi = h->nranks > 1;
+    mgc_slab_stats st{};
+    int64_t g[MGC_NCOUNT];
+    int cnt[MGC_NCOUNT];
+    int rc = MGC_OK;
+    auto exchange = [&](int kind, uint32_t epoch, int list) -> int {
+        if (!multi) return MGC_OK;
+        st.exchanges++;
+        return mgc_halo_exchange(h, kind, epoch, list);
+    };
+    auto reduce = [&]() -> int { /* the counter block summed over all slabs: every rank decides alike */
+        st.reductions++;
+        if (multi) return mgc_allreduce_counts(h, g);
+        dev.read_counts(cnt);
+        for (int i = 0; i < MGC_NCOUNT; ++i) g[i] = cnt[i];
+        return MGC_OK;
+    };
+#define MGC_SLAB_TRY(call) do { if ((rc = (call)) != MGC_OK) return rc; } while (0)
+    const int lmask = lay.list_mask, rl = lay.rl_base;
+    int batch = P.relabel_batch < 2 ? 2 : P.relabel_batch + (P.relabel_batch & 1); /* even: every rank keeps the same list parity */
+    uint32_t phase = 2 * (uint32_t)(lmask + 1), rep = 2;
+    dev.zero_count(lay.cnt_dis);
+    dev.zero_count(lay.cnt_rel);
+    dev.zero_count(MGC_CNT_DEFERRED);
+    for (int outer = 0; outer < P.max_outer; ++outer) {
+        mgc_range_push("global relabel");
+        /* flow a full border message left behind during the colour phases must have crossed before the masks are read */
+        if (multi && outer > 0) {
+            for (;;) {
+                MGC_SLAB_TRY(reduce());
+                if (g[MGC_CNT_DEFERRED] == 0) break;
+                dev.zero_count(MGC_CNT_DEFERRED);
+                MGC_SLAB_TRY(exchange(1, phase - 1, 0));
+                st.deferred_drains++;
+            }
+        }
+        dev.absorb_all();
+        dev.zero_count(rl);
+        dev.zero_count(rl + 1);
+        int nxt = rl + (int)((rep + 1) & 1u);
+        if (outer == 0 || !lay.incremental || !P.incremental_relabel) {
+            dev.fill_heights_inf();
+            dev.relabel_all(rep + 1, nxt);
+        } else {
+            for (;;) { /* which tiles may have lost the support of their labels (closure across the slab borders) */
+                dev.zero_count(MGC_CNT_CHANGED);
+                for (int b = 0; b < 8; ++b) dev.suspect_pass();
+                MGC_SLAB_TRY(exchange(2, 0, 0));
+                MGC_SLAB_TRY(reduce());
+                if (g[MGC_CNT_CHANGED] == 0) break;
+            }
+            dev.reset_suspect(rep + 1, nxt);
+        }
+        st.relabel_passes++;
+        for (;;) {
+            for (;;) { /* passes to the LOCAL fixpoint: no collective (labels only go down, stale ghost labels are upper bounds) */
+                dev.read_counts(cnt);
+                if (cnt[nxt] == 0) break;
+                for (int b = 0; b < batch; ++b) {
+                    rep++;
+                    const int cur = rl + (int)(rep & 1u);
+                    nxt = rl + (int)((rep + 1) & 1u);
+                    dev.zero_count(nxt);
+                    dev.relabel_list(cur, rep + 1, nxt, -1);
+                    st.relabel_passes++;
+                }
+            }
+            dev.zero_count(MGC_CNT_DEFERRED);
+            MGC_SLAB_TRY(exchange(0, rep + 1, nxt));
+            MGC_SLAB_TRY(reduce());
+            if (g[nxt] == 0 && g[MGC_CNT_DEFERRED] == 0) break; /* the exchange woke nobody anywhere and left nothing behind: global fixpoint */
+        }
+        st.outer++;
+        mgc_range_pop();
+
+        /* ---- who can still push towards the sink? */
+        phase += 2 * (uint32_t)(lmask + 1); /* fresh stamps: anything queued before the relabel is void */
+        for (int i = 0; i <= lmask; ++i) dev.zero_count(i);
+        dev.zero_count(lay.cnt_active);
+        dev.activate_all(phase);
+        MGC_SLAB_TRY(reduce());
+        if (g[lay.cnt_active] == 0) {
+            st.converged = 1;
+            break;
+        }
+
+        /* ---- colour phases, border (labels + outbox flow) exchanged after each */
+        mgc_range_push("colour phases");
+        dev.zero_count(MGC_CNT_DEFERRED);
+        for (int r = 0; r < P.rounds_per_relabel; ++r) {
+            for (int c = 0; c < lay.ncolours; ++c) {
+                const int lst = (int)(phase & (uint32_t)lmask);
+                dev.discharge(lst, phase, P.max_cycles, P.max_sweeps);
+                dev.zero_count(lst);
+                MGC_SLAB_TRY(exchange(1, phase, 0));
+                st.phases++;
+                phase++;
+            }
+            if ((r + 1) % P.check_rounds == 0 && r + 1 < P.rounds_per_relabel) {
+                MGC_SLAB_TRY(reduce());
+                int64_t pending = g[MGC_CNT_DEFERRED];
+                for (int i = 0; i <= lmask; ++i) pending += g[i];
+                if (pending == 0) break;
+            }
+        }
+        mgc_range_pop();
+    }
+    MGC_SLAB_TRY(reduce());
+#undef MGC_SLAB_TRY
+    st.discharge_tiles = g[lay.cnt_dis];
+    st.relabel_tiles = g[lay.cnt_rel];
+    mgc_flush_zero(h);
+    if (dev.first_error != hipSuccess) return mgc_fail(h, MGC_ERR_HIP, "slab solver: HIP error %s", hipGetErrorString(dev.first_error));
+    if (hipStreamSynchronize(h->stream) != hipSuccess) return mgc_fail(h, MGC_ERR_HIP, "slab solver: stream synchronisation failed");
+    dev.resolve_timing();
+    h->stats.discharge_ms = dev.discharge_ms + dev.block_ms;
+    h->stats.discharge_wave_ms = dev.discharge_ms;
+    h->stats.discharge_wave_launches = dev.seen[0];
+    h->stats.timing_stride = h->timing ? h->timing_stride : 0;
+    h->stats.relabel_ms = dev.relabel_ms;
+    h->stats.discharge_launches = dev.discharge_launches;
+    h->stats.relabel_launches = dev.relabel_launches;
+    h->stats.reserved[0] = dev.readbacks;
+    dev.read_counts(cnt); /* this slab's own share (mgc_get_stats is per handle; the global totals are in mgc_slab_stats) */
+    h->stats.discharge_tiles = cnt[lay.cnt_dis];
+    h->stats.relabel_tiles = cnt[lay.cnt_rel];
+    h->stats.discharge_wave_tiles = h->L.ndir == 6 ? cnt[MGC_CNT_WAVE_TILES] : cnt[lay.cnt_dis];
+    h->stats.global_relabels = st.outer;
+    h->stats.phases = st.phases;
+    if (out) *out = st;
+    if (!st.converged) return mgc_fail(h, MGC_ERR_NOT_CONVERGED, "slab solver did not converge within %d global relabels", P.max_outer);
+    return MGC_OK;
+}
+
+extern "C" {
+
+int mgc_solve_slab(mgc_handle h, mgc_slab_stats* out)
+{
+    if (!h) return MGC_ERR_INVALID;
+    if (!h->built) return mgc_fail(h, MGC_ERR_STATE, "mgc_solve_slab before mgc_build");
+    if (h->nranks > 1 && !h->comm) return mgc_fail(h, MGC_ERR_STATE, "mgc_solve_slab: this slab has neighbours, call mgc_comm_init first");
+    MGC_HIP(h, hipSetDevice(h->device));
+    MgcRange range_("mgc_solve_slab");
+    h->solved = false;
+    float ms = 0.f;
+    MGC_HIP(h, hipEventRecord(h->ev[0], h->stream));
+    const int rc = h->L.ndir == MGC26_NDIR ? mgc_solve_slab_on<HipDev26>(h, mgc_layout26(), out) : mgc_solve_slab_on<HipDev>(h, mgc_layout6(), out);
+    if (rc == MGC_OK) {
+        MGC_HIP(h, hipEventRecord(h->ev[1], h->stream));
+        MGC_HIP(h, hipStreamSynchronize(h->stream));
+        MGC_HIP(h, hipEventElapsedTime(&ms, h->ev[0], h->ev[1]));
+        h->stats.solve_ms = ms;
+    }
+    return rc;
 }
 
 int mgc_destroy(mgc_handle h)
@@ -3001,6 +3156,10 @@ int mgc_set_param(mgc_handle h, const char* name, int64_t value)
     else if (!strcmp(name, "wave_grid_dis") && value > 0) h->wave_grid_dis = (int)value;
     else if (!strcmp(name, "wave_grid_rel") && value > 0) h->wave_grid_rel = (int)value;
     else if (!strcmp(name, "first_relabel_dt")) h->use_dt = value != 0;
+    else if (!strcmp(name, "halo_max_records") && value >= 1) { /* record slots of a border message (all slabs of a volume alike!) */
+        const int64_t T = (int64_t)h->L.gy * h->L.gx;
+        h->L.halo_max_rec = (int)(value < T ? value : T);
+    }
     else if (!strcmp(name, "wave_stagger") && value >= 0) h->wave_stagger = (int)value;
     else if (!strcmp(name, "list_shards") && (value == 1 || value == MGC_NSHARD)) { /* regions per work list (MgcLattice::scount); between solves only */
         mgc_flush_zero(h);

@@ -679,12 +679,19 @@ MGC_HD void mgc_halo_pack_tile(X& x, const MgcLattice& L, int side, int kind, in
     });
     x.par([&](int t) {
         if (t == 0) {
-            const int sl = changed ? x.atomic_add(count, 1) : -1;
+            int sl = changed ? x.atomic_add(count, 1) : -1;
+            if (sl >= L.halo_max_rec) { /* the message is full: this tile keeps its news for the next exchange */
+                sl = -1;
+                x.atomic_add(&L.count[MGC_CNT_DEFERRED], 1);
+            }
             x.S.flag[0] = sl;
             slot1[i] = sl + 1;
         }
     });
-    if (!changed) return;
+    if (x.S.flag[0] < 0) { /* (uniform: written before the barrier that ended the step above) */
+        x.par([&](int) {}); /* x.S.flag[0] is reused by the next tile of this block */
+        return;
+    }
     x.par([&](int t) {
         char* rec = recs + (int64_t)x.S.flag[0] * mgc_halo_rec_bytes(kind);
         double* flow = (double*)rec;

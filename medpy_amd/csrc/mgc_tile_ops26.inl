@@ -517,10 +517,14 @@ MGC_HD void mgc26_halo_pack_tile(X& x, const MgcLattice& L, int side, int kind, 
         if (t < MGC_TF) lab[(int64_t)i * MGC_TF + t] = L.height[(int64_t)own * MGC_TV + mgc_face_voxel(f_own, t)];
         if (kind && t == 0) {
             const uint32_t fl = L.oflags[ghost] & 1u;
-            const int sl = fl ? x.atomic_add(count, 1) : -1;
+            int sl = fl ? x.atomic_add(count, 1) : -1;
+            if (sl >= L.halo_max_rec) { /* the message is full: what the ghost tile collected stays there until the next exchange */
+                sl = -1;
+                x.atomic_add(&L.count[MGC_CNT_DEFERRED], 1);
+            }
             x.S.flag[0] = sl;
             slot1[i] = sl + 1;
-            if (fl) L.oflags[ghost] = 0;
+            if (sl >= 0) L.oflags[ghost] = 0;
         }
     });
     if (!kind) return;

@@ -21,6 +21,7 @@ import numpy as np
 (OP_ABSORB_ALL, OP_FILL_INF, OP_ZERO_COUNT, OP_RELABEL_ALL, OP_RELABEL_LIST, OP_ACTIVATE, OP_DISCHARGE, OP_SUSPECT_PASS,
  OP_RESET_SUSPECT) = range(9)
 CNT_CHANGED = 21  # MGC_CNT_CHANGED (mgc_common.h)
+CNT_DEFERRED = 28  # MGC_CNT_DEFERRED: border tiles a full message left for the next exchange
 
 
 class LoopbackExchange(object):
@@ -147,6 +148,8 @@ class RcclExchange(object):
         dist.broadcast_object_list(box, src=0, group=group)
         slab.comm_init(box[0])
 
+    native = True  # solve_slabs hands the whole schedule to the library (mgc_solve_slab)
+
     def exchange(self, kind, epoch, lst):
         self.slabs[0].exchange(kind, epoch, lst)
 
@@ -190,6 +193,14 @@ def solve_slabs(slabs, ex, rounds_per_relabel=8, max_cycles=None, max_sweeps=Non
     still converges to the exact distances); the borders are exchanged after every colour phase.  Later global
     relabels are incremental like the single-GPU driver's (mgc_driver.inl): the DIRTY / SUSPECT flags of the border
     tiles travel as halo kind 2 until the suspect closure is stable everywhere."""
+    if getattr(ex, "native", False) and len(slabs) == 1 and hasattr(slabs[0], "solve_native"):
+        # the library's own transport: the schedule below runs inside libmedpyhip (mgc_solve_slab), no call per kernel from here
+        for name, value in (("rounds_per_relabel", rounds_per_relabel), ("max_cycles", max_cycles), ("max_sweeps", max_sweeps),
+                            ("max_outer", max_outer), ("check_rounds", check_rounds), ("relabel_batch", relabel_batch),
+                            ("incremental_relabel", int(bool(incremental_relabel)))):
+            if value is not None and not (name == "rounds_per_relabel" and value == 8 and getattr(slabs[0], "ndir", 6) == 26):
+                slabs[0].set_param(name, value)
+        return slabs[0].solve_native()
     relabel_batch = max(2, relabel_batch + (relabel_batch & 1))  # even: every rank keeps the same list parity
     # where the solver variant keeps its lists / counters (MgcLayout, mgc_driver.inl:51-62)
     if getattr(slabs[0], "ndir", 6) == 26:
@@ -214,7 +225,15 @@ def solve_slabs(slabs, ex, rounds_per_relabel=8, max_cycles=None, max_sweeps=Non
         st["reductions"] += 1
         return ex.global_counts()
 
+    for s in slabs:
+        s.op(OP_ZERO_COUNT, CNT_DEFERRED)
     for outer in range(max_outer):
+        # ---- flow that a full border message left behind during the colour phases has to cross before the masks are read
+        while outer > 0 and int(global_counts()[CNT_DEFERRED]) != 0:
+            for s in slabs:
+                s.op(OP_ZERO_COUNT, CNT_DEFERRED)
+            exchange(1, phase - 1, 0)
+            st["deferred_drains"] = st.get("deferred_drains", 0) + 1
         # ---- global relabel: tile BFS passes to a local fixpoint, border label exchange, until nothing moves anywhere
         for s in slabs:
             s.op(OP_ABSORB_ALL)
@@ -246,8 +265,11 @@ def solve_slabs(slabs, ex, rounds_per_relabel=8, max_cycles=None, max_sweeps=Non
                         s.op(OP_ZERO_COUNT, nxt)
                         s.op(OP_RELABEL_LIST, cur, rep + 1, nxt)
                     st["relabel_passes"] += 1
+            for s in slabs:
+                s.op(OP_ZERO_COUNT, CNT_DEFERRED)
             exchange(0, rep + 1, nxt)
-            if global_counts()[nxt] == 0:  # the exchange woke nobody anywhere: global fixpoint
+            g = global_counts()
+            if g[nxt] == 0 and g[CNT_DEFERRED] == 0:  # the exchange woke nobody anywhere and left nothing behind: global fixpoint
                 break
         st["outer"] += 1
 
@@ -262,6 +284,8 @@ def solve_slabs(slabs, ex, rounds_per_relabel=8, max_cycles=None, max_sweeps=Non
             break
 
         # ---- colour phases, border (labels + outbox flow) exchanged after each
+        for s in slabs:
+            s.op(OP_ZERO_COUNT, CNT_DEFERRED)
         for r in range(rounds_per_relabel):
             for _c in range(ncol):
                 lst = phase & lmask
@@ -273,7 +297,7 @@ def solve_slabs(slabs, ex, rounds_per_relabel=8, max_cycles=None, max_sweeps=Non
                 phase += 1
             if (r + 1) % check_rounds == 0 and r + 1 < rounds_per_relabel:
                 c = global_counts()
-                if int(np.sum(c[:lmask + 1])) == 0:
+                if int(np.sum(c[:lmask + 1])) + int(c[CNT_DEFERRED]) == 0:
                     break
     c = ex.global_counts()
     st["discharge_tiles"], st["relabel_tiles"] = int(c[c_dis]), int(c[c_rel])
@@ -365,6 +389,15 @@ class HipSlab(object):
         out = np.zeros(32, dtype=np.int32)
         self._call("mgc_read_counts", self._lib.ptr(out))
         return out
+
+    def set_param(self, name, value):
+        self._call("mgc_set_param", name.encode(), int(value))
+
+    def solve_native(self):
+        """the distributed schedule inside the library (mgc_solve_slab): needs comm_init() when the volume has several slabs"""
+        st = self._lib.SlabStats()
+        self._call("mgc_solve_slab", self._C.byref(st))
+        return st.as_dict()
 
     def halo_bytes(self, kind):
         n = self._C.c_int64(0)

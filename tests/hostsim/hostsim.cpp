@@ -336,6 +336,7 @@ struct HostDev {
         for (int i = 0; i < 8; ++i) L.list[i] = lists.data() + i * nt;
         L.count = count.data(); L.stamp = stamp.data(); L.rstamp = rstamp.data(); L.status = status.data();
         L.scount = L.count; L.nshard = 1; L.shard_cap = (int)nt;
+        L.halo_max_rec = L.gy * L.gx; /* a border message holds every border tile unless a test says otherwise (hostsim_set_halo_max) */
         for (int sd = 0; sd < 2; ++sd) {
             hshadow[sd].assign((size_t)L.gy * L.gx * MGC_TF, (int32_t)MGC_HINF);
             L.hshadow[sd] = hshadow[sd].data();
@@ -388,6 +389,8 @@ extern "C" {
 
 void hostsim_set_wave_mode(int mode) { g_wave_mode = mode; }
 void hostsim_set_dt(int on) { g_use_dt = on; }
+/* record slots of a compacted border message (MgcLattice::halo_max_rec); which: 6 or 26 */
+void hostsim_set_halo_max(void* h, int which, int n);
 void hostsim_set_act_exact(int n) { g_act_exact_max = n; }
 
 /* work-profile read-out: copies and clears the counters; tiles != NULL with ntiles > 0 arms / returns the per-tile discharge counts */
@@ -474,6 +477,7 @@ int hostsim_halo_unpack(void* h, int side, int kind, const void* buf, int on_dev
 
 /* labels of the LOCAL planes (ghost planes included; the caller slices the owned range) */
 int hostsim_labels(void* h, uint8_t* out) { ((HostDev*)h)->labels(out); return 0; }
+void hostsim_set_halo_max(void* h, int which, int n);
 
 /* ---- one-call convenience: single slab, the C++ schedule of mgc_driver.inl ---- */
 int hostsim_solve(const int64_t* shape, const double* w0, const double* w1, const double* w2, const double* trcap,
@@ -604,6 +608,7 @@ struct HostDev26 {
         for (int i = 0; i < 18; ++i) L.list[i] = lists.data() + i * nt;
         L.count = count.data(); L.stamp = stamp.data(); L.rstamp = rstamp.data(); L.status = status.data();
         L.scount = L.count; L.nshard = 1; L.shard_cap = (int)nt;
+        L.halo_max_rec = L.gy * L.gx; /* a border message holds every border tile unless a test says otherwise (hostsim_set_halo_max) */
     }
 
     /* w[d*N + id] = capacity of the arc from LOCAL voxel id in direction d (0..25, mgc26_offset order), 0 where there
@@ -733,3 +738,10 @@ int hostsim26_halo_unpack(void* h, int side, int kind, const void* buf, int on_d
 int hostsim26_labels(void* h, uint8_t* out) { ((HostDev26*)h)->labels(out); return 0; }
 
 } /* extern "C" */
+
+extern "C" void hostsim_set_halo_max(void* h, int which, int n)
+{
+    MgcLattice& L = which == 26 ? ((HostDev26*)h)->L : ((HostDev*)h)->L;
+    const int T = L.gy * L.gx;
+    L.halo_max_rec = n < 1 ? 1 : (n < T ? n : T);
+}

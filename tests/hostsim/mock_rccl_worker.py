@@ -10,6 +10,7 @@ import numpy as np
 
 root, nranks, conn, gen = sys.argv[1], int(sys.argv[2]), int(sys.argv[3]), sys.argv[4]
 shape = tuple(int(v) for v in sys.argv[5].split("x"))
+NATIVE = len(sys.argv) > 7 and sys.argv[7] == "native"  # the schedule inside the library (mgc_solve_slab) instead of slab.py's
 sys.path.insert(0, root)
 from medpy_amd import synthetic  # noqa: E402
 from medpy_amd.slab import HipSlab, solve_slabs  # noqa: E402
@@ -17,6 +18,8 @@ from medpy_amd.slab import HipSlab, solve_slabs  # noqa: E402
 
 class ThreadRcclExchange(object):
     """RcclExchange without torch.distributed: the unique id is handed over in-process"""
+
+    native = NATIVE
 
     def __init__(self, slab, id_bytes):
         self.slabs = [slab]

@@ -144,6 +144,11 @@ class SimSlab(object):
         self._L.hostsim_read_counts(self._h, out)
         return out
 
+    def set_halo_max(self, n):
+        """record slots of a compacted border message (MgcLattice::halo_max_rec): small values force the deferral path"""
+        self._L.hostsim_set_halo_max.argtypes = [C.c_void_p, C.c_int, C.c_int]
+        self._L.hostsim_set_halo_max(self._h, 6, int(n))
+
     def halo_bytes(self, kind):
         n = C.c_int64(0)
         self._L.hostsim_halo_bytes(self._h, int(kind), C.byref(n))
@@ -249,6 +254,10 @@ class SimSlab26(object):
         out = np.zeros(32, np.int32)
         self._L.hostsim26_read_counts(self._h, out)
         return out
+
+    def set_halo_max(self, n):
+        self._L.hostsim_set_halo_max.argtypes = [C.c_void_p, C.c_int, C.c_int]
+        self._L.hostsim_set_halo_max(self._h, 26, int(n))
 
     def halo_bytes(self, kind):
         n = C.c_int64(0)

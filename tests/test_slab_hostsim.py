@@ -60,6 +60,38 @@ def test_loopback_slabs_wave_forms(mode):
         sim.set_wave_mode(0)
 
 
+@pytest.mark.parametrize("conn,halo_max", [(6, 1), (6, 3), (26, 1), (26, 2)])
+def test_full_border_messages_defer_and_drain(conn, halo_max):
+    """A compacted border message holds MgcLattice::halo_max_rec records and travels in one transfer of known size; a border
+    tile that finds it full keeps its labels / flow for the next exchange (mgc_halo_pack_tile, mgc26_halo_pack_tile), and the
+    schedule neither takes "nothing woke up" for a fixpoint nor starts a global relabel while any are left.  With one to
+    three record slots nearly every exchange overflows: the cut must not care."""
+    import sim
+    from medpy_amd import synthetic
+    from medpy_amd.slab import LoopbackExchange, solve_slabs
+    from oracle import energy_numpy, pipeline
+    shape = (40, 24, 24)
+    if conn == 6:
+        w, tr, ref = _problem("sphere", shape)
+        slabs = [sim.SimSlab(shape, r, 3) for r in range(3)]
+    else:
+        s = synthetic.sphere(shape)
+        wo = energy_numpy.boundary_weights_offsets(s["term"], s["image"], energy_numpy.forward_offsets(3, 26), s["sigma"])
+        g = pipeline.build_graph(s["fg"], s["bg"], weights=wo, connectivity=26)
+        tr = np.array([g.get_trcap(i) for i in range(s["fg"].size)])
+        g.maxflow()
+        ref = g.labels().reshape(shape).astype(bool)
+        w = sim.weights26(shape, wo)
+        slabs = [sim.SimSlab26(shape, r, 3) for r in range(3)]
+    for s_ in slabs:
+        s_.load(w, tr)
+        s_.set_halo_max(halo_max)
+    st = solve_slabs(slabs, LoopbackExchange(slabs))
+    assert st["converged"] == 1
+    np.testing.assert_array_equal(np.concatenate([s_.finish()[0] for s_ in slabs], axis=0), ref)
+    print("halo_max_rec %d, %d-neighbourhood: %d exchanges, %d drains before a global relabel" % (halo_max, conn, st["exchanges"], st.get("deferred_drains", 0)))
+
+
 def test_schedule_independent_of_slab_count():
     import sim
     from medpy_amd.slab import LoopbackExchange, solve_slabs
