@@ -39,6 +39,7 @@
 #include "mgc_tile_ops26.inl"
 #include "mgc_wave_ops.inl"
 #include "mgc_dt_ops.inl"
+#include "mgc_brick_ops.inl"
 #include "mgc_terms.h"
 #include "mgc_driver.inl"
 
@@ -445,9 +446,9 @@ struct alignas(16) MgcTileSharedR { /* what the relabel / activate operations to
     int32_t nbr[8], inflag[8], faceflag[8], depflag[8], flag[2], satflag, excflag;
 };
 
-template <int V, class SH = MgcTileSharedR, bool LAUNDER_EVERY_STEP = false>
+template <int V, class SH = MgcTileSharedR, bool LAUNDER_EVERY_STEP = false, int TOTAL = MGC_TV> /* TOTAL lanes (voxels) per workgroup: a tile, or a brick of eight */
 struct GpuBlockV {
-    static constexpr int NT = MGC_TV / V;
+    static constexpr int NT = TOTAL / V;
     static constexpr int LOG_NT = NT == 512 ? 9 : (NT == 256 ? 8 : 7);
     template <class T>
     struct Reg {
@@ -516,6 +517,23 @@ __global__ __launch_bounds__(MGC_TV / MGC_RELABEL_V) void k_relabel_v(MgcLattice
     for (int i = blockIdx.x; i < n; i += gridDim.x) {
         x.new_tile();
         mgc_relabel_tile(x, L, mgc_list_at(L, lst, view, i), epoch, next_list, first != 0);
+        __syncthreads();
+    }
+}
+
+/* global-relabel pass over a list of BRICKS (2 x 2 x 2 tiles, mgc_brick_ops.inl): 512 threads, eight voxels each */
+typedef GpuBlockV<8, MgcBrickShared, false, MGC_BV> GpuBlockB;
+__global__ __launch_bounds__(MGC_TV) void k_relabel_b(MgcLattice L, int lst, uint32_t epoch, int next_list, int zero_list)
+{
+    __shared__ MgcBrickShared S;
+    GpuBlockB x(S);
+    MgcListView view;
+    const int n = mgc_list_view(L, lst, view);
+    if (blockIdx.x == 0 && threadIdx.x == 0 && n) atomicAdd(&L.count[9], 4 * n); /* (in tile visits, for the schedule's cost estimate: a brick visit ~ four) */
+    mgc_clear_counter(L, zero_list); /* consumed by the previous pass; the next pass appends to it */
+    for (int i = blockIdx.x; i < n; i += gridDim.x) {
+        x.new_tile();
+        mgc_relabel_brick(x, L, mgc_list_at(L, lst, view, i), epoch, next_list);
         __syncthreads();
     }
 }
@@ -684,7 +702,7 @@ __global__ __launch_bounds__(MGC_TV) void k_suspect_pass(MgcLattice L)
 }
 
 template <bool FULL>
-__global__ __launch_bounds__(MGC_TV) void k_reset_suspect(MgcLattice L, uint32_t epoch, int list)
+__global__ __launch_bounds__(MGC_TV) void k_reset_suspect(MgcLattice L, uint32_t epoch, int list, int bricks)
 {
     /* a workgroup scans the status words of 512 consecutive tiles (one per lane), then resets the few that are suspect:
      * launching a 512-lane tile operation per tile just to test one flag cost 320 us per global relabel at 512^3 */
@@ -708,7 +726,8 @@ __global__ __launch_bounds__(MGC_TV) void k_reset_suspect(MgcLattice L, uint32_t
         if ((int)threadIdx.x < n) {
             const int tile = sel[threadIdx.x];
             L.status[tile] = (L.status[tile] & ~(MGC_ST_SUSPECT | MGC_ST_DIRTY | (FULL ? MGC26_ST_DEP_MASK : (63u << MGC_ST_DEP_SHIFT)))) | MGC_ST_ALLINF;
-            mgc_enqueue(x, L, list, L.rstamp, epoch, tile);
+            if (bricks) mgc_enqueue_brick(x, L, list, epoch, mgc_brick_of_tile(L, tile)); /* the passes of this relabel run over bricks (k_relabel_b) */
+            else mgc_enqueue(x, L, list, L.rstamp, epoch, tile);
         }
         __syncthreads();
     }
@@ -1676,6 +1695,8 @@ struct mgc_graph {
     void* d_vout = nullptr;    /* MgcValidateOut of mgc_validate */
     uint16_t* d_dt16 = nullptr; /* scratch of the distance-transform relabel (uint16 per voxel, tile-major), allocated on first use */
     bool all_residual = false; /* k_build found every n-link inside the volume residual */
+    int use_bricks = 1;        /* incremental global relabels run their passes over bricks of 2 x 2 x 2 tiles (parameter relabel_bricks) */
+    bool brick_mode = false;   /* ... the relabel in progress does */
     int use_dt = 1;            /* first global relabel as a distance transform when all_residual (parameter first_relabel_dt) */
     int rank = 0, nranks = 1;
     int64_t plane0 = 0, plane1 = 0, own0 = 0, own1 = 0; /* global plane ranges of a slab */
@@ -1837,6 +1858,7 @@ struct HipDevT {
     void relabel_all(uint32_t epoch, int next)
     {
         flush_zero();
+        h->brick_mode = false; /* a from-scratch relabel runs over tiles */
         const int id = time_begin(1);
         if constexpr (FULL) hipLaunchKernelGGL(k26_relabel_all, dim3(grid(h->L.ntiles)), dim3(MGC_TV), 0, h->stream, h->L, epoch, next);
         else if (!(h->use_filters & 1)) hipLaunchKernelGGL(k_relabel_all, dim3(grid(h->L.ntiles)), dim3(MGC_TV), 0, h->stream, h->L, epoch, next);
@@ -1883,7 +1905,8 @@ struct HipDevT {
     {
         flush_zero();
         const int id = time_begin(1);
-        if constexpr (FULL) hipLaunchKernelGGL(k26_relabel_list, dim3(grid(h->L.ntiles)), dim3(MGC_TV), 0, h->stream, h->L, lst, epoch, next);
+        if (!FULL && h->brick_mode) hipLaunchKernelGGL(k_relabel_b, dim3(grid(mgc_brick_count(h->L))), dim3(MGC_TV), 0, h->stream, h->L, lst, epoch, next, zero_list);
+        else if constexpr (FULL) hipLaunchKernelGGL(k26_relabel_list, dim3(grid(h->L.ntiles)), dim3(MGC_TV), 0, h->stream, h->L, lst, epoch, next);
         else if (h->wave_kernels & 8) hipLaunchKernelGGL(k_relabel_v, dim3(grid(h->L.ntiles)), dim3(MGC_TV / MGC_RELABEL_V), 0, h->stream, h->L, lst, lst, epoch, next, zero_list, 0);
         else if (h->wave_kernels & 2) { hipLaunchKernelGGL(k_relabel_w, dim3(h->wave_grid_rel), dim3(MGCW_LANES), 0, h->stream, h->L, lst, lst, epoch, next, zero_list, 0, h->tk_rel); h->tk_rel ^= 1; }
         else hipLaunchKernelGGL(k_relabel_list, dim3(grid(h->L.ntiles)), dim3(MGC_TV), 0, h->stream, h->L, lst, epoch, next, zero_list);
@@ -1902,7 +1925,9 @@ struct HipDevT {
     {
         flush_zero();
         const int id = time_begin(1);
-        if (FULL || !(h->use_filters & 4)) hipLaunchKernelGGL(k_reset_suspect<FULL>, dim3(grid((h->L.ntiles + MGC_TV - 1) / MGC_TV)), dim3(MGC_TV), 0, h->stream, h->L, epoch, list);
+        /* the passes of an incremental relabel run over bricks of 2 x 2 x 2 tiles (mgc_brick_ops.inl): single handle, 6-neighbourhood */
+        h->brick_mode = !FULL && h->use_bricks && h->nranks == 1 && !(h->use_filters & 4);
+        if (FULL || !(h->use_filters & 4)) hipLaunchKernelGGL(k_reset_suspect<FULL>, dim3(grid((h->L.ntiles + MGC_TV - 1) / MGC_TV)), dim3(MGC_TV), 0, h->stream, h->L, epoch, list, h->brick_mode ? 1 : 0);
         else {
             flush_zero();
             hipLaunchKernelGGL(k_filter, dim3(filter_grid()), dim3(256), 0, h->stream, h->L, 2, 6, fslot(0));
@@ -3156,6 +3181,7 @@ int mgc_set_param(mgc_handle h, const char* name, int64_t value)
     else if (!strcmp(name, "wave_grid_dis") && value > 0) h->wave_grid_dis = (int)value;
     else if (!strcmp(name, "wave_grid_rel") && value > 0) h->wave_grid_rel = (int)value;
     else if (!strcmp(name, "first_relabel_dt")) h->use_dt = value != 0;
+    else if (!strcmp(name, "relabel_bricks")) h->use_bricks = value != 0;
     else if (!strcmp(name, "halo_max_records") && value >= 1) { /* record slots of a border message (all slabs of a volume alike!) */
         const int64_t T = (int64_t)h->L.gy * h->L.gx;
         h->L.halo_max_rec = (int)(value < T ? value : T);

@@ -26,6 +26,7 @@ static long long g26_sweeps, g26_dirs; /* direction masks of the 26-neighbourhoo
 #include "../../medpy_amd/csrc/mgc_tile_ops26.inl"
 #include "../../medpy_amd/csrc/mgc_wave_ops.inl"
 #include "../../medpy_amd/csrc/mgc_dt_ops.inl"
+#include "../../medpy_amd/csrc/mgc_brick_ops.inl"
 #include "../../medpy_amd/csrc/mgc_driver.inl"
 #include <cstdio>
 
@@ -162,6 +163,33 @@ struct HostWave {
     void fresh() {}
     int use_here(int v) { return v; }
 };
+/* executor of the brick operations (mgc_brick_ops.inl): 4096 lanes, run one after another */
+struct HostBrick {
+    template <class T>
+    struct Reg {
+        T v[MGC_BV];
+        T& operator[](int t) { return v[t]; }
+    };
+    MgcBrickShared& S;
+    explicit HostBrick(MgcBrickShared& s) : S(s) {}
+    template <class F>
+    void par(F f)
+    {
+        for (int t = 0; t < MGC_BV; ++t) f(t);
+    }
+    template <class F>
+    bool any(F f)
+    {
+        bool r = false;
+        for (int t = 0; t < MGC_BV; ++t) r |= (bool)f(t);
+        return r;
+    }
+    int shard(const MgcLattice&) const { return 0; }
+    int atomic_add(int32_t* p, int v) { int o = *p; *p += v; return o; }
+    uint32_t atomic_exch(uint32_t* p, uint32_t v) { uint32_t o = *p; *p = v; return o; }
+};
+static int g_bricks = 1; /* incremental relabels run their passes over bricks of 2 x 2 x 2 tiles (hostsim_set_bricks), as the library does */
+
 /* which form of the two hot tile operations the simulator runs: bit 0 = wave discharge, bit 1 = wave relabel,
  * bit 2 = the wave discharge computes exact in-tile labels first (MGCW_BFS) */
 static int g_wave_mode = 0;
@@ -202,10 +230,13 @@ struct HostDev {
             else mgc_absorb_tile(x, L, t);
         }
     }
+    bool brick_mode = false; /* the passes of the relabel in progress run over bricks (set by reset_suspect, as in the library) */
+    MgcBrickShared BS;
     void relabel_all(uint32_t epoch, int next)
     {
         HostBlock x(S);
         HostWave w(WS);
+        brick_mode = false;
         for (int t = 0; t < L.ntiles; ++t) {
             if (L.status[t] & 2u) L.count[9]++;
             if (g_wave_mode & 2) mgcw_relabel_tile(w, L, t, epoch, next, true);
@@ -244,8 +275,15 @@ struct HostDev {
         HostBlock x(S);
         HostWave w(WS);
         const int n = L.count[lst];
-        L.count[9] += n;
         if (zero_list >= 0) L.count[zero_list] = 0;
+        if (brick_mode) {
+            HostBrick b(BS);
+            L.count[9] += 4 * n;
+            g_prof[29] += n;
+            for (int i = 0; i < n; ++i) mgc_relabel_brick(b, L, L.list[lst][i], epoch, next);
+            return;
+        }
+        L.count[9] += n;
         for (int i = 0; i < n; ++i) {
             if (g_wave_mode & 2) mgcw_relabel_tile(w, L, L.list[lst][i], epoch, next, false);
             else mgc_relabel_tile(x, L, L.list[lst][i], epoch, next, false);
@@ -293,10 +331,19 @@ struct HostDev {
     void reset_suspect(uint32_t epoch, int list)
     {
         HostBlock x(S);
+        brick_mode = g_bricks && spec.nranks == 1;
         for (int t = 0; t < L.ntiles; ++t) {
             if (!g_tile_discharges.empty() && (L.status[t] & MGC_ST_SUSPECT) && mgc_owned(L, t))
                 reset_snapshot.emplace_back(t, std::vector<int32_t>(&L.height[(int64_t)t * MGC_TV], &L.height[(int64_t)t * MGC_TV] + MGC_TV));
-            mgc_reset_suspect_tile(x, L, t, epoch, list);
+            if (brick_mode) { /* what k_reset_suspect does with bricks = 1 */
+                if (L.status[t] & MGC_ST_SUSPECT) {
+                    for (int v = 0; v < MGC_TV; ++v) L.height[(int64_t)t * MGC_TV + v] = MGC_HINF;
+                    L.status[t] = (L.status[t] & ~(MGC_ST_SUSPECT | MGC_ST_DIRTY | (63u << MGC_ST_DEP_SHIFT))) | MGC_ST_ALLINF;
+                    mgc_enqueue_brick(x, L, list, epoch, mgc_brick_of_tile(L, t));
+                }
+            } else {
+                mgc_reset_suspect_tile(x, L, t, epoch, list);
+            }
         }
     }
     void discharge(int lst, uint32_t phase, int cycles, int sweeps)
@@ -389,6 +436,7 @@ extern "C" {
 
 void hostsim_set_wave_mode(int mode) { g_wave_mode = mode; }
 void hostsim_set_dt(int on) { g_use_dt = on; }
+void hostsim_set_bricks(int on) { g_bricks = on; }
 /* record slots of a compacted border message (MgcLattice::halo_max_rec); which: 6 or 26 */
 void hostsim_set_halo_max(void* h, int which, int n);
 void hostsim_set_act_exact(int n) { g_act_exact_max = n; }

@@ -302,3 +302,29 @@ def test_activation_by_status_word_reaches_the_same_cut(gen, shape):
         sim.lib().hostsim_set_act_exact(4096)
     assert st["converged"] == 1
     np.testing.assert_array_equal(lab, ref)
+
+
+@pytest.mark.parametrize("gen,shape", [("sphere", (40, 40, 40)), ("hard", (48, 32, 40)), ("sphere", (9, 21, 35)), ("ties", (24, 16, 16)),
+                                       ("hard", (17, 8, 50))])
+def test_incremental_relabel_over_bricks(gen, shape):
+    """mgc_brick_ops.inl (same source as k_relabel_b): the passes of an incremental global relabel over bricks of 2 x 2 x 2 tiles
+    relax to the same fixpoint as the tile passes -- so every global relabel leaves the same labels, the discharges between
+    them do the same, and the solve ends with the same cut -- in about half the passes."""
+    import sim
+    out = {}
+    for bricks in (0, 1):
+        sim.lib().hostsim_set_bricks(bricks)
+        try:
+            kw = dict(wave_mode=1)
+            if gen == "ties":
+                kw["term"] = "difference_linear"
+            lab, ref, st = _sim_case(gen, shape, **kw)
+        finally:
+            sim.lib().hostsim_set_bricks(1)
+        assert st["converged"] == 1
+        out[bricks] = (lab, st)
+        if gen != "ties":
+            np.testing.assert_array_equal(lab, ref)
+    np.testing.assert_array_equal(out[0][0], out[1][0])
+    assert out[0][1]["outer"] == out[1][1]["outer"] and out[0][1]["phases"] == out[1][1]["phases"] and out[0][1]["discharge_tiles"] == out[1][1]["discharge_tiles"]
+    print(gen, shape, "relabel passes: tiles", out[0][1]["relabel_passes"], "bricks", out[1][1]["relabel_passes"])
