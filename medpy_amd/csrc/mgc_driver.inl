@@ -35,6 +35,7 @@ struct MgcSolveParams {
     int relabel_batch;      /* BFS passes launched between two counter read-backs         */
     int check_rounds;       /* colour rounds launched between two counter read-backs      */
     int incremental_relabel;/* 1: later global relabels touch suspect tiles only          */
+    int stop_below;         /* the colour rounds of a cycle end early when no more than this many tiles are queued (0: only when none are) */
     int adaptive_rounds;    /* k > 0: the number of rounds between two relabels doubles (up to 4x) while a relabel visits more
                                than k times as many tiles as the discharges of the cycle before it did                   */
 };
@@ -78,6 +79,7 @@ static inline MgcSolveParams mgc_default_params(int ndir = 6)
     p.relabel_batch = 8;
     p.check_rounds = 4;
     p.incremental_relabel = 1;
+    p.stop_below = 0;
     p.adaptive_rounds = ndir == 26 ? 9 : 3; /* a tile visit of a relabel costs 1/3 of a discharge (9 vs 27 ns), 1/9 in the full neighbourhood (20 vs 175 ns) */
     return p;
 }
@@ -203,7 +205,7 @@ int mgc_solve(Dev& dev, const MgcLattice& L, const MgcSolveParams& P, MgcSolveSt
                 st.readbacks++;
                 int pending = 0;
                 for (int i = 0; i <= lay.list_mask; ++i) pending += cnt[i];
-                if (pending == 0) break;
+                if (pending <= P.stop_below) break; /* (a few stragglers: their tiles keep their excess flag and come back after the relabel) */
             }
         }
         dev.range_pop();

@@ -263,11 +263,14 @@ MGC_HD void mgc26_discharge_tile(X& x, const MgcLattice& L, int tile, uint32_t p
     auto R = [&](int d, int t) -> double& { return d < NREG ? rr[d < NREG ? d : 0][t] : x.S.rl[d >= NREG ? d - NREG : 0][t]; };
     typename X::template Reg<int> hme;
     typename X::template Reg<uint32_t> pushed; /* directions this voxel pushed along */
+    typename X::template Reg<uint32_t> stw;    /* lane 28: the tile's status word, fetched with the state (nobody else writes it during this launch) */
     const int64_t base = (int64_t)tile * MGC_TV;
 
     x.par([&](int t) { mgc26_load_nbrs(x, L, tile, t); });
     x.par([&](int t) {
         pushed[t] = 0;
+        stw[t] = 0;
+        if (t == 28) stw[t] = L.status[tile];
         e[t] = L.excess[base + t];
         snk[t] = L.sink[base + t];
 #pragma unroll
@@ -440,6 +443,27 @@ MGC_HD void mgc26_discharge_tile(X& x, const MgcLattice& L, int tile, uint32_t p
 
     /* a residual plane changed iff somebody pushed along it or along its opposite (the receiver's reverse arc): the others --
      * typically 10 of 26 -- are not written back */
+    /* wake-ups first, the write-back behind them: a returning atomic issued after the ~40 stores would wait for them to retire */
+    x.par([&](int t) {
+        /* wake-ups: lanes 0..26 the neighbours that received something, lane 13 (the centre) the tile itself when its budget ran
+         * out with work left -- ONE claim and ONE position draw for all of them (two dependent trips; as separate steps the
+         * tile's own wake-up waited for the neighbours' and the status word for both) */
+        int wake = -1;
+        uint32_t target = 0;
+        if (t < 27 && t != 13 && x.S.nbrflag[t] && x.S.nbr[t] >= 0) {
+            int tz, ty, tx;
+            mgc_tile_coords(L, tile, tz, ty, tx);
+            const int mine = mgc26_colour(L, tz, ty, tx);
+            const int theirs = mgc26_colour(L, tz + t / 9 - 1, ty + (t / 3) % 3 - 1, tx + t % 3 - 1);
+            target = phase + (uint32_t)((theirs - mine) & 7);
+            wake = x.S.nbr[t];
+            if (!mgc_owned(L, wake)) x.atomic_or(&L.oflags[wake], 1u); /* ghost: the halo exchange ships what it received */
+        }
+        if (t == 13 && active) { wake = tile; target = phase + 8; }
+        if (wake >= 0) mgc_enqueue(x, L, (int)(target & 15u), L.stamp, target, wake);
+        /* DIRTY only if a residual arc disappeared: otherwise no distance in the tile (or through it) can have changed */
+        if (t == 28) L.status[tile] = (stw[t] & ~MGC_ST_SINK) | (has_sink ? MGC_ST_SINK : 0u) | (x.S.satflag ? MGC_ST_DIRTY : 0u);
+    });
     const uint32_t PM = x.uniform(x.S.pushmask);
     x.par([&](int t) {
         L.excess[base + t] = e[t];
@@ -452,20 +476,6 @@ MGC_HD void mgc26_discharge_tile(X& x, const MgcLattice& L, int tile, uint32_t p
         }
         L.rmask32[base + t] = m;
         L.height[base + t] = x.S.hs[mgc_hs_index(t >> 6, (t >> 3) & 7, t & 7)];
-    });
-    x.par([&](int t) {
-        if (t < 27 && t != 13 && x.S.nbrflag[t] && x.S.nbr[t] >= 0) {
-            int tz, ty, tx;
-            mgc_tile_coords(L, tile, tz, ty, tx);
-            const int mine = mgc26_colour(L, tz, ty, tx);
-            const int theirs = mgc26_colour(L, tz + t / 9 - 1, ty + (t / 3) % 3 - 1, tx + t % 3 - 1);
-            const uint32_t target = phase + (uint32_t)((theirs - mine) & 7);
-            mgc_enqueue(x, L, (int)(target & 15u), L.stamp, target, x.S.nbr[t]);
-            if (!mgc_owned(L, x.S.nbr[t])) x.atomic_or(&L.oflags[x.S.nbr[t]], 1u); /* ghost: the halo exchange ships what it received */
-        }
-        if (t == 27 && active) mgc_enqueue(x, L, (int)((phase + 8) & 15u), L.stamp, phase + 8, tile);
-        /* DIRTY only if a residual arc disappeared: otherwise no distance in the tile (or through it) can have changed */
-        if (t == 28) L.status[tile] = (L.status[tile] & ~MGC_ST_SINK) | (has_sink ? MGC_ST_SINK : 0u) | (x.S.satflag ? MGC_ST_DIRTY : 0u);
     });
     x.mark(L, 3); /* store */
 }

@@ -188,7 +188,7 @@ struct HostBrick {
     int atomic_add(int32_t* p, int v) { int o = *p; *p += v; return o; }
     uint32_t atomic_exch(uint32_t* p, uint32_t v) { uint32_t o = *p; *p = v; return o; }
 };
-static int g_bricks = 1; /* incremental relabels run their passes over bricks of 2 x 2 x 2 tiles (hostsim_set_bricks), as the library does */
+static int g_bricks = 0; /* incremental relabels run their passes over bricks of 2 x 2 x 2 tiles (hostsim_set_bricks; the library's relabel_bricks, off by default) */
 
 /* which form of the two hot tile operations the simulator runs: bit 0 = wave discharge, bit 1 = wave relabel,
  * bit 2 = the wave discharge computes exact in-tile labels first (MGCW_BFS) */

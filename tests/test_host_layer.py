@@ -320,7 +320,7 @@ def test_incremental_relabel_over_bricks(gen, shape):
                 kw["term"] = "difference_linear"
             lab, ref, st = _sim_case(gen, shape, **kw)
         finally:
-            sim.lib().hostsim_set_bricks(1)
+            sim.lib().hostsim_set_bricks(0)
         assert st["converged"] == 1
         out[bricks] = (lab, st)
         if gen != "ties":
