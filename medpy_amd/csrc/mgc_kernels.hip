@@ -510,13 +510,16 @@ __global__ __launch_bounds__(MGC_TV / MGC_RELABEL_V) void k_relabel_v(MgcLattice
 {
     __shared__ MgcTileSharedR S;
     GpuBlockR x(S);
+    /* the workgroup's first list entry is fetched together with the list length, not after it (one dependent trip less per
+     * visit: a pass is five of them around ~3 us of relaxation); an index beyond the length reads a stale entry that is not used */
+    const int spec = L.nshard == 1 && (int)blockIdx.x < L.shard_cap ? L.list[lst][blockIdx.x] : 0;
     MgcListView view;
     const int n = mgc_list_view(L, cnt, view);
     if (blockIdx.x == 0 && threadIdx.x == 0 && n) atomicAdd(&L.count[9], n);
     mgc_clear_counter(L, zero_list); /* consumed by the previous pass; the next pass appends to it */
     for (int i = blockIdx.x; i < n; i += gridDim.x) {
         x.new_tile();
-        mgc_relabel_tile(x, L, mgc_list_at(L, lst, view, i), epoch, next_list, first != 0);
+        mgc_relabel_tile(x, L, (i == (int)blockIdx.x && L.nshard == 1) ? spec : mgc_list_at(L, lst, view, i), epoch, next_list, first != 0);
         __syncthreads();
     }
 }
@@ -997,7 +1000,7 @@ __device__ __forceinline__ double mgc_block_sum(double v, double* scratch)
 
 /* TERM: the boundary term as a compile-time constant (the kernel dispatches once), so g(.) is straight-line code */
 template <bool FULL, int TERM> /* FULL: 26-neighbourhood */
-__device__ __forceinline__ void k_build_tiles(const MgcLattice& L, const MgcBuildArgs& A, double* img, double* scratch, double* wf)
+__device__ __forceinline__ void k_build_tiles(const MgcLattice& L, const MgcBuildArgs& A, double* img, double* scratch, double* wf, int* tflag_lds)
 {
     const int t = threadIdx.x;
     const bool take_abs = (TERM == MGC_TERM_MAXIMUM_LINEAR || TERM == MGC_TERM_MAXIMUM_EXPONENTIAL || TERM == MGC_TERM_MAXIMUM_POWER);
@@ -1023,6 +1026,7 @@ __device__ __forceinline__ void k_build_tiles(const MgcLattice& L, const MgcBuil
             }
         }
         __syncthreads();
+        if (t == 0) *tflag_lds = 0; /* everybody is past the previous tile's look at it; this tile's votes come after the next barrier */
         const int lz = t >> 6, ly = (t >> 3) & 7, lx = t & 7;
         const int64_t gz = z0 + lz, gy = y0 + ly, gx = x0 + lx;
         const bool valid = gz < L.dz && gy < L.dy && gx < L.dx;
@@ -1094,6 +1098,7 @@ __device__ __forceinline__ void k_build_tiles(const MgcLattice& L, const MgcBuil
                 if (d % 4 == 3) asm volatile("" ::: "memory"); /* four weights in flight, not 26: 26 keep 151 VGPRs alive (one workgroup per CU) */
             });
         }
+        if constexpr (FULL) __syncthreads(); /* the reset of the vote word above, before the votes below (the 6-neighbourhood path has its weight hand-over barrier in between) */
         /* t-links: regional term, then fg marker, then bg marker (generate.py:159-172) */
         double tr = 0.0, fc = 0.0;
         if (valid) {
@@ -1115,9 +1120,26 @@ __device__ __forceinline__ void k_build_tiles(const MgcLattice& L, const MgcBuil
             if (A.bg && A.bg[id]) mgc_add_tweights(tr, fc, 0.0, MGC_MARKER_MAX);
         }
         const int64_t v = (int64_t)tile * MGC_TV + t;
-        A.tr0[v] = tr;
+        /* which signs of t-link the tile holds, whether a flow constant has to be summed: ONE barrier (the waves vote, one lane
+         * per wave ORs the result into an LDS word) where three barrier-reductions stood */
+        {
+            const int bits = (__ballot(tr < 0.0) != 0ull ? 2 : 0) | (__ballot(tr > 0.0) != 0ull ? 1 : 0) | (__ballot(fc != 0.0) != 0ull ? 4 : 0);
+            if ((t & 63) == 0 && bits) atomicOr(tflag_lds, bits);
+        }
+        __syncthreads();
+        const int tbits = *tflag_lds;
+        const int any_sink = tbits & 2, any_exc = tbits & 1;
         L.excess[v] = tr > 0.0 ? tr : 0.0;
-        L.sink[v] = tr < 0.0 ? -tr : 0.0;
+        if constexpr (!FULL) {
+            /* 6-neighbourhood: the merged t-links and the residual sink links of a tile are only READ where the tile holds a t-link
+             * of the sign in question (A.tflags, status bit MGC_ST_SINK: k_discharge_w, k_cut_value6, k_validate ...), so they are only
+             * written there: 16 of the 79 bytes per voxel this kernel writes, for 98 % of the tiles of a marker-seeded volume */
+            if (tbits & 3) A.tr0[v] = tr;
+            if (any_sink) L.sink[v] = tr < 0.0 ? -tr : 0.0;
+        } else {
+            A.tr0[v] = tr;
+            L.sink[v] = tr < 0.0 ? -tr : 0.0;
+        }
         if constexpr (!FULL) {
             /* is every n-link of the volume residual?  (then the first global relabel is a distance transform, mgc_dt_ops.inl) */
             const uint32_t need = (gx > 0 ? 1u : 0u) | (gx + 1 < L.dx ? 2u : 0u) | (gy > 0 ? 4u : 0u) | (gy + 1 < L.dy ? 8u : 0u) |
@@ -1132,8 +1154,6 @@ __device__ __forceinline__ void k_build_tiles(const MgcLattice& L, const MgcBuil
         /* (labels are not initialised here: every solve starts by filling them, mgc_driver.inl) */
         if (!FULL && t < 6 * MGC_TF / 2) /* 192 lanes x 16 bytes clear the 6x64 outbox */
             *(double2*)(L.obox + (int64_t)tile * 6 * MGC_TF + t * 2) = make_double2(0.0, 0.0);
-        const int any_sink = __syncthreads_or(tr < 0.0);
-        const int any_exc = __syncthreads_or(tr > 0.0);
         if (t == 0) {
             L.oflags[tile] = 0;
             L.stamp[tile] = 0;
@@ -1143,7 +1163,7 @@ __device__ __forceinline__ void k_build_tiles(const MgcLattice& L, const MgcBuil
         }
         /* flow constant: only voxels whose t-links were merged more than once contribute (regional term + marker, fg and bg
          * marker on one voxel): most tiles skip the ten barriers of the tree sum */
-        if (__syncthreads_or(fc != 0.0)) {
+        if (tbits & 4) { /* uniform */
             const double s = mgc_block_sum(fc, scratch);
             if (t == 0) A.fpart[tile] = mgc_owned(L, tile) ? s : 0.0;
             __syncthreads();
@@ -1164,7 +1184,8 @@ __global__ __launch_bounds__(MGC_TV, FULL ? 2 : MGC_BUILD_WAVES6) void k_build(M
     __shared__ double img[1000]; /* 10x10x10: tile + one-voxel halo, already |.|'d for the maximum terms */
     __shared__ double scratch[MGC_TV];
     __shared__ double wf[FULL ? 1 : 3 * 576]; /* 6-neighbourhood: the forward n-link weights of the tile and its lower faces */
-    k_build_tiles<FULL, TERM>(L, A, img, scratch, wf);
+    __shared__ int tflag;
+    k_build_tiles<FULL, TERM>(L, A, img, scratch, wf, &tflag);
 }
 
 template <bool FULL>
@@ -1222,7 +1243,7 @@ __global__ __launch_bounds__(MGC_TV) void k_refresh_mask(MgcLattice L)
 {
     for (int tile = blockIdx.x; tile < L.ntiles; tile += gridDim.x) {
         const int t = threadIdx.x;
-        const bool snk = L.sink[(int64_t)tile * MGC_TV + t] > 0.0;
+        const bool snk = (L.ndir != 6 || (L.status[tile] & MGC_ST_SINK)) && L.sink[(int64_t)tile * MGC_TV + t] > 0.0; /* (the plane is only written where a sink link exists) */
         uint32_t m = 0;
         for (int d = 0; d < L.ndir; ++d)
             if (L.rcap[((int64_t)tile * L.ndir + d) * MGC_TV + t] > 0.0) m |= 1u << d;
@@ -1484,7 +1505,9 @@ __global__ __launch_bounds__(MGC_TV) void k_validate(MgcLattice L, MgcBuildArgs 
         const bool owned = mgc_owned(L, tile);
         if (owned && gz < L.dz && gy < L.dy && gx < L.dx) {
             const int64_t v = (int64_t)tile * MGC_TV + t;
-            const double e = L.excess[v], sk = L.sink[v], tr = tr0[v];
+            /* (6-neighbourhood: k_build writes these two planes only for tiles that hold a t-link of the sign) */
+            const uint32_t tfl = L.ndir == 6 ? A.tflags[tile] : 3u;
+            const double e = L.excess[v], sk = (tfl & 2u) ? L.sink[v] : 0.0, tr = tfl ? tr0[v] : 0.0;
             const int lab = L.height[v] < MGC_HINF ? 0 : 1;
             const double src0 = tr > 0.0 ? tr : 0.0, snk0 = tr < 0.0 ? -tr : 0.0;
             unsigned neg = (e < 0.0) | (sk < 0.0);
@@ -1610,12 +1633,13 @@ __global__ void k_get_nweights_offset(MgcLattice L, MgcBuildArgs A, int dz, int 
     }
 }
 
-__global__ void k_untile_f64(MgcLattice L, const double* tiled, double* out)
+__global__ void k_untile_f64(MgcLattice L, const double* tiled, const uint8_t* tflags, double* out)
 {
     for (int64_t id = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; id < L.nvox; id += (int64_t)gridDim.x * blockDim.x) {
         int tile, loc;
         mgc_node_to_tile(L, id, tile, loc);
-        out[id] = tiled[(int64_t)tile * MGC_TV + loc];
+        /* (6-neighbourhood: k_build leaves the plane of a tile without t-links unwritten) */
+        out[id] = (L.ndir != 6 || tflags[tile]) ? tiled[(int64_t)tile * MGC_TV + loc] : 0.0;
     }
 }
 
@@ -3128,7 +3152,7 @@ int mgc_get_tweights(mgc_handle h, double* out)
     MGC_HIP(h, hipSetDevice(h->device));
     double* d = nullptr;
     MGC_HIP(h, hipMalloc((void**)&d, (size_t)h->nvox * sizeof(double)));
-    hipLaunchKernelGGL(k_untile_f64, dim3(1024), dim3(256), 0, h->stream, h->L, (const double*)h->d_tr0, d);
+    hipLaunchKernelGGL(k_untile_f64, dim3(1024), dim3(256), 0, h->stream, h->L, (const double*)h->d_tr0, (const uint8_t*)h->d_tflags, d);
     hipError_t e = hipGetLastError();
     if (e == hipSuccess) e = hipMemcpyAsync(out, d, (size_t)h->nvox * sizeof(double), hipMemcpyDeviceToHost, h->stream);
     if (e == hipSuccess) e = hipStreamSynchronize(h->stream);

@@ -381,10 +381,12 @@ MGC_HD void mgc_discharge_tile(X& x, const MgcLattice& L, int tile, uint32_t pha
          * is what used to spill in this phase */
         x.async_to_lds(t, &x.S.r[0][0], t_rcap, 6 * MGC_TV * (int)sizeof(double));
         e[t] = t_excess[(unsigned)t];
-        snk[t] = t_sink[(unsigned)t];
+        snk[t] = t_sink[(unsigned)t]; /* (meaningful only under MGC_ST_SINK: selected below, after the loads are on their way) */
+        const uint32_t st_now = L.status[tile];
         mgc_load_nbrs(x, L, tile, t);
         mgc_load_halo_inbox(x, L, tile, t);
         ob0[t] = ob1[t] = ob2[t] = 0.0;
+        if (!(st_now & MGC_ST_SINK)) snk[t] = 0.0; /* the build writes the sink plane only where a tile has a sink link */
         x.async_wait(); /* the DMA must have landed before the barrier that ends this step */
     });
     x.par([&](int t) { /* absorb the staged inbox (LDS only): e += delta, reverse residual += delta, fixed face order */
