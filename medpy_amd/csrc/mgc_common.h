@@ -43,10 +43,6 @@
 #define MGC_ST_DEP_SHIFT 8
 /* counter slots no layout uses as a work list (6-neighbourhood: lists 0..7, totals 8 / 9; 26-neighbourhood: lists 0..17,
  * totals 18..20; tickets of the wave kernels 24..27) */
-#define MGC_CNT_QSTATE 10      /* (6-neighbourhood) queue relabel, mgc_ring_push: ONE 64-bit word over slots 10 / 11 -- low half = tile visits
-                                  completed, high half = positions handed out in the ring (entries pushed + positions skipped) */
-#define MGC_CNT_QHEAD 12       /* ... the ticket of its consumers */
-#define MGC_CNT_QEXIT 13       /* ... workgroups that have left: the last one clears these four words for the next relabel */
 #define MGC_CNT_CHANGED 21     /* suspect-closure pass changed something */
 #define MGC_CNT_FILTER 22      /* length of the scratch list the tile filters fill (absorb / relabel seeding / suspect reset) */
 #define MGC_CNT_FILTER_ACT 23  /* ... of the activation filter */
@@ -101,8 +97,6 @@ struct MgcLattice {
     int       shard_cap;      /* entries per region = ntiles (a list holds a tile at most once) */
     uint32_t* stamp;          /* [ntiles] de-duplication stamp for list appends (discharge) */
     uint32_t* rstamp;         /* [ntiles] same for the relabel lists                */
-    int32_t*  ring;           /* [ntiles] queue relabel (mgc_relabel_tile<X, true>): tiles woken while the relabel runs, -1 = free slot;
-                                 all -1 between two relabels.  NULL: the relabel runs in passes only */
     uint32_t* status;         /* [ntiles] bit1 (2): the tile holds a residual arc to the sink; bit2 (4): DIRTY = discharged
                                  since the last global relabel; bit3 (8): SUSPECT (labels must be recomputed);
                                  bits 8..13: faces through which the tile's labels are supported by a neighbour */

@@ -131,10 +131,6 @@ int mgc_solve(Dev& dev, const MgcLattice& L, const MgcSolveParams& P, MgcSolveSt
              * a look at the counters a stream drain) */
             int batch = outer > 0 && last_passes > P.relabel_batch ? (int)last_passes : P.relabel_batch;
             int64_t passes_now = 0;
-            if (dev.relabel_queue(lists[k % 3], rep + 1)) { /* all of them in one launch, which ends at the fixpoint: nothing to look at */
-                rep++;
-                st.relabel_passes++;
-            } else
             for (;;) {
                 for (int b = 0; b < batch; ++b, ++k) {
                     rep++;

@@ -497,16 +497,6 @@ struct GpuBlockV {
     /* a value every lane of the workgroup holds alike (read from LDS after a barrier): scalar for the branches on it */
     __device__ __forceinline__ uint32_t uniform(uint32_t v) const { return (uint32_t)__builtin_amdgcn_readfirstlane((int)v); }
     __device__ __forceinline__ void atomic_and(uint32_t* p, uint32_t v) { atomicAnd(p, v); }
-    /* queue relabel (mgc_relabel_tile<X, true>): what two visits of one launch share goes past the per-XCD L2s -- device-scope
-     * accesses (sc1 loads miss, sc1 stores write through), and drain() = every memory operation of this thread has been
-     * performed (stores are acknowledged from where they became visible) */
-    __device__ __forceinline__ int32_t ldc(const int32_t* p) const { return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
-    __device__ __forceinline__ uint32_t ldc(const uint32_t* p) const { return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
-    __device__ __forceinline__ void stc(int32_t* p, int32_t v) const { __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
-    __device__ __forceinline__ void stc(uint32_t* p, uint32_t v) const { __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
-    __device__ __forceinline__ void drain() const { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); }
-    __device__ __forceinline__ unsigned long long atomic_add64(unsigned long long* p, unsigned long long v) { return atomicAdd(p, v); }
-    __device__ __forceinline__ int32_t atomic_cas(int32_t* p, int32_t expect, int32_t v) { return atomicCAS(p, expect, v); }
 };
 
 #ifndef MGC_RELABEL_V
@@ -643,56 +633,6 @@ __global__ __launch_bounds__(MGC_TV) void k_absorb(MgcLattice L)
         x.new_tile();
         mgc_absorb_tile(x, L, tile);
         __syncthreads();
-    }
-}
-
-/* Queue relabel: every pass of one global relabel in a single launch (mgc_relabel_tile<X, true>).  Seeds = the `n` entries of
- * list `lst` (queued and marked with `epoch` by the kernel before); everything woken afterwards goes through L.ring.  One
- * ticket sequence covers both: tickets below n name a seed, the others a ring position the workgroup waits at -- until a
- * tile arrives there, or until every seed and every pushed entry has been visited.  Workgroups that are not resident at
- * once are harmless: nobody waits for a workgroup, only for tiles. */
-__global__ __launch_bounds__(MGC_TV / MGC_RELABEL_V) void k_relabel_q(MgcLattice L, int lst, int cnt, uint32_t epoch)
-{
-    __shared__ MgcTileSharedR S;
-    __shared__ int next_tile;
-    GpuBlockR x(S);
-    MgcListView view;
-    const int n = mgc_list_view(L, cnt, view);
-    unsigned long long* const q = (unsigned long long*)(L.count + MGC_CNT_QSTATE);
-    int visited = 0;
-    for (;;) {
-        if (threadIdx.x == 0) {
-            const int ticket = atomicAdd(&L.count[MGC_CNT_QHEAD], 1);
-            int tile = -2;
-            if (ticket < n) {
-                tile = L.list[lst][ticket];
-            } else {
-                int32_t* const slot = &L.ring[(uint32_t)(ticket - n) % (uint32_t)L.shard_cap];
-                for (int spin = 0;; ++spin) {
-                    if (__hip_atomic_load(slot, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) >= 0) {
-                        tile = atomicExch(slot, -1);
-                        if (tile >= 0) break;
-                    }
-                    if ((spin & 3) == 3) {
-                        const unsigned long long s = __hip_atomic_load(q, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                        if ((uint32_t)s == (uint32_t)(s >> 32) + (uint32_t)n) { tile = -2; break; } /* fixpoint: nothing waits, nobody is at work */
-                    }
-                    __builtin_amdgcn_s_sleep(16);
-                }
-            }
-            next_tile = tile;
-        }
-        __syncthreads();
-        const int tile = __builtin_amdgcn_readfirstlane(next_tile);
-        if (tile < 0) break;
-        x.new_tile();
-        mgc_relabel_tile<GpuBlockR, true>(x, L, tile, epoch, -1, false);
-        visited++;
-    }
-    if (threadIdx.x == 0) {
-        if (visited) atomicAdd(&L.count[9], visited);
-        if (atomicAdd(&L.count[MGC_CNT_QEXIT], 1) == (int)gridDim.x - 1) /* everybody has seen the fixpoint: the queue words start the next relabel at zero */
-            L.count[MGC_CNT_QSTATE] = L.count[MGC_CNT_QSTATE + 1] = L.count[MGC_CNT_QHEAD] = L.count[MGC_CNT_QEXIT] = 0;
     }
 }
 
@@ -1779,8 +1719,6 @@ struct mgc_graph {
     void* d_vout = nullptr;    /* MgcValidateOut of mgc_validate */
     uint16_t* d_dt16 = nullptr; /* scratch of the distance-transform relabel (uint16 per voxel, tile-major), allocated on first use */
     bool all_residual = false; /* k_build found every n-link inside the volume residual */
-    int use_queue = 0;         /* the passes of a global relabel run as one launch over a queue (k_relabel_q; parameter relabel_queue) */
-    int queue_grid = 2048;     /* ... its workgroups (parameter queue_grid) */
     int use_bricks = 0;        /* incremental global relabels run their passes over bricks of 2 x 2 x 2 tiles (parameter relabel_bricks).  Measured on MI355X
                                   at 512^3: a third fewer passes (318 -> 202 launches) but 67 us instead of 31 us per pass -- 118 VGPRs allow two
                                   workgroups per CU, and a brick relaxes eight times the voxels over twice the rounds: 40.6 vs 36.3 ms per step,
@@ -1989,18 +1927,6 @@ struct HipDevT {
         check(hipGetLastError());
         time_end(id);
         relabel_launches += 7;
-        return true;
-    }
-    /* every remaining pass of the global relabel in progress as ONE launch (k_relabel_q); false: not in this configuration, run passes */
-    bool relabel_queue(int lst, uint32_t epoch)
-    {
-        if (FULL || !h->use_queue || !h->L.ring || h->nranks != 1 || h->brick_mode || h->L.nshard != 1) return false;
-        flush_zero();
-        const int id = time_begin(1);
-        hipLaunchKernelGGL(k_relabel_q, dim3(h->queue_grid), dim3(MGC_TV / MGC_RELABEL_V), 0, h->stream, h->L, lst, lst, epoch);
-        check(hipGetLastError());
-        time_end(id);
-        relabel_launches++;
         return true;
     }
     void relabel_list(int lst, uint32_t epoch, int next, int zero_list = -1)
@@ -2297,11 +2223,6 @@ static int mgc_create_impl(int ndim, const int64_t* shape, int connectivity, int
     if ((rc = mgc_alloc(h, &L.stamp, nt))) return rc;
     if ((rc = mgc_alloc(h, &L.rstamp, nt))) return rc;
     if ((rc = mgc_alloc(h, &L.status, nt))) return rc;
-    L.ring = nullptr;
-    if (L.ndir == 6 && !slab) { /* queue relabel: free slots hold -1 */
-        if ((rc = mgc_alloc(h, &L.ring, nt))) return rc;
-        MGC_HIP(h, hipMemsetAsync(L.ring, 0xff, (size_t)nt * sizeof(int32_t), h->stream));
-    }
     if ((rc = mgc_alloc(h, &h->d_tr0, nv))) return rc;
     if ((rc = mgc_alloc(h, &h->d_tflags, nt))) return rc;
     if ((rc = mgc_alloc(h, &h->d_tsum, nt))) return rc;
@@ -2776,7 +2697,7 @@ int mgc_destroy(mgc_handle h)
     MgcLattice& L = h->L;
     void* ptrs[] = {L.rcap, L.cap0, L.excess, L.sink, L.height, L.rmask, L.rmask32, L.obox, L.oflags, L.list[0], L.list[1], L.list[2],
                     L.list[3], L.list[4], L.list[5], L.list[6], L.list[7], L.list[8], L.list[9], L.list[10], L.list[11], L.list[12],
-                    L.list[13], L.list[14], L.list[15], L.list[16], L.list[17], L.count, L.stamp, L.rstamp, L.status, L.ring, h->d_tr0, h->d_part, h->d_part2, h->d_scalar,
+                    L.list[13], L.list[14], L.list[15], L.list[16], L.list[17], L.count, L.stamp, L.rstamp, L.status, h->d_tr0, h->d_part, h->d_part2, h->d_scalar,
                     h->d_labels, h->d_tflags, h->d_tsum, h->d_image, h->d_prob, h->d_fg, h->d_bg, h->d_tr_in, h->d_eslot, h->d_eval, h->d_erun, L.hshadow[0], L.hshadow[1], h->d_vout, h->d_dt16, h->d_halo, h->d_xchg[0], h->d_xchg[1], h->d_xchg[2], h->d_xchg[3], h->d_cnt64};
     for (void* p : ptrs)
         if (p) (void)hipFree(p);
@@ -3290,8 +3211,6 @@ int mgc_set_param(mgc_handle h, const char* name, int64_t value)
     else if (!strcmp(name, "wave_grid_rel") && value > 0) h->wave_grid_rel = (int)value;
     else if (!strcmp(name, "first_relabel_dt")) h->use_dt = value != 0;
     else if (!strcmp(name, "relabel_bricks")) h->use_bricks = value != 0;
-    else if (!strcmp(name, "relabel_queue")) h->use_queue = value != 0;
-    else if (!strcmp(name, "queue_grid") && value > 0) h->queue_grid = (int)value;
     else if (!strcmp(name, "halo_max_records") && value >= 1) { /* record slots of a border message (all slabs of a volume alike!) */
         const int64_t T = (int64_t)h->L.gy * h->L.gx;
         h->L.halo_max_rec = (int)(value < T ? value : T);

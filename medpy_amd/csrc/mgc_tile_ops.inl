@@ -218,53 +218,19 @@ MGC_HD void mgc_tile_bfs(X& x, MaskFn mask)
  * Passes repeat (driver) until no tile changes: exact distances to the sink, MGC_HINF for
  * voxels that cannot reach it -- the set the reference reads out with what_segment().
  * ------------------------------------------------------------------------------------- */
-/* QUEUE form of the global relabel (RING = true): all passes of a relabel in ONE launch.  The relaxation is monotone -- labels
- * only come down, every visit relaxes a tile to its fixpoint under the halo it sees -- so the passes were never needed for
- * the result, only to make one visit's labels visible to the next (a kernel boundary).  Here a woken tile goes into a ring
- * the workgroups of the SAME launch draw from, and what two visits share travels past the per-XCD L2s:
- *   labels and status words are read and written with the executor's device-coherent accesses (x.ldc / x.stc);
- *   a visit clears the tile's "queued" mark (rstamp) BEFORE it reads anything, so a neighbour that improves afterwards
- *   queues the tile again -- and one that improved before is seen by the reads (its labels were written, and had arrived
- *   (x.drain), before it tried to queue this tile);
- *   a visit counts as completed (low half of MGC_CNT_QSTATE) after its own pushes (high half): "completed == seeds +
- *   pushed" in one 64-bit read is the fixpoint, and stays true.
- * The label wave of an incremental relabel needs ~25 dependent visits; as passes those were 25 launches of ~25 us each. */
 template <class X>
-MGC_HD void mgc_ring_push(X& x, const MgcLattice& L, int tile)
-{
-    unsigned long long* const q = (unsigned long long*)(L.count + MGC_CNT_QSTATE);
-    for (;;) {
-        const uint32_t pos = (uint32_t)(x.atomic_add64(q, 1ull << 32) >> 32);
-        if (x.atomic_cas(&L.ring[pos % (uint32_t)L.shard_cap], -1, tile) == -1) return;
-        /* the slot still holds an entry nobody has fetched (cannot happen while fewer than ntiles entries wait, which the
-         * marks guarantee; kept as a guard): the position is skipped and counts as a visit */
-        (void)x.atomic_add64(q, 1ull);
-    }
-}
-
-template <class X, bool RING = false>
 MGC_HD void mgc_relabel_tile(X& x, const MgcLattice& L, int tile, uint32_t next_epoch, int next_list, bool first_pass)
 {
     /* first pass of a global relabel: every label is INF, so only tiles holding a sink arc can seed anything */
-    if (!RING && first_pass && (!(L.status[tile] & 2u) || !mgc_owned(L, tile))) return;
+    if (first_pass && (!(L.status[tile] & 2u) || !mgc_owned(L, tile))) return;
     typename X::template Reg<int> m, h0, stw;
     const int64_t base = (int64_t)tile * MGC_TV;
-    auto shared_i32 = [&](const int32_t* p) -> int32_t { if constexpr (RING) return x.ldc(p); else return *p; }; /* what another visit of this launch may have written */
-    auto shared_u32 = [&](const uint32_t* p) -> uint32_t { if constexpr (RING) return x.ldc(p); else return *p; };
-    if constexpr (RING) {
-        x.par([&](int t) { /* not queued any more: whoever improves from here on queues the tile again */
-            if (t == 0) {
-                (void)x.atomic_exch(&L.rstamp[tile], 0u);
-                x.drain();
-            }
-        });
-    }
     x.par([&](int t) { /* one trip to HBM: masks, own labels, label halo, the status word */
         const int z = t >> 6, y = (t >> 3) & 7, xx = t & 7;
         mgc_load_nbrs(x, L, tile, t);
-        if (t == 6) stw[t] = (int)shared_u32(&L.status[tile]); /* (rewritten below: fetched here, with everything else) */
+        if (t == 6) stw[t] = (int)L.status[tile]; /* (rewritten below: fetched here, with everything else) */
         m[t] = L.rmask[base + t];
-        h0[t] = shared_i32(&L.height[base + t]);
+        h0[t] = L.height[base + t];
         x.S.hs[mgc_hs_index(z, y, xx)] = h0[t];
         if (t < 6 * MGC_TF) {
             const int f = t >> 6, k = t & 63;
@@ -272,8 +238,8 @@ MGC_HD void mgc_relabel_tile(X& x, const MgcLattice& L, int tile, uint32_t next_
             mgc_tile_coords(L, tile, tz, ty, tx);
             const int nt = mgc_tile_nbr(L, tz, ty, tx, f);
             const int mine = mgc_face_voxel(f, k);
-            const int32_t* const hp = &L.height[(int64_t)(nt < 0 ? 0 : nt) * MGC_TV + mgc_face_voxel(f ^ 1, k)];
-            x.S.hs[mgc_hs_index(mine >> 6, (mine >> 3) & 7, mine & 7) + mgc_hs_step(f)] = nt < 0 ? MGC_HINF : shared_i32(hp);
+            x.S.hs[mgc_hs_index(mine >> 6, (mine >> 3) & 7, mine & 7) + mgc_hs_step(f)] =
+                nt < 0 ? MGC_HINF : L.height[(int64_t)nt * MGC_TV + mgc_face_voxel(f ^ 1, k)];
         }
     });
     /* relax from the CURRENT labels, not from scratch: inside a global relabel labels only go down, so they are upper
@@ -303,39 +269,22 @@ MGC_HD void mgc_relabel_tile(X& x, const MgcLattice& L, int tile, uint32_t next_
         const int h = x.S.hs[mgc_hs_index(t >> 6, (t >> 3) & 7, t & 7)];
         int wake = -1;
         bool won = false;
-        if (!RING && t < 6 && x.S.faceflag[t] && x.S.nbr[t] >= 0 && mgc_owned(L, x.S.nbr[t])) {
+        if (t < 6 && x.S.faceflag[t] && x.S.nbr[t] >= 0 && mgc_owned(L, x.S.nbr[t])) {
             wake = x.S.nbr[t];
             won = x.atomic_exch(&L.rstamp[wake], next_epoch) != next_epoch;
         }
-        if (h < h0[t]) {
-            if constexpr (RING) x.stc(&L.height[base + t], h);
-            else L.height[base + t] = h;
-        }
+        if (h < h0[t]) L.height[base + t] = h;
         if (t == 6) {
             uint32_t dep = 0;
             for (int f = 0; f < 6; ++f) dep |= x.S.depflag[f] ? (1u << f) : 0u;
-            const uint32_t st_new = ((uint32_t)stw[t] & ~((63u << MGC_ST_DEP_SHIFT) | (x.S.flag[0] ? MGC_ST_ALLINF : 0u))) | (dep << MGC_ST_DEP_SHIFT);
-            if constexpr (RING) x.stc(&L.status[tile], st_new);
-            else L.status[tile] = st_new;
+            L.status[tile] = ((uint32_t)stw[t] & ~((63u << MGC_ST_DEP_SHIFT) | (x.S.flag[0] ? MGC_ST_ALLINF : 0u))) | (dep << MGC_ST_DEP_SHIFT);
         }
         if (won) { /* first to queue it for the next pass (what mgc_enqueue does after its claim) */
             const int sh = x.shard(L);
             const int pos = x.atomic_add(mgc_counter(L, next_list, sh), 1);
             L.list[next_list][(int64_t)sh * L.shard_cap + pos] = wake;
         }
-        if constexpr (RING) x.drain(); /* the labels have arrived before anybody is told about them */
     });
-    if constexpr (RING) {
-        x.par([&](int t) { /* wake-ups: mark, then a ring entry (the executor's atomics return: they have happened before the barrier) */
-            if (t < 6 && x.S.faceflag[t] && x.S.nbr[t] >= 0 && mgc_owned(L, x.S.nbr[t])) {
-                const int wake = x.S.nbr[t];
-                if (x.atomic_exch(&L.rstamp[wake], next_epoch) != next_epoch) mgc_ring_push(x, L, wake);
-            }
-        });
-        x.par([&](int t) { /* this visit is over */
-            if (t == 0) (void)x.atomic_add64((unsigned long long*)(L.count + MGC_CNT_QSTATE), 1ull);
-        });
-    }
 }
 
 /* ---------------------------------------------------------------------------------------

@@ -14,7 +14,6 @@
  * either backend with the same code.
  */
 #include <stdint.h>
-#include <stdio.h>
 #include <stdlib.h>
 #include <string.h>
 
@@ -90,14 +89,6 @@ struct HostBlockT {
     void atomic_and(uint32_t* p, uint32_t v) { *p &= v; }
     void mark(const MgcLattice&, int id) { g_prof[id & 15]++; }
     void wave_fence() {}
-    /* queue relabel (mgc_relabel_tile<X, true>): one address space, one thread -- every access is coherent */
-    int32_t ldc(const int32_t* p) const { return *p; }
-    uint32_t ldc(const uint32_t* p) const { return *p; }
-    void stc(int32_t* p, int32_t v) const { *p = v; }
-    void stc(uint32_t* p, uint32_t v) const { *p = v; }
-    void drain() const {}
-    unsigned long long atomic_add64(unsigned long long* p, unsigned long long v) { const unsigned long long o = *p; *p += v; return o; }
-    int32_t atomic_cas(int32_t* p, int32_t expect, int32_t v) { const int32_t o = *p; if (o == expect) *p = v; return o; }
     /* exact in-tile labels: reference implementation = chaotic relaxation from scratch (mgc_tile_bfs) */
     template <class MaskFn, class RegI>
     void tile_labels(MaskFn mask, RegI& out)
@@ -203,8 +194,6 @@ static int g_bricks = 0; /* incremental relabels run their passes over bricks of
  * bit 2 = the wave discharge computes exact in-tile labels first (MGCW_BFS) */
 static int g_wave_mode = 0;
 static int g_act_exact_max = 4096; /* hostsim_set_act_exact: see mgcw_activate_tile */
-static FILE* g_trace = NULL; /* one line per wave-form discharge: phase, tile, sweeps (hostsim_trace) */
-static int g_queue = 0;  /* the passes of a global relabel as one queue (hostsim_set_queue: 1 oldest first, 2 newest first) */
 static int g_gap = 0;    /* gap cut every n-th colour round (hostsim_set_gap; 0: never) */
 static int g_use_dt = 1; /* the first global relabel may be a distance transform (hostsim_set_dt) */
 
@@ -221,7 +210,7 @@ struct HostDev {
     std::vector<int32_t> height, lists, count;
     std::vector<uint8_t> rmask;
     std::vector<uint32_t> oflags, stamp, rstamp, status;
-    std::vector<int32_t> hshadow[2], ring;
+    std::vector<int32_t> hshadow[2];
 
     void fill_heights_inf()
     {
@@ -280,42 +269,6 @@ struct HostDev {
         for (int t = 0; t < L.ntiles; ++t) mgc_dt_finish_tile(w, L, t);
         L.count[9] += L.ntiles;
         g_prof[28]++;
-        return true;
-    }
-    /* the library's k_relabel_q, one visit at a time: seeds first, then whatever the visits pushed into the ring -- oldest first
-     * (g_queue = 1, what the tickets of the kernel approximate) or newest first (2: any order must reach the same labels) */
-    bool relabel_queue(int lst, uint32_t epoch)
-    {
-        if (!g_queue || spec.nranks != 1 || brick_mode) return false;
-        HostBlock x(S);
-        unsigned long long* const q = (unsigned long long*)(L.count + MGC_CNT_QSTATE);
-        const int n = L.count[lst];
-        std::vector<int> ready(L.list[lst], L.list[lst] + n);
-        if (g_queue == 2) std::reverse(ready.begin(), ready.end());
-        uint32_t drained = 0;
-        size_t at = 0;
-        int64_t visits = 0;
-        for (;;) {
-            for (; drained < (uint32_t)(*q >> 32); ++drained) { /* what arrived since the last look */
-                int32_t& slot = L.ring[drained % (uint32_t)L.shard_cap];
-                if (slot >= 0) { ready.push_back(slot); slot = -1; }
-            }
-            int tile;
-            if (g_queue == 2) {
-                if (ready.empty()) break;
-                tile = ready.back();
-                ready.pop_back();
-            } else {
-                if (at == ready.size()) break;
-                tile = ready[at++];
-            }
-            mgc_relabel_tile<HostBlock, true>(x, L, tile, epoch, -1, false);
-            visits++;
-        }
-        if ((uint32_t)*q != (uint32_t)(*q >> 32) + (uint32_t)n) g_prof[45]++; /* the fixpoint test of the kernel would not hold: a bug */
-        L.count[9] += (int)visits;
-        g_prof[44] += visits;
-        *q = 0;
         return true;
     }
     void relabel_list(int lst, uint32_t epoch, int next, int zero_list = -1)
@@ -424,9 +377,7 @@ struct HostDev {
         for (int i = 0; i < n; ++i) {
             if ((int)g_tile_discharges.size() == L.ntiles) g_tile_discharges[L.list[lst][i]]++;
             if (g_wave_mode & 1) {
-                const int64_t sweeps_before = g_prof[2];
                 mgcw_discharge_tile(w, L, L.list[lst][i], phase, sweeps, (g_wave_mode & 4) ? MGCW_BFS : 0);
-                if (g_trace) fprintf(g_trace, "%u %d %d\n", phase, L.list[lst][i], (int)(g_prof[2] - sweeps_before));
                 g_prof[3]++;
             } else {
                 mgc_discharge_tile(x, L, L.list[lst][i], phase, cycles, sweeps);
@@ -449,8 +400,6 @@ struct HostDev {
         obox.assign(nt * 6 * MGC_TF, 0.0); height.assign(nt * MGC_TV, MGC_HINF); lists.assign(8 * nt, 0);
         count.assign(MGC_NCOUNT, 0); rmask.assign(nt * MGC_TV, 0);
         oflags.assign(nt, 0); stamp.assign(nt, 0); rstamp.assign(nt, 0); status.assign(nt, 0);
-        ring.assign(nt, -1);
-        L.ring = ring.data();
         L.rcap = rcap.data(); L.cap0 = NULL; L.excess = excess.data(); L.sink = sink.data(); L.height = height.data();
         L.rmask = rmask.data(); L.obox = obox.data(); L.oflags = oflags.data();
         for (int i = 0; i < 8; ++i) L.list[i] = lists.data() + i * nt;
@@ -510,8 +459,6 @@ extern "C" {
 void hostsim_set_wave_mode(int mode) { g_wave_mode = mode; }
 void hostsim_set_dt(int on) { g_use_dt = on; }
 void hostsim_set_gap(int every) { g_gap = every; }
-void hostsim_set_queue(int mode) { g_queue = mode; }
-void hostsim_trace(const char* path) { if (g_trace) fclose(g_trace); g_trace = path && *path ? fopen(path, "w") : NULL; }
 void hostsim_set_bricks(int on) { g_bricks = on; }
 /* record slots of a compacted border message (MgcLattice::halo_max_rec); which: 6 or 26 */
 void hostsim_set_halo_max(void* h, int which, int n);
@@ -669,7 +616,6 @@ struct HostDev26 {
     void range_push(const char*) {}
     void range_pop() {}
     void gap_cut(int) {}
-    bool relabel_queue(int, uint32_t) { return false; }
     void zero_count(int i) { L.count[i] = 0; }
     void read_counts(int* out) { memcpy(out, L.count, MGC_NCOUNT * sizeof(int)); }
     void absorb_all() {}
