@@ -200,7 +200,6 @@ int mgc_solve(Dev& dev, const MgcLattice& L, const MgcSolveParams& P, MgcSolveSt
                 st.phases++;
                 phase++;
             }
-            dev.gap_cut(r);
             if ((r + 1) % P.check_rounds == 0 && r + 1 < rounds) {
                 dev.read_counts(cnt);
                 st.readbacks++;

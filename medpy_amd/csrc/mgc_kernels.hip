@@ -1808,7 +1808,6 @@ struct HipDevT {
     int suspect_batch() const { return 2; } /* closure passes between two looks at the "changed" flag: a pass settles a brick */
     void range_push(const char* name) { mgc_range_push(name); } /* roctx range around a stretch of the schedule (mgc_driver.inl) */
     void range_pop() { mgc_range_pop(); }
-    void gap_cut(int) {}
     struct Span { int a, b, kind; };
     std::vector<Span> spans;
     void check(hipError_t e) { if (e != hipSuccess && first_error == hipSuccess) first_error = e; }

@@ -14,6 +14,7 @@
  * either backend with the same code.
  */
 #include <stdint.h>
+#include <stdio.h>
 #include <stdlib.h>
 #include <string.h>
 
@@ -194,7 +195,7 @@ static int g_bricks = 0; /* incremental relabels run their passes over bricks of
  * bit 2 = the wave discharge computes exact in-tile labels first (MGCW_BFS) */
 static int g_wave_mode = 0;
 static int g_act_exact_max = 4096; /* hostsim_set_act_exact: see mgcw_activate_tile */
-static int g_gap = 0;    /* gap cut every n-th colour round (hostsim_set_gap; 0: never) */
+static FILE* g_trace = NULL; /* one line per wave-form discharge: phase, tile, sweeps (hostsim_trace; tools/sim_launch_model.py) */
 static int g_use_dt = 1; /* the first global relabel may be a distance transform (hostsim_set_dt) */
 
 typedef HostBlockT<MgcTileShared> HostBlock;
@@ -347,27 +348,6 @@ struct HostDev {
             }
         }
     }
-    void gap_cut(int r)
-    {
-        if (!g_gap || (r + 1) % g_gap) return;
-        std::vector<int64_t> hist(1 << 16, 0);
-        int hmax = 0;
-        for (int64_t i = 0; i < (int64_t)L.ntiles * MGC_TV; ++i) {
-            const int h = L.height[i];
-            if (h < MGC_HINF && L.rmask[i] /* (a voxel nobody can leave and that cannot leave: isolated padding) */) {
-                const int b = h < 65535 ? h : 65535;
-                hist[b]++;
-                if (b > hmax) hmax = b;
-            }
-        }
-        int g = -1;
-        for (int b = 1; b < hmax; ++b) if (!hist[b]) { g = b; break; }
-        g_prof[40]++;
-        if (g < 0) return;
-        g_prof[41]++;
-        for (int64_t i = 0; i < (int64_t)L.ntiles * MGC_TV; ++i)
-            if (L.height[i] < MGC_HINF && L.height[i] > g) { L.height[i] = MGC_HINF; g_prof[42]++; }
-    }
     void discharge(int lst, uint32_t phase, int cycles, int sweeps)
     {
         HostBlock x(S);
@@ -377,7 +357,9 @@ struct HostDev {
         for (int i = 0; i < n; ++i) {
             if ((int)g_tile_discharges.size() == L.ntiles) g_tile_discharges[L.list[lst][i]]++;
             if (g_wave_mode & 1) {
+                const int64_t sweeps_before = g_prof[2];
                 mgcw_discharge_tile(w, L, L.list[lst][i], phase, sweeps, (g_wave_mode & 4) ? MGCW_BFS : 0);
+                if (g_trace) fprintf(g_trace, "%u %d %d\n", phase, L.list[lst][i], (int)(g_prof[2] - sweeps_before));
                 g_prof[3]++;
             } else {
                 mgc_discharge_tile(x, L, L.list[lst][i], phase, cycles, sweeps);
@@ -458,7 +440,7 @@ extern "C" {
 
 void hostsim_set_wave_mode(int mode) { g_wave_mode = mode; }
 void hostsim_set_dt(int on) { g_use_dt = on; }
-void hostsim_set_gap(int every) { g_gap = every; }
+void hostsim_trace(const char* path) { if (g_trace) fclose(g_trace); g_trace = path && *path ? fopen(path, "w") : NULL; }
 void hostsim_set_bricks(int on) { g_bricks = on; }
 /* record slots of a compacted border message (MgcLattice::halo_max_rec); which: 6 or 26 */
 void hostsim_set_halo_max(void* h, int which, int n);
@@ -615,7 +597,6 @@ struct HostDev26 {
     }
     void range_push(const char*) {}
     void range_pop() {}
-    void gap_cut(int) {}
     void zero_count(int i) { L.count[i] = 0; }
     void read_counts(int* out) { memcpy(out, L.count, MGC_NCOUNT * sizeof(int)); }
     void absorb_all() {}

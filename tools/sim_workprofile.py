@@ -38,7 +38,6 @@ def main():
     L.hostsim_prof.argtypes = [np.ctypeslib.ndpointer(np.int64), np.ctypeslib.ndpointer(np.int32), C.c_int]
     L.hostsim_prof(prof, tiles, nt)  # arm
     L.hostsim_set_wave_mode(mode)
-    L.hostsim_set_gap(int(os.environ.get("GAP", "0")))
     t0 = time.time()
     labels, st = sim.solve((n, n, n), w, tr, sweeps=sweeps, rounds=rounds)
     L.hostsim_set_wave_mode(0)
@@ -63,8 +62,6 @@ def main():
     for name, m in (("inside", inside), ("shell", shell), ("outside", outside)):
         print("  %-8s tiles %6d  discharges %8d  (%.2f per tile)" % (name, m.sum(), tiles[m].sum(), tiles[m].sum() / max(1, m.sum())))
     print("  per-voxel: discharges %.2f relabels %.2f" % (st["discharge_tiles"] / nt, st["relabel_tiles"] / nt))
-    if prof[40]:
-        print("gap cuts: %d looks, %d found a gap, %d labels cut off" % (prof[40], prof[41], prof[42]))
     if prof[24]:
         print("incremental relabels reset %d tiles: %.1f%% got their labels back unchanged, %.1f%% unchanged on all six faces; "
               "%.1f voxels changed per reset tile" % (prof[24], 100.0 * prof[25] / prof[24], 100.0 * prof[26] / prof[24], prof[27] / prof[24]))
