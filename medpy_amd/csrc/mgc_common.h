@@ -43,6 +43,7 @@
 #define MGC_ST_DEP_SHIFT 8
 /* counter slots no layout uses as a work list (6-neighbourhood: lists 0..7, totals 8 / 9; 26-neighbourhood: lists 0..17,
  * totals 18..20; tickets of the wave kernels 24..27) */
+#define MGC_CNT_SINK_TILES 13  /* (6-neighbourhood) k_build: tiles that hold a sink link */
 #define MGC_CNT_CHANGED 21     /* suspect-closure pass changed something */
 #define MGC_CNT_FILTER 22      /* length of the scratch list the tile filters fill (absorb / relabel seeding / suspect reset) */
 #define MGC_CNT_FILTER_ACT 23  /* ... of the activation filter */

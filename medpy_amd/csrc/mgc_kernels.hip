@@ -399,7 +399,7 @@ void k_discharge_w(MgcLattice L, int lst, uint32_t phase, int sweeps, int flags,
         w.new_tile();
         w.mark(1); /* between two tiles */
         /* the tile id is wave-uniform: keep it (and every base address derived from it) in SGPRs */
-        if (__builtin_amdgcn_readfirstlane(st) & (int)MGC_ST_SINK) mgcw_discharge_impl<true>(w, L, tile, phase, sweeps, flags);
+        if (__builtin_amdgcn_readfirstlane(st) & (int)MGC_ST_SINK) mgcw_discharge_impl<true>(w, L, tile, phase, sweeps, flags | ((flags & MGCW_BFS_SINK) ? MGCW_BFS : 0));
         else mgcw_discharge_impl<false>(w, L, tile, phase, sweeps, flags);
 #if MGCW_RUNAHEAD
         tile = w.next_tile; /* resolved inside the visit (hint_begin / hint_end in mgcw_discharge_impl) */
@@ -1010,6 +1010,7 @@ __device__ __forceinline__ void k_build_tiles(const MgcLattice& L, const MgcBuil
      * by up to eight.  (gridDim.x is a multiple of 8 or smaller than 8.) */
     const int nx = gridDim.x >= 8 ? 8 : 1;
     const int chunk = (L.ntiles + nx - 1) / nx, stride = (int)gridDim.x / nx;
+    int sink_tiles = 0; /* (thread 0) tiles of this workgroup that hold a sink link */
     for (int idx = (int)blockIdx.x / nx; idx < chunk; idx += stride) {
         const int tile = ((int)blockIdx.x % nx) * chunk + idx;
         if (tile >= L.ntiles) break;
@@ -1160,6 +1161,7 @@ __device__ __forceinline__ void k_build_tiles(const MgcLattice& L, const MgcBuil
             L.rstamp[tile] = 0;
             L.status[tile] = (any_sink ? MGC_ST_SINK : 0u) | (any_exc ? MGC_ST_EXCESS : 0u);
             A.tflags[tile] = (uint8_t)((any_exc ? 1 : 0) | (any_sink ? 2 : 0));
+            sink_tiles += any_sink ? 1 : 0;
         }
         /* flow constant: only voxels whose t-links were merged more than once contribute (regional term + marker, fg and bg
          * marker on one voxel): most tiles skip the ten barriers of the tree sum */
@@ -1171,6 +1173,7 @@ __device__ __forceinline__ void k_build_tiles(const MgcLattice& L, const MgcBuil
             A.fpart[tile] = 0.0;
         }
     }
+    if (!FULL && t == 0 && sink_tiles) atomicAdd(&L.count[MGC_CNT_SINK_TILES], sink_tiles); /* once per workgroup (mgc_build: exact_sink_tiles) */
 }
 
 /* One kernel per (neighbourhood, boundary term): g(.) is straight-line code, and every instance gets the registers ITS term
@@ -1719,6 +1722,11 @@ struct mgc_graph {
     void* d_vout = nullptr;    /* MgcValidateOut of mgc_validate */
     uint16_t* d_dt16 = nullptr; /* scratch of the distance-transform relabel (uint16 per voxel, tile-major), allocated on first use */
     bool all_residual = false; /* k_build found every n-link inside the volume residual */
+    int exact_sink_tiles = 1;  /* k_discharge_w: exact in-tile labels per visit for the tiles that hold a sink link (MGCW_BFS_SINK; parameter
+                                  exact_sink_tiles): 0 never, 2 always, 1 when most tiles of the volume hold one (markers scattered over the
+                                  volume: 512^3 tie-heavy volume 1081 -> 790 ms; sink links only on the faces, as in the headline volume: the
+                                  few visits of those tiles cost 0.7 ms of 36 more with it) */
+    int sink_tiles = 0;        /* tiles holding a sink link, as built */
     int use_bricks = 0;        /* incremental global relabels run their passes over bricks of 2 x 2 x 2 tiles (parameter relabel_bricks).  Measured on MI355X
                                   at 512^3: a third fewer passes (318 -> 202 launches) but 67 us instead of 31 us per pass -- 118 VGPRs allow two
                                   workgroups per CU, and a brick relaxes eight times the voxels over twice the rounds: 40.6 vs 36.3 ms per step,
@@ -1998,7 +2006,7 @@ struct HipDevT {
         /* one wave per tile has the higher throughput (2 048 tiles in flight, fewer instructions per tile), eight waves per tile
          * the shorter latency (36 us against 60 us for one tile): short lists -- small volumes, the tail of a solve -- are a
          * single tile deep per launch and go to the workgroup form.  Both forms keep the same state in HBM. */
-        else if (wave_form) { hipLaunchKernelGGL(k_discharge_w, dim3(h->wave_grid_dis), dim3(MGCW_LANES), 0, h->stream, h->L, lst, phase, sweeps, (h->wave_kernels & 4) ? MGCW_BFS : 0, h->tk_dis, zero_idx, h->wave_stagger); h->tk_dis ^= 1; }
+        else if (wave_form) { hipLaunchKernelGGL(k_discharge_w, dim3(h->wave_grid_dis), dim3(MGCW_LANES), 0, h->stream, h->L, lst, phase, sweeps, ((h->wave_kernels & 4) ? MGCW_BFS : 0) | ((h->exact_sink_tiles == 2 || (h->exact_sink_tiles == 1 && 2 * (int64_t)h->sink_tiles > h->L.ntiles)) ? MGCW_BFS_SINK : 0), h->tk_dis, zero_idx, h->wave_stagger); h->tk_dis ^= 1; }
         else hipLaunchKernelGGL(k_discharge, dim3(grid(h->L.ntiles)), dim3(MGC_TV), 0, h->stream, h->L, lst, phase,
                                 (h->wave_kernels & 1) && !(h->wave_kernels & 4) ? -1 : cycles, sweeps, zero_idx); /* same labelling policy as the wave form */
         check(hipGetLastError());
@@ -2973,6 +2981,7 @@ int mgc_build(mgc_handle h)
     MGC_HIP(h, hipStreamSynchronize(h->stream));
     /* every n-link of the volume residual (and nothing added on top that the mask refresh could have changed): the first
      * global relabel of the solve is a distance transform (mgc_dt_ops.inl) */
+    h->sink_tiles = L.ndir == 6 ? h->h_count[MGC_CNT_SINK_TILES] : 0;
     h->all_residual = L.ndir == 6 && A.term != MGC_TERM_NONE && h->h_count[MGC_CNT_NOT_FULL] == 0 && !h->n_edges && h->nranks == 1 &&
                       L.dz + L.dy + L.dx < MGC_DT_INF - 8;
     float ms = 0.f;
@@ -3210,6 +3219,7 @@ int mgc_set_param(mgc_handle h, const char* name, int64_t value)
     else if (!strcmp(name, "wave_grid_rel") && value > 0) h->wave_grid_rel = (int)value;
     else if (!strcmp(name, "first_relabel_dt")) h->use_dt = value != 0;
     else if (!strcmp(name, "relabel_bricks")) h->use_bricks = value != 0;
+    else if (!strcmp(name, "exact_sink_tiles") && value >= 0 && value <= 2) h->exact_sink_tiles = (int)value;
     else if (!strcmp(name, "halo_max_records") && value >= 1) { /* record slots of a border message (all slabs of a volume alike!) */
         const int64_t T = (int64_t)h->L.gy * h->L.gx;
         h->L.halo_max_rec = (int)(value < T ? value : T);

@@ -71,12 +71,16 @@ def _build_oracle():
 # every lattice handle at creation, medpy_amd/_lib.py:apply_env_params) plus the two-voxels-per-thread 26-neighbourhood
 # discharge (wave_kernels bit 4).
 _FORMS_MODULES = ("test_gpu_parity", "test_gpu_edge_cases", "test_gpu_slabs", "test_gpu_full_neighbourhood")
-LARGE_VOLUME_FORMS = "wave_min_tiles=0,activate_exact_max=0,wave_kernels=25"
+LARGE_VOLUME_FORMS = "wave_min_tiles=0,activate_exact_max=0,wave_kernels=25,exact_sink_tiles=2"
+STORED_LABEL_FORMS = "wave_min_tiles=0,exact_sink_tiles=0"  # the wave discharge without the exact labelling of tiles that hold a sink link
 
 
 def pytest_generate_tests(metafunc):
     if metafunc.module.__name__.rsplit(".", 1)[-1] in _FORMS_MODULES and "kernel_forms" in metafunc.fixturenames:
-        metafunc.parametrize("kernel_forms", ["as_shipped", "large_volume_forms"], indirect=True)
+        forms = ["as_shipped", "large_volume_forms"]
+        if metafunc.module.__name__.rsplit(".", 1)[-1] == "test_gpu_parity":
+            forms.append("stored_label_forms")
+        metafunc.parametrize("kernel_forms", forms, indirect=True)
 
 
 @pytest.fixture(autouse=True)
@@ -84,6 +88,8 @@ def kernel_forms(request, monkeypatch):
     mode = getattr(request, "param", "as_shipped")
     if mode == "large_volume_forms":
         monkeypatch.setenv("MEDPY_HIP_PARAMS", LARGE_VOLUME_FORMS)
+    elif mode == "stored_label_forms":
+        monkeypatch.setenv("MEDPY_HIP_PARAMS", STORED_LABEL_FORMS)
     return mode
 
 

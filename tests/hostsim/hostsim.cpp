@@ -192,7 +192,7 @@ struct HostBrick {
 static int g_bricks = 0; /* incremental relabels run their passes over bricks of 2 x 2 x 2 tiles (hostsim_set_bricks; the library's relabel_bricks, off by default) */
 
 /* which form of the two hot tile operations the simulator runs: bit 0 = wave discharge, bit 1 = wave relabel,
- * bit 2 = the wave discharge computes exact in-tile labels first (MGCW_BFS) */
+ * bit 2 = the wave discharge computes exact in-tile labels first (MGCW_BFS); bit 3 = only in tiles holding a sink link (MGCW_BFS_SINK) */
 static int g_wave_mode = 0;
 static int g_act_exact_max = 4096; /* hostsim_set_act_exact: see mgcw_activate_tile */
 static FILE* g_trace = NULL; /* one line per wave-form discharge: phase, tile, sweeps (hostsim_trace; tools/sim_launch_model.py) */
@@ -358,7 +358,7 @@ struct HostDev {
             if ((int)g_tile_discharges.size() == L.ntiles) g_tile_discharges[L.list[lst][i]]++;
             if (g_wave_mode & 1) {
                 const int64_t sweeps_before = g_prof[2];
-                mgcw_discharge_tile(w, L, L.list[lst][i], phase, sweeps, (g_wave_mode & 4) ? MGCW_BFS : 0);
+                mgcw_discharge_tile(w, L, L.list[lst][i], phase, sweeps, ((g_wave_mode & 4) ? MGCW_BFS : 0) | ((g_wave_mode & 8) ? MGCW_BFS_SINK : 0));
                 if (g_trace) fprintf(g_trace, "%u %d %d\n", phase, L.list[lst][i], (int)(g_prof[2] - sweeps_before));
                 g_prof[3]++;
             } else {

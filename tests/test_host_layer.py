@@ -86,7 +86,7 @@ def test_hostsim_solver_matches_bk(gen, shape):
     np.testing.assert_array_equal(lab, ref)
 
 
-@pytest.mark.parametrize("mode", [1, 2, 3, 7])
+@pytest.mark.parametrize("mode", [1, 2, 3, 7, 9])
 @pytest.mark.parametrize("gen,shape", [("sphere", (16, 16, 16)), ("sphere", (40, 40, 40)), ("hard", (32, 32, 32)),
                                        ("sphere", (9, 21, 35)), ("sphere", (5, 8, 64)), ("ties", (24, 16, 16))])
 def test_hostsim_wave_forms_match_bk(gen, shape, mode):
