@@ -612,7 +612,11 @@ MGC_HD void mgc_shadow_reset(const MgcLattice& L, int tile, int k)
     if (L.hshadow[1] && L.tz_own_hi < L.gz && layer == L.tz_own_hi - 1) L.hshadow[1][(int64_t)i * MGC_TF + k] = MGC_HINF;
 }
 
-/* suspect tiles: labels := INF, queued for the first relabel pass; flags retired */
+/* suspect tiles: labels := INF, flags retired; queued for the first relabel pass if a label can come from somewhere -- the
+ * tile holds a sink link, or a face neighbour keeps labels (it is neither suspect nor all-INF; a neighbour that is being
+ * reset at this moment shows one bit or the other, whichever side of its status store this read falls on), or lies in
+ * another slab.  A reset tile in the middle of reset tiles would relax INF against INF on that visit; it is woken when
+ * the label wave reaches a neighbour (mgc_relabel_tile wakes across a face on labels alone). */
 template <class X>
 MGC_HD void mgc_reset_suspect_tile(X& x, const MgcLattice& L, int tile, uint32_t epoch, int list)
 {
@@ -622,8 +626,15 @@ MGC_HD void mgc_reset_suspect_tile(X& x, const MgcLattice& L, int tile, uint32_t
             L.height[(int64_t)tile * MGC_TV + t] = MGC_HINF;
             if (t < MGC_TF) mgc_shadow_reset(L, tile, t);
             if (t == 0) {
+                int tz, ty, tx;
+                mgc_tile_coords(L, tile, tz, ty, tx);
+                bool source = (st & MGC_ST_SINK) != 0;
+                for (int f = 0; f < 6; ++f) {
+                    const int nt = mgc_tile_nbr(L, tz, ty, tx, f);
+                    if (nt >= 0 && (!mgc_owned(L, nt) || !(L.status[nt] & (MGC_ST_SUSPECT | MGC_ST_ALLINF)))) source = true;
+                }
                 L.status[tile] = (st & ~(MGC_ST_SUSPECT | MGC_ST_DIRTY | (63u << MGC_ST_DEP_SHIFT))) | MGC_ST_ALLINF;
-                mgc_enqueue(x, L, list, L.rstamp, epoch, tile);
+                if (source) mgc_enqueue(x, L, list, L.rstamp, epoch, tile);
             }
         });
     }

@@ -2,6 +2,7 @@
 
     python tools/rocpd_summary.py stats  <results.db>  > profiles/<round>_kernel_stats.csv
     python tools/rocpd_summary.py pmc    <results.db>  > profiles/<round>_pmc_<counter>.csv
+    python tools/rocpd_summary.py timeline <results.db>  > profiles/<round>_timeline.csv    (every dispatch in order: start, gap to the one before, duration)
 """
 import sqlite3
 import sys
@@ -17,6 +18,15 @@ def main():
         tot = sum(r[2] for r in rows) or 1
         for n, c, s, a, mn, mx in rows:
             print('"%s",%d,%.3f,%.3f,%.3f,%.3f,%.2f' % (n, c, s / 1e3, a / 1e3, mn / 1e3, mx / 1e3, 100.0 * s / tot))
+    elif mode == "timeline":
+        cols = [r[1] for r in cur.execute("pragma table_info(kernels)").fetchall()]
+        st, en = ("start", "end") if "start" in cols else ("start_timestamp", "end_timestamp")
+        rows = cur.execute("select name, %s, %s from kernels order by %s" % (st, en, st)).fetchall()
+        print("start_us,gap_us,duration_us,kernel")
+        t0, last_end = (rows[0][1] if rows else 0), None
+        for n, a, b in rows:
+            print("%.2f,%.2f,%.2f,%s" % ((a - t0) / 1e3, 0.0 if last_end is None else (a - last_end) / 1e3, (b - a) / 1e3, n.split("(")[0].replace("void ", "")))
+            last_end = b
     elif mode == "json":
         # python tools/rocpd_summary.py json <fetch.db> <write.db> > profiles/pmc_discharge.json
         import json
