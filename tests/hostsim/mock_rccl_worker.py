@@ -5,12 +5,14 @@ import json
 import os
 import sys
 import threading
+import time
 
 import numpy as np
 
 root, nranks, conn, gen = sys.argv[1], int(sys.argv[2]), int(sys.argv[3]), sys.argv[4]
 shape = tuple(int(v) for v in sys.argv[5].split("x"))
 NATIVE = len(sys.argv) > 7 and sys.argv[7] == "native"  # the schedule inside the library (mgc_solve_slab) instead of slab.py's
+ROUNDS = int(sys.argv[8]) if len(sys.argv) > 8 else 2  # colour rounds between two global relabels (the tests: 2, many relabels on small volumes)
 sys.path.insert(0, root)
 from medpy_amd import synthetic  # noqa: E402
 from medpy_amd.slab import HipSlab, solve_slabs  # noqa: E402
@@ -45,7 +47,9 @@ def run(r):
         sl.set_boundary(s["term"], s["image"][z], s["sigma"], False)
         sl.set_markers(s["fg"][z], s["bg"][z])
         sl.build()
-        st = solve_slabs([sl], ThreadRcclExchange(sl, uid), rounds_per_relabel=2)
+        t0 = time.perf_counter()
+        st = solve_slabs([sl], ThreadRcclExchange(sl, uid), rounds_per_relabel=ROUNDS)
+        st["solve_ms"] = round((time.perf_counter() - t0) * 1e3, 1)
         lab, part = sl.finish()
         out[r] = (lab, part, st)
     except Exception as e:  # noqa: BLE001
