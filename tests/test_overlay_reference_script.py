@@ -89,11 +89,11 @@ def test_overlay_module_surface():
         sys.modules.update(saved)
 
 
-SHIPPED_SCRIPT = os.path.join(ROOT, "build", "ref_bin", "medpy_graphcut_voxel.py")  # written by __graft_entry__.build()
+SHIPPED_SCRIPT = os.path.join(ROOT, "oracle", "_ref", "bin", "medpy_graphcut_voxel.py")  # written by __graft_entry__.build()
 
 
 @pytest.mark.gpu
-@pytest.mark.skipif(not os.path.exists(SHIPPED_SCRIPT), reason="build/ref_bin/medpy_graphcut_voxel.py did not travel (run __graft_entry__.build() where /root/reference exists)")
+@pytest.mark.skipif(not os.path.exists(SHIPPED_SCRIPT), reason="oracle/_ref/bin/medpy_graphcut_voxel.py did not travel (run __graft_entry__.build() where /root/reference exists)")
 @pytest.mark.parametrize("flag,term", [("diff_exp", "difference_exponential"), ("diff_div", "difference_division")])
 def test_reference_voxel_script_unmodified_on_the_hip_path(tmp_path, flag, term):
     """The reference's bin/medpy_graphcut_voxel.py, byte for byte (shipped to the GPU box as a build product), run by
