@@ -192,15 +192,16 @@ typedef GpuBlockT<MgcTileShared26D, MGC26_LAUNDER> GpuBlock26D;
  * wave executor for the one-wave-per-tile operations (mgc_wave_ops.inl): a workgroup IS one wave64,
  * Reg<T, N> = N registers, votes = ballots, no workgroup barrier anywhere
  * ==================================================================================== */
-struct GpuWave {
+template <class SH> /* MgcWaveShared (discharge: labels, inbox, sink links) or MgcWaveSharedR (relabel: labels only) */
+struct GpuWaveT {
     template <class T, int N>
     struct Reg {
         T v[N];
         __device__ __forceinline__ T& operator()(int, int k) { return v[k]; }
     };
-    MgcWaveShared& S;
+    SH& S;
     int lane;
-    __device__ __forceinline__ explicit GpuWave(MgcWaveShared& s) : S(s), lane((int)threadIdx.x) {}
+    __device__ __forceinline__ explicit GpuWaveT(SH& s) : S(s), lane((int)threadIdx.x) {}
     /* top of every tile: the lane id becomes opaque to the optimiser, so lane-dependent addresses and masks are recomputed
      * per tile (a few VALU ops) instead of being hoisted out of the tile loop and kept alive in registers that the
      * discharge needs for its state */
@@ -348,6 +349,9 @@ struct GpuWave {
     template <class T>
     __device__ __forceinline__ void st(T* p, int l, T v) { *(T*)((char*)p + (unsigned)(l * (int)sizeof(T))) = v; }
 };
+typedef GpuWaveT<MgcWaveShared> GpuWave;
+struct alignas(16) MgcWaveSharedR { int32_t hs[1000]; }; /* what a relabel visit touches of MgcWaveShared: 4 KB, 32 waves per CU */
+typedef GpuWaveT<MgcWaveSharedR> GpuWaveR;
 
 /* Work distribution of the wave kernels: a wave takes list position blockIdx.x first, then draws further positions from
  * a ticket counter (tiles differ a lot in cost, a static stride leaves a tail).  Two ticket slots alternate from launch
@@ -419,18 +423,20 @@ void k_discharge_w(MgcLattice L, int lst, uint32_t phase, int sweeps, int flags,
  * filter's scratch list (`cnt` = its counter), else `cnt` = lst */
 __global__ __launch_bounds__(MGCW_LANES) void k_relabel_w(MgcLattice L, int lst, int cnt, uint32_t epoch, int next_list, int zero_list, int first, int tk)
 {
-    __shared__ MgcWaveShared S;
-    GpuWave w(S);
+    __shared__ MgcWaveSharedR S;
+    GpuWaveR w(S);
+    /* the wave's first list entry is fetched together with the list length (see k_relabel_v); positions are strided, not
+     * ticketed: a pass is rarely deeper than the resident waves, and a ticket is one more trip and one more hot word */
+    const int spec = L.nshard == 1 && (int)blockIdx.x < L.shard_cap ? L.list[lst][blockIdx.x] : 0;
     MgcListView view;
     const int n = mgc_list_view(L, cnt, view);
-    if (blockIdx.x == 0 && threadIdx.x == 0) {
-        if (n) atomicAdd(&L.count[9], n);
-        L.count[tk ^ 1] = 0;
-    }
+    if (blockIdx.x == 0 && threadIdx.x == 0 && n) atomicAdd(&L.count[9], n);
+    (void)tk;
     mgc_clear_counter(L, zero_list); /* consumed by the previous pass; the next pass appends to it */
-    for (int i = (int)blockIdx.x; i < n; i = mgcw_next_ticket(L, tk)) {
+    for (int i = (int)blockIdx.x; i < n; i += (int)gridDim.x) {
         w.new_tile();
-        mgcw_relabel_tile(w, L, __builtin_amdgcn_readfirstlane(mgc_list_at(L, lst, view, i)), epoch, next_list, first != 0);
+        const int tile = (i == (int)blockIdx.x && L.nshard == 1) ? spec : mgc_list_at(L, lst, view, i);
+        mgcw_relabel_tile(w, L, __builtin_amdgcn_readfirstlane(tile), epoch, next_list, first != 0);
     }
 }
 

@@ -91,10 +91,10 @@ MGC_HD void mgcw_static_for(F&& f)
 /* hs[] cell of slot k (z-layer) of lane l = (y, x) */
 MGC_HD int mgcw_hs(int l, int k) { return (k + 1) * 100 + ((l >> 3) + 1) * 10 + (l & 7) + 1; }
 
-/* one trip to HBM for what the six neighbours contribute: lane l fetches, per face, the label of the voxel its face
- * cell touches and the outbox slot the neighbour may have filled for it (emptied if so).  Results go to LDS. */
+/* one trip to HBM for what the six neighbours contribute to a relabel visit: lane l fetches, per face, the label of the
+ * voxel its face cell touches.  Results go to LDS.  (The discharge fetches labels and inbox with mgcw_halo_issue / commit.) */
 template <class W>
-MGC_HD void mgcw_load_halo(W& w, const MgcLattice& L, int tile, int l, bool with_inbox)
+MGC_HD void mgcw_load_halo(W& w, const MgcLattice& L, int tile, int l)
 {
     int tz, ty, tx;
     mgc_tile_coords(L, tile, tz, ty, tx);
@@ -103,17 +103,8 @@ MGC_HD void mgcw_load_halo(W& w, const MgcLattice& L, int tile, int l, bool with
         const int nt = mgc_tile_nbr(L, tz, ty, tx, f);
         const int mine = mgc_face_voxel(f, l);
         int32_t hv = MGC_HINF;
-        double din = 0.0;
-        if (nt >= 0) {
-            hv = w.ld(L.height + (int64_t)nt * MGC_TV, mgc_face_voxel(f ^ 1, l));
-            if (with_inbox) {
-                double* const slots = L.obox + ((int64_t)nt * 6 + (f ^ 1)) * MGC_TF;
-                din = w.ld(slots, l);
-                if (din != 0.0) w.st(slots, l, 0.0);
-            }
-        }
+        if (nt >= 0) hv = w.ld(L.height + (int64_t)nt * MGC_TV, mgc_face_voxel(f ^ 1, l));
         w.S.hs[mgc_hs_index(mine >> 6, (mine >> 3) & 7, mine & 7) + mgc_hs_step(f)] = hv;
-        if (with_inbox) w.S.inbox[f][l] = din;
     }
 }
 
@@ -179,45 +170,66 @@ MGC_HD int mgcw_nbr_label(W& w, RegI& h, int l)
 /* ---------------------------------------------------------------------------------------
  * Label relaxation of a whole tile to its fixpoint: h(u) = min(h(u), 1 if u has a sink arc, 1 + h(v) over residual
  * arcs u->v), halo frozen.  arc(l, K, D) says whether the arc of (lane, slot) in direction D (6 = sink) is residual.
- * Slots are visited only while "dirty" (something changed in the slot or in one of its two z-neighbours since its
- * last visit); in-plane information moves one voxel per visit (Jacobi inside a slot: all lanes read, then all
- * write), information along z moves through the whole column within one visit sequence (registers).
- * Labels only decrease, so the fixpoint is the same whatever the order.
+ * One round = the lane's z-column swept down and up in registers (information along z crosses all eight layers at
+ * once), then one in-plane step for all eight slots against the labels the wave published in LDS after the round
+ * before; ONE vote per round ("did any lane lower a label?").  Labels only decrease, so the fixpoint is the same
+ * whatever the order.  (Round 2 visited slot by slot with a vote each: 16 votes per round and a wave-uniform branch per
+ * slot -- the scalar half of the kernel.)
+ * w.S.hs must hold the tile's current labels and the halo when this is called.
  * ------------------------------------------------------------------------------------- */
 template <class W, class RegI, class ArcFn>
 MGC_HD void mgcw_relax(W& w, RegI& h, ArcFn arc)
 {
-    typename W::template Reg<int, 1> cand;
-    uint32_t dirty = 0xffu;
-    auto visit = [&](auto KK) MGCW_INL {
-        constexpr int K = decltype(KK)::value;
-        if (!(dirty & (1u << K))) return;
-        w.lanes([&](int l) MGCW_INL {
-            int c = arc(l, KK, std::integral_constant<int, 6>{}) ? 1 : MGC_HINF;
-            mgcw_static_for<6>([&](auto DD) MGCW_INL {
-                constexpr int D = decltype(DD)::value;
-                const int hv = mgcw_nbr_label<K, D>(w, h, l);
-                const int cd = arc(l, KK, DD) ? hv + 1 : MGC_HINF;
-                c = cd < c ? cd : c;
-            });
-            cand(l, 0) = c;
+    typename W::template Reg<int, 1> moved;
+    typename W::template Reg<int, 2> hz; /* the halo below slot 0 / above slot 7 (frozen) */
+    w.lanes([&](int l) MGCW_INL {
+        hz(l, 0) = w.S.hs[mgcw_hs(l, 0) - 100];
+        hz(l, 1) = w.S.hs[mgcw_hs(l, 7) + 100];
+        mgcw_static_for<8>([&](auto KK) MGCW_INL { /* a sink arc gives 1, once and for all */
+            constexpr int K = decltype(KK)::value;
+            if (arc(l, KK, std::integral_constant<int, 6>{}) && h(l, K) > 1) {
+                h(l, K) = 1;
+                w.S.hs[mgcw_hs(l, K)] = 1;
+            }
         });
-        const bool changed = w.any([&](int l) MGCW_INL -> bool { return cand(l, 0) < h(l, K); });
-        if (changed) {
-            w.lanes([&](int l) MGCW_INL {
-                if (cand(l, 0) < h(l, K)) {
-                    h(l, K) = cand(l, 0);
-                    w.S.hs[mgcw_hs(l, K)] = cand(l, 0);
-                }
+    });
+    for (;;) {
+        w.lanes([&](int l) MGCW_INL {
+            int ch = 0;
+            auto lower = [&](auto KK, bool has_arc, int hv) MGCW_INL {
+                constexpr int K = decltype(KK)::value;
+                const int c = has_arc ? hv + 1 : MGC_HINF; /* hv == MGC_HINF gives a value above every label */
+                if (c < h(l, K)) { h(l, K) = c; ch = 1; }
+            };
+            mgcw_static_for<8>([&](auto KK) MGCW_INL { /* from below, slot 0 upwards */
+                constexpr int K = decltype(KK)::value;
+                int hb = hz(l, 0);
+                if constexpr (K > 0) hb = h(l, K - 1);
+                lower(KK, arc(l, KK, std::integral_constant<int, 4>{}), hb);
             });
-            dirty |= (K > 0 ? 1u << (K - 1) : 0u) | (K < 7 ? 1u << (K + 1) : 0u);
-        } else {
-            dirty &= ~(1u << K);
-        }
-    };
-    while (dirty) {
-        mgcw_static_for<8>([&](auto KK) MGCW_INL { visit(KK); });
-        mgcw_static_for<8>([&](auto KK) MGCW_INL { visit(std::integral_constant<int, 7 - decltype(KK)::value>{}); });
+            mgcw_static_for<8>([&](auto KK) MGCW_INL { /* from above, slot 7 downwards */
+                constexpr int K = 7 - decltype(KK)::value;
+                constexpr std::integral_constant<int, K> KC{};
+                int ha = hz(l, 1);
+                if constexpr (K < 7) ha = h(l, K + 1);
+                lower(KC, arc(l, KC, std::integral_constant<int, 5>{}), ha);
+            });
+            mgcw_static_for<8>([&](auto KK) MGCW_INL { /* in-plane: the neighbours as published after the round before */
+                constexpr int K = decltype(KK)::value;
+                mgcw_static_for<4>([&](auto DD) MGCW_INL {
+                    constexpr int D = decltype(DD)::value;
+                    lower(KK, arc(l, KK, DD), w.S.hs[mgcw_hs(l, K) + mgc_hs_step(D)]);
+                });
+            });
+            moved(l, 0) = ch;
+        });
+        if (!w.any([&](int l) MGCW_INL -> bool { return moved(l, 0) != 0; })) break;
+        w.lanes([&](int l) MGCW_INL { /* publish (a lane that lowered nothing rewrites what is there) */
+            mgcw_static_for<8>([&](auto KK) MGCW_INL {
+                constexpr int K = decltype(KK)::value;
+                w.S.hs[mgcw_hs(l, K)] = h(l, K);
+            });
+        });
     }
 }
 
@@ -681,64 +693,82 @@ MGC_HD void mgcw_relabel_tile(W& w, const MgcLattice& L, int tile, uint32_t next
 {
     if (first_pass && (!(L.status[tile] & 2u) || !mgc_owned(L, tile))) return;
     typename W::template Reg<int, 8> m, h0, h;
+    typename W::template Reg<int, 1> st0; /* the tile's status word (rewritten in the tail: fetched here, with everything else) */
     const int64_t base = (int64_t)tile * MGC_TV;
     int tz, ty, tx;
     mgc_tile_coords(L, tile, tz, ty, tx);
-    w.lanes([&](int l) MGCW_INL {
+    w.lanes([&](int l) MGCW_INL { /* one trip to HBM: masks, labels, label halo, status word */
+        st0(l, 0) = (int)L.status[tile];
         mgcw_static_for<8>([&](auto KK) MGCW_INL {
             constexpr int K = decltype(KK)::value;
             m(l, K) = w.ld(L.rmask + base, K * 64 + l);
             h0(l, K) = w.ld(L.height + base, K * 64 + l);
+        });
+        mgcw_load_halo(w, L, tile, l);
+        mgcw_static_for<8>([&](auto KK) MGCW_INL {
+            constexpr int K = decltype(KK)::value;
             h(l, K) = h0(l, K);
             w.S.hs[mgcw_hs(l, K)] = h0(l, K);
         });
-        mgcw_load_halo(w, L, tile, l, false);
     });
     mgcw_relax(w, h, [&](int l, auto KK, auto DD) MGCW_INL -> bool {
         constexpr int K = decltype(KK)::value;
         constexpr int D = decltype(DD)::value;
         return ((m(l, K) >> D) & 1) != 0;
     });
-    /* which faces saw a label drop that could lower the neighbour; which faces support a label */
-    uint32_t wake = 0, dep = 0; /* bit masks: lanes index them with their id */
-    mgcw_static_for<6>([&](auto DD) MGCW_INL {
-        constexpr int D = decltype(DD)::value;
-        bool wk = false, dp = false;
+    /* which faces saw a label drop that could lower the neighbour; which faces support a label; did any label come down?
+     * Every lane collects its own bits over its eight slots, then one vote per bit */
+    typename W::template Reg<int, 1> bits; /* 0..5: wake across face D, 6..11: face D supports a label, 12: lowered */
+    w.lanes([&](int l) MGCW_INL {
+        const int y = l >> 3, x = l & 7;
+        int b = 0;
         mgcw_static_for<8>([&](auto KK) MGCW_INL {
             constexpr int K = decltype(KK)::value;
-            if constexpr (D == 4 && K != 0) return;
-            if constexpr (D == 5 && K != 7) return;
-            auto on_face = [&](int l) MGCW_INL -> bool {
-                const int y = l >> 3, x = l & 7;
-                return D == 0 ? x == 0 : (D == 1 ? x == 7 : (D == 2 ? y == 0 : (D == 3 ? y == 7 : true)));
-            };
-            dp = dp || w.any([&](int l) MGCW_INL -> bool {
-                return on_face(l) && h(l, K) < MGC_HINF && ((m(l, K) >> D) & 1) && mgcw_nbr_label<K, D>(w, h, l) + 1 == h(l, K);
-            });
-            /* wake the neighbour across a face only if its adjacent voxel could improve: labels only go down during a
-             * relabel, so a halo value is an upper bound of the neighbour's current label */
-            wk = wk || w.any([&](int l) MGCW_INL -> bool {
-                return on_face(l) && h(l, K) < h0(l, K) && h(l, K) + 1 < mgcw_nbr_label<K, D>(w, h, l);
+            const int hm = h(l, K);
+            if (hm < h0(l, K)) b |= 1 << 12;
+            mgcw_static_for<6>([&](auto DD) MGCW_INL {
+                constexpr int D = decltype(DD)::value;
+                if constexpr (D == 4 && K != 0) return;
+                if constexpr (D == 5 && K != 7) return;
+                const bool on_face = D == 0 ? x == 0 : (D == 1 ? x == 7 : (D == 2 ? y == 0 : (D == 3 ? y == 7 : true)));
+                if (!on_face) return;
+                const int hv = mgcw_nbr_label<K, D>(w, h, l); /* the halo voxel behind the face */
+                if (hm < MGC_HINF && ((m(l, K) >> D) & 1) && hv + 1 == hm) b |= 1 << (6 + D);
+                /* wake the neighbour across a face only if its adjacent voxel could improve: labels only go down during a
+                 * relabel, so a halo value is an upper bound of the neighbour's current label */
+                if (hm < h0(l, K) && hm + 1 < hv) b |= 1 << D;
             });
         });
-        wake |= wk ? (1u << D) : 0u;
-        dep |= dp ? (1u << D) : 0u;
+        bits(l, 0) = b;
     });
-    bool lowered = false; /* some label of the tile came down: it is not "all INF" (any more) */
-    mgcw_static_for<8>([&](auto KK) MGCW_INL {
-        constexpr int K = decltype(KK)::value;
-        lowered = lowered || w.any([&](int l) MGCW_INL -> bool { return h(l, K) < h0(l, K); });
+    uint32_t wake = 0, dep = 0;
+    mgcw_static_for<6>([&](auto DD) MGCW_INL {
+        constexpr int D = decltype(DD)::value;
+        if (w.any([&](int l) MGCW_INL -> bool { return ((bits(l, 0) >> D) & 1) != 0; })) wake |= 1u << D;
+        if (w.any([&](int l) MGCW_INL -> bool { return ((bits(l, 0) >> (6 + D)) & 1) != 0; })) dep |= 1u << D;
     });
-    w.lanes([&](int l) MGCW_INL { /* one block of global traffic: labels + wake-ups */
+    const bool lowered = w.any([&](int l) MGCW_INL -> bool { return ((bits(l, 0) >> 12) & 1) != 0; });
+    w.lanes([&](int l) MGCW_INL { /* one block of global traffic: wake-ups + labels.  The claim of a neighbour (a returning atomic)
+                                     goes out BEFORE the label stores: a wave's memory operations retire in issue order */
+        int woken = -1;
+        bool won = false;
+        if (l < 6 && ((wake >> l) & 1u)) {
+            const int nt = mgc_tile_nbr(L, tz, ty, tx, l);
+            if (nt >= 0 && mgc_owned(L, nt)) {
+                woken = nt;
+                won = w.atomic_exch(&L.rstamp[nt], next_epoch) != next_epoch;
+            }
+        }
         mgcw_static_for<8>([&](auto KK) MGCW_INL {
             constexpr int K = decltype(KK)::value;
             if (h(l, K) < h0(l, K)) w.st(L.height + base, K * 64 + l, h(l, K));
         });
-        if (l < 6 && ((wake >> l) & 1u)) {
-            const int nt = mgc_tile_nbr(L, tz, ty, tx, l);
-            if (nt >= 0) mgc_enqueue(w, L, next_list, L.rstamp, next_epoch, nt);
+        if (l == 6) L.status[tile] = ((uint32_t)st0(l, 0) & ~((63u << MGC_ST_DEP_SHIFT) | (lowered ? MGC_ST_ALLINF : 0u))) | (dep << MGC_ST_DEP_SHIFT);
+        if (won) { /* first to queue it for the next pass (what mgc_enqueue does after its claim) */
+            const int sh = w.shard(L);
+            const int pos = w.atomic_add(mgc_counter(L, next_list, sh), 1);
+            L.list[next_list][(int64_t)sh * L.shard_cap + pos] = woken;
         }
-        if (l == 6) L.status[tile] = (L.status[tile] & ~((63u << MGC_ST_DEP_SHIFT) | (lowered ? MGC_ST_ALLINF : 0u))) | (dep << MGC_ST_DEP_SHIFT);
     });
 }
 
