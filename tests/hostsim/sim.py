@@ -13,7 +13,8 @@ _lib = None
 def build():
     src = os.path.join(_HERE, "hostsim.cpp")
     deps = [src] + [os.path.join(_HERE, "..", "..", "medpy_amd", "csrc", f) for f in
-                    ("mgc_tile_ops.inl", "mgc_tile_ops26.inl", "mgc_wave_ops.inl", "mgc_dt_ops.inl", "mgc_driver.inl", "mgc_common.h")]
+                    ("mgc_tile_ops.inl", "mgc_tile_ops26.inl", "mgc_wave_ops.inl", "mgc_dt_ops.inl", "mgc_brick_ops.inl", "mgc_driver.inl", "mgc_common.h", "mgc_terms.h")
+                    if os.path.exists(os.path.join(_HERE, "..", "..", "medpy_amd", "csrc", f))]
     if os.path.exists(_SO) and all(os.path.getmtime(_SO) >= os.path.getmtime(d) for d in deps):
         return
     subprocess.check_call(["g++", "-O2", "-std=c++17", "-Wno-unknown-pragmas", "-fPIC", "-shared", "-o", _SO, src])
