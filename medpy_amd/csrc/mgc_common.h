@@ -43,11 +43,6 @@
 #define MGC_ST_DEP_SHIFT 8
 /* counter slots no layout uses as a work list (6-neighbourhood: lists 0..7, totals 8 / 9; 26-neighbourhood: lists 0..17,
  * totals 18..20; tickets of the wave kernels 24..27) */
-#define MGC_CNT_PAIR_SNAP 10   /* (6-neighbourhood, k_discharge_w2: both colours of a round in one launch) 1 + the length the second colour's list
-                                  had when the launch began: its first entries were written by earlier launches */
-#define MGC_CNT_PAIR_DONE 11   /* ... tiles of the first colour finished */
-#define MGC_CNT_PAIR_STARTED 12 /* ... tiles of the first colour whose "started" mark (tstate) has arrived */
-#define MGC_CNT_PAIR_FAILED 14 /* ... a wait inside such a launch gave up (never cleared: the solve reports an error) */
 #define MGC_CNT_SINK_TILES 13  /* (6-neighbourhood) k_build: tiles that hold a sink link */
 #define MGC_CNT_CHANGED 21     /* suspect-closure pass changed something */
 #define MGC_CNT_FILTER 22      /* length of the scratch list the tile filters fill (absorb / relabel seeding / suspect reset) */
@@ -103,10 +98,6 @@ struct MgcLattice {
     int       shard_cap;      /* entries per region = ntiles (a list holds a tile at most once) */
     uint32_t* stamp;          /* [ntiles] de-duplication stamp for list appends (discharge) */
     uint32_t* rstamp;         /* [ntiles] same for the relabel lists                */
-    int32_t*  psync;          /* [128] k_discharge_w2: the words its waves poll, each on a cache line of its own, away from the list counters
-                                 and tickets: [0] snapshot, [32] first-colour tiles done, [64] ... started, [96] a wait gave up */
-    uint32_t* tstate;         /* [ntiles] k_discharge_w2: 2 * phase = the tile's discharge of that phase has started, 2 * phase + 1 = is over;
-                                 NULL: the colours of a round run in launches of their own */
     uint32_t* status;         /* [ntiles] bit1 (2): the tile holds a residual arc to the sink; bit2 (4): DIRTY = discharged
                                  since the last global relabel; bit3 (8): SUSPECT (labels must be recomputed);
                                  bits 8..13: faces through which the tile's labels are supported by a neighbour */

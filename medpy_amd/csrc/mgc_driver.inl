@@ -194,16 +194,7 @@ int mgc_solve(Dev& dev, const MgcLattice& L, const MgcSolveParams& P, MgcSolveSt
         /* ---- colour phases ---- */
         dev.range_push("colour phases");
         for (int r = 0; r < rounds; ++r) {
-            int done = 0;
-            if (lay.ncolours == 2) { /* the device may run both colours of the round as one launch */
-                done = dev.discharge_round((int)(phase & (uint32_t)lay.list_mask), phase, P.max_sweeps);
-                for (int c = 0; c < done; ++c) {
-                    dev.zero_count((int)(phase & (uint32_t)lay.list_mask));
-                    st.phases++;
-                    phase++;
-                }
-            }
-            for (int c = done; c < lay.ncolours; ++c) {
+            for (int c = 0; c < lay.ncolours; ++c) {
                 const int lst = (int)(phase & (uint32_t)lay.list_mask);
                 dev.discharge(lst, phase, P.max_cycles, P.max_sweeps);
                 dev.zero_count(lst);

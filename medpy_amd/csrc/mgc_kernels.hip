@@ -192,7 +192,7 @@ typedef GpuBlockT<MgcTileShared26D, MGC26_LAUNDER> GpuBlock26D;
  * wave executor for the one-wave-per-tile operations (mgc_wave_ops.inl): a workgroup IS one wave64,
  * Reg<T, N> = N registers, votes = ballots, no workgroup barrier anywhere
  * ==================================================================================== */
-template <class SH, bool PAIR = false> /* SH: MgcWaveShared (discharge: labels, inbox, sink links) or MgcWaveSharedR (relabel: labels only) */
+template <class SH> /* MgcWaveShared (discharge: labels, inbox, sink links) or MgcWaveSharedR (relabel: labels only) */
 struct GpuWaveT {
     template <class T, int N>
     struct Reg {
@@ -348,45 +348,8 @@ struct GpuWaveT {
     __device__ __forceinline__ T ld(const T* p, int l) { return *(const T*)((const char*)p + (unsigned)(l * (int)sizeof(T))); }
     template <class T>
     __device__ __forceinline__ void st(T* p, int l, T v) { *(T*)((char*)p + (unsigned)(l * (int)sizeof(T))) = v; }
-    /* what a neighbour tile wrote or will read (mgc_wave_ops.inl).  PAIR: both colours of a round run in this launch
-     * (k_discharge_w2), so these go past the per-XCD L2s: device-scope loads miss, device-scope stores write through */
-    template <class T>
-    __device__ __forceinline__ T ld_sh(const T* p, int l) const
-    {
-        if constexpr (PAIR) return __hip_atomic_load(p + l, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        else return *(const T*)((const char*)p + (unsigned)(l * (int)sizeof(T)));
-    }
-    template <class T>
-    __device__ __forceinline__ void st_sh(T* p, int l, T v) const
-    {
-        if constexpr (PAIR) __hip_atomic_store(p + l, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        else *(T*)((char*)p + (unsigned)(l * (int)sizeof(T))) = v;
-    }
-    /* end of a tile visit.  PAIR, first colour of the round: once everything this wave stored has arrived (the shared part went
-     * through to memory), the tile is marked done -- the tiles of the second colour next to it may start -- and counted */
-    int first_colour = 0;
-    /* the halo of the visit is back, so the "started" mark this wave stored before its loads has arrived: count it */
-    __device__ __forceinline__ void loads_back(const MgcLattice& L) const
-    {
-        if constexpr (PAIR) {
-            if (first_colour && threadIdx.x == 0) atomicAdd(&L.psync[64], 1);
-        }
-    }
-    __device__ __forceinline__ void visit_done(const MgcLattice& L, int tile, uint32_t phase) const
-    {
-        if constexpr (PAIR) {
-            if (first_colour) {
-                asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-                if (threadIdx.x == 0) { /* (whoever waits for this tile polls its mark; whoever waits for all of them, the count: no order between the two) */
-                    __hip_atomic_store(&L.tstate[tile], 2u * phase + 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                    atomicAdd(&L.psync[32], 1);
-                }
-            }
-        }
-    }
 };
 typedef GpuWaveT<MgcWaveShared> GpuWave;
-typedef GpuWaveT<MgcWaveShared, true> GpuWaveP;
 struct alignas(16) MgcWaveSharedR { int32_t hs[1000]; }; /* what a relabel visit touches of MgcWaveShared: 4 KB, 32 waves per CU */
 typedef GpuWaveT<MgcWaveSharedR> GpuWaveR;
 
@@ -453,90 +416,6 @@ void k_discharge_w(MgcLattice L, int lst, uint32_t phase, int sweeps, int flags,
 #endif
     }
     if (MGCW_RUNAHEAD && MGCW_PREFETCH) asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); /* (nothing may still be on its way into this wave's LDS when it ends) */
-    w.flush_marks(L);
-}
-
-/* BOTH colours of a round in one launch.  A colour phase is only 2.6 visits deep on the resident waves, so a quarter of
- * every launch is waves waiting for its last visits (tools/sim_launch_model.py); here the tiles of the second colour start
- * while the last tiles of the first are still at work.  One ticket sequence: tickets below nA name the tiles of list A
- * (phase), the others the tiles of list B (phase + 1).  A tile of B may run once every face neighbour that is in list A
- * has finished (tstate: a first-colour wave marks its tile "started" before it loads anything and "done" after everything
- * it stored has arrived; the marks of all of them are in place before the first B tile is looked at: MGC_CNT_PAIR_STARTED).
- * What a neighbour wrote is read past the L2s (GpuWaveP::ld_sh / st_sh).  B's list grows while A runs: the entries it held
- * when the launch began (MGC_CNT_PAIR_SNAP: tiles that ran out of sweeps in their last visit, mostly) are available at once,
- * the rest once every A tile is done (MGC_CNT_PAIR_DONE).  Per-tile results do not depend on the order of the visits, so
- * the labels and flows are those of two launches.  A spin that does not end (a bug) gives up and flags the run. */
-#define MGCW_PAIR_SPINS (1 << 22)
-__global__ __launch_bounds__(MGCW_LANES) __attribute__((amdgpu_waves_per_eu(MGCW_DISCHARGE_WAVES, MGCW_DISCHARGE_WAVES)))
-void k_discharge_w2(MgcLattice L, int lstA, uint32_t phase, int sweeps, int flags, int tk)
-{
-    __shared__ MgcWaveShared S;
-    GpuWaveP w(S);
-    const int lstB = (int)((phase + 1) & 3u);
-    int32_t* const lenB = mgc_counter(L, lstB, 0); /* (one region per list: checked by the host) */
-    const int nA = *mgc_counter(L, lstA, 0);
-    int cB0 = 0;
-    if (threadIdx.x == 0) { /* the length of B's list before this launch appended to it: whoever comes first writes it down */
-        const int c = __hip_atomic_load(lenB, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        const int old = atomicCAS(&L.psync[0], 0, c + 1);
-        cB0 = (old ? old : c + 1) - 1;
-    }
-    cB0 = __builtin_amdgcn_readfirstlane(cB0);
-    if (blockIdx.x == 0 && threadIdx.x == 0) L.count[tk ^ 1] = 0; /* the next launch's ticket word */
-    int visits = 0, failed = 0, all_started = 0;
-    for (int i = (int)blockIdx.x;; i = mgcw_next_ticket(L, tk)) {
-        int tile = -1, is_a = 1;
-        if (i < nA) {
-            tile = L.list[lstA][i];
-        } else {
-            is_a = 0;
-            const int j = i - nA;
-            if (j < cB0) {
-                tile = L.list[lstB][j];
-            } else { /* the part of the list this launch writes: final, and its entries in place, once every A tile is done */
-                int spins = 0;
-                while (__hip_atomic_load(&L.psync[32], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != nA) {
-                    if (++spins > MGCW_PAIR_SPINS) { failed = 1; break; }
-                    __builtin_amdgcn_s_sleep(100); /* ~2.7 us: the wait is for whole tile visits */
-                }
-                all_started = 1;
-                if (failed || j >= __hip_atomic_load(lenB, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) break;
-                tile = __hip_atomic_load(&L.list[lstB][j], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-            }
-        }
-        tile = __builtin_amdgcn_readfirstlane(tile);
-        const uint32_t ph = is_a ? phase : phase + 1;
-        int st = (int)L.status[tile];
-        if (is_a) {
-            if (threadIdx.x == 0) __hip_atomic_store(&L.tstate[tile], 2u * phase, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); /* counted when the halo is back (loads_back) */
-        } else { /* every first-colour neighbour of this launch must be done */
-            int tz, ty, tx;
-            mgc_tile_coords(L, tile, tz, ty, tx);
-            const int lane = (int)threadIdx.x;
-            const int nt = lane < 6 ? mgc_tile_nbr(L, tz, ty, tx, lane) : -1;
-            int spins = 0;
-            for (;;) {
-                int started = nA;
-                if (!all_started) started = __hip_atomic_load(&L.psync[64], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                const uint32_t ts = nt >= 0 ? __hip_atomic_load(&L.tstate[nt], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : 0u;
-                all_started = __builtin_amdgcn_readfirstlane(started) == nA;
-                const bool wait = !all_started || ts == 2u * phase;
-                if (!__any((int)wait)) break;
-                if (++spins > MGCW_PAIR_SPINS) { failed = 1; break; }
-                __builtin_amdgcn_s_sleep(32);
-            }
-            if (failed) break;
-        }
-        w.new_tile();
-        w.first_colour = is_a;
-        if (__builtin_amdgcn_readfirstlane(st) & (int)MGC_ST_SINK) mgcw_discharge_impl<true>(w, L, tile, ph, sweeps, flags | ((flags & MGCW_BFS_SINK) ? MGCW_BFS : 0));
-        else mgcw_discharge_impl<false>(w, L, tile, ph, sweeps, flags);
-        visits++;
-    }
-    if (threadIdx.x == 0) {
-        if (visits) { atomicAdd(&L.count[8], visits); atomicAdd(&L.count[MGC_CNT_WAVE_TILES], visits); }
-        if (failed) atomicAdd(&L.psync[96], 1);
-    }
     w.flush_marks(L);
 }
 
@@ -1849,9 +1728,6 @@ struct mgc_graph {
     void* d_vout = nullptr;    /* MgcValidateOut of mgc_validate */
     uint16_t* d_dt16 = nullptr; /* scratch of the distance-transform relabel (uint16 per voxel, tile-major), allocated on first use */
     bool all_residual = false; /* k_build found every n-link inside the volume residual */
-    int64_t pair_launches_total = 0;
-    int pair_phases = 0;       /* both colours of a round in one launch (k_discharge_w2; parameter pair_phases) */
-    int pair_min_tiles = 2048; /* ... when the lists are at least this long at the last look */
     int exact_sink_tiles = 1;  /* k_discharge_w: exact in-tile labels per visit for the tiles that hold a sink link (MGCW_BFS_SINK; parameter
                                   exact_sink_tiles): 0 never, 2 always, 1 when most tiles of the volume hold one (markers scattered over the
                                   volume: 512^3 tie-heavy volume 1081 -> 790 ms; sink links only on the faces, as in the headline volume: the
@@ -2117,25 +1993,6 @@ struct HipDevT {
         }
         check(hipGetLastError());
     }
-    /* both colour phases of a round (lists lst = phase & 3 and (phase + 1) & 3) as ONE launch, k_discharge_w2; returns the phases
-     * it ran: 2, or 0 = not in this configuration (the caller launches the phases one by one) */
-    int discharge_round(int lst, uint32_t phase, int sweeps)
-    {
-        if (FULL || !h->pair_phases || !h->L.tstate || h->nranks != 1 || h->L.nshard != 1 || !(h->wave_kernels & 1) ||
-            h->est_phase_tiles < h->pair_min_tiles) return 0;
-        flush_zero(); /* (the lists the round before consumed) */
-        check(hipMemsetAsync(h->L.psync, 0, 96 * sizeof(int32_t), h->stream)); /* (not the "gave up" word) */
-        const int id = time_begin(0);
-        hipLaunchKernelGGL(k_discharge_w2, dim3(h->wave_grid_dis), dim3(MGCW_LANES), 0, h->stream, h->L, lst, phase, sweeps,
-                           ((h->wave_kernels & 4) ? MGCW_BFS : 0) | ((h->exact_sink_tiles == 2 || (h->exact_sink_tiles == 1 && 2 * (int64_t)h->sink_tiles > h->L.ntiles)) ? MGCW_BFS_SINK : 0), h->tk_dis);
-        h->tk_dis ^= 1;
-        check(hipGetLastError());
-        time_end(id);
-        discharge_launches++;
-        h->pair_launches_total++;
-        last_discharged = -1; /* (its two lists are cleared through the mask, before the next launch) */
-        return 2;
-    }
     void discharge(int lst, uint32_t phase, int cycles, int sweeps)
     {
         const int zero_idx = h->pending_zero; /* cleared inside the kernel: nothing sits between two colour phases */
@@ -2379,14 +2236,6 @@ static int mgc_create_impl(int ndim, const int64_t* shape, int connectivity, int
     if ((rc = mgc_alloc(h, &L.stamp, nt))) return rc;
     if ((rc = mgc_alloc(h, &L.rstamp, nt))) return rc;
     if ((rc = mgc_alloc(h, &L.status, nt))) return rc;
-    L.tstate = nullptr;
-    L.psync = nullptr;
-    if (L.ndir == 6 && !slab) {
-        if ((rc = mgc_alloc(h, &L.tstate, nt))) return rc;
-        MGC_HIP(h, hipMemsetAsync(L.tstate, 0, (size_t)nt * sizeof(uint32_t), h->stream));
-        if ((rc = mgc_alloc(h, &L.psync, (int64_t)128))) return rc;
-        MGC_HIP(h, hipMemsetAsync(L.psync, 0, 128 * sizeof(int32_t), h->stream));
-    }
     if ((rc = mgc_alloc(h, &h->d_tr0, nv))) return rc;
     if ((rc = mgc_alloc(h, &h->d_tflags, nt))) return rc;
     if ((rc = mgc_alloc(h, &h->d_tsum, nt))) return rc;
@@ -2861,7 +2710,7 @@ int mgc_destroy(mgc_handle h)
     MgcLattice& L = h->L;
     void* ptrs[] = {L.rcap, L.cap0, L.excess, L.sink, L.height, L.rmask, L.rmask32, L.obox, L.oflags, L.list[0], L.list[1], L.list[2],
                     L.list[3], L.list[4], L.list[5], L.list[6], L.list[7], L.list[8], L.list[9], L.list[10], L.list[11], L.list[12],
-                    L.list[13], L.list[14], L.list[15], L.list[16], L.list[17], L.count, L.stamp, L.rstamp, L.status, L.tstate, L.psync, h->d_tr0, h->d_part, h->d_part2, h->d_scalar,
+                    L.list[13], L.list[14], L.list[15], L.list[16], L.list[17], L.count, L.stamp, L.rstamp, L.status, h->d_tr0, h->d_part, h->d_part2, h->d_scalar,
                     h->d_labels, h->d_tflags, h->d_tsum, h->d_image, h->d_prob, h->d_fg, h->d_bg, h->d_tr_in, h->d_eslot, h->d_eval, h->d_erun, L.hshadow[0], L.hshadow[1], h->d_vout, h->d_dt16, h->d_halo, h->d_xchg[0], h->d_xchg[1], h->d_xchg[2], h->d_xchg[3], h->d_cnt64};
     for (void* p : ptrs)
         if (p) (void)hipFree(p);
@@ -3181,12 +3030,6 @@ int mgc_maxflow(mgc_handle h, double* flow)
             for (int k = 0; k < 4; ++k) { dev.timed[k] = dev26.timed[k]; dev.seen[k] = dev26.seen[k]; }
         }
         mgc_flush_zero(h);
-        if (L.psync && h->pair_launches_total) { /* did a wait inside k_discharge_w2 give up? */
-            int32_t gave_up = 0;
-            if (hipMemcpyAsync(&gave_up, L.psync + 96, sizeof(int32_t), hipMemcpyDeviceToHost, h->stream) != hipSuccess ||
-                hipStreamSynchronize(h->stream) != hipSuccess || gave_up)
-                return mgc_fail(h, MGC_ERR_HIP, "solver: a wave of k_discharge_w2 waited in vain (%d)", (int)gave_up);
-        }
         if (dev.first_error != hipSuccess)
             return mgc_fail(h, MGC_ERR_HIP, "solver: HIP error %s", hipGetErrorString(dev.first_error));
         if (rc) { /* the work counters of the truncated run stay readable (mgc_get_stats) */
@@ -3382,8 +3225,6 @@ int mgc_set_param(mgc_handle h, const char* name, int64_t value)
     else if (!strcmp(name, "wave_grid_rel") && value > 0) h->wave_grid_rel = (int)value;
     else if (!strcmp(name, "first_relabel_dt")) h->use_dt = value != 0;
     else if (!strcmp(name, "relabel_bricks")) h->use_bricks = value != 0;
-    else if (!strcmp(name, "pair_phases")) h->pair_phases = value != 0;
-    else if (!strcmp(name, "pair_min_tiles") && value >= 0) h->pair_min_tiles = (int)value;
     else if (!strcmp(name, "exact_sink_tiles") && value >= 0 && value <= 2) h->exact_sink_tiles = (int)value;
     else if (!strcmp(name, "halo_max_records") && value >= 1) { /* record slots of a border message (all slabs of a volume alike!) */
         const int64_t T = (int64_t)h->L.gy * h->L.gx;

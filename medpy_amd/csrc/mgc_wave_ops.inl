@@ -125,16 +125,14 @@ MGC_HD void mgcw_halo_issue(W& w, const MgcLattice& L, int tile, int l, RegI& hv
         hv(l, F) = MGC_HINF;
         din(l, F) = 0.0;
         if (nt >= 0) {
-            /* (ld_sh / st_sh: what a NEIGHBOUR tile wrote or will read -- labels, outbox, outbox flags, list entries.  Plain
-             * accesses, except where both colours of a round run in ONE launch, k_discharge_w2: there they go past the per-XCD L2s) */
-            hv(l, F) = w.ld_sh(L.height + (int64_t)nt * MGC_TV, mgc_face_voxel(F ^ 1, l));
-            din(l, F) = w.ld_sh(L.obox + ((int64_t)nt * 6 + (F ^ 1)) * MGC_TF, l);
+            hv(l, F) = w.ld(L.height + (int64_t)nt * MGC_TV, mgc_face_voxel(F ^ 1, l));
+            din(l, F) = w.ld(L.obox + ((int64_t)nt * 6 + (F ^ 1)) * MGC_TF, l);
         }
     });
     ofl(l, 0) = 0; /* lane l < 6: the outbox flags of the neighbour across face l */
     if (l < 6) {
         const int nt = mgc_tile_nbr(L, tz, ty, tx, l);
-        if (nt >= 0) ofl(l, 0) = (int)w.ld_sh(L.oflags + nt, 0);
+        if (nt >= 0) ofl(l, 0) = (int)L.oflags[nt];
     }
 }
 
@@ -307,7 +305,6 @@ MGC_HD void mgcw_discharge_impl(W& w, const MgcLattice& L, int tile, uint32_t ph
             if (nt >= 0 && (((uint32_t)ofl(l, 0) >> (l ^ 1)) & 1u)) w.atomic_and(&L.oflags[nt], ~(1u << (l ^ 1)));
         }
     });
-    w.loads_back(L); /* (this wave's earlier memory operations have been performed: they retire in issue order) */
     w.mark(4); /* loads issued, halo + inbox back and staged */
     /* ---- absorb the staged inbox: e += delta, reverse residual += delta, fixed face order ---- */
     w.lanes([&](int l) MGCW_INL {
@@ -657,7 +654,7 @@ MGC_HD void mgcw_discharge_impl(W& w, const MgcLattice& L, int tile, uint32_t ph
         w.lanes([&](int l) MGCW_INL {
             mgcw_static_for<8>([&](auto KK) MGCW_INL {
                 constexpr int K = decltype(KK)::value;
-                w.st_sh(t_height, K * 64 + l, h(l, K));
+                w.st(t_height, K * 64 + l, h(l, K));
             });
         });
     }
@@ -668,16 +665,15 @@ MGC_HD void mgcw_discharge_impl(W& w, const MgcLattice& L, int tile, uint32_t ph
 #pragma unroll
         for (int f = 0; f < 6; ++f) {
             const double ob = w.S.inbox[f][l];
-            if (ob != 0.0) w.st_sh(t_obox + f * MGC_TF, l, ob);
+            if (ob != 0.0) w.st(t_obox + f * MGC_TF, l, ob);
         }
         /* (the two lists as wave-uniform pointers selected per lane: indexing L.list[] with a per-lane list id would be a LOAD of
          * the pointer, and waiting for it would wait for every store above) */
-        if (wk(l, 2)) w.st_sh((l == 6 ? list_self : list_nbr) + (int64_t)w.shard(L) * L.shard_cap, w.use_here(wk(l, 3)), (int32_t)wk(l, 0));
+        if (wk(l, 2)) (l == 6 ? list_self : list_nbr)[(int64_t)w.shard(L) * L.shard_cap + w.use_here(wk(l, 3))] = wk(l, 0);
         /* DIRTY only if a residual arc disappeared: otherwise no distance in the tile (or through it) can have changed */
         if (l == 7) L.status[tile] = ((uint32_t)st0(l, 0) & ~(MGC_ST_SINK | MGC_ST_EXCESS)) | (has_sink ? MGC_ST_SINK : 0u) | (saturated ? MGC_ST_DIRTY : 0u) | (has_exc ? MGC_ST_EXCESS : 0u);
     });
     w.mark(3); /* tail votes + stores */
-    w.visit_done(L, tile, phase);
 }
 
 template <class W>

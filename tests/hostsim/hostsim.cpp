@@ -163,10 +163,6 @@ struct HostWave {
     template <class T> void st(T* p, int l, T v) { p[l] = v; }
     void fresh() {}
     int use_here(int v) { return v; }
-    template <class T> T ld_sh(const T* p, int l) const { return p[l]; }
-    template <class T> void st_sh(T* p, int l, T v) const { p[l] = v; }
-    void visit_done(const MgcLattice&, int, uint32_t) const {}
-    void loads_back(const MgcLattice&) const {}
 };
 /* executor of the brick operations (mgc_brick_ops.inl): 4096 lanes, run one after another */
 struct HostBrick {
@@ -352,7 +348,6 @@ struct HostDev {
             }
         }
     }
-    int discharge_round(int, uint32_t, int) { return 0; } /* (the library may run both colours of a round as one launch: same visits) */
     void discharge(int lst, uint32_t phase, int cycles, int sweeps)
     {
         HostBlock x(S);
@@ -637,7 +632,6 @@ struct HostDev26 {
         for (int t = 0; t < L.ntiles; ++t)
             if (mgc26_activate_tile(x, L, t, phase)) L.count[MGC26_CNT_ACTIVE]++;
     }
-    int discharge_round(int, uint32_t, int) { return 0; }
     void discharge(int lst, uint32_t phase, int cycles, int sweeps)
     {
         HostBlock26D x(S);
