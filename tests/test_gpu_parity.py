@@ -288,6 +288,23 @@ def test_ties_dyadic_bit_exact():
     assert flow == ref.flow
 
 
+def test_ties_dyadic_bit_exact_in_the_wave_kernels_as_shipped():
+    """The same at 96^3, where the colour phases are long enough for the wave kernels WITHOUT any test parameter, and where
+    every tile holds a sink link: the library switches the exact in-tile labelling of such tiles on by itself
+    (exact_sink_tiles = 1, decided from k_build's count).  Dyadic weights: bit-exact labels and flow, whatever the schedule."""
+    from medpy_amd import synthetic
+    s = synthetic.ties((96, 96, 96))
+    img = s["image"].copy()
+    img.flat[0], img.flat[1] = 0.0, 4.0
+    g = _run(s["fg"], s["bg"], "difference_linear", img)
+    flow = g.maxflow()
+    st = g.stats()
+    assert st["discharge_wave_tiles"] > 0, st  # k_discharge_w ran (not only the 512-thread form)
+    ref = pipeline.graphcut_voxel(s["fg"], s["bg"], term="difference_linear", image=img)
+    np.testing.assert_array_equal(g.labels(), ref.labels)
+    assert flow == ref.flow
+
+
 def test_layouts_and_dtypes():
     """F-ordered / strided views as medpy.io.load returns them (io/load.py:127) and integer images."""
     from medpy_amd import synthetic
