@@ -2631,7 +2631,10 @@ static int mgc_solve_slab_on(mgc_handle h, const MgcLayout lay, mgc_slab_stats* 
             break;
         }
 
-        /* ---- colour phases, border (labels + outbox flow) exchanged after each */
+        /* ---- colour phases.  Border labels + outbox flow are exchanged once per ROUND of the two colours (6-neighbourhood): what a
+         * tile of the first colour pushed over the slab border waits in its outbox one phase longer -- region discharge only
+         * ever assumes a neighbour's labels and outbox as of SOME earlier moment -- and a solve needs half the exchanges.  The
+         * 26-neighbourhood pushes into the ghost tiles in place and exchanges after every phase. */
         mgc_range_push("colour phases");
         dev.zero_count(MGC_CNT_DEFERRED);
         for (int r = 0; r < P.rounds_per_relabel; ++r) {
@@ -2639,7 +2642,7 @@ static int mgc_solve_slab_on(mgc_handle h, const MgcLayout lay, mgc_slab_stats* 
                 const int lst = (int)(phase & (uint32_t)lmask);
                 dev.discharge(lst, phase, P.max_cycles, P.max_sweeps);
                 dev.zero_count(lst);
-                MGC_SLAB_TRY(exchange(1, phase, 0));
+                if (lay.ncolours != 2 || c == 1) MGC_SLAB_TRY(exchange(1, phase, 0));
                 st.phases++;
                 phase++;
             }

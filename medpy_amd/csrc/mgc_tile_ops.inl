@@ -770,7 +770,12 @@ MGC_HD void mgc_halo_unpack_tile(X& x, const MgcLattice& L, int side, int kind, 
         if (kind) {
             if (lab[MGC_TF]) {
                 x.atomic_or(&L.oflags[ghost], 1u << f);
-                mgc_enqueue(x, L, (int)((epoch + 1) & 3u), L.stamp, epoch + 1, own);
+                /* the owned tile absorbs this in the next phase of ITS colour: the borders are exchanged once per round of the two
+                 * colours, so the message carries tiles of both (after every phase it would always be epoch + 1) */
+                int tz, ty, tx;
+                mgc_tile_coords(L, own, tz, ty, tx);
+                const uint32_t target = epoch + 1 + ((uint32_t)(mgc_tile_colour(L, tz, ty, tx) ^ (int)((epoch + 1) & 1u)) & 1u);
+                mgc_enqueue(x, L, (int)(target & 3u), L.stamp, target, own);
             }
         } else if (lowered) {
             mgc_enqueue(x, L, list, L.rstamp, epoch, own);

@@ -190,7 +190,8 @@ def solve_slabs(slabs, ex, rounds_per_relabel=8, max_cycles=None, max_sweeps=Non
     Every loop decision that involves the other ranks is taken on globally summed counters, so all ranks run the same
     outer control flow.  Between two border exchanges of a global relabel every rank iterates its own slabs to a LOCAL
     fixpoint (labels only go down during a relabel, so stale ghost labels are upper bounds and the chaotic iteration
-    still converges to the exact distances); the borders are exchanged after every colour phase.  Later global
+    still converges to the exact distances); the borders are exchanged after every round of the two colours (after every
+    colour phase in the 26-neighbourhood, whose pushes land in the ghost tiles in place).  Later global
     relabels are incremental like the single-GPU driver's (mgc_driver.inl): the DIRTY / SUSPECT flags of the border
     tiles travel as halo kind 2 until the suspect closure is stable everywhere."""
     if getattr(ex, "native", False) and len(slabs) == 1 and hasattr(slabs[0], "solve_native"):
@@ -292,7 +293,8 @@ def solve_slabs(slabs, ex, rounds_per_relabel=8, max_cycles=None, max_sweeps=Non
                 for s in slabs:
                     s.op(OP_DISCHARGE, lst, phase, max_cycles, max_sweeps)
                     s.op(OP_ZERO_COUNT, lst)
-                exchange(1, phase, 0)
+                if ncol != 2 or _c == 1:  # 6-neighbourhood: once per round of the two colours (mgc_halo_unpack_tile queues by colour)
+                    exchange(1, phase, 0)
                 st["phases"] += 1
                 phase += 1
             if (r + 1) % check_rounds == 0 and r + 1 < rounds_per_relabel:
