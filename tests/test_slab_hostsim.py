@@ -36,6 +36,8 @@ def test_loopback_slabs_match_oracle(gen, shape, nslabs):
     assert st["converged"] == 1
     labels = np.concatenate([s.finish()[0] for s in slabs], axis=0)
     np.testing.assert_array_equal(labels, ref)
+    # the borders travel once per round of the two colours, not after every phase: fewer exchanges than phases + relabel rounds
+    assert st["exchanges"] < st["phases"] + st["relabel_passes"], st
     # slab boundaries fall on tile layers and partition the planes
     assert slabs[0].own0 == 0 and slabs[-1].own1 == shape[0]
     assert all(a.own1 == b.own0 for a, b in zip(slabs, slabs[1:]))
