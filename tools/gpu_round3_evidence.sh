@@ -11,20 +11,7 @@ cd $ROOT; D=$(find $OUT/tl -name "*.db" | head -1); [ -n "$D" ] && python tools/
 # roctx ranges of the solve (marker trace in a run of its own: no counters)
 cd /tmp; MEDPY_HIP_ROCTX=1 timeout 300 rocprofv3 --marker-trace --kernel-trace --stats -d $OUT/mk -- python $ROOT/bench.py --steps 1 --warmup 1 --no-cpu > $OUT/mk.log 2>&1
 cd $ROOT; D=$(find $OUT/mk -name "*.db" | head -1)
-[ -n "$D" ] && python - "$D" > gpurun_out/r3_roctx_ranges.csv <<'P'
-import sqlite3, sys
-cur = sqlite3.connect(sys.argv[1]).cursor()
-tabs = [r[0] for r in cur.execute("select name from sqlite_master where type in ('table','view')")]
-t = [x for x in tabs if x.lower() in ("regions", "markers")] or [x for x in tabs if "region" in x.lower() or "marker" in x.lower()]
-print("range,calls,total_us,avg_us")
-if t:
-    cols = [r[1] for r in cur.execute("pragma table_info(%s)" % t[0])]
-    st, en = ("start", "end") if "start" in cols else ("start_timestamp", "end_timestamp")
-    for n, c, s in cur.execute("select name, count(*), sum(%s - %s) from %s group by name order by 3 desc" % (en, st, t[0])):
-        print('"%s",%d,%.1f,%.1f' % (n, c, s / 1e3, s / 1e3 / c))
-else:
-    print('"(no marker table in this rocpd schema: %s)",0,0,0' % ",".join(tabs[:12]))
-P
+[ -n "$D" ] && python tools/rocpd_summary.py ranges $D > gpurun_out/r3_roctx_ranges.csv
 rm -rf $OUT/mk
 python bench.py 2>gpurun_out/r3_bench.err | tail -1 > gpurun_out/r3_bench_n1.json
 python bench.py --config 3 --no-cpu 2>>gpurun_out/r3_bench.err | tail -1 > gpurun_out/r3_bench_config3.json

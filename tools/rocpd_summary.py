@@ -2,6 +2,7 @@
 
     python tools/rocpd_summary.py stats  <results.db>  > profiles/<round>_kernel_stats.csv
     python tools/rocpd_summary.py pmc    <results.db>  > profiles/<round>_pmc_<counter>.csv
+    python tools/rocpd_summary.py ranges <results.db>  > profiles/<round>_roctx_ranges.csv  (rocprofv3 --marker-trace with MEDPY_HIP_ROCTX=1: host time per named range)
     python tools/rocpd_summary.py timeline <results.db>  > profiles/<round>_timeline.csv    (every dispatch in order: start, gap to the one before, duration)
 """
 import sqlite3
@@ -18,6 +19,21 @@ def main():
         tot = sum(r[2] for r in rows) or 1
         for n, c, s, a, mn, mx in rows:
             print('"%s",%d,%.3f,%.3f,%.3f,%.3f,%.2f' % (n, c, s / 1e3, a / 1e3, mn / 1e3, mx / 1e3, 100.0 * s / tot))
+    elif mode == "ranges":
+        import collections
+        import json
+        acc = collections.OrderedDict()
+        for ext, dur in cur.execute("select extdata, duration from regions where category like 'MARKER%' order by start"):
+            try:
+                name = json.loads(ext).get("message", "?")
+            except ValueError:
+                name = "?"
+            a = acc.setdefault(name, [0, 0])
+            a[0] += 1
+            a[1] += dur
+        print("range,calls,total_us,avg_us")
+        for name, (c, d) in sorted(acc.items(), key=lambda kv: -kv[1][1]):
+            print('"%s",%d,%.1f,%.1f' % (name, c, d / 1e3, d / 1e3 / c))
     elif mode == "timeline":
         cols = [r[1] for r in cur.execute("pragma table_info(kernels)").fetchall()]
         st, en = ("start", "end") if "start" in cols else ("start_timestamp", "end_timestamp")
