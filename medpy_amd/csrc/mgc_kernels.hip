@@ -1733,6 +1733,7 @@ struct mgc_graph {
                                   volume: 512^3 tie-heavy volume 1081 -> 790 ms; sink links only on the faces, as in the headline volume: the
                                   few visits of those tiles cost 0.7 ms of 36 more with it) */
     int sink_tiles = 0;        /* tiles holding a sink link, as built */
+    int sink_sweeps = 8;       /* sweep budget of a visit while exact_sink_tiles = 1 has switched the exact labelling on (parameter sink_sweeps) */
     int use_bricks = 0;        /* incremental global relabels run their passes over bricks of 2 x 2 x 2 tiles (parameter relabel_bricks).  Measured on MI355X
                                   at 512^3: a third fewer passes (318 -> 202 launches) but 67 us instead of 31 us per pass -- 118 VGPRs allow two
                                   workgroups per CU, and a brick relaxes eight times the voxels over twice the rounds: 40.6 vs 36.3 ms per step,
@@ -2012,7 +2013,13 @@ struct HipDevT {
         /* one wave per tile has the higher throughput (2 048 tiles in flight, fewer instructions per tile), eight waves per tile
          * the shorter latency (36 us against 60 us for one tile): short lists -- small volumes, the tail of a solve -- are a
          * single tile deep per launch and go to the workgroup form.  Both forms keep the same state in HBM. */
-        else if (wave_form) { hipLaunchKernelGGL(k_discharge_w, dim3(h->wave_grid_dis), dim3(MGCW_LANES), 0, h->stream, h->L, lst, phase, sweeps, ((h->wave_kernels & 4) ? MGCW_BFS : 0) | ((h->exact_sink_tiles == 2 || (h->exact_sink_tiles == 1 && 2 * (int64_t)h->sink_tiles > h->L.ntiles)) ? MGCW_BFS_SINK : 0), h->tk_dis, zero_idx, h->wave_stagger); h->tk_dis ^= 1; }
+        else if (wave_form) {
+            const bool exact_sink = h->exact_sink_tiles == 2 || (h->exact_sink_tiles == 1 && 2 * (int64_t)h->sink_tiles > h->L.ntiles);
+            /* a visit that starts from exact in-tile labels needs fewer sweeps to move what it can (tie-heavy 512^3: 796 ms at 12, 731 at 8, 788 at 6) */
+            if (exact_sink && h->exact_sink_tiles == 1 && sweeps > h->sink_sweeps) sweeps = h->sink_sweeps;
+            hipLaunchKernelGGL(k_discharge_w, dim3(h->wave_grid_dis), dim3(MGCW_LANES), 0, h->stream, h->L, lst, phase, sweeps, ((h->wave_kernels & 4) ? MGCW_BFS : 0) | (exact_sink ? MGCW_BFS_SINK : 0), h->tk_dis, zero_idx, h->wave_stagger);
+            h->tk_dis ^= 1;
+        }
         else hipLaunchKernelGGL(k_discharge, dim3(grid(h->L.ntiles)), dim3(MGC_TV), 0, h->stream, h->L, lst, phase,
                                 (h->wave_kernels & 1) && !(h->wave_kernels & 4) ? -1 : cycles, sweeps, zero_idx); /* same labelling policy as the wave form */
         check(hipGetLastError());
@@ -3229,6 +3236,7 @@ int mgc_set_param(mgc_handle h, const char* name, int64_t value)
     else if (!strcmp(name, "first_relabel_dt")) h->use_dt = value != 0;
     else if (!strcmp(name, "relabel_bricks")) h->use_bricks = value != 0;
     else if (!strcmp(name, "exact_sink_tiles") && value >= 0 && value <= 2) h->exact_sink_tiles = (int)value;
+    else if (!strcmp(name, "sink_sweeps") && value > 0) h->sink_sweeps = (int)value;
     else if (!strcmp(name, "halo_max_records") && value >= 1) { /* record slots of a border message (all slabs of a volume alike!) */
         const int64_t T = (int64_t)h->L.gy * h->L.gx;
         h->L.halo_max_rec = (int)(value < T ? value : T);
