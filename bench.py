@@ -385,10 +385,15 @@ def main():
             achieved = (b_alg * vox_per_launch) / (avg_ms * 1e-3) / 1e9 if avg_ms > 0 else 0.0
             out["phases_ms"] = {"solve": round(pst["solve_ms"], 3), "discharge_kernels": round(pst["discharge_ms"], 3),
                                 "relabel_kernels": round(pst["relabel_ms"], 3), "rank": 0}
-            out["roofline"] = {"bound": "hbm", "kernel": "k_discharge_w" if conn == 6 else "k26_discharge", "achieved": round(achieved, 2),
-                               "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBS, 5), "traffic": None,
-                               "avg_launch_ms": round(avg_ms, 4), "launches_per_step": launches, "voxels_per_launch": round(vox_per_launch, 1),
+            timed = avg_ms > 0  # the library's own schedule (mgc_solve_slab, RCCL transport) times its launches; a schedule driven from Python does not
+            out["roofline"] = {"bound": "hbm", "kernel": "k_discharge_w" if conn == 6 else "k26_discharge", "achieved": round(achieved, 2) if timed else None,
+                               "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBS, 5) if timed else None, "traffic": None,
+                               "avg_launch_ms": round(avg_ms, 4) if timed else None, "launches_per_step": launches if timed else None,
+                               "voxels_per_launch": round(vox_per_launch, 1) if timed else None,
                                "bytes_per_voxel": b_alg, "scope": "rank 0's slab, last step; per-GPU algorithmic GB/s of the whole job: per_gpu_algorithmic_gbs"}
+            if not timed:
+                out["roofline"]["timing"] = ("not available in this run: the launches of a slab are timed by the library's own schedule (mgc_solve_slab over "
+                                             "RCCL); this run drove the schedule from Python over the development transport")
         if not args.no_cpu and world == 1 and not args.config and not args.strong:
             out["cpu_baseline"] = cpu_baseline_in_run(args.cpu_sample, not args.cpu_sample_only)
         else:
