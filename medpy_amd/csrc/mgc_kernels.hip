@@ -1701,6 +1701,12 @@ struct mgc_graph {
     hipStream_t stream = nullptr;
     hipEvent_t ev[4] = {nullptr, nullptr, nullptr, nullptr};
     std::vector<hipEvent_t> ev_pool; /* per-launch timing */
+    /* launches issued one by one through mgc_solver_op (a schedule driven from outside, medpy_amd/slab.py): an event pair around
+     * every discharge / relabel launch since the last mgc_build, resolved by mgc_finish into the same mgc_stats fields the
+     * library's own schedules fill */
+    struct OpSpan { int a, b, kind; }; /* kind 0: k_discharge_w, 1: relabel pass, 3: k_discharge (short list) */
+    std::vector<hipEvent_t> op_ev;
+    std::vector<OpSpan> op_spans;
     MgcLattice L{};
     /* inputs resident in HBM */
     void* d_image = nullptr; int img_dtype = 0; int term = MGC_TERM_NONE; double sigma = 0; double spacing[3] = {1, 1, 1};
@@ -2085,7 +2091,24 @@ static int mgc_solver_op_on(mgc_handle h, int op, int64_t a0, int64_t a1, int64_
     Dev dev;
     dev.h = h;
     const bool timing = h->timing;
-    h->timing = false; /* per-launch events are resolved by mgc_maxflow only */
+    h->timing = false; /* (the per-launch events of a HipDevT live as long as it does: here the handle keeps the pairs, see op_spans) */
+    int span_kind = -1;
+    if (op == MGC_OP_DISCHARGE) span_kind = (h->L.ndir != 6 || ((h->wave_kernels & 1) && h->est_phase_tiles >= h->wave_min_tiles)) ? 0 : 3;
+    else if (op == MGC_OP_RELABEL_LIST || op == MGC_OP_RELABEL_ALL || op == MGC_OP_RESET_SUSPECT) span_kind = 1;
+    int ev_a = -1;
+    if (timing && span_kind >= 0) {
+        dev.flush_zero(); /* (a pending counter clear is not part of the launch that is timed) */
+        const size_t need = 2 * h->op_spans.size() + 2;
+        while (h->op_ev.size() < need) {
+            hipEvent_t e;
+            if (hipEventCreate(&e) != hipSuccess) break;
+            h->op_ev.push_back(e);
+        }
+        if (h->op_ev.size() >= need) {
+            ev_a = (int)(2 * h->op_spans.size());
+            (void)hipEventRecord(h->op_ev[ev_a], h->stream);
+        }
+    }
     switch (op) {
     case MGC_OP_ABSORB_ALL: dev.absorb_all(); break;
     case MGC_OP_FILL_INF: dev.fill_heights_inf(); break;
@@ -2100,6 +2123,10 @@ static int mgc_solver_op_on(mgc_handle h, int op, int64_t a0, int64_t a1, int64_
     case MGC_OP_SUSPECT_PASS: dev.suspect_pass(); break;
     case MGC_OP_RESET_SUSPECT: dev.reset_suspect((uint32_t)a0, (int)a1); break;
     default: h->timing = timing; return mgc_fail(h, MGC_ERR_INVALID, "unknown solver op %d", op);
+    }
+    if (ev_a >= 0) {
+        (void)hipEventRecord(h->op_ev[ev_a + 1], h->stream);
+        h->op_spans.push_back({ev_a, ev_a + 1, span_kind});
     }
     h->timing = timing;
     h->solved = false;
@@ -2730,6 +2757,7 @@ int mgc_destroy(mgc_handle h)
     for (int i = 0; i < 4; ++i)
         if (h->ev[i]) (void)hipEventDestroy(h->ev[i]);
     for (hipEvent_t e : h->ev_pool) (void)hipEventDestroy(e);
+    for (hipEvent_t e : h->op_ev) (void)hipEventDestroy(e);
     if (h->stream) (void)hipStreamDestroy(h->stream);
     delete h;
     return MGC_OK;
@@ -3010,6 +3038,7 @@ int mgc_build(mgc_handle h)
     h->built = true;
     h->solved = false;
     h->labels_valid = false;
+    h->op_spans.clear(); /* (launch-by-launch timing: the pairs of the solve before) */
     h->labels_on_host = false;
     return MGC_OK;
 }
@@ -3089,7 +3118,26 @@ int mgc_finish(mgc_handle h, double* flow_partial)
     MgcLattice& L = h->L;
     { const int rc = mgc_launch_readout(h, 1, nullptr); if (rc) return rc; }
     MGC_HIP(h, hipMemcpyAsync(h->h_scalar, h->d_scalar, 8 * sizeof(double), hipMemcpyDeviceToHost, h->stream));
+    if (!h->op_spans.empty()) MGC_HIP(h, hipMemcpyAsync(h->h_count, L.count, MGC_NCOUNT * sizeof(int32_t), hipMemcpyDeviceToHost, h->stream));
     MGC_HIP(h, hipStreamSynchronize(h->stream));
+    if (!h->op_spans.empty()) { /* the solve was driven launch by launch (mgc_solver_op): its kernel times */
+        double ms_kind[4] = {0.0, 0.0, 0.0, 0.0};
+        int64_t n_kind[4] = {0, 0, 0, 0};
+        for (const auto& sp : h->op_spans) {
+            float ms = 0.f;
+            if (hipEventElapsedTime(&ms, h->op_ev[sp.a], h->op_ev[sp.b]) == hipSuccess) { ms_kind[sp.kind] += ms; n_kind[sp.kind]++; }
+        }
+        h->stats.discharge_wave_ms = ms_kind[0];
+        h->stats.discharge_wave_launches = n_kind[0];
+        h->stats.discharge_ms = ms_kind[0] + ms_kind[3];
+        h->stats.discharge_launches = n_kind[0] + n_kind[3];
+        h->stats.relabel_ms = ms_kind[1];
+        h->stats.relabel_launches = n_kind[1];
+        h->stats.timing_stride = 1;
+        h->stats.discharge_tiles = h->h_count[L.ndir == 6 ? 8 : MGC26_CNT_DIS];
+        h->stats.discharge_wave_tiles = L.ndir == 6 ? h->h_count[MGC_CNT_WAVE_TILES] : h->stats.discharge_tiles;
+        h->op_spans.clear();
+    }
     h->flow = h->flow_const + h->h_scalar[1];
     h->solved = true;
     h->labels_on_host = false;
