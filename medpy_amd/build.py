@@ -6,7 +6,7 @@ HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(HERE, "csrc")
 LIB = os.path.join(HERE, "libmedpyhip.so")
 SOURCES = ["mgc_kernels.hip", "msg_sparse.hip"]
-DEPS = ["mgc_kernels.hip", "msg_sparse.hip", "msg_node_ops.inl", "mgc_tile_ops.inl", "mgc_tile_ops26.inl", "mgc_wave_ops.inl", "mgc_dt_ops.inl", "mgc_brick_ops.inl", "mgc_terms.h", "mgc_driver.inl", "mgc_common.h", os.path.join("..", "..", "include", "medpy_hip.h")]
+DEPS = ["mgc_kernels.hip", "msg_sparse.hip", "msg_node_ops.inl", "mgc_tile_ops.inl", "mgc_tile_ops26.inl", "mgc_wave_ops.inl", "mgc_wave_ops26.inl", "mgc_dt_ops.inl", "mgc_brick_ops.inl", "mgc_terms.h", "mgc_driver.inl", "mgc_common.h", os.path.join("..", "..", "include", "medpy_hip.h")]
 FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-ffp-contract=off", "-fPIC", "-shared", "-ldl"]
 
 

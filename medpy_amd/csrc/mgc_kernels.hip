@@ -38,6 +38,7 @@
 #include "mgc_tile_ops.inl"
 #include "mgc_tile_ops26.inl"
 #include "mgc_wave_ops.inl"
+#include "mgc_wave_ops26.inl"
 #include "mgc_dt_ops.inl"
 #include "mgc_brick_ops.inl"
 #include "mgc_terms.h"
@@ -199,6 +200,33 @@ struct GpuWaveT {
         T v[N];
         __device__ __forceinline__ T& operator()(int, int k) { return v[k]; }
     };
+    /* N doubles per lane that live in ACCUMULATOR registers (a wave that runs alone on its SIMD owns 256 of them on top of its
+     * 256 vector registers): moved with v_accvgpr_read / v_accvgpr_write around every use.  The "a" constraints keep the value
+     * in the accumulator file between the statements; they are not volatile, so unused moves disappear. */
+    template <int N>
+    struct RegA {
+        int lo[N], hi[N];
+        __device__ __forceinline__ double get(int, int k) const
+        {
+            int l, h;
+            asm volatile("v_accvgpr_read_b32 %0, %1" : "=v"(l) : "a"(lo[k])); /* volatile: a read is cheaper than keeping its result alive, */
+            asm volatile("v_accvgpr_read_b32 %0, %1" : "=v"(h) : "a"(hi[k])); /* which is what common-subexpression elimination would do      */
+            return __hiloint2double(h, l);
+        }
+        __device__ __forceinline__ void init(int, int k, double v) /* the first value (nothing is read) */
+        {
+            asm volatile("v_accvgpr_write_b32 %0, %1" : "=a"(lo[k]) : "v"(__double2loint(v))); /* volatile: stays where it is written (the */
+            asm volatile("v_accvgpr_write_b32 %0, %1" : "=a"(hi[k]) : "v"(__double2hiint(v))); /* optimiser sank these into the first uses)  */
+        }
+        /* "+a": the new value is tied to the register of the old one, so a value that is updated on one side of a branch needs no
+         * copy where the paths join (with "=a" every update is a new value that the allocator has to merge back: the accumulator
+         * file overflowed into scratch memory) */
+        __device__ __forceinline__ void set(int, int k, double v)
+        {
+            asm volatile("v_accvgpr_write_b32 %0, %1" : "+a"(lo[k]) : "v"(__double2loint(v)));
+            asm volatile("v_accvgpr_write_b32 %0, %1" : "+a"(hi[k]) : "v"(__double2hiint(v)));
+        }
+    };
     SH& S;
     int lane;
     __device__ __forceinline__ explicit GpuWaveT(SH& s) : S(s), lane((int)threadIdx.x) {}
@@ -320,6 +348,31 @@ struct GpuWaveT {
     /* a value every lane of the workgroup holds alike (read from LDS after a barrier): scalar for the branches on it */
     __device__ __forceinline__ uint32_t uniform(uint32_t v) const { return (uint32_t)__builtin_amdgcn_readfirstlane((int)v); }
     __device__ __forceinline__ void atomic_and(uint32_t* p, uint32_t v) { atomicAnd(p, v); }
+    /* ---- mgc_wave_ops26.inl ---- */
+    /* OR over the wave: four DPP row shifts leave the OR of every 16-lane row in its last lane, four v_readlane collect them */
+    template <class F>
+    __device__ __forceinline__ uint32_t wave_or(F f)
+    {
+        int v = (int)f(lane);
+        v |= __builtin_amdgcn_update_dpp(0, v, 0x111, 0xf, 0xf, true); /* row_shr:1 */
+        v |= __builtin_amdgcn_update_dpp(0, v, 0x112, 0xf, 0xf, true); /* row_shr:2 */
+        v |= __builtin_amdgcn_update_dpp(0, v, 0x114, 0xf, 0xf, true); /* row_shr:4 */
+        v |= __builtin_amdgcn_update_dpp(0, v, 0x118, 0xf, 0xf, true); /* row_shr:8 */
+        return (uint32_t)(__builtin_amdgcn_readlane(v, 15) | __builtin_amdgcn_readlane(v, 31) | __builtin_amdgcn_readlane(v, 47) | __builtin_amdgcn_readlane(v, 63));
+    }
+    /* a wave-uniform word per k, all of them in one register: lane k holds word k */
+    __device__ __forceinline__ void uput(Reg<int, 1>& store, int k, uint32_t v) { store.v[0] = lane == k ? (int)v : store.v[0]; }
+    __device__ __forceinline__ uint32_t uget(Reg<int, 1>& store, int k) { return (uint32_t)__builtin_amdgcn_readlane(store.v[0], k); }
+    /* LDS read-modify-write of a word only this lane touches: ds_and / ds_or without return, nobody waits */
+    __device__ __forceinline__ void lds_and(uint32_t* p, uint32_t v) { (void)__hip_atomic_fetch_and(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP); }
+    __device__ __forceinline__ void lds_or(uint32_t* p, uint32_t v) { (void)__hip_atomic_fetch_or(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP); }
+    /* global word no other wave touches during the launch: memory atomics without return (one wave's atomics on one address
+     * are performed in the order it issued them) */
+    __device__ __forceinline__ void gadd(double* p, double v) { (void)__hip_atomic_fetch_add(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
+    __device__ __forceinline__ void pin(double& x) { asm volatile("" : "+v"(x)); }
+    /* the loads issued so far are not moved below this point, nor later ones above it */
+    __device__ __forceinline__ void load_batch_end() { __builtin_amdgcn_sched_barrier(0); }
+    __device__ __forceinline__ void gor(uint32_t* p, uint32_t v) { (void)__hip_atomic_fetch_or(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
 #if defined(MGCW_PROFILE) /* development build (tools/gpu_sections.py): cycles per section of a tile discharge, per wave */
     unsigned long long last = 0, acc[8] = {0, 0, 0, 0, 0, 0, 0, 0};
     unsigned int cnt[8] = {0, 0, 0, 0, 0, 0, 0, 0};
@@ -440,6 +493,34 @@ __global__ __launch_bounds__(MGCW_LANES) void k_relabel_w(MgcLattice L, int lst,
     }
 }
 
+
+/* ---- 26-neighbourhood, one wave per tile (mgc_wave_ops26.inl): the wave runs ALONE on its SIMD and owns the whole 512-entry
+ * register file (excess + 26 residual planes of a z-column per lane = 432 registers); four tiles in flight per CU ---- */
+typedef GpuWaveT<MgcWaveShared26> GpuWave26;
+__global__ __launch_bounds__(MGCW_LANES) __attribute__((amdgpu_waves_per_eu(1, 1)))
+void k26_discharge_w(MgcLattice L, int lst, uint32_t phase, int sweeps, int passes, int raises, int flags, int tk)
+{
+    __shared__ MgcWaveShared26 S;
+    GpuWave26 w(S);
+    if (blockIdx.x == 0) {
+        MgcListView view;
+        const int n = mgc_list_view(L, lst, view);
+        if (threadIdx.x == 0 && n) atomicAdd(&L.count[MGC26_CNT_DIS], n);
+    }
+    if (blockIdx.x == 0 && threadIdx.x == 0) L.count[tk ^ 1] = 0; /* the next launch's ticket word */
+    w.list_begin(L, lst);
+    w.tk = tk;
+    int tile = __builtin_amdgcn_readfirstlane(w.entry_load((int)blockIdx.x)); /* first visit: no ticket */
+    while (tile >= 0) {
+        w.new_tile();
+        w.mark(7); /* between two tiles */
+        mgcw26_discharge_tile(w, L, tile, phase, sweeps, passes, raises, flags);
+        w.ticket_issue(L); /* a free wave takes the next unclaimed tile: ticket -> list entry */
+        w.hint_begin();
+        tile = __builtin_amdgcn_readfirstlane(w.lsv);
+    }
+    w.flush_marks(L);
+}
 
 /* ======================================================================================
  * block executor with V voxels per thread (512 / V threads per tile): the global-relabel passes.
@@ -1762,6 +1843,8 @@ struct mgc_graph {
     int tk_dis = MGC_CNT_TICKET_DIS, tk_rel = MGC_CNT_TICKET_REL; /* ticket slot of the next wave launch (alternates) */
     int est_phase_tiles = 1 << 30; /* length of the discharge lists at the last counter read-back */
     int sweeps_sparse26 = 8;       /* 26-neighbourhood: sweep budget of a discharge while fewer than 20 % of a colour's tiles are active */
+    int wave_grid26 = 0;           /* persistent grid of k26_discharge_w: one wave per SIMD (it needs the whole register file) */
+    int w26_passes = 2, w26_raises = 1, w26_flags = 0; /* k26_discharge_w: passes over the steps / relabel rounds per sweep, MGCW26_* flags */
     int activate_exact_max = 4096; /* activation looks at the voxels of its candidate tiles only when there are at most this many (mgcw_activate_tile) */
     int wave_stagger = 0;          /* development knob of k_discharge_w (see there) */
     int wave_min_tiles = 512;      /* shorter lists are discharged by the workgroup-per-tile kernel (measured: 128^3 4.8 -> 3.4 ms, 256^3 10.8 -> 10.5 ms,
@@ -2013,7 +2096,11 @@ struct HipDevT {
              * paced by launches and relabels: let a tile work longer.  Measured at 512^3: config 3 102.8 ms at 3 sweeps, 129.8 at
              * 6; markers only 494 ms at 3, 431 at 8. */
             if (h->sweeps_sparse26 > 0 && (int64_t)h->est_phase_tiles * 40 < h->L.ntiles) sweeps = h->sweeps_sparse26;
-            if (h->wave_kernels & 16) hipLaunchKernelGGL(k26_discharge_v, dim3(grid(h->L.ntiles)), dim3(MGC_TV / 2), 0, h->stream, h->L, lst, phase, cycles, sweeps);
+            if ((h->wave_kernels & 32) && cycles < 0) { /* one wave per tile, the tile in registers (stored labels only) */
+                hipLaunchKernelGGL(k26_discharge_w, dim3(h->wave_grid26), dim3(MGCW_LANES), 0, h->stream, h->L, lst, phase, sweeps, h->w26_passes, h->w26_raises, h->w26_flags, h->tk_dis);
+                h->tk_dis ^= 1;
+            }
+            else if (h->wave_kernels & 16) hipLaunchKernelGGL(k26_discharge_v, dim3(grid(h->L.ntiles)), dim3(MGC_TV / 2), 0, h->stream, h->L, lst, phase, cycles, sweeps);
             else hipLaunchKernelGGL(k26_discharge, dim3(h->grid26_dis > 0 ? (h->grid26_dis < h->L.ntiles ? h->grid26_dis : h->L.ntiles) : grid(h->L.ntiles)), dim3(MGC_TV), 0, h->stream, h->L, lst, phase, cycles, sweeps);
         }
         /* one wave per tile has the higher throughput (2 048 tiles in flight, fewer instructions per tile), eight waves per tile
@@ -2290,6 +2377,9 @@ static int mgc_create_impl(int ndim, const int64_t* shape, int connectivity, int
         MGC_HIP(h, hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu_rel, k_relabel_w, MGCW_LANES, 0));
         h->wave_grid_dis = prop.multiProcessorCount * (per_cu_dis > 0 ? per_cu_dis : 8);
         h->wave_grid_rel = prop.multiProcessorCount * (per_cu_rel > 0 ? per_cu_rel : 16);
+        int per_cu_26 = 0;
+        MGC_HIP(h, hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu_26, k26_discharge_w, MGCW_LANES, 0));
+        h->wave_grid26 = prop.multiProcessorCount * (per_cu_26 > 0 ? per_cu_26 : 4);
     }
     return MGC_OK;
 }
@@ -3280,6 +3370,10 @@ int mgc_set_param(mgc_handle h, const char* name, int64_t value)
     else if (!strcmp(name, "wave_min_tiles") && value >= 0) h->wave_min_tiles = (int)value;
     else if (!strcmp(name, "sweeps_sparse26") && value >= 0) h->sweeps_sparse26 = (int)value;
     else if (!strcmp(name, "wave_grid_dis") && value > 0) h->wave_grid_dis = (int)value;
+    else if (!strcmp(name, "wave_grid26") && value > 0) h->wave_grid26 = (int)value;
+    else if (!strcmp(name, "w26_passes") && value > 0) h->w26_passes = (int)value;
+    else if (!strcmp(name, "w26_raises") && value > 0) h->w26_raises = (int)value;
+    else if (!strcmp(name, "w26_flags") && value >= 0) h->w26_flags = (int)value;
     else if (!strcmp(name, "wave_grid_rel") && value > 0) h->wave_grid_rel = (int)value;
     else if (!strcmp(name, "first_relabel_dt")) h->use_dt = value != 0;
     else if (!strcmp(name, "relabel_bricks")) h->use_bricks = value != 0;

@@ -426,79 +426,78 @@ class EmbeddedLatticeGraph(object):
 
 
 class Graph(object):
-    """Plain container for a graph-cut problem (nodes numbered from 1, dict n-weights ``{(a, b): (w_ab, w_ba)}``, dict
-    t-weights ``{node: (w_source, w_sink)}``): reference medpy/graphcut/graph.py:31-264, consumed by
-    ``graph_to_dimacs`` (write.py:29-76).  Holds no device state."""
+    """Host-side description of a small graph-cut problem, the input format of ``graph_to_dimacs``.
+
+    Same public surface as the reference's container (medpy/graphcut/graph.py:31-264; what write.py:29-76 reads):
+    nodes are numbered 1..n, ``set_nweights`` takes ``{(a, b): (w_ab, w_ba)}``, ``add_tweights`` takes
+    ``{node: (w_source, w_sink)}``, marker nodes get a terminal weight of ``MAX``.  Holds no device state."""
 
     MAX = 65535
 
     def __init__(self):
-        self.__nodes = 0
-        self.__snodes = []
-        self.__tnodes = []
-        self.__nweights = {}
-        self.__tweights = {}
+        self._count = 0
+        self._markers = {"source": [], "sink": []}
+        self._edges = {}      # (a, b) -> (w_ab, w_ba), insertion order = output order
+        self._terminal = {}   # node -> (w_source, w_sink), insertion order = output order
 
+    # ---- building ----
     def set_nodes(self, nodes):
-        self.__nodes = int(nodes)
+        self._count = int(nodes)
+
+    def _mark(self, side, nodes):
+        self._markers[side] = list(nodes)
+        weight = (self.MAX, 0) if side == "source" else (0, self.MAX)
+        self._terminal.update(dict.fromkeys(self._markers[side], weight))
 
     def set_source_nodes(self, source_nodes):
-        self.__snodes = list(source_nodes)
-        for snode in self.__snodes:
-            self.__tweights[snode] = (self.MAX, 0)
+        self._mark("source", source_nodes)
 
     def set_sink_nodes(self, sink_nodes):
-        self.__tnodes = list(sink_nodes)
-        for tnode in self.__tnodes:
-            self.__tweights[tnode] = (0, self.MAX)
+        self._mark("sink", sink_nodes)
 
     def set_nweights(self, nweights):
-        self.__nweights = nweights
+        self._edges = nweights
 
     def add_tweights(self, tweights):
-        self.__tweights.update(tweights)
+        self._terminal.update(tweights)
 
+    # ---- reading ----
     def get_node_count(self):
-        return self.__nodes
+        return self._count
 
     def get_nodes(self):
-        return list(range(1, self.__nodes + 1))
+        return list(range(1, self._count + 1))
 
     def get_source_nodes(self):
-        return self.__snodes
+        return self._markers["source"]
 
     def get_sink_nodes(self):
-        return self.__tnodes
+        return self._markers["sink"]
 
     def get_edges(self):
-        return list(self.__nweights.keys())
+        return list(self._edges)
 
     def get_nweights(self):
-        return self.__nweights
+        return self._edges
 
     def get_tweights(self):
-        return self.__tweights
+        return self._terminal
 
     def inconsistent(self):
-        """False when the graph is consistent, else a list of messages (graph.py:227-264)"""
-        messages = []
-        for node in list(self.__tweights.keys()):
-            if not node <= self.__nodes:
-                messages.append("Node {} in t-weights but not in nodes.".format(node))
-        for node in self.__snodes:
-            if not node <= self.__nodes:
-                messages.append("Node {} in s-nodes but not in nodes.".format(node))
-        for node in self.__tnodes:
-            if not node <= self.__nodes:
-                messages.append("Node {} in t-nodes but not in nodes.".format(node))
-        for e in list(self.__nweights.keys()):
-            if not e[0] <= self.__nodes:
-                messages.append("Node {} in edge {} but not in nodes.".format(e[0], e))
-            if not e[1] <= self.__nodes:
-                messages.append("Node {} in edge {} but not in nodes.".format(e[1], e))
-            if (e[1], e[0]) in self.__nweights:
-                messages.append("The reversed edges of {} is also in the n-weights.".format(e))
-        return messages if messages else False
+        """``False`` for a well-formed graph, otherwise one message per defect: a node id above the node count in the
+        t-weights, the markers or an edge, and every edge whose reverse is stored as an edge of its own (the weights of
+        both directions belong into ONE entry)."""
+        def unknown(node):
+            return node > self._count
+
+        problems = ["t-weights name node {}, the graph has {} nodes".format(n, self._count) for n in self._terminal if unknown(n)]
+        for side in ("source", "sink"):
+            problems += ["{} marker on node {}, the graph has {} nodes".format(side, n, self._count) for n in self._markers[side] if unknown(n)]
+        for edge in self._edges:
+            problems += ["edge {} ends in node {}, the graph has {} nodes".format(edge, n, self._count) for n in edge if unknown(n)]
+            if tuple(reversed(edge)) in self._edges:
+                problems.append("edge {} is stored in both directions".format(edge))
+        return problems or False
 
 
 class GCGraph(object):

@@ -8,13 +8,10 @@ class ArgumentError(Exception):
 
 
 def split_marker(marker, fg_id=1, bg_id=2):
-    """Split a marker image into fg / bg binary masks; reference wrapper.py:39-69."""
-    img_marker = numpy.asarray(marker)
-    img_fgmarker = numpy.zeros(img_marker.shape, numpy.bool_)
-    img_fgmarker[img_marker == fg_id] = True
-    img_bgmarker = numpy.zeros(img_marker.shape, numpy.bool_)
-    img_bgmarker[img_marker == bg_id] = True
-    return img_fgmarker, img_bgmarker
+    """(foreground mask, background mask) of a marker image: the voxels equal to ``fg_id`` / ``bg_id``.
+    Contract of the reference's helper (medpy/graphcut/wrapper.py:39-69); two comparisons."""
+    marker = numpy.asarray(marker)
+    return marker == fg_id, marker == bg_id
 
 
 def relabel(label_image, start=1):
@@ -28,20 +25,19 @@ def relabel(label_image, start=1):
 
 
 def graphcut_stawiaski(regions, gradient=False, foreground=False, background=False):
-    """Executes a Stawiaski label graph cut; reference wrapper.py:239-310 (a single 4-tuple argument is unpacked like
-    there).  Returns the segmentation as boolean array of the region image's shape."""
+    """Region graph cut with Stawiaski's boundary term in one call: ``(regions, gradient, foreground, background)`` (or one
+    4-tuple holding them, as the reference accepts) -> boolean segmentation of the region image's shape.
+    Contract: reference medpy/graphcut/wrapper.py:239-310 (incl. ``ArgumentError`` for differing shapes)."""
     from .energy_label import boundary_stawiaski
     from .generate import graph_from_labels
-    if gradient is False and foreground is False and background is False:
+    if (gradient, foreground, background) == (False, False, False):
         regions, gradient, foreground, background = regions
-    img_region = numpy.asarray(regions)
-    img_gradient = numpy.asarray(gradient)
-    img_fg = numpy.asarray(foreground, dtype=numpy.bool_)
-    img_bg = numpy.asarray(background, dtype=numpy.bool_)
-    if not (img_region.shape == img_gradient.shape == img_fg.shape == img_bg.shape):
+    regions, gradient = numpy.asarray(regions), numpy.asarray(gradient)
+    masks = [numpy.asarray(m, dtype=numpy.bool_) for m in (foreground, background)]
+    if len({a.shape for a in (regions, gradient, *masks)}) != 1:
         raise ArgumentError("All supplied images must be of the same shape.")
-    img_region = relabel(img_region)
-    gcgraph = graph_from_labels(img_region, img_fg, img_bg, boundary_term=boundary_stawiaski, boundary_term_args=(img_gradient))
-    gcgraph.maxflow()
-    mapping = numpy.concatenate([[False], gcgraph.labels()])  # region id -> True where what_segment != SINK
-    return mapping[img_region].astype(numpy.bool_)
+    regions = relabel(regions)  # ids 1..n in order of first appearance: node k - 1 is region k
+    graph = graph_from_labels(regions, masks[0], masks[1], boundary_term=boundary_stawiaski, boundary_term_args=gradient)
+    graph.maxflow()
+    in_foreground = numpy.concatenate(([False], graph.labels())).astype(numpy.bool_)  # indexed by region id
+    return in_foreground[regions]

@@ -26,6 +26,7 @@ static long long g26_sweeps, g26_dirs; /* direction masks of the 26-neighbourhoo
 #define MGC26_COUNT_STEPS(mask) (g26_sweeps++, g26_dirs += __builtin_popcount(mask))
 #include "../../medpy_amd/csrc/mgc_tile_ops26.inl"
 #include "../../medpy_amd/csrc/mgc_wave_ops.inl"
+#include "../../medpy_amd/csrc/mgc_wave_ops26.inl"
 #include "../../medpy_amd/csrc/mgc_dt_ops.inl"
 #include "../../medpy_amd/csrc/mgc_brick_ops.inl"
 #include "../../medpy_amd/csrc/mgc_driver.inl"
@@ -106,14 +107,38 @@ struct HostBlockT {
     void async_wait() {}
 };
 /* host form of the wave executor of mgc_wave_ops.inl: a "wave" is a loop over its 64 lanes */
-struct HostWave {
+template <class SH>
+struct HostWaveT {
     template <class T, int N>
     struct Reg {
         T v[MGCW_LANES][N];
         T& operator()(int l, int k) { return v[l][k]; }
     };
-    MgcWaveShared& S;
-    explicit HostWave(MgcWaveShared& s) : S(s) {}
+    template <int N>
+    struct RegA { /* (GPU: accumulator registers) */
+        double v[MGCW_LANES][N];
+        void init(int l, int k, double x) { v[l][k] = x; }
+        void set(int l, int k, double x) { v[l][k] = x; }
+        double get(int l, int k) const { return v[l][k]; }
+    };
+    SH& S;
+    explicit HostWaveT(SH& s) : S(s) {}
+    /* ---- mgc_wave_ops26.inl ---- */
+    template <class F>
+    uint32_t wave_or(F f)
+    {
+        uint32_t r = 0;
+        for (int l = 0; l < MGCW_LANES; ++l) r |= (uint32_t)f(l);
+        return r;
+    }
+    void uput(Reg<int, 1>& store, int k, uint32_t v) { store(k, 0) = (int)v; }
+    uint32_t uget(Reg<int, 1>& store, int k) { return (uint32_t)store(k, 0); }
+    void lds_and(uint32_t* p, uint32_t v) { *p &= v; }
+    void lds_or(uint32_t* p, uint32_t v) { *p |= v; }
+    void gadd(double* p, double v) { *p += v; }
+    void gor(uint32_t* p, uint32_t v) { *p |= v; }
+    void pin(double&) {}
+    void load_batch_end() {}
     template <class F>
     void lanes(F f)
     {
@@ -164,6 +189,8 @@ struct HostWave {
     void fresh() {}
     int use_here(int v) { return v; }
 };
+typedef HostWaveT<MgcWaveShared> HostWave;
+typedef HostWaveT<MgcWaveShared26> HostWave26;
 /* executor of the brick operations (mgc_brick_ops.inl): 4096 lanes, run one after another */
 struct HostBrick {
     template <class T>
@@ -192,8 +219,10 @@ struct HostBrick {
 static int g_bricks = 0; /* incremental relabels run their passes over bricks of 2 x 2 x 2 tiles (hostsim_set_bricks; the library's relabel_bricks, off by default) */
 
 /* which form of the two hot tile operations the simulator runs: bit 0 = wave discharge, bit 1 = wave relabel,
- * bit 2 = the wave discharge computes exact in-tile labels first (MGCW_BFS); bit 3 = only in tiles holding a sink link (MGCW_BFS_SINK) */
+ * bit 2 = the wave discharge computes exact in-tile labels first (MGCW_BFS); bit 3 = only in tiles holding a sink link (MGCW_BFS_SINK);
+ * bit 4 = the 26-neighbourhood discharge runs one wave per tile (mgc_wave_ops26.inl) */
 static int g_wave_mode = 0;
+static int g_w26_passes = 2, g_w26_raises = 1, g_w26_flags = 0; /* hostsim_set_w26: step passes / relabel rounds per sweep of the 26-neighbourhood wave discharge */
 static int g_act_exact_max = 4096; /* hostsim_set_act_exact: see mgcw_activate_tile */
 static FILE* g_trace = NULL; /* one line per wave-form discharge: phase, tile, sweeps (hostsim_trace; tools/sim_launch_model.py) */
 static int g_use_dt = 1; /* the first global relabel may be a distance transform (hostsim_set_dt) */
@@ -439,6 +468,7 @@ struct HostDev {
 extern "C" {
 
 void hostsim_set_wave_mode(int mode) { g_wave_mode = mode; }
+void hostsim_set_w26(int passes, int raises, int flags) { g_w26_passes = passes; g_w26_raises = raises; g_w26_flags = flags; }
 void hostsim_set_dt(int on) { g_use_dt = on; }
 void hostsim_trace(const char* path) { if (g_trace) fclose(g_trace); g_trace = path && *path ? fopen(path, "w") : NULL; }
 void hostsim_set_bricks(int on) { g_bricks = on; }
@@ -632,12 +662,18 @@ struct HostDev26 {
         for (int t = 0; t < L.ntiles; ++t)
             if (mgc26_activate_tile(x, L, t, phase)) L.count[MGC26_CNT_ACTIVE]++;
     }
+    MgcWaveShared26 WS;
     void discharge(int lst, uint32_t phase, int cycles, int sweeps)
     {
         HostBlock26D x(S);
+        HostWave26 w(WS);
         const int n = L.count[lst];
         L.count[MGC26_CNT_DIS] += n;
-        for (int i = 0; i < n; ++i) mgc26_discharge_tile(x, L, L.list[lst][i], phase, cycles, sweeps);
+        if (getenv("HOSTSIM_TRACE26")) fprintf(stderr, "%d ", n);
+        for (int i = 0; i < n; ++i) {
+            if ((g_wave_mode & 16) && cycles < 0) mgcw26_discharge_tile(w, L, L.list[lst][i], phase, sweeps, g_w26_passes, g_w26_raises, g_w26_flags); /* one wave per tile, stored labels */
+            else mgc26_discharge_tile(x, L, L.list[lst][i], phase, cycles, sweeps);
+        }
     }
     std::vector<uint32_t> oflags;
     MgcSlabSpec spec;
@@ -715,8 +751,9 @@ int hostsim_solve26(const int64_t* shape, const double* w, const double* trcap, 
     memcpy(stats_out, &st, sizeof(st));
     d->labels(labels_out);
     delete d;
-    if (getenv("HOSTSIM_PROF26")) fprintf(stderr, "26-neighbourhood discharge: %lld sweeps, %.2f of 26 directions per sweep\n", g26_sweeps, g26_sweeps ? (double)g26_dirs / g26_sweeps : 0.0);
+    if (getenv("HOSTSIM_PROF26")) fprintf(stderr, "26-neighbourhood discharge: %lld sweeps, %.2f of 26 directions per sweep; wave form: %lld sweeps (pass A), %lld visits\n", g26_sweeps, g26_sweeps ? (double)g26_dirs / g26_sweeps : 0.0, (long long)g_prof[1], (long long)g_prof[0]);
     g26_sweeps = g26_dirs = 0;
+    g_prof[0] = g_prof[1] = 0;
     return rc;
 }
 

@@ -13,7 +13,7 @@ _lib = None
 def build():
     src = os.path.join(_HERE, "hostsim.cpp")
     deps = [src] + [os.path.join(_HERE, "..", "..", "medpy_amd", "csrc", f) for f in
-                    ("mgc_tile_ops.inl", "mgc_tile_ops26.inl", "mgc_wave_ops.inl", "mgc_dt_ops.inl", "mgc_brick_ops.inl", "mgc_driver.inl", "mgc_common.h", "mgc_terms.h")
+                    ("mgc_tile_ops.inl", "mgc_tile_ops26.inl", "mgc_wave_ops.inl", "mgc_wave_ops26.inl", "mgc_dt_ops.inl", "mgc_brick_ops.inl", "mgc_driver.inl", "mgc_common.h", "mgc_terms.h")
                     if os.path.exists(os.path.join(_HERE, "..", "..", "medpy_amd", "csrc", f))]
     if os.path.exists(_SO) and all(os.path.getmtime(_SO) >= os.path.getmtime(d) for d in deps):
         return
@@ -45,7 +45,8 @@ STAT_NAMES = ("outer", "relabel_passes", "relabel_tiles", "phases", "discharge_t
 
 def set_wave_mode(mode):
     """which form of the hot tile operations the simulator runs: bit0 wave discharge, bit1 wave relabel (mgc_wave_ops.inl,
-    one wave per tile), bit2 the wave discharge starts from exact in-tile labels; 0 = the 512-lane workgroup forms"""
+    one wave per tile), bit2 the wave discharge starts from exact in-tile labels, bit4 (16) the 26-neighbourhood discharge runs one wave
+    per tile (mgc_wave_ops26.inl); 0 = the 512-lane workgroup forms"""
     lib().hostsim_set_wave_mode(int(mode))
 
 
@@ -184,7 +185,13 @@ def weights26(shape, weights_by_offset):
     return w
 
 
-def solve26(shape, weights_by_offset, trcap, rounds=0, cycles=0, sweeps=0, max_outer=0):
+def solve26(shape, weights_by_offset, trcap, rounds=0, cycles=0, sweeps=0, max_outer=0, wave_mode=None):
+    if wave_mode is not None:  # bit 4 (16): the discharge runs one wave per tile (mgc_wave_ops26.inl)
+        set_wave_mode(wave_mode)
+        try:
+            return solve26(shape, weights_by_offset, trcap, rounds, cycles, sweeps, max_outer)
+        finally:
+            set_wave_mode(0)
     """26-neighbourhood: weights_by_offset = {offset: array (NaN where no neighbour)} for the 13 forward offsets
     (oracle/energy_numpy.py:boundary_weights_offsets).  Returns (labels, stats)."""
     L = lib()

@@ -147,8 +147,9 @@ def test_hostsim_dyadic_ties_exact():
     np.testing.assert_array_equal(lab, g.labels().reshape(img.shape))
 
 
+@pytest.mark.parametrize("wave", [0, 16], ids=["workgroup_form", "wave_form"])
 @pytest.mark.parametrize("gen,shape", [("sphere", (16, 16, 16)), ("hard", (24, 24, 24)), ("sphere", (9, 21, 30)), ("sphere", (1, 24, 40))])
-def test_hostsim_full_neighbourhood_matches_bk(gen, shape):
+def test_hostsim_full_neighbourhood_matches_bk(gen, shape, wave):
     """26-neighbourhood tile ops (mgc_tile_ops26.inl, same source as the k26_* kernels) vs the BK oracle fed the
     26-neighbour edge list."""
     import sim
@@ -160,13 +161,13 @@ def test_hostsim_full_neighbourhood_matches_bk(gen, shape):
     g = pipeline.build_graph(s["fg"], s["bg"], weights=w, connectivity=26)
     tr = np.array([g.get_trcap(i) for i in range(s["fg"].size)])
     g.maxflow()
-    lab, st = sim.solve26(shape, w, tr)
+    lab, st = sim.solve26(shape, w, tr, wave_mode=wave)
     assert st["converged"] == 1
     np.testing.assert_array_equal(lab, g.labels().reshape(shape))
 
 
 @pytest.mark.parametrize("gen,shape", [("hard", (32, 32, 32)), ("ties", (24, 24, 24)), ("sphere", (24, 40, 17))])
-@pytest.mark.parametrize("rounds,cycles,sweeps", [(1, -1, 2), (1, 1, 1), (2, -1, 4)])
+@pytest.mark.parametrize("rounds,cycles,sweeps", [(1, -1, 2), (1, 1, 1), (2, -1, 4), (1, -1, -2), (2, -1, -4)])
 def test_hostsim_full_neighbourhood_incremental_relabel(gen, shape, rounds, cycles, sweeps):
     """Short colour rounds force many global relabels; all but the first recompute only the SUSPECT tiles (26 supporting
     neighbour tiles in the status word, mgc26_suspect_tile).  Labels must still be the BK oracle's."""
@@ -179,7 +180,8 @@ def test_hostsim_full_neighbourhood_incremental_relabel(gen, shape, rounds, cycl
     g = pipeline.build_graph(s["fg"], s["bg"], weights=w, connectivity=26)
     tr = np.array([g.get_trcap(i) for i in range(s["fg"].size)])
     g.maxflow()
-    lab, st = sim.solve26(shape, w, tr, rounds=rounds, cycles=cycles, sweeps=sweeps)
+    wave = 16 if sweeps < 0 else 0  # (negative sweeps: the same budget through the one-wave-per-tile discharge, mgc_wave_ops26.inl)
+    lab, st = sim.solve26(shape, w, tr, rounds=rounds, cycles=cycles, sweeps=abs(sweeps), wave_mode=wave)
     assert st["converged"] == 1 and st["outer"] >= 5
     np.testing.assert_array_equal(lab, g.labels().reshape(shape))
 

@@ -17,6 +17,7 @@ ap.add_argument("--conn", type=int, default=6)
 ap.add_argument("--reps", type=int, default=3)
 ap.add_argument("--lib", default=None)
 ap.add_argument("--tag", default="")
+ap.add_argument("--regional", action="store_true", help="add the regional_probability_map term of BASELINE config 3")
 ap.add_argument("variants", nargs="*")
 a = ap.parse_args()
 if a.lib:
@@ -32,6 +33,9 @@ ref = None
 for v in (a.variants or ["base"]):
     g = VoxelGraph((n, n, n), connectivity=a.conn)  # a fresh handle per variant: defaults restored
     g._set_boundary(s["term"], s["image"], s["sigma"], False)
+    if a.regional:
+        rg = synthetic.regional((n, n, n))
+        g._set_regional(rg["prob"], rg["alpha"])
     g._set_markers(s["fg"], s["bg"])
     if v != "base":
         for kv in v.split(","):
@@ -49,7 +53,7 @@ for v in (a.variants or ["base"]):
     if ref is None:
         ref = lab.copy()
     st = bst
-    print(json.dumps({"tag": a.tag, "n": n, "wl": a.wl, "conn": a.conn, "variant": v, "ms": round(best * 1e3, 2), "mvox_s": round(n ** 3 / best / 1e6, 1),
+    print(json.dumps({"tag": a.tag, "n": n, "wl": a.wl, "conn": a.conn, "regional": a.regional, "variant": v, "ms": round(best * 1e3, 2), "mvox_s": round(n ** 3 / best / 1e6, 1),
                       "same_labels": bool((lab == ref).all()), "flow": fl, "build_ms": round(st["build_ms"], 2), "solve_ms": round(st["solve_ms"], 2),
                       "discharge_ms": round(st["discharge_ms"], 2), "relabel_ms": round(st["relabel_ms"], 2),
                       "relabels": st["global_relabels"], "phases": st["phases"], "dis_tiles": st["discharge_tiles"],
