@@ -692,6 +692,35 @@ __global__ __launch_bounds__(MGC_TV) void k26_activate(MgcLattice L, uint32_t ph
     if (threadIdx.x == 0 && nact) atomicAdd(&L.count[MGC26_CNT_ACTIVE], nact);
 }
 
+/* the same, one WAVE per tile (four tiles per workgroup): sixteen independent loads per lane and one vote instead of a barrier
+ * per tile -- the pass streams 12 bytes per voxel of every tile that is not all-INF (k26_activate: 1.7 ms at 512^3, twice per solve) */
+__global__ __launch_bounds__(256) void k26_activate_w(MgcLattice L, uint32_t phase)
+{
+    const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+    int nact = 0;
+    for (int tile = (int)blockIdx.x * 4 + wv; tile < L.ntiles; tile += (int)gridDim.x * 4) {
+        if (!mgc_owned(L, tile) || (L.status[tile] & MGC_ST_ALLINF)) continue; /* (wave-uniform) */
+        const double* const e = L.excess + (int64_t)tile * MGC_TV;
+        const int32_t* const h = L.height + (int64_t)tile * MGC_TV;
+        bool a = false;
+#pragma unroll
+        for (int k = 0; k < 8; ++k) a = a || (e[k * 64 + lane] > 0.0 && h[k * 64 + lane] < MGC_HINF);
+        if (__ballot(a) != 0ull) {
+            if (lane == 0) {
+                int tz, ty, tx;
+                mgc_tile_coords(L, tile, tz, ty, tx);
+                const uint32_t target = phase + (((uint32_t)mgc26_colour(L, tz, ty, tx) - phase) & 7u);
+                if (atomicExch(&L.stamp[tile], target) != target) { /* (mgc_enqueue) */
+                    const int pos = atomicAdd(mgc_counter(L, (int)(target & 15u), 0), 1);
+                    L.list[target & 15u][pos] = tile;
+                }
+            }
+            nact++;
+        }
+    }
+    if (lane == 0 && nact) atomicAdd(&L.count[MGC26_CNT_ACTIVE], nact);
+}
+
 #ifndef MGC26_DISCHARGE_WAVES
 #define MGC26_DISCHARGE_WAVES 4 /* waves per SIMD the register allocator leaves room for: 128 VGPRs, 2 workgroups per CU
                                    (13 of the 26 residuals live in LDS, see MgcTileShared26D) */
@@ -1060,6 +1089,7 @@ struct MgcBuildArgs {
     double* tr0;         /* out: merged tr_cap per voxel, tile-major */
     double* fpart;       /* out: per-tile partial of the flow constant */
     uint8_t* tflags;     /* out: per tile, bit 0: some voxel has a source link (tr0 > 0), bit 1: a sink link (tr0 < 0) -- as built */
+    int prepush;         /* 26-neighbourhood: settle source -> u -> v -> sink paths inside a tile while its weights are in registers (k_build_prepush26) */
 };
 
 /* Graph::add_tweights, graph.h:416-425 */
@@ -1087,7 +1117,7 @@ __device__ __forceinline__ double mgc_block_sum(double v, double* scratch)
 
 /* TERM: the boundary term as a compile-time constant (the kernel dispatches once), so g(.) is straight-line code */
 template <bool FULL, int TERM> /* FULL: 26-neighbourhood */
-__device__ __forceinline__ void k_build_tiles(const MgcLattice& L, const MgcBuildArgs& A, double* img, double* scratch, double* wf, int* tflag_lds)
+__device__ __forceinline__ void k_build_tiles(const MgcLattice& L, const MgcBuildArgs& A, double* img, double* scratch, double* wf, int* tflag_lds, double* pre_lds)
 {
     const int t = threadIdx.x;
     const bool take_abs = (TERM == MGC_TERM_MAXIMUM_LINEAR || TERM == MGC_TERM_MAXIMUM_EXPONENTIAL || TERM == MGC_TERM_MAXIMUM_POWER);
@@ -1120,6 +1150,42 @@ __device__ __forceinline__ void k_build_tiles(const MgcLattice& L, const MgcBuil
         const bool valid = gz < L.dz && gy < L.dy && gx < L.dx;
         const int64_t id = (gz * L.dy + gy) * L.dx + gx;
         const int me = mgc_hs_index(lz, ly, lx);
+        /* t-links: regional term, then fg marker, then bg marker (generate.py:159-172); then which signs of t-link the tile holds and
+         * whether a flow constant has to be summed: ONE barrier (the waves vote, one lane per wave ORs the result into an LDS
+         * word) where three barrier-reductions stood.  The 26-neighbourhood path runs this BEFORE its weights (the pre-push needs the
+         * t-links), the 6-neighbourhood path behind them (its weight hand-over barrier separates the reset of the vote word from the votes). */
+        double tr = 0.0, fc = 0.0;
+        int tbits = 0;
+        auto tlinks_and_vote = [&]() __attribute__((always_inline)) {
+            if (valid) {
+                if (A.tr_in) tr = A.tr_in[id];
+                if (A.prob) {
+                    double cs, ck;
+                    if (A.prob_dtype == MGC_F32) {
+                        const float p = ((const float*)A.prob)[id], al = (float)A.alpha;
+                        cs = (double)(p * al);
+                        ck = (double)((1.0f - p) * al);
+                    } else {
+                        const double p = ((const double*)A.prob)[id];
+                        cs = p * A.alpha;
+                        ck = (1.0 - p) * A.alpha;
+                    }
+                    mgc_add_tweights(tr, fc, cs, ck);
+                }
+                if (A.fg && A.fg[id]) mgc_add_tweights(tr, fc, MGC_MARKER_MAX, 0.0);
+                if (A.bg && A.bg[id]) mgc_add_tweights(tr, fc, 0.0, MGC_MARKER_MAX);
+            }
+            const int bits = (__ballot(tr < 0.0) != 0ull ? 2 : 0) | (__ballot(tr > 0.0) != 0ull ? 1 : 0) | (__ballot(fc != 0.0) != 0ull ? 4 : 0);
+            if ((t & 63) == 0 && bits) atomicOr(tflag_lds, bits);
+            __syncthreads();
+            tbits = *tflag_lds;
+        };
+        if constexpr (FULL) {
+            __syncthreads(); /* the reset of the vote word above, before the votes */
+            tlinks_and_vote();
+        }
+        const bool pre = FULL && A.prepush && (tbits & 3) == 3; /* (uniform) the tile holds source links AND sink links */
+        double exc_out = tr > 0.0 ? tr : 0.0, snk_out = tr < 0.0 ? -tr : 0.0; /* (the 6-neighbourhood path: after its tlinks_and_vote below) */
         uint32_t m = 0;
         if constexpr (!FULL) {
             /* Every n-link weight is evaluated ONCE, by the lower voxel of its pair (g(lower, upper), the operand order of the
@@ -1168,7 +1234,7 @@ __device__ __forceinline__ void k_build_tiles(const MgcLattice& L, const MgcBuil
                                 (gx > 0 ? 16u : 0u) | (gx + 1 < L.dx ? 32u : 0u);
             double* const plane0 = L.rcap + ((int64_t)tile * MGC26_NDIR) * MGC_TV + t;
             const double mine = TERM != MGC_TERM_NONE ? img[me] : 0.0;
-            mgcw_static_for<MGC26_NDIR>([&](auto dc) __attribute__((always_inline)) {
+            auto weight = [&](auto dc) __attribute__((always_inline)) -> double {
                 constexpr int d = decltype(dc)::value;
                 constexpr int c = d < 13 ? d : d + 1;
                 constexpr int dz = c / 9 - 1, dy = (c / 3) % 3 - 1, dx = c % 3 - 1;
@@ -1180,44 +1246,80 @@ __device__ __forceinline__ void k_build_tiles(const MgcLattice& L, const MgcBuil
                     w = d >= 13 ? mgc_boundary_g(TERM, mine, other, A.p0) : mgc_boundary_g(TERM, other, mine, A.p0); /* g(lower, upper) */
                     if (A.has_spacing) w = w / A.div26[d];
                 }
-                plane0[(int64_t)d * MGC_TV] = w;
-                if (L.cap0) L.cap0[((int64_t)tile * MGC26_NDIR + d) * MGC_TV + t] = w;
-                if (w > 0.0) m |= 1u << d;
-                if (d % 4 == 3) asm volatile("" ::: "memory"); /* four weights in flight, not 26: 26 keep 151 VGPRs alive (one workgroup per CU) */
-            });
-        }
-        if constexpr (FULL) __syncthreads(); /* the reset of the vote word above, before the votes below (the 6-neighbourhood path has its weight hand-over barrier in between) */
-        /* t-links: regional term, then fg marker, then bg marker (generate.py:159-172) */
-        double tr = 0.0, fc = 0.0;
-        if (valid) {
-            if (A.tr_in) tr = A.tr_in[id];
-            if (A.prob) {
-                double cs, ck;
-                if (A.prob_dtype == MGC_F32) {
-                    const float p = ((const float*)A.prob)[id], al = (float)A.alpha;
-                    cs = (double)(p * al);
-                    ck = (double)((1.0f - p) * al);
-                } else {
-                    const double p = ((const double*)A.prob)[id];
-                    cs = p * A.alpha;
-                    ck = (1.0 - p) * A.alpha;
-                }
-                mgc_add_tweights(tr, fc, cs, ck);
+                if (L.cap0) L.cap0[((int64_t)tile * MGC26_NDIR + d) * MGC_TV + t] = w; /* (as built) */
+                return w;
+            };
+            if (pre) {
+                /* ---- PRE-PUSH (no reference counterpart; part of the solver, not of the energy terms): with a regional term every
+                 * tile holds voxels with a source link next to voxels with a sink link, and the first colour round of the solve
+                 * would visit EVERY tile (120 KB in, up to 120 KB out per visit) to move flow one voxel over.  Here, while the
+                 * tile's weights are in registers anyway, every voxel that holds excess pushes min(excess, weight, what the
+                 * neighbour's sink link still takes) to its neighbours INSIDE the tile, direction by direction (one writer per
+                 * target voxel and step: fixed order of f64 operations), and the receiver hands it straight on to the sink.  The result is a valid
+                 * preflow (flow on u -> v -> sink paths only; no voxel gains excess); what it leaves is what the solve starts
+                 * from.  Directions go in opposite pairs (d, 25 - d): the residual of d at a voxel changes by what it pushed
+                 * along d and by what its neighbour pushed back along 25 - d, so both planes of a pair are stored together. ---- */
+                double* const dfc = pre_lds;                 /* [512] what the voxels' sink links still take */
+                double e = tr > 0.0 ? tr : 0.0;
+                dfc[t] = tr < 0.0 ? -tr : 0.0;
+                __syncthreads();
+                mgcw_static_for<13>([&](auto ic) __attribute__((always_inline)) {
+                    constexpr int i = decltype(ic)::value;
+                    constexpr int dA = i, dB = 25 - i;
+                    constexpr int c = dA; /* dA < 13 */
+                    constexpr int dz = c / 9 - 1, dy = (c / 3) % 3 - 1, dx = c % 3 - 1;
+                    double* const revA = pre_lds + MGC_TV * (1 + 2 * (i & 1)); /* [512] what arrived along dA (double-buffered over the pairs) */
+                    double* const revB = revA + MGC_TV;                          /* ... along dB */
+                    double wA = weight(std::integral_constant<int, dA>{}), wB = weight(std::integral_constant<int, dB>{});
+                    const int za = lz + dz, ya = ly + dy, xa = lx + dx, zb = lz - dz, yb = ly - dy, xb = lx - dx;
+                    const bool inA = za >= 0 && za < 8 && ya >= 0 && ya < 8 && xa >= 0 && xa < 8; /* my neighbour along dA lies in the tile */
+                    const bool inB = zb >= 0 && zb < 8 && yb >= 0 && yb < 8 && xb >= 0 && xb < 8;
+                    const int vA = t + dz * 64 + dy * 8 + dx, vB = t - (dz * 64 + dy * 8 + dx);
+                    double pA = 0.0, pB = 0.0;
+                    if (inA) {
+                        if (e > 0.0 && wA > 0.0) {
+                            const double q = dfc[vA];
+                            pA = fmin(e, fmin(wA, q));
+                            if (pA > 0.0) { dfc[vA] = q - pA; e -= pA; }
+                        }
+                        revA[vA] = pA;
+                    }
+                    __syncthreads();
+                    if (inB) {
+                        if (e > 0.0 && wB > 0.0) {
+                            const double q = dfc[vB];
+                            pB = fmin(e, fmin(wB, q));
+                            if (pB > 0.0) { dfc[vB] = q - pB; e -= pB; }
+                        }
+                        revB[vB] = pB;
+                    }
+                    __syncthreads();
+                    wA = (wA - pA) + (inA ? revB[t] : 0.0); /* my neighbour along dA pushed back to me along dB */
+                    wB = (wB - pB) + (inB ? revA[t] : 0.0);
+                    plane0[(int64_t)dA * MGC_TV] = wA;
+                    plane0[(int64_t)dB * MGC_TV] = wB;
+                    if (wA > 0.0) m |= 1u << dA;
+                    if (wB > 0.0) m |= 1u << dB;
+                });
+                __syncthreads();
+                exc_out = e;
+                snk_out = dfc[t];
+                __syncthreads(); /* (dfc is rewritten by the next tile) */
+            } else {
+                mgcw_static_for<MGC26_NDIR>([&](auto dc) __attribute__((always_inline)) {
+                    constexpr int d = decltype(dc)::value;
+                    const double w = weight(dc);
+                    plane0[(int64_t)d * MGC_TV] = w;
+                    if (w > 0.0) m |= 1u << d;
+                    if (d % 4 == 3) asm volatile("" ::: "memory"); /* four weights in flight, not 26: 26 keep 151 VGPRs alive (one workgroup per CU) */
+                });
             }
-            if (A.fg && A.fg[id]) mgc_add_tweights(tr, fc, MGC_MARKER_MAX, 0.0);
-            if (A.bg && A.bg[id]) mgc_add_tweights(tr, fc, 0.0, MGC_MARKER_MAX);
         }
+        if constexpr (!FULL) tlinks_and_vote();
         const int64_t v = (int64_t)tile * MGC_TV + t;
-        /* which signs of t-link the tile holds, whether a flow constant has to be summed: ONE barrier (the waves vote, one lane
-         * per wave ORs the result into an LDS word) where three barrier-reductions stood */
-        {
-            const int bits = (__ballot(tr < 0.0) != 0ull ? 2 : 0) | (__ballot(tr > 0.0) != 0ull ? 1 : 0) | (__ballot(fc != 0.0) != 0ull ? 4 : 0);
-            if ((t & 63) == 0 && bits) atomicOr(tflag_lds, bits);
-        }
-        __syncthreads();
-        const int tbits = *tflag_lds;
         const int any_sink = tbits & 2, any_exc = tbits & 1;
-        L.excess[v] = tr > 0.0 ? tr : 0.0;
+        if constexpr (!FULL) { exc_out = tr > 0.0 ? tr : 0.0; snk_out = tr < 0.0 ? -tr : 0.0; }
+        L.excess[v] = exc_out;
         if constexpr (!FULL) {
             /* 6-neighbourhood: the merged t-links and the residual sink links of a tile are only READ where the tile holds a t-link
              * of the sign in question (A.tflags, status bit MGC_ST_SINK: k_discharge_w, k_cut_value6, k_validate ...), so they are only
@@ -1225,8 +1327,8 @@ __device__ __forceinline__ void k_build_tiles(const MgcLattice& L, const MgcBuil
             if (tbits & 3) A.tr0[v] = tr;
             if (any_sink) L.sink[v] = tr < 0.0 ? -tr : 0.0;
         } else {
-            A.tr0[v] = tr;
-            L.sink[v] = tr < 0.0 ? -tr : 0.0;
+            A.tr0[v] = tr;       /* (as built: the cut value and the invariant check start from the merged t-link) */
+            L.sink[v] = snk_out; /* (what the pre-push left of it) */
         }
         if constexpr (!FULL) {
             /* is every n-link of the volume residual?  (then the first global relabel is a distance transform, mgc_dt_ops.inl) */
@@ -1236,7 +1338,7 @@ __device__ __forceinline__ void k_build_tiles(const MgcLattice& L, const MgcBuil
             if (tr < 0.0) m |= MGC_MASK_SINK;
             L.rmask[v] = (uint8_t)m;
         } else {
-            if (tr < 0.0) m |= MGC26_MASK_SINK;
+            if (snk_out > 0.0) m |= MGC26_MASK_SINK;
             L.rmask32[v] = m;
         }
         /* (labels are not initialised here: every solve starts by filling them, mgc_driver.inl) */
@@ -1259,6 +1361,8 @@ __device__ __forceinline__ void k_build_tiles(const MgcLattice& L, const MgcBuil
         } else if (t == 0) {
             A.fpart[tile] = 0.0;
         }
+        if constexpr (FULL) __syncthreads(); /* the weights above read the image tile in LDS, the next tile's load overwrites it (the
+                                                6-neighbourhood path has its vote barrier behind the weights) */
     }
     if (!FULL && t == 0 && sink_tiles) atomicAdd(&L.count[MGC_CNT_SINK_TILES], sink_tiles); /* once per workgroup (mgc_build: exact_sink_tiles) */
 }
@@ -1268,14 +1372,18 @@ __device__ __forceinline__ void k_build_tiles(const MgcLattice& L, const MgcBuil
 #ifndef MGC_BUILD_WAVES6
 #define MGC_BUILD_WAVES6 6 /* three workgroups per CU: 80 VGPRs and 32 B of scratch for the exponential term; measured 3.74 ms vs 4.28 ms at 4 (and 4.35 at 5) for 512^3 */
 #endif
+#ifndef MGC_BUILD_WAVES26
+#define MGC_BUILD_WAVES26 4 /* two workgroups per CU: 128 VGPRs */
+#endif
 template <bool FULL, int TERM> /* FULL: 26-neighbourhood */
-__global__ __launch_bounds__(MGC_TV, FULL ? 2 : MGC_BUILD_WAVES6) void k_build(MgcLattice L, MgcBuildArgs A)
+__global__ __launch_bounds__(MGC_TV, FULL ? MGC_BUILD_WAVES26 : MGC_BUILD_WAVES6) void k_build(MgcLattice L, MgcBuildArgs A)
 {
     __shared__ double img[1000]; /* 10x10x10: tile + one-voxel halo, already |.|'d for the maximum terms */
     __shared__ double scratch[MGC_TV];
     __shared__ double wf[FULL ? 1 : 3 * 576]; /* 6-neighbourhood: the forward n-link weights of the tile and its lower faces */
     __shared__ int tflag;
-    k_build_tiles<FULL, TERM>(L, A, img, scratch, wf, &tflag);
+    __shared__ double pre_lds[FULL ? 5 * MGC_TV : 1]; /* pre-push: residual sink capacities + two double-buffered hand-off planes */
+    k_build_tiles<FULL, TERM>(L, A, img, scratch, wf, &tflag, pre_lds);
 }
 
 template <bool FULL>
@@ -1421,6 +1529,66 @@ __global__ __launch_bounds__(MGC_TV) void k_cut_value(MgcLattice L, MgcBuildArgs
         }
         /* only tiles the cut passes through (or that hold t-links on the paying side) contribute: the others skip the ten
          * barriers of the tree sum (the sum of zeros is the same 0.0) */
+        if (__syncthreads_or(s != 0.0)) {
+            const double tot = mgc_block_sum(s, scratch);
+            if (t == 0) part[tile] = tot;
+            __syncthreads();
+        } else if (t == 0) {
+            part[tile] = 0.0;
+        }
+    }
+}
+
+/* 26-neighbourhood form of k_cut_value.  With a regional term EVERY voxel pays a t-link, so no tile can be skipped; but only the
+ * tiles the cut passes through pay n-links.  A tile whose label summary (tsum, k_labels8) says "all on one side" and whose 26
+ * neighbour tiles say the same pays t-links only: one coalesced read of the merged t-links and the block sum -- no label volume,
+ * no 26 byte loads per voxel.  Every other tile takes the general path.  Same additions in the same order as k_cut_value. */
+__global__ __launch_bounds__(MGC_TV) void k_cut_value26(MgcLattice L, MgcBuildArgs A, const double* tr0, const uint8_t* labels, const uint8_t* tsum, double* part)
+{
+    __shared__ double scratch[MGC_TV];
+    __shared__ int mixed;
+    const int t = threadIdx.x;
+    for (int tile = blockIdx.x; tile < L.ntiles; tile += gridDim.x) {
+        int tz, ty, tx;
+        mgc_tile_coords(L, tile, tz, ty, tx);
+        const bool owned = mgc_owned(L, tile);
+        if (t == 0) mixed = 0;
+        __syncthreads();
+        const int side = tsum ? (int)tsum[tile] : 2;
+        if (t < 27 && owned) { /* is any of the 27 tiles around (and including) this one not wholly on `side`? */
+            const int nz = tz + t / 9 - 1, ny = ty + (t / 3) % 3 - 1, nx = tx + t % 3 - 1;
+            if (side > 1) mixed = 1;
+            else if (nz >= 0 && nz < L.gz && ny >= 0 && ny < L.gy && nx >= 0 && nx < L.gx) {
+                const int nt = mgc_tile_id(L, nz, ny, nx);
+                if (!mgc_owned(L, nt) || (int)tsum[nt] != side) mixed = 1;
+            }
+        }
+        __syncthreads();
+        const bool general = mixed != 0; /* (uniform) */
+        const int lz = t >> 6, ly = (t >> 3) & 7, lx = t & 7;
+        const int64_t gz = (int64_t)tz * 8 + lz, gy = (int64_t)ty * 8 + ly, gx = (int64_t)tx * 8 + lx;
+        double s = 0.0;
+        if (gz < L.dz && gy < L.dy && gx < L.dx && owned) {
+            const double tr = tr0[(int64_t)tile * MGC_TV + t];
+            if (!general) {
+                if (side == 1) { if (tr < 0.0) s += -tr; } /* source side: pays its sink link (no n-link leaves the 27 tiles' common side) */
+                else if (tr > 0.0) s += tr;                /* sink side: pays its source link */
+            } else {
+                const int64_t id = (gz * L.dy + gy) * L.dx + gx;
+                if (labels[id]) {
+                    if (tr < 0.0) s += -tr;
+                    for (int d = 0; d < MGC26_NDIR; ++d) {
+                        int dz, dy, dx;
+                        mgc26_offset(d, dz, dy, dx);
+                        const int64_t nz = gz + dz, ny = gy + dy, nx = gx + dx;
+                        if (nz >= 0 && nz < L.dz && ny >= 0 && ny < L.dy && nx >= 0 && nx < L.dx && !labels[(nz * L.dy + ny) * L.dx + nx])
+                            s += mgc_built_capacity(L, A, tile, t, gz, gy, gx, d);
+                    }
+                } else if (tr > 0.0) {
+                    s += tr;
+                }
+            }
+        }
         if (__syncthreads_or(s != 0.0)) {
             const double tot = mgc_block_sum(s, scratch);
             if (t == 0) part[tile] = tot;
@@ -1844,6 +2012,8 @@ struct mgc_graph {
     int est_phase_tiles = 1 << 30; /* length of the discharge lists at the last counter read-back */
     int sweeps_sparse26 = 8;       /* 26-neighbourhood: sweep budget of a discharge while fewer than 20 % of a colour's tiles are active */
     int wave_grid26 = 0;           /* persistent grid of k26_discharge_w: one wave per SIMD (it needs the whole register file) */
+    bool rounds_set = false, sparse26_set = false; /* the caller chose rounds_per_relabel / sweeps_sparse26 (mgc_set_param): no automatic choice */
+    int prepush = 1;               /* k_build (26-neighbourhood): settle source -> u -> v -> sink paths inside a tile while its weights are in registers (parameter prepush) */
     int w26_passes = 2, w26_raises = 1, w26_flags = 0; /* k26_discharge_w: passes over the steps / relabel rounds per sweep, MGCW26_* flags */
     int activate_exact_max = 4096; /* activation looks at the voxels of its candidate tiles only when there are at most this many (mgcw_activate_tile) */
     int wave_stagger = 0;          /* development knob of k_discharge_w (see there) */
@@ -2072,7 +2242,10 @@ struct HipDevT {
     void activate_all(uint32_t phase)
     {
         flush_zero();
-        if constexpr (FULL) hipLaunchKernelGGL(k26_activate, dim3(grid(h->L.ntiles)), dim3(MGC_TV), 0, h->stream, h->L, phase);
+        if constexpr (FULL) {
+            if (h->L.nshard == 1 && (h->use_filters & 2)) hipLaunchKernelGGL(k26_activate_w, dim3(grid((h->L.ntiles + 3) / 4)), dim3(256), 0, h->stream, h->L, phase);
+            else hipLaunchKernelGGL(k26_activate, dim3(grid(h->L.ntiles)), dim3(MGC_TV), 0, h->stream, h->L, phase);
+        }
         else if (!(h->use_filters & 2)) hipLaunchKernelGGL(k_activate, dim3(grid(h->L.ntiles)), dim3(MGC_TV), 0, h->stream, h->L, phase);
         else {
             /* only tiles whose status says "holds excess" are examined voxel by voxel */
@@ -2256,6 +2429,7 @@ static int mgc_launch_readout(mgc_handle h, int slot, hipEvent_t after_labels)
         hipLaunchKernelGGL(k_cut_value6, dim3(grid), dim3(MGC_TV), 0, h->stream, L, h->build_args, (const double*)h->d_tr0, 6, dev.fslot(0), h->d_part, dev.fnext(0));
         dev.filter_done(0, true);
     }
+    else if (L.ndir == MGC26_NDIR) hipLaunchKernelGGL(k_cut_value26, dim3(grid), dim3(MGC_TV), 0, h->stream, L, h->build_args, (const double*)h->d_tr0, (const uint8_t*)h->d_labels, rows8 ? (const uint8_t*)h->d_tsum : (const uint8_t*)nullptr, h->d_part);
     else hipLaunchKernelGGL(k_cut_value, dim3(grid), dim3(MGC_TV), 0, h->stream, L, h->build_args, (const double*)h->d_tr0, (const uint8_t*)h->d_labels, h->d_part);
     MGC_HIP(h, hipGetLastError());
     mgc_sum_partials(h, (int64_t)L.ntiles, h->d_scalar + slot);
@@ -3074,6 +3248,7 @@ int mgc_build(mgc_handle h)
         A.div26[d] = sqrt(acc);
     }
     A.prob = h->d_prob; A.prob_dtype = h->prob_dtype; A.alpha = h->alpha;
+    A.prepush = h->prepush;
     A.fg = h->d_fg; A.bg = h->d_bg; A.tr_in = h->d_tr_in;
     A.tr0 = h->d_tr0; A.fpart = h->d_part; A.tflags = h->d_tflags;
     if (h->n_edges && !L.cap0) { /* explicit edges change capacities that the image no longer determines */
@@ -3151,7 +3326,19 @@ int mgc_maxflow(mgc_handle h, double* flow)
         if (L.ndir == 6) {
             rc = mgc_solve(dev, L, h->params, st);
         } else {
-            rc = mgc_solve(dev26, L, h->params, st, mgc_layout26());
+            /* A graph whose source -> u -> v -> sink paths k_build settled (regional term + pre-push) starts with a sixth of its tiles
+             * active and most of their excess enclosed: it pays to look at the labels again after three colour rounds instead of six,
+             * and the long visits of sparse phases (sweeps_sparse26) only shuffle excess that the next relabel declares dead.  Measured
+             * at 512^3 (BASELINE config 3, profiles/r4_prepush_schedule.jsonl): 107.9 ms with the general defaults, 51.6 ms with these.
+             * Only where the caller set neither knob. */
+            MgcSolveParams P = h->params;
+            const int sparse_before = h->sweeps_sparse26;
+            if (h->prepush && h->d_prob) {
+                if (!h->rounds_set) P.rounds_per_relabel = 3;
+                if (!h->sparse26_set) h->sweeps_sparse26 = P.max_sweeps;
+            }
+            rc = mgc_solve(dev26, L, P, st, mgc_layout26());
+            h->sweeps_sparse26 = sparse_before;
             dev.first_error = dev26.first_error;
             dev.spans.clear();
             for (const auto& sp : dev26.spans) dev.spans.push_back({sp.a, sp.b, sp.kind});
@@ -3354,7 +3541,7 @@ int mgc_get_node_num(mgc_handle h, int64_t* n)
 int mgc_set_param(mgc_handle h, const char* name, int64_t value)
 {
     if (!h || !name) return MGC_ERR_INVALID;
-    if (!strcmp(name, "rounds_per_relabel") && value > 0) h->params.rounds_per_relabel = (int)value;
+    if (!strcmp(name, "rounds_per_relabel") && value > 0) { h->params.rounds_per_relabel = (int)value; h->rounds_set = true; }
     else if (!strcmp(name, "max_cycles") && value != 0) h->params.max_cycles = (int)value; /* < 0 (26-neighbourhood): stored labels, no in-tile BFS */
     else if (!strcmp(name, "max_sweeps") && value > 0) h->params.max_sweeps = (int)value;
     else if (!strcmp(name, "max_outer") && value > 0) h->params.max_outer = (int)value;
@@ -3368,9 +3555,10 @@ int mgc_set_param(mgc_handle h, const char* name, int64_t value)
     else if (!strcmp(name, "use_filters")) h->use_filters = (int)value;
     else if (!strcmp(name, "wave_kernels")) h->wave_kernels = (int)value;
     else if (!strcmp(name, "wave_min_tiles") && value >= 0) h->wave_min_tiles = (int)value;
-    else if (!strcmp(name, "sweeps_sparse26") && value >= 0) h->sweeps_sparse26 = (int)value;
+    else if (!strcmp(name, "sweeps_sparse26") && value >= 0) { h->sweeps_sparse26 = (int)value; h->sparse26_set = true; }
     else if (!strcmp(name, "wave_grid_dis") && value > 0) h->wave_grid_dis = (int)value;
     else if (!strcmp(name, "wave_grid26") && value > 0) h->wave_grid26 = (int)value;
+    else if (!strcmp(name, "prepush")) h->prepush = value != 0;
     else if (!strcmp(name, "w26_passes") && value > 0) h->w26_passes = (int)value;
     else if (!strcmp(name, "w26_raises") && value > 0) h->w26_raises = (int)value;
     else if (!strcmp(name, "w26_flags") && value >= 0) h->w26_flags = (int)value;

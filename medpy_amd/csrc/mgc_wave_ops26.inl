@@ -162,45 +162,92 @@ MGC_HD void mgcw26_discharge_tile(W& w, const MgcLattice& L, int tile, uint32_t 
     {
         typename W::template Reg<int, 8> hv, hi;
         w.lanes([&](int l) MGCW_INL {
-            mgcw_static_for<8>([&](auto BB) MGCW_INL {
+            mgcw_static_for<8>([&](auto BB) MGCW_INL { /* (branch-free: a label outside the grid is MGC_HINF by a select, not by a skipped load) */
                 constexpr int B = decltype(BB)::value;
                 int nt, loc;
                 hi(l, B) = mgcw26_halo_cell(L, tz, ty, tx, B, l, nt, loc);
-                hv(l, B) = MGC_HINF;
-                if (hi(l, B) >= 0 && nt >= 0) hv(l, B) = L.height[(int64_t)nt * MGC_TV + loc];
+                const int v = L.height[(int64_t)(nt >= 0 ? nt : tile) * MGC_TV + loc];
+                hv(l, B) = (hi(l, B) >= 0 && nt >= 0) ? v : MGC_HINF;
             });
+            /* (1) what goes to LDS: masks, labels, sink links, the residual planes that live there -- loaded into temporaries,
+             * stored to LDS behind the loads of (2) */
+            typename W::template Reg<int, 8> tm, th;
+            typename W::template Reg<double, 8> ts, tp[MGCW26_NLDS > 0 ? MGCW26_NLDS : 1];
+            mgcw_static_for<8>([&](auto KK) MGCW_INL {
+                constexpr int K = decltype(KK)::value;
+                tm(l, K) = (int)w.ld(t_rmask, K * 64 + l);
+                th(l, K) = w.ld(t_height, K * 64 + l);
+                ts(l, K) = 0.0;
+                mgcw_static_for<MGC26_NDIR>([&](auto DD) MGCW_INL {
+                    constexpr int D = decltype(DD)::value;
+                    if constexpr (mgcw26_plane_home(D) == 2) tp[mgcw26_lds_plane(D)](l, K) = w.ld(t_rcap + D * MGC_TV, K * 64 + l);
+                });
+            });
+            if (SINK) mgcw_static_for<8>([&](auto KK) MGCW_INL { constexpr int K = decltype(KK)::value; ts(l, K) = w.ld(t_sink, K * 64 + l); });
+            /* (2) excess and the planes in ordinary registers: straight into their registers */
             mgcw_static_for<8>([&](auto KK) MGCW_INL {
                 constexpr int K = decltype(KK)::value;
                 e(l, K) = w.ld(t_excess, K * 64 + l);
-            });
-            mgcw_static_for<MGC26_NDIR>([&](auto DD) MGCW_INL { /* plane by plane, a few planes per batch: the loads land in ordinary
-                                                                    registers, and there are 256 of those for 416 values */
-                constexpr int D = decltype(DD)::value;
-                mgcw_static_for<8>([&](auto KK) MGCW_INL {
-                    constexpr int K = decltype(KK)::value;
-                    RINIT(DD, KK, l, w.ld(t_rcap + D * MGC_TV, K * 64 + l));
-                });
-                if constexpr (D % 6 == 5) w.load_batch_end();
-            });
-            /* the values are in their registers HERE (the optimiser sinks a load to its first use otherwise: into the steps) */
-            mgcw_static_for<8>([&](auto KK) MGCW_INL {
-                constexpr int K = decltype(KK)::value;
-                w.pin(e(l, K));
                 mgcw_static_for<MGC26_NDIR>([&](auto DD) MGCW_INL {
                     constexpr int D = decltype(DD)::value;
-                    if constexpr (mgcw26_plane_home(D) == 0) w.pin(r[D](l, K));
+                    if constexpr (mgcw26_plane_home(D) == 0) RINIT(DD, KK, l, w.ld(t_rcap + D * MGC_TV, K * 64 + l));
                 });
             });
             mgcw_static_for<8>([&](auto KK) MGCW_INL {
                 constexpr int K = decltype(KK)::value;
-                w.S.m[K * 64 + l] = w.ld(t_rmask, K * 64 + l);
-                w.S.hs[mgcw_hs(l, K)] = w.ld(t_height, K * 64 + l);
-                w.S.snk[K * 64 + l] = SINK ? w.ld(t_sink, K * 64 + l) : 0.0;
+                w.S.m[K * 64 + l] = (uint32_t)tm(l, K);
+                w.S.hs[mgcw_hs(l, K)] = th(l, K);
+                w.S.snk[K * 64 + l] = ts(l, K);
+                mgcw_static_for<MGC26_NDIR>([&](auto DD) MGCW_INL {
+                    constexpr int D = decltype(DD)::value;
+                    if constexpr (mgcw26_plane_home(D) == 2) RINIT(DD, KK, l, tp[mgcw26_lds_plane(D)](l, K));
+                });
             });
             mgcw_static_for<8>([&](auto BB) MGCW_INL {
                 constexpr int B = decltype(BB)::value;
                 if (hi(l, B) >= 0) w.S.hs[hi(l, B)] = hv(l, B);
             });
+            /* (3) the planes in accumulator registers: a load lands in an ordinary register and is moved; the moves are volatile
+             * statements no load crosses, so the loads of a batch are WRITTEN before the moves of the batch before it -- two
+             * planes per batch, two batches in flight.  (A load followed by its move, plane by plane, was one trip to HBM per
+             * value: 140 k cycles per tile.) */
+            {
+                typename W::template Reg<double, 16> tb[2];
+                auto plane_of = [](int i) constexpr -> int { return i < 7 ? 5 + i : 14 + (i - 7); }; /* the 15 planes at home 1 */
+                auto issue = [&](auto BB) MGCW_INL {
+                    constexpr int B = decltype(BB)::value;
+                    mgcw_static_for<2>([&](auto JJ) MGCW_INL {
+                        constexpr int J = decltype(JJ)::value, I = 2 * B + J;
+                        if constexpr (I < 15) {
+                            constexpr int D = plane_of(I);
+                            static_assert(mgcw26_plane_home(D) == 1, "plane_of lists the accumulator planes");
+                            mgcw_static_for<8>([&](auto KK) MGCW_INL {
+                                constexpr int K = decltype(KK)::value;
+                                tb[B & 1](l, J * 8 + K) = w.ld(t_rcap + D * MGC_TV, K * 64 + l);
+                            });
+                        }
+                    });
+                };
+                auto commit = [&](auto BB) MGCW_INL {
+                    constexpr int B = decltype(BB)::value;
+                    mgcw_static_for<2>([&](auto JJ) MGCW_INL {
+                        constexpr int J = decltype(JJ)::value, I = 2 * B + J;
+                        if constexpr (I < 15) {
+                            constexpr int D = plane_of(I);
+                            mgcw_static_for<8>([&](auto KK) MGCW_INL {
+                                constexpr int K = decltype(KK)::value;
+                                ra[D].init(l, K, tb[B & 1](l, J * 8 + K));
+                            });
+                        }
+                    });
+                };
+                issue(std::integral_constant<int, 0>{});
+                mgcw_static_for<8>([&](auto BB) MGCW_INL {
+                    constexpr int B = decltype(BB)::value;
+                    if constexpr (B + 1 < 8) issue(std::integral_constant<int, B + 1>{});
+                    commit(BB);
+                });
+            }
             satl(l, 0) = 0;
             nbm(l, 0) = 0;
             cmv(l, 0) = 0;
@@ -266,6 +313,7 @@ MGC_HD void mgcw26_discharge_tile(W& w, const MgcLattice& L, int tile, uint32_t 
             w.lanes([&](int l) MGCW_INL { w.S.out[D][l] = outv(l, 0); });
             OUT |= 1u << D;
         }
+        w.mark(5); /* one step */
     };
     auto slot = [&](auto KK) MGCW_INL {
         constexpr int K = decltype(KK)::value;
@@ -371,10 +419,11 @@ MGC_HD void mgcw26_discharge_tile(W& w, const MgcLattice& L, int tile, uint32_t 
                         }
                     });
                 }
+                w.mark(6); /* a slot's flush (and the votes between its last step and here) */
             });
             if (!moved) break;
         }
-        w.mark(2); /* steps + flush */
+        w.mark(2); /* (the rest of the passes over the steps) */
 
         /* ---- pass R, the local relabel: a voxel that still holds excess rises to 1 + the lowest label behind a residual arc
          * (no change while one of them is still admissible).  Slot by slot; inside a slot all lanes read before any writes ---- */

@@ -24,7 +24,9 @@ st = g.stats(); pr = g.profile()
 names = {"s7": "between two tiles: ticket, list entry        (mark 7)",
          "load": "halo + state loaded, LDS staged              (mark 0)",
          "labels": "pass A: push masks from the labels           (mark 1)",
-         "sweep": "steps + flush of what left the tile          (mark 2)",
+         "faceflags": "one (slot, direction) step that ran          (mark 5)",
+         "s6": "a slot's flush + skipped steps behind it     (mark 6)",
+         "sweep": "rest of the passes over the steps            (mark 2)",
          "store": "pass R: local relabel                        (mark 3)",
          "votes": "tail: wake-ups, write-back                   (mark 4)"}
 tot = sum(pr[k]["cycles"] for k in names)
