@@ -1539,43 +1539,47 @@ __global__ __launch_bounds__(MGC_TV) void k_cut_value(MgcLattice L, MgcBuildArgs
     }
 }
 
-/* 26-neighbourhood form of k_cut_value.  With a regional term EVERY voxel pays a t-link, so no tile can be skipped; but only the
- * tiles the cut passes through pay n-links.  A tile whose label summary (tsum, k_labels8) says "all on one side" and whose 26
- * neighbour tiles say the same pays t-links only: one coalesced read of the merged t-links and the block sum -- no label volume,
- * no 26 byte loads per voxel.  Every other tile takes the general path.  Same additions in the same order as k_cut_value. */
-__global__ __launch_bounds__(MGC_TV) void k_cut_value26(MgcLattice L, MgcBuildArgs A, const double* tr0, const uint8_t* labels, const uint8_t* tsum, double* part)
+/* 26-neighbourhood form of k_cut_value, one WAVE per tile (four tiles per workgroup, no barrier).  With a regional term EVERY
+ * voxel pays a t-link, so no tile can be skipped; but only the tiles the cut passes through pay n-links.  A tile whose label
+ * summary (tsum, k_labels8) says "all on one side" and whose 26 neighbour tiles say the same pays t-links only: one coalesced
+ * read of the merged t-links -- no label volume, no 26 byte loads per voxel.  Every other tile takes the general path.
+ * The sum of a tile has a fixed order (a lane adds its eight voxels in z order, then a shuffle tree over the lanes); the
+ * workgroup form spent its time in ten barriers per tile behind one dependent load (2.1 ms at 512^3). */
+__global__ __launch_bounds__(256) void k_cut_value26(MgcLattice L, MgcBuildArgs A, const double* tr0, const uint8_t* labels, const uint8_t* tsum, double* part)
 {
-    __shared__ double scratch[MGC_TV];
-    __shared__ int mixed;
-    const int t = threadIdx.x;
-    for (int tile = blockIdx.x; tile < L.ntiles; tile += gridDim.x) {
+    const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+    for (int tile = (int)blockIdx.x * 4 + wv; tile < L.ntiles; tile += (int)gridDim.x * 4) {
         int tz, ty, tx;
         mgc_tile_coords(L, tile, tz, ty, tx);
-        const bool owned = mgc_owned(L, tile);
-        if (t == 0) mixed = 0;
-        __syncthreads();
+        if (!mgc_owned(L, tile)) { /* (wave-uniform) */
+            if (lane == 0) part[tile] = 0.0;
+            continue;
+        }
         const int side = tsum ? (int)tsum[tile] : 2;
-        if (t < 27 && owned) { /* is any of the 27 tiles around (and including) this one not wholly on `side`? */
-            const int nz = tz + t / 9 - 1, ny = ty + (t / 3) % 3 - 1, nx = tx + t % 3 - 1;
-            if (side > 1) mixed = 1;
-            else if (nz >= 0 && nz < L.gz && ny >= 0 && ny < L.gy && nx >= 0 && nx < L.gx) {
+        bool differs = side > 1; /* is any of the 27 tiles around (and including) this one not wholly on `side`? */
+        if (lane < 27 && !differs) {
+            const int nz = tz + lane / 9 - 1, ny = ty + (lane / 3) % 3 - 1, nx = tx + lane % 3 - 1;
+            if (nz >= 0 && nz < L.gz && ny >= 0 && ny < L.gy && nx >= 0 && nx < L.gx) {
                 const int nt = mgc_tile_id(L, nz, ny, nx);
-                if (!mgc_owned(L, nt) || (int)tsum[nt] != side) mixed = 1;
+                differs = !mgc_owned(L, nt) || (int)tsum[nt] != side;
             }
         }
-        __syncthreads();
-        const bool general = mixed != 0; /* (uniform) */
-        const int lz = t >> 6, ly = (t >> 3) & 7, lx = t & 7;
-        const int64_t gz = (int64_t)tz * 8 + lz, gy = (int64_t)ty * 8 + ly, gx = (int64_t)tx * 8 + lx;
+        const bool general = __ballot(differs) != 0ull;
+        const int ly = lane >> 3, lx = lane & 7;
+        const int64_t gy = (int64_t)ty * 8 + ly, gx = (int64_t)tx * 8 + lx;
         double s = 0.0;
-        if (gz < L.dz && gy < L.dy && gx < L.dx && owned) {
+#pragma unroll
+        for (int lz = 0; lz < 8; ++lz) {
+            const int64_t gz = (int64_t)tz * 8 + lz;
+            const int t = lz * 64 + lane;
+            if (!(gz < L.dz && gy < L.dy && gx < L.dx)) continue;
             const double tr = tr0[(int64_t)tile * MGC_TV + t];
             if (!general) {
                 if (side == 1) { if (tr < 0.0) s += -tr; } /* source side: pays its sink link (no n-link leaves the 27 tiles' common side) */
                 else if (tr > 0.0) s += tr;                /* sink side: pays its source link */
             } else {
                 const int64_t id = (gz * L.dy + gy) * L.dx + gx;
-                if (labels[id]) {
+                if (labels[id]) { /* source side: pays its sink link and every n-link into T */
                     if (tr < 0.0) s += -tr;
                     for (int d = 0; d < MGC26_NDIR; ++d) {
                         int dz, dy, dx;
@@ -1584,18 +1588,14 @@ __global__ __launch_bounds__(MGC_TV) void k_cut_value26(MgcLattice L, MgcBuildAr
                         if (nz >= 0 && nz < L.dz && ny >= 0 && ny < L.dy && nx >= 0 && nx < L.dx && !labels[(nz * L.dy + ny) * L.dx + nx])
                             s += mgc_built_capacity(L, A, tile, t, gz, gy, gx, d);
                     }
-                } else if (tr > 0.0) {
+                } else if (tr > 0.0) { /* sink side: pays its source link */
                     s += tr;
                 }
             }
         }
-        if (__syncthreads_or(s != 0.0)) {
-            const double tot = mgc_block_sum(s, scratch);
-            if (t == 0) part[tile] = tot;
-            __syncthreads();
-        } else if (t == 0) {
-            part[tile] = 0.0;
-        }
+#pragma unroll
+        for (int off = 32; off > 0; off >>= 1) s += __shfl_down(s, off, 64);
+        if (lane == 0) part[tile] = s;
     }
 }
 
@@ -2429,7 +2429,7 @@ static int mgc_launch_readout(mgc_handle h, int slot, hipEvent_t after_labels)
         hipLaunchKernelGGL(k_cut_value6, dim3(grid), dim3(MGC_TV), 0, h->stream, L, h->build_args, (const double*)h->d_tr0, 6, dev.fslot(0), h->d_part, dev.fnext(0));
         dev.filter_done(0, true);
     }
-    else if (L.ndir == MGC26_NDIR) hipLaunchKernelGGL(k_cut_value26, dim3(grid), dim3(MGC_TV), 0, h->stream, L, h->build_args, (const double*)h->d_tr0, (const uint8_t*)h->d_labels, rows8 ? (const uint8_t*)h->d_tsum : (const uint8_t*)nullptr, h->d_part);
+    else if (L.ndir == MGC26_NDIR) hipLaunchKernelGGL(k_cut_value26, dim3((grid + 3) / 4 < 8192 ? (grid + 3) / 4 : 8192), dim3(256), 0, h->stream, L, h->build_args, (const double*)h->d_tr0, (const uint8_t*)h->d_labels, rows8 ? (const uint8_t*)h->d_tsum : (const uint8_t*)nullptr, h->d_part);
     else hipLaunchKernelGGL(k_cut_value, dim3(grid), dim3(MGC_TV), 0, h->stream, L, h->build_args, (const double*)h->d_tr0, (const uint8_t*)h->d_labels, h->d_part);
     MGC_HIP(h, hipGetLastError());
     mgc_sum_partials(h, (int64_t)L.ntiles, h->d_scalar + slot);

@@ -30,7 +30,7 @@ def graphcut_stawiaski(regions, gradient=False, foreground=False, background=Fal
     Contract: reference medpy/graphcut/wrapper.py:239-310 (incl. ``ArgumentError`` for differing shapes)."""
     from .energy_label import boundary_stawiaski
     from .generate import graph_from_labels
-    if (gradient, foreground, background) == (False, False, False):
+    if all(arg is False for arg in (gradient, foreground, background)):  # the one-argument form
         regions, gradient, foreground, background = regions
     regions, gradient = numpy.asarray(regions), numpy.asarray(gradient)
     masks = [numpy.asarray(m, dtype=numpy.bool_) for m in (foreground, background)]

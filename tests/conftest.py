@@ -73,6 +73,7 @@ def _build_oracle():
 _FORMS_MODULES = ("test_gpu_parity", "test_gpu_edge_cases", "test_gpu_slabs", "test_gpu_full_neighbourhood")
 LARGE_VOLUME_FORMS = "wave_min_tiles=0,activate_exact_max=0,wave_kernels=25,exact_sink_tiles=2"
 STORED_LABEL_FORMS = "wave_min_tiles=0,exact_sink_tiles=0"  # the wave discharge without the exact labelling of tiles that hold a sink link
+WAVE26_FORMS = "wave_kernels=41,prepush=0"  # 26-neighbourhood: the one-wave-per-tile discharge (k26_discharge_w), graph as built (no pre-push)
 
 
 def pytest_generate_tests(metafunc):
@@ -80,6 +81,8 @@ def pytest_generate_tests(metafunc):
         forms = ["as_shipped", "large_volume_forms"]
         if metafunc.module.__name__.rsplit(".", 1)[-1] == "test_gpu_parity":
             forms.append("stored_label_forms")
+        if metafunc.module.__name__.rsplit(".", 1)[-1] == "test_gpu_full_neighbourhood":
+            forms.append("wave26_forms")
         metafunc.parametrize("kernel_forms", forms, indirect=True)
 
 
@@ -90,6 +93,8 @@ def kernel_forms(request, monkeypatch):
         monkeypatch.setenv("MEDPY_HIP_PARAMS", LARGE_VOLUME_FORMS)
     elif mode == "stored_label_forms":
         monkeypatch.setenv("MEDPY_HIP_PARAMS", STORED_LABEL_FORMS)
+    elif mode == "wave26_forms":
+        monkeypatch.setenv("MEDPY_HIP_PARAMS", WAVE26_FORMS)
     return mode
 
 
