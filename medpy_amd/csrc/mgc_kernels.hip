@@ -2012,6 +2012,7 @@ struct mgc_graph {
     int est_phase_tiles = 1 << 30; /* length of the discharge lists at the last counter read-back */
     int sweeps_sparse26 = 8;       /* 26-neighbourhood: sweep budget of a discharge while fewer than 20 % of a colour's tiles are active */
     int wave_grid26 = 0;           /* persistent grid of k26_discharge_w: one wave per SIMD (it needs the whole register file) */
+    int relabel_exchange_every = 4; /* slabs: relabel passes between two exchanges of the border labels (0: iterate to the local fixpoint first, round 3's schedule) */
     bool rounds_set = false, sparse26_set = false; /* the caller chose rounds_per_relabel / sweeps_sparse26 (mgc_set_param): no automatic choice */
     int prepush = 1;               /* k_build (26-neighbourhood): settle source -> u -> v -> sink paths inside a tile while its weights are in registers (parameter prepush) */
     int w26_passes = 2, w26_raises = 1, w26_flags = 0; /* k26_discharge_w: passes over the steps / relabel rounds per sweep, MGCW26_* flags */
@@ -2178,7 +2179,9 @@ struct HipDevT {
      * passes would leave them (mgc_dt_ops.inl).  false: not applicable to this graph, run the passes. */
     bool first_relabel_dt()
     {
-        if (FULL || !h->use_dt || !h->all_residual) return false;
+        /* only on a graph as built: a solve that runs again on its own residual graph (after MGC_ERR_NOT_CONVERGED, without a rebuild) has
+         * saturated arcs, and all_residual is what k_build counted (labels_valid: some solve of this build filled the labels already) */
+        if (FULL || !h->use_dt || !h->all_residual || h->labels_valid) return false;
         if (!h->d_dt16) {
             if (hipMalloc((void**)&h->d_dt16, (size_t)h->L.ntiles * MGC_TV * sizeof(uint16_t)) != hipSuccess) { (void)hipGetLastError(); return false; }
             h->device_bytes += (int64_t)h->L.ntiles * MGC_TV * (int64_t)sizeof(uint16_t);
@@ -2897,6 +2900,31 @@ static int mgc_solve_slab_on(mgc_handle h, const MgcLayout lay, mgc_slab_stats* 
             dev.reset_suspect(rep + 1, nxt);
         }
         st.relabel_passes++;
+        if (h->relabel_exchange_every > 0) {
+            /* The label wave of a global relabel has to cross every slab border on its way through the volume.  Border labels
+             * therefore travel every `xk` passes, whether or not this slab has reached its local fixpoint: labels only go down
+             * during a relabel, so a ghost label is an upper bound whenever it is read, and a wave that reaches a border is on the
+             * other side at most xk passes later.  (Round 3 iterated every slab to its LOCAL fixpoint between two exchanges:
+             * eight slabs of a 2048 x 1024 x 1024 volume needed 6 280 passes where one handle needs 1 483,
+             * profiles/r4_slab_scaling_one_gpu.jsonl.)  Every rank runs the same number of passes (a pass over an empty list is a
+             * ~4 us no-op) and the ranks compare notes every second exchange. */
+            const int xk = h->relabel_exchange_every + (h->relabel_exchange_every & 1); /* even: every rank keeps the same list parity */
+            for (int round = 0;; ++round) {
+                for (int b = 0; b < xk; ++b) {
+                    rep++;
+                    const int cur = rl + (int)(rep & 1u);
+                    nxt = rl + (int)((rep + 1) & 1u);
+                    dev.zero_count(nxt);
+                    dev.relabel_list(cur, rep + 1, nxt, -1);
+                    st.relabel_passes++;
+                }
+                if (round % 2 == 0) dev.zero_count(MGC_CNT_DEFERRED); /* (counts what the exchanges since the last look left behind) */
+                MGC_SLAB_TRY(exchange(0, rep + 1, nxt));
+                if (round % 2 == 0) continue;
+                MGC_SLAB_TRY(reduce());
+                if (g[nxt] == 0 && g[MGC_CNT_DEFERRED] == 0) break; /* nobody is queued anywhere, nothing was left behind: global fixpoint */
+            }
+        } else
         for (;;) {
             for (;;) { /* passes to the LOCAL fixpoint: no collective (labels only go down, stale ghost labels are upper bounds) */
                 dev.read_counts(cnt);
@@ -3291,6 +3319,9 @@ int mgc_build(mgc_handle h)
     /* every n-link of the volume residual (and nothing added on top that the mask refresh could have changed): the first
      * global relabel of the solve is a distance transform (mgc_dt_ops.inl) */
     h->sink_tiles = L.ndir == 6 ? h->h_count[MGC_CNT_SINK_TILES] : 0;
+    /* the two build counters are read: their slots (MGC_CNT_NOT_FULL is MGC_CNT_DEFERRED during a solve) are cleared with the next
+     * batch of counter clears, whichever schedule drives the solve */
+    h->zero_mask |= (1u << MGC_CNT_NOT_FULL) | (1u << MGC_CNT_SINK_TILES);
     h->all_residual = L.ndir == 6 && A.term != MGC_TERM_NONE && h->h_count[MGC_CNT_NOT_FULL] == 0 && !h->n_edges && h->nranks == 1 &&
                       L.dz + L.dy + L.dx < MGC_DT_INF - 8;
     float ms = 0.f;
@@ -3559,6 +3590,7 @@ int mgc_set_param(mgc_handle h, const char* name, int64_t value)
     else if (!strcmp(name, "wave_grid_dis") && value > 0) h->wave_grid_dis = (int)value;
     else if (!strcmp(name, "wave_grid26") && value > 0) h->wave_grid26 = (int)value;
     else if (!strcmp(name, "prepush")) h->prepush = value != 0;
+    else if (!strcmp(name, "relabel_exchange_every") && value >= 0) h->relabel_exchange_every = (int)value;
     else if (!strcmp(name, "w26_passes") && value > 0) h->w26_passes = (int)value;
     else if (!strcmp(name, "w26_raises") && value > 0) h->w26_raises = (int)value;
     else if (!strcmp(name, "w26_flags") && value >= 0) h->w26_flags = (int)value;

@@ -655,8 +655,12 @@ MGC_HD void mgc_reset_suspect_tile(X& x, const MgcLattice& L, int tile, uint32_t
  *     kind 0 (relabel passes):   record = int32 label[64]                                   (256 B)
  *     kind 1 (discharge phases): record = double flow[64] ; int32 label[64] ; int32 flag ; pad (784 B)
  *     kind 2 (suspect closure of an incremental relabel): int32 status[T]  (DIRTY | SUSPECT bits; dense, 4 B per tile)
- * The transport moves the header, then `count` records (mgc_halo_exchange).  The sender zeroes `count`
- * before packing.  (Dense, every exchange moved 772 B per border tile: 12.6 MB per side at 1024 x 1024.)
+ * A message is BOUNDED: the header plus L.halo_max_rec record slots, moved in ONE transfer whose size both sides know without
+ * asking the device (mgc_halo_exchange).  A border tile that finds the message full keeps what it has to say -- its shadow
+ * stays behind, its flow stays in the outbox -- gets slot1 = 0, counts in MGC_CNT_DEFERRED and goes out with the next
+ * exchange; the schedules do not take "nothing woke up" for a fixpoint, nor start a global relabel, while that counter is
+ * non-zero.  `count` is the number of tiles that WANTED a slot (it can exceed halo_max_rec; readers use slot1, not count).  The
+ * sender zeroes `count` before packing.  (Dense, every exchange moved 772 B per border tile: 12.6 MB per side at 1024 x 1024.)
  * ------------------------------------------------------------------------------------- */
 MGC_HD int64_t mgc_halo_off_count(const MgcLattice& L) { return (int64_t)L.gy * L.gx * 4; }
 MGC_HD int64_t mgc_halo_off_rec(const MgcLattice& L) { return (mgc_halo_off_count(L) + 4 + 15) / 16 * 16; }

@@ -183,8 +183,8 @@ def sync_image_range(slabs, ex):
         s.set_image_range(-g[0], g[1], g[2])
 
 
-def solve_slabs(slabs, ex, rounds_per_relabel=8, max_cycles=None, max_sweeps=None, max_outer=100000, check_rounds=4, relabel_batch=8,
-                incremental_relabel=True):
+def solve_slabs(slabs, ex, rounds_per_relabel=None, max_cycles=None, max_sweeps=None, max_outer=100000, check_rounds=4, relabel_batch=8,
+                incremental_relabel=True, exchange_every=4):
     """Drives the local slabs to a maximum preflow.  Returns a stats dict (global numbers).
 
     Every loop decision that involves the other ranks is taken on globally summed counters, so all ranks run the same
@@ -196,12 +196,15 @@ def solve_slabs(slabs, ex, rounds_per_relabel=8, max_cycles=None, max_sweeps=Non
     tiles travel as halo kind 2 until the suspect closure is stable everywhere."""
     if getattr(ex, "native", False) and len(slabs) == 1 and hasattr(slabs[0], "solve_native"):
         # the library's own transport: the schedule below runs inside libmedpyhip (mgc_solve_slab), no call per kernel from here
+        # None = the library's default for the slab's neighbourhood (rounds_per_relabel: 8 / 6)
         for name, value in (("rounds_per_relabel", rounds_per_relabel), ("max_cycles", max_cycles), ("max_sweeps", max_sweeps),
                             ("max_outer", max_outer), ("check_rounds", check_rounds), ("relabel_batch", relabel_batch),
-                            ("incremental_relabel", int(bool(incremental_relabel)))):
-            if value is not None and not (name == "rounds_per_relabel" and value == 8 and getattr(slabs[0], "ndir", 6) == 26):
+                            ("incremental_relabel", int(bool(incremental_relabel))), ("relabel_exchange_every", exchange_every)):
+            if value is not None:
                 slabs[0].set_param(name, value)
-        return slabs[0].solve_native()
+        return slabs[0].solve_native()  # (converged == 0 in the stats when max_outer ran out, as the Python schedule reports it)
+    if rounds_per_relabel is None:
+        rounds_per_relabel = 6 if getattr(slabs[0], "ndir", 6) == 26 else 8
     relabel_batch = max(2, relabel_batch + (relabel_batch & 1))  # even: every rank keeps the same list parity
     # where the solver variant keeps its lists / counters (MgcLayout, mgc_driver.inl:51-62)
     if getattr(slabs[0], "ndir", 6) == 26:
@@ -257,7 +260,31 @@ def solve_slabs(slabs, ex, rounds_per_relabel=8, max_cycles=None, max_sweeps=Non
             for s in slabs:
                 s.op(OP_RESET_SUSPECT, rep + 1, nxt)
         st["relabel_passes"] += 1
-        while True:
+        rounds_done = 0
+        while exchange_every > 0:
+            # Border labels travel every `xk` passes, whether or not a slab has reached its local fixpoint: the label wave of the
+            # relabel crosses a slab border at most xk passes after it reaches it (labels only go down during a relabel, so a ghost
+            # label is an upper bound whenever it is read).  Every rank runs the same number of passes; counters are compared
+            # every second exchange.  (mgc_solve_slab runs the same loop.)
+            xk = exchange_every + (exchange_every & 1)
+            for _b in range(xk):
+                rep += 1
+                cur, nxt = rl + (rep & 1), rl + ((rep + 1) & 1)
+                for s in slabs:
+                    s.op(OP_ZERO_COUNT, nxt)
+                    s.op(OP_RELABEL_LIST, cur, rep + 1, nxt)
+                st["relabel_passes"] += 1
+            if rounds_done % 2 == 0:
+                for s in slabs:
+                    s.op(OP_ZERO_COUNT, CNT_DEFERRED)
+            exchange(0, rep + 1, nxt)
+            rounds_done += 1
+            if rounds_done % 2 == 1:
+                continue
+            g = global_counts()
+            if g[nxt] == 0 and g[CNT_DEFERRED] == 0:
+                break
+        while exchange_every <= 0:  # round 3's schedule: every slab to its local fixpoint between two exchanges
             while any(int(s.read_counts()[nxt]) != 0 for s in slabs):  # local read-back, no collective
                 for _b in range(relabel_batch):
                     rep += 1
@@ -398,7 +425,11 @@ class HipSlab(object):
     def solve_native(self):
         """the distributed schedule inside the library (mgc_solve_slab): needs comm_init() when the volume has several slabs"""
         st = self._lib.SlabStats()
-        self._call("mgc_solve_slab", self._C.byref(st))
+        try:
+            self._call("mgc_solve_slab", self._C.byref(st))
+        except self._lib.MedpyHipError as err:
+            if err.code != self._lib.ERR_NOT_CONVERGED:
+                raise  # (the stats are filled before the library reports max_outer exhausted: converged stays 0)
         return st.as_dict()
 
     def halo_bytes(self, kind):

@@ -199,3 +199,24 @@ def test_bench_multi_gpu_code_path_at_reduced_size(flags, conn):
                                    boundary_term_args=(img, 15.0, False), **({"connectivity": 26} if conn == 26 else {}))
     assert out["config"]["flow"] == pytest.approx(g.maxflow(), rel=1e-9)
     assert out["config"]["fg_fraction"] == pytest.approx(float(g.labels().mean()), abs=1e-5)
+
+
+def test_two_slabs_give_the_single_handle_labels_at_bench_size():
+    """512 x 1024 x 1024 (the per-pair size of BASELINE config 4's family), 6-neighbourhood: the SHA-256 of the label volume two
+    slabs assemble equals that of the same volume solved on one handle -- voxel for voxel, not only flow and invariants.
+    Both fit one MI355X (46 GB each); a process per configuration (tools/gpu_slab_scaling.py)."""
+    import json
+    import os
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    recs = {}
+    for n in (1, 2):
+        res = subprocess.run([sys.executable, os.path.join(root, "tools", "gpu_slab_scaling.py"), "256", "1024", "6", str(n)],
+                             env=dict(os.environ, SLAB_TOTAL_PLANES="512"), capture_output=True, text=True, timeout=1500, cwd=root)
+        assert res.returncode == 0, (res.stdout[-2000:], res.stderr[-2000:])
+        recs[n] = json.loads([ln for ln in res.stdout.splitlines() if ln.startswith("{")][-1])
+    assert recs[1]["shape"] == recs[2]["shape"] == [512, 1024, 1024]
+    assert recs[2]["converged"] == 1
+    assert recs[2]["labels_sha256"] == recs[1]["labels_sha256"]
+    assert recs[2]["flow"] == pytest.approx(recs[1]["flow"], rel=1e-12)
