@@ -52,12 +52,12 @@ def kernel_source_hash():
     return h.hexdigest()[:16]
 
 
-def pmc_traffic_per_launch():
+def pmc_traffic_per_launch(name="pmc_discharge.json"):
     """HBM bytes per k_discharge_w launch from the rocprofv3 PMC passes of tools/profile_round.sh (FETCH_SIZE and WRITE_SIZE in
-    separate passes over this very command; profiles/pmc_discharge.json).  Only reported when those passes ran on the kernel
+    separate passes over this very command; profiles/pmc_discharge.json; --config 3: profiles/pmc_discharge26.json, k26_discharge).  Only reported when those passes ran on the kernel
     sources of this tree (hash of medpy_amd/csrc); 8-byte-per-lane reads are not the access width FETCH_SIZE was calibrated
     for (MI355X_MICROARCH.md, HBM), so both the raw and the doubled read figure are given."""
-    path = os.path.join(ROOT, "profiles", "pmc_discharge.json")
+    path = os.path.join(ROOT, "profiles", name)
     if not os.path.exists(path):
         return None, None
     d = json.load(open(path))
@@ -389,7 +389,8 @@ def main():
             avg_ms = (acc["discharge_wave_ms"] if wave else acc["discharge_ms"]) / launches
             vox_per_launch = (acc["discharge_wave_tiles"] if wave else acc["discharge_tiles"]) * 512.0 / launches
             achieved = (b_alg * vox_per_launch) / (avg_ms * 1e-3) / 1e9 if avg_ms > 0 else 0.0
-            traffic, traffic_info = pmc_traffic_per_launch() if conn == 6 and not args.config else (None, None)
+            traffic, traffic_info = (pmc_traffic_per_launch() if conn == 6 and not args.config else
+                                     (pmc_traffic_per_launch("pmc_discharge26.json") if args.config == 3 else (None, None)))
             out["phases_ms"] = {"build": round(acc["build_ms"] / args.steps, 3), "solve": round(acc["solve_ms"] / args.steps, 3),
                                 "discharge_kernels": round(acc["discharge_ms"] / args.steps, 3),
                                 "relabel_kernels": round(acc["relabel_ms"] / args.steps, 3),

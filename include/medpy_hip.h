@@ -124,6 +124,15 @@ const char* mgc_last_error(mgc_handle h); /* h may be NULL: error of the last fa
  * spacing: ndim doubles or NULL (False). */
 int mgc_set_boundary(mgc_handle h, int term, const void* image, int dtype, double sigma, const double* spacing);
 
+/* Integer-valued images (CT, MR: uint8 / uint16 / int16, or floats that hold integers): the exponential and power terms
+ * depend on the two intensities only through d = |I_p - I_q| (difference terms) or max(|I_p|, |I_q|) (maximum terms), an
+ * integer below `n`.  table[d] = the boundary function of d as the REFERENCE evaluates it on the host -- NumPy's exp / pow,
+ * energy_voxel.py:226-236, 290-300, 444-452, 506-513, floored at sys.float_info.min -- replaces the device's own exp / pow
+ * (OCML, <= 2 ulp away): the n-link weights are then BIT-IDENTICAL to the reference's on such images.  The spacing division
+ * still happens on the device (IEEE division).  Call after mgc_set_boundary (which forgets a table set earlier); n = 0
+ * forgets it; n <= 65536; an intensity pair beyond the table falls back to the device's own evaluation. */
+int mgc_set_boundary_lut(mgc_handle h, const double* table, int64_t n);
+
 /* Replaces regional_probability_map(graph, (probability_map, alpha)) (energy_voxel.py:33-65)
  * -> set_tweights_all (graph.py:551-552).  dtype MGC_F32 or MGC_F64: products are evaluated in
  * that dtype, as NumPy does for the reference. */

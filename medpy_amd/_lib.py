@@ -103,6 +103,7 @@ SIGNATURES = {
     "mgc_destroy": (_INT, [_VP]),
     "mgc_last_error": (C.c_char_p, [_VP]),
     "mgc_set_boundary": (_INT, [_VP, _INT, _VP, _INT, _DBL, C.POINTER(_DBL)]),
+    "mgc_set_boundary_lut": (_INT, [_VP, _VP, _I64]),
     "mgc_set_regional_probability": (_INT, [_VP, _VP, _INT, _DBL]),
     "mgc_set_markers": (_INT, [_VP, _VP, _VP]),
     "mgc_add_edges": (_INT, [_VP, _I64, _VP, _VP, _VP, _VP]),

@@ -1089,6 +1089,8 @@ struct MgcBuildArgs {
     double* tr0;         /* out: merged tr_cap per voxel, tile-major */
     double* fpart;       /* out: per-tile partial of the flow constant */
     uint8_t* tflags;     /* out: per tile, bit 0: some voxel has a source link (tr0 > 0), bit 1: a sink link (tr0 < 0) -- as built */
+    const double* lut;   /* mgc_set_boundary_lut: the term by table for integer-valued images, or NULL */
+    int lut_n;
     int prepush;         /* 26-neighbourhood: settle source -> u -> v -> sink paths inside a tile while its weights are in registers (k_build_prepush26) */
 };
 
@@ -1195,7 +1197,7 @@ __device__ __forceinline__ void k_build_tiles(const MgcLattice& L, const MgcBuil
             if (TERM != MGC_TERM_NONE) {
                 auto pair_weight = [&](int axis, int lo, bool ok) -> double { /* lo = img[] index of the lower voxel; ok = both voxels exist */
                     if (!ok) return 0.0;
-                    double w = mgc_boundary_g(TERM, img[lo], img[lo + (axis == 0 ? 1 : (axis == 1 ? 10 : 100))], A.p0);
+                    double w = mgc_boundary_g(TERM, img[lo], img[lo + (axis == 0 ? 1 : (axis == 1 ? 10 : 100))], A.p0, A.lut, A.lut_n);
                     if (A.has_spacing) w = w / A.inv_axis[axis]; /* energy_voxel.py:657-658 */
                     return w;
                 };
@@ -1243,7 +1245,7 @@ __device__ __forceinline__ void k_build_tiles(const MgcLattice& L, const MgcBuil
                 double w = 0.0;
                 if (has && TERM != MGC_TERM_NONE) {
                     const double other = img[me + dz * 100 + dy * 10 + dx];
-                    w = d >= 13 ? mgc_boundary_g(TERM, mine, other, A.p0) : mgc_boundary_g(TERM, other, mine, A.p0); /* g(lower, upper) */
+                    w = d >= 13 ? mgc_boundary_g(TERM, mine, other, A.p0, A.lut, A.lut_n) : mgc_boundary_g(TERM, other, mine, A.p0, A.lut, A.lut_n); /* g(lower, upper) */
                     if (A.has_spacing) w = w / A.div26[d];
                 }
                 if (L.cap0) L.cap0[((int64_t)tile * MGC26_NDIR + d) * MGC_TV + t] = w; /* (as built) */
@@ -1484,7 +1486,7 @@ __device__ __forceinline__ double mgc_built_capacity(const MgcLattice& L, const 
     }
     const double me = mgc_load_as_double(A.image, A.img_dtype, (gz * L.dy + gy) * L.dx + gx, take_abs);
     const double nb = mgc_load_as_double(A.image, A.img_dtype, ((gz + dz) * L.dy + (gy + dy)) * L.dx + (gx + dx), take_abs);
-    double w = mgc_boundary_g(A.term, fwd ? me : nb, fwd ? nb : me, A.p0); /* (lower voxel, upper voxel) like the reference slices */
+    double w = mgc_boundary_g(A.term, fwd ? me : nb, fwd ? nb : me, A.p0, A.lut, A.lut_n); /* (lower voxel, upper voxel) like the reference slices */
     if (A.has_spacing) w = w / (L.ndir == 6 ? A.inv_axis[d >> 1] : A.div26[d]);
     return w;
 }
@@ -1961,6 +1963,7 @@ struct mgc_graph {
     void* d_image = nullptr; int img_dtype = 0; int term = MGC_TERM_NONE; double sigma = 0; double spacing[3] = {1, 1, 1};
     int has_spacing = 0;
     void* d_prob = nullptr; int prob_dtype = 0; double alpha = 0;
+    void* d_lut = nullptr; int lut_n = 0; /* mgc_set_boundary_lut: the boundary function by table (doubles) */
     uint8_t* d_fg = nullptr; uint8_t* d_bg = nullptr;
     double* d_tr_in = nullptr; double flow_const_in = 0;
     /* pending explicit edges (host copy kept until build) */
@@ -3040,7 +3043,7 @@ int mgc_destroy(mgc_handle h)
     void* ptrs[] = {L.rcap, L.cap0, L.excess, L.sink, L.height, L.rmask, L.rmask32, L.obox, L.oflags, L.list[0], L.list[1], L.list[2],
                     L.list[3], L.list[4], L.list[5], L.list[6], L.list[7], L.list[8], L.list[9], L.list[10], L.list[11], L.list[12],
                     L.list[13], L.list[14], L.list[15], L.list[16], L.list[17], L.count, L.stamp, L.rstamp, L.status, h->d_tr0, h->d_part, h->d_part2, h->d_scalar,
-                    h->d_labels, h->d_tflags, h->d_tsum, h->d_image, h->d_prob, h->d_fg, h->d_bg, h->d_tr_in, h->d_eslot, h->d_eval, h->d_erun, L.hshadow[0], L.hshadow[1], h->d_vout, h->d_dt16, h->d_halo, h->d_xchg[0], h->d_xchg[1], h->d_xchg[2], h->d_xchg[3], h->d_cnt64};
+                    h->d_labels, h->d_tflags, h->d_tsum, h->d_image, h->d_lut, h->d_prob, h->d_fg, h->d_bg, h->d_tr_in, h->d_eslot, h->d_eval, h->d_erun, L.hshadow[0], L.hshadow[1], h->d_vout, h->d_dt16, h->d_halo, h->d_xchg[0], h->d_xchg[1], h->d_xchg[2], h->d_xchg[3], h->d_cnt64};
     for (void* p : ptrs)
         if (p) (void)hipFree(p);
     if (h->h_count) (void)hipHostFree(h->h_count);
@@ -3083,6 +3086,7 @@ int mgc_set_boundary(mgc_handle h, int term, const void* image, int dtype, doubl
     if (term < MGC_TERM_NONE || term > MGC_TERM_MAXIMUM_POWER) return mgc_fail(h, MGC_ERR_INVALID, "unknown boundary term %d", term);
     MGC_HIP(h, hipSetDevice(h->device));
     h->term = term;
+    h->lut_n = 0; /* (a table belongs to one image / term / sigma) */
     h->range_set = false; /* a range handed over for the previous image does not describe this one */
     h->built = h->solved = false;
     if (term == MGC_TERM_NONE) return MGC_OK;
@@ -3096,6 +3100,23 @@ int mgc_set_boundary(mgc_handle h, int term, const void* image, int dtype, doubl
     if (spacing)
         for (int k = 0; k < h->ndim; ++k) h->spacing[3 - h->ndim + k] = spacing[k];
     return mgc_upload(h, &h->d_image, image, (size_t)h->nvox * es);
+}
+
+int mgc_set_boundary_lut(mgc_handle h, const double* table, int64_t n)
+{
+    if (!h) return MGC_ERR_INVALID;
+    if (n < 0 || n > 65536 || (n > 0 && !table)) return mgc_fail(h, MGC_ERR_INVALID, "mgc_set_boundary_lut: 0 <= n <= 65536 entries");
+    MGC_HIP(h, hipSetDevice(h->device));
+    h->built = h->solved = false;
+    h->lut_n = 0;
+    if (n == 0) return MGC_OK;
+    const int term = h->term;
+    if (term != MGC_TERM_DIFFERENCE_EXPONENTIAL && term != MGC_TERM_MAXIMUM_EXPONENTIAL && term != MGC_TERM_DIFFERENCE_POWER && term != MGC_TERM_MAXIMUM_POWER)
+        return mgc_fail(h, MGC_ERR_STATE, "mgc_set_boundary_lut: only the exponential and power terms are evaluated by table (the others are IEEE-basic arithmetic)");
+    const int rc = mgc_upload(h, &h->d_lut, table, (size_t)n * sizeof(double));
+    if (rc != MGC_OK) return rc;
+    h->lut_n = (int)n;
+    return MGC_OK;
 }
 
 int mgc_set_regional_probability(mgc_handle h, const void* pm, int dtype, double alpha)
@@ -3277,6 +3298,7 @@ int mgc_build(mgc_handle h)
     }
     A.prob = h->d_prob; A.prob_dtype = h->prob_dtype; A.alpha = h->alpha;
     A.prepush = h->prepush;
+    A.lut = h->lut_n > 0 ? (const double*)h->d_lut : nullptr; A.lut_n = h->lut_n;
     A.fg = h->d_fg; A.bg = h->d_bg; A.tr_in = h->d_tr_in;
     A.tr0 = h->d_tr0; A.fpart = h->d_part; A.tflags = h->d_tflags;
     if (h->n_edges && !L.cap0) { /* explicit edges change capacities that the image no longer determines */

@@ -36,11 +36,15 @@ __device__ __forceinline__ double mgc_load_as_double(const void* p, int dtype, i
 
 /* g(.) of the eight boundary terms, operation for operation as NumPy evaluates them in the
  * reference (energy_voxel.py:103-114, 226-236, 337-345, 444-452 and the difference twins). */
-__device__ __forceinline__ double mgc_boundary_g(int term, double a, double b, double p0)
+__device__ __forceinline__ double mgc_boundary_g(int term, double a, double b, double p0, const double* lut = nullptr, int lut_n = 0)
 {
     const bool use_max = (term == MGC_TERM_MAXIMUM_LINEAR || term == MGC_TERM_MAXIMUM_EXPONENTIAL ||
                           term == MGC_TERM_MAXIMUM_POWER); /* MAXIMUM_DIVISION: difference skeleton, :347 */
     double x = use_max ? fmax(a, b) : fabs(a - b);
+    if (lut) { /* integer-valued image: the host's own evaluation of the term, by table (mgc_set_boundary_lut) */
+        const int i = (int)x;
+        if (x >= 0.0 && x < (double)lut_n && (double)i == x) return lut[i];
+    }
     switch (term) {
     case MGC_TERM_DIFFERENCE_LINEAR:
     case MGC_TERM_MAXIMUM_LINEAR:

@@ -20,6 +20,48 @@ class termtype(enum.IntEnum):
     SINK = 1
 
 
+def boundary_table(term, image, sigma, limit=65536):
+    """The exponential / power boundary function of an INTEGER-VALUED image by table, or None.
+
+    On such images (CT / MR data: uint8, uint16, int16; floats that hold whole numbers) the reference's term functions see
+    only whole-number arguments d = |I_p - I_q| (difference terms) or max(|I_p|, |I_q|) (maximum terms), because
+    ``__skeleton_base`` casts the image to float64 first (reference energy_voxel.py:633-634).  Evaluating the term ONCE per
+    possible d with the very NumPy operations the reference applies to its arrays (energy_voxel.py:226-236 / 290-300:
+    power(x, 2), /= pow(sigma, 2), *= -1, exp, floor at float_info.min; 444-452 / 506-513: 1 / (x + 1), power(x, sigma), floor)
+    makes the n-link weights bit-identical to the reference's -- the device's own exp / pow (OCML) is up to 2 ulp away, which
+    is enough to flip a tie.  The linear and division terms are IEEE-basic arithmetic and need no table."""
+    import math
+    import sys
+    if not (term.endswith("exponential") or term.endswith("power")) or sigma is None:
+        return None
+    image = numpy.asarray(image)
+    if image.size == 0:
+        return None
+    if image.dtype.kind not in "iuf":
+        return None
+    if image.dtype.kind == "f":
+        probe = image.ravel()[:4096]
+        if not numpy.array_equal(probe, numpy.rint(probe)) or not numpy.array_equal(image, numpy.rint(image)):
+            return None
+    lo, hi = float(image.min()), float(image.max())
+    if not (math.isfinite(lo) and math.isfinite(hi)):
+        return None
+    top = max(abs(lo), abs(hi)) if term.startswith("maximum") else hi - lo
+    if top + 1 > limit:
+        return None
+    x = numpy.arange(int(top) + 1, dtype=float)
+    if term.endswith("exponential"):
+        x = numpy.power(x, 2)
+        x /= math.pow(sigma, 2)
+        x *= -1
+        x = numpy.exp(x)
+    else:
+        x = 1.0 / (x + 1)
+        x = numpy.power(x, sigma)
+    x[x <= 0] = sys.float_info.min
+    return numpy.ascontiguousarray(x, dtype=numpy.float64)
+
+
 class VoxelGraph(object):
     """What ``graph_from_voxels`` returns: the stand-in for ``maxflow.GraphDouble``.
 
@@ -80,6 +122,9 @@ class VoxelGraph(object):
             sp = (C.c_double * len(self._shape))(*[float(s) for s in spacing])
         self._call("mgc_set_boundary", _lib.TERM_IDS[term], _lib.ptr(image), _lib.DTYPE_IDS[image.dtype],
                    float(sigma) if sigma is not None else 0.0, sp)
+        table = boundary_table(term, image, sigma)
+        if table is not None:
+            self._call("mgc_set_boundary_lut", _lib.ptr(table), table.size)
 
     def _set_regional(self, prob, alpha):
         prob = numpy.asarray(prob)

@@ -386,6 +386,10 @@ class HipSlab(object):
         sp = (C.c_double * 3)(*[float(v) for v in spacing]) if spacing else None
         self._call("mgc_set_boundary", _lib.TERM_IDS[term], _lib.ptr(image), _lib.DTYPE_IDS[image.dtype],
                    float(sigma) if sigma is not None else 0.0, sp)
+        from .graphcut.graph import boundary_table
+        table = boundary_table(term, image, sigma)  # integer-valued planes: the term by table (a function of d alone: the same on every slab)
+        if table is not None:
+            self._call("mgc_set_boundary_lut", _lib.ptr(table), table.size)
 
     def image_range(self):
         out = np.zeros(3, dtype=np.float64)

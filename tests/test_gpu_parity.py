@@ -389,3 +389,55 @@ def test_boundary_image_of_another_shape_like_the_reference_tests():
     with pytest.raises(ValueError):
         gc.graph_from_voxels(np.zeros((2, 2)), np.zeros((2, 2)), boundary_term=_term_fn("difference_linear"),
                              boundary_term_args=(np.zeros((3, 3)), False))
+
+
+@pytest.mark.parametrize("term,sigma", [("difference_exponential", 15.0), ("maximum_exponential", 400.0), ("difference_power", 1.7), ("maximum_power", 0.6)])
+@pytest.mark.parametrize("dtype", [np.uint8, np.uint16, np.int16, np.float32])
+def test_integer_valued_images_get_bit_identical_exp_and_pow_weights(term, sigma, dtype):
+    """Integer-valued images (CT / MR): the exponential and power terms are evaluated by a table the host fills with the
+    reference's own NumPy operations (mgc_set_boundary_lut; reference energy_voxel.py:226-236, 290-300, 444-452, 506-513), so
+    the n-link weights equal the reference's BIT FOR BIT (the device's exp / pow alone are up to 2 ulp away), with and without
+    spacing; the labels equal BK's, or differ only where the reference's own residual graph is ambiguous (exact ties)."""
+    rng = np.random.default_rng(5)
+    shape = (12, 20, 17)
+    hi = 200 if dtype in (np.uint8,) else 3000
+    lo = -1500 if dtype in (np.int16, np.float32) else 0
+    img = rng.integers(lo, hi, shape).astype(dtype)
+    fg = np.zeros(shape, bool); fg[5:7, 9:11, 8:10] = True
+    bg = np.zeros(shape, bool); bg[0] = bg[-1] = True; bg[:, 0] = bg[:, -1] = True; bg[:, :, 0] = bg[:, :, -1] = True
+    for spacing in (False, (1.0, 0.7, 2.5)):
+        g = _run(fg, bg, term, img, sigma, spacing=spacing)
+        want = energy_numpy.boundary_weights(term, img, sigma, spacing)
+        for axis in range(3):
+            got = g.nweights(axis)
+            assert got.tobytes() == np.ascontiguousarray(want[axis], dtype=np.float64).tobytes(), (term, dtype, spacing, axis)
+        flow = g.maxflow()
+        ref = pipeline.graphcut_voxel(fg, bg, term=term, image=img, sigma=sigma, spacing=spacing)
+        labels = g.labels()
+        if (labels != ref.labels).any():
+            # identical capacities, but random whole-number images repeat weights everywhere: exact ties, broken by the order
+            # in which a solver adds its flows.  A differing voxel must lie in the reference's own ambiguity set, and the cuts
+            # must have the same capacity as exact rationals (oracle/cutcheck.py)
+            i, j, ww = cutcheck.lattice_edges(shape, want)
+            tr = np.where(fg, 65535.0, 0.0) - np.where(bg, 65535.0, 0.0)
+            cutcheck.assert_labels_equivalent(labels, ref, exact=(i, j, ww, ww, tr))
+        assert flow == pytest.approx(ref.flow, rel=1e-12)
+
+
+def test_ties_volume_capacities_are_the_reference_doubles():
+    """the tie-heavy synthetic (intensities 0..3 held in float32, sigma 1): with table-evaluated weights every capacity is the
+    reference's own double (rounds 1-3: <= 2 ulp off); what is left between the two label volumes is summation order on exact
+    ties, inside the ambiguity set"""
+    from medpy_amd import synthetic
+    s = synthetic.ties((40, 40, 40))
+    g = _run(s["fg"], s["bg"], s["term"], s["image"], s["sigma"])
+    want = energy_numpy.boundary_weights(s["term"], s["image"], s["sigma"])
+    for axis in range(3):
+        assert g.nweights(axis).tobytes() == np.ascontiguousarray(want[axis], dtype=np.float64).tobytes()
+    g.maxflow()
+    ref = pipeline.graphcut_voxel(s["fg"], s["bg"], term=s["term"], image=s["image"], sigma=s["sigma"])
+    labels = g.labels()
+    if (labels != ref.labels).any():
+        i, j, ww = cutcheck.lattice_edges(s["image"].shape, want)
+        tr = np.where(s["fg"], 65535.0, 0.0) - np.where(s["bg"], 65535.0, 0.0)
+        cutcheck.assert_labels_equivalent(labels, ref, exact=(i, j, ww, ww, tr))

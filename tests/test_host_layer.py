@@ -330,3 +330,25 @@ def test_incremental_relabel_over_bricks(gen, shape):
     np.testing.assert_array_equal(out[0][0], out[1][0])
     assert out[0][1]["outer"] == out[1][1]["outer"] and out[0][1]["phases"] == out[1][1]["phases"] and out[0][1]["discharge_tiles"] == out[1][1]["discharge_tiles"]
     print(gen, shape, "relabel passes: tiles", out[0][1]["relabel_passes"], "bricks", out[1][1]["relabel_passes"])
+
+
+def test_boundary_table_is_the_reference_term_on_whole_numbers():
+    """medpy_amd.graphcut.graph.boundary_table (what mgc_set_boundary_lut uploads): entry d is bit for bit what the NumPy
+    restatement of the reference's term gives for an intensity difference (or maximum) of d; None where no table applies."""
+    from medpy_amd.graphcut.graph import boundary_table
+    from oracle import energy_numpy
+    rng = np.random.default_rng(2)
+    img = rng.integers(0, 900, (9, 11)).astype(np.uint16)
+    for term, sigma in (("difference_exponential", 12.5), ("difference_power", 1.3)):
+        t = boundary_table(term, img, sigma)
+        assert t is not None and t.size == int(img.max()) - int(img.min()) + 1
+        w = energy_numpy.boundary_weights(term, img, sigma)[1]
+        d = np.abs(img[:, :-1].astype(float) - img[:, 1:].astype(float)).astype(int)
+        assert t[d].tobytes() == np.ascontiguousarray(w, dtype=np.float64).tobytes()
+    for term, sigma in (("maximum_exponential", 300.0), ("maximum_power", 0.8)):
+        shifted = img.astype(np.int16) - 400
+        t = boundary_table(term, shifted, sigma)
+        assert t is not None and t.size == int(np.abs(shifted.astype(int)).max()) + 1  # indexed by max(|I_p|, |I_q|)
+    assert boundary_table("difference_division", img, 3.0) is None  # IEEE-basic terms need no table
+    assert boundary_table("difference_exponential", img.astype(np.float32) + 0.5, 3.0) is None  # not whole numbers
+    assert boundary_table("difference_exponential", (img.astype(np.int64) * 1000), 3.0) is None  # range beyond the table limit

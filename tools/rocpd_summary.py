@@ -46,10 +46,11 @@ def main():
     elif mode == "json":
         # python tools/rocpd_summary.py json <fetch.db> <write.db> > profiles/pmc_discharge.json
         import json
-        out = {"kernel": "k_discharge_w"}
+        kern = sys.argv[4] if len(sys.argv) > 4 else "k_discharge_w"  # (json <fetch.db> <write.db> k26_discharge: the 26-neighbourhood kernel of bench.py --config 3)
+        out = {"kernel": kern}
         for key, db in (("fetch_kib_per_launch", sys.argv[2]), ("write_kib_per_launch", sys.argv[3])):
             c = sqlite3.connect(db).cursor()
-            n, v = c.execute("select count(*), avg(value) from counters_collection where kernel_name like 'k_discharge_w%'").fetchone()
+            n, v = c.execute("select count(*), avg(value) from counters_collection where kernel_name like ?", (kern + "(%",)).fetchone()
             out[key] = v
             out[key.replace("kib_per_launch", "launches")] = n
         import hashlib, os
