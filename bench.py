@@ -396,7 +396,8 @@ def main():
                                 "relabel_kernels": round(acc["relabel_ms"] / args.steps, 3),
                                 "global_relabels": acc["global_relabels"] / args.steps, "colour_phases": acc["phases"] / args.steps,
                                 "tile_discharges": acc["discharge_tiles"] / args.steps, "tile_relabels": acc["relabel_tiles"] / args.steps}
-            out["roofline"] = {"bound": "hbm", "kernel": "k_discharge_w" if conn == 6 else "k26_discharge", "achieved": round(achieved, 2),
+            # (a graph with a regional term is pre-pushed by k_build and discharged by the one-wave-per-tile kernel, mgc_maxflow's choice)
+            out["roofline"] = {"bound": "hbm", "kernel": "k_discharge_w" if conn == 6 else ("k26_discharge_w" if regional else "k26_discharge"), "achieved": round(achieved, 2),
                                "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBS, 5), "traffic": traffic,
                                "traffic_source": traffic_info, "avg_launch_ms": round(avg_ms, 4), "launches_per_step": launches / args.steps,
                                "voxels_per_launch": round(vox_per_launch, 1), "bytes_per_voxel": b_alg,

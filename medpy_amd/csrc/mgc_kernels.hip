@@ -2016,7 +2016,8 @@ struct mgc_graph {
     int sweeps_sparse26 = 8;       /* 26-neighbourhood: sweep budget of a discharge while fewer than 20 % of a colour's tiles are active */
     int wave_grid26 = 0;           /* persistent grid of k26_discharge_w: one wave per SIMD (it needs the whole register file) */
     int relabel_exchange_every = 4; /* slabs: relabel passes between two exchanges of the border labels (0: iterate to the local fixpoint first, round 3's schedule) */
-    bool rounds_set = false, sparse26_set = false; /* the caller chose rounds_per_relabel / sweeps_sparse26 (mgc_set_param): no automatic choice */
+    bool rounds_set = false, sparse26_set = false, wave_set = false;
+    bool w26_auto = false; /* (during a solve) k26_discharge_w chosen by mgc_maxflow for a pre-pushed graph */ /* the caller chose rounds_per_relabel / sweeps_sparse26 (mgc_set_param): no automatic choice */
     int prepush = 1;               /* k_build (26-neighbourhood): settle source -> u -> v -> sink paths inside a tile while its weights are in registers (parameter prepush) */
     int w26_passes = 2, w26_raises = 1, w26_flags = 0; /* k26_discharge_w: passes over the steps / relabel rounds per sweep, MGCW26_* flags */
     int activate_exact_max = 4096; /* activation looks at the voxels of its candidate tiles only when there are at most this many (mgcw_activate_tile) */
@@ -2275,8 +2276,8 @@ struct HipDevT {
              * paced by launches and relabels: let a tile work longer.  Measured at 512^3: config 3 102.8 ms at 3 sweeps, 129.8 at
              * 6; markers only 494 ms at 3, 431 at 8. */
             if (h->sweeps_sparse26 > 0 && (int64_t)h->est_phase_tiles * 40 < h->L.ntiles) sweeps = h->sweeps_sparse26;
-            if ((h->wave_kernels & 32) && cycles < 0) { /* one wave per tile, the tile in registers (stored labels only) */
-                hipLaunchKernelGGL(k26_discharge_w, dim3(h->wave_grid26), dim3(MGCW_LANES), 0, h->stream, h->L, lst, phase, sweeps, h->w26_passes, h->w26_raises, h->w26_flags, h->tk_dis);
+            if (((h->wave_kernels & 32) || h->w26_auto) && cycles < 0) { /* one wave per tile, the tile in registers (stored labels only) */
+                hipLaunchKernelGGL(k26_discharge_w, dim3(h->wave_grid26), dim3(MGCW_LANES), 0, h->stream, h->L, lst, phase, sweeps, h->w26_auto ? 1 : h->w26_passes, h->w26_raises, h->w26_flags, h->tk_dis);
                 h->tk_dis ^= 1;
             }
             else if (h->wave_kernels & 16) hipLaunchKernelGGL(k26_discharge_v, dim3(grid(h->L.ntiles)), dim3(MGC_TV / 2), 0, h->stream, h->L, lst, phase, cycles, sweeps);
@@ -2548,7 +2549,7 @@ static int mgc_create_impl(int ndim, const int64_t* shape, int connectivity, int
     MGC_HIP(h, hipHostMalloc((void**)&h->h_scalar, 8 * sizeof(double), hipHostMallocDefault));
     MGC_HIP(h, hipMemsetAsync(L.count, 0, MGC_NCOUNT * (1 + MGC_NSHARD) * sizeof(int32_t), h->stream));
     MGC_HIP(h, hipStreamSynchronize(h->stream));
-    if (const char* wv = getenv("MEDPY_HIP_WAVE")) h->wave_kernels = atoi(wv); /* development aid: A/B the kernel forms */
+    if (const char* wv = getenv("MEDPY_HIP_WAVE")) { h->wave_kernels = atoi(wv); h->wave_set = true; } /* development aid: A/B the kernel forms */
     { /* persistent grids of the wave kernels: as many waves as the device keeps resident */
         hipDeviceProp_t prop;
         MGC_HIP(h, hipGetDeviceProperties(&prop, device));
@@ -3389,9 +3390,14 @@ int mgc_maxflow(mgc_handle h, double* flow)
             if (h->prepush && h->d_prob) {
                 if (!h->rounds_set) P.rounds_per_relabel = 3;
                 if (!h->sparse26_set) h->sweeps_sparse26 = P.max_sweeps;
+                /* ... and what is left to discharge are the heavy tiles (every voxel holds excess): there the one-wave-per-tile kernel,
+                 * with ONE pass over the steps per sweep, is the faster form (config 3: 14.8 vs 19.6 ms of discharges; on graphs that
+                 * were not pre-pushed it is the slower one, 97 vs 61 ms) */
+                h->w26_auto = !h->wave_set && P.max_cycles < 0;
             }
             rc = mgc_solve(dev26, L, P, st, mgc_layout26());
             h->sweeps_sparse26 = sparse_before;
+            h->w26_auto = false;
             dev.first_error = dev26.first_error;
             dev.spans.clear();
             for (const auto& sp : dev26.spans) dev.spans.push_back({sp.a, sp.b, sp.kind});
@@ -3606,7 +3612,7 @@ int mgc_set_param(mgc_handle h, const char* name, int64_t value)
     else if (!strcmp(name, "incremental_relabel")) h->params.incremental_relabel = value != 0;
     else if (!strcmp(name, "adaptive_rounds") && value >= 0) h->params.adaptive_rounds = (int)value; /* 0 = off, k = threshold */
     else if (!strcmp(name, "use_filters")) h->use_filters = (int)value;
-    else if (!strcmp(name, "wave_kernels")) h->wave_kernels = (int)value;
+    else if (!strcmp(name, "wave_kernels")) { h->wave_kernels = (int)value; h->wave_set = true; }
     else if (!strcmp(name, "wave_min_tiles") && value >= 0) h->wave_min_tiles = (int)value;
     else if (!strcmp(name, "sweeps_sparse26") && value >= 0) { h->sweeps_sparse26 = (int)value; h->sparse26_set = true; }
     else if (!strcmp(name, "wave_grid_dis") && value > 0) h->wave_grid_dis = (int)value;

@@ -17,7 +17,7 @@ T=$(find $OUT/trace -name "*.db" | head -1); F=$(find $OUT/fetch -name "*.db" | 
 [ -n "$T" ] && python tools/rocpd_summary.py stats $T > gpurun_out/r4_config3_trace.csv
 [ -n "$F" ] && python tools/rocpd_summary.py pmc $F > gpurun_out/r4_config3_fetch.csv
 [ -n "$W" ] && python tools/rocpd_summary.py pmc $W > gpurun_out/r4_config3_write.csv
-[ -n "$F" ] && [ -n "$W" ] && python tools/rocpd_summary.py json $F $W k26_discharge > gpurun_out/pmc_discharge26.json
+[ -n "$F" ] && [ -n "$W" ] && python tools/rocpd_summary.py json $F $W k26_discharge_w > gpurun_out/pmc_discharge26.json
 rm -rf $OUT
 # the bench lines read the PMC summaries from profiles/: put the fresh ones there first (same sources: the hash inside says so)
 cp gpurun_out/pmc_discharge.json gpurun_out/pmc_discharge26.json profiles/ 2>/dev/null
