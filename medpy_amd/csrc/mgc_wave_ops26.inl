@@ -146,7 +146,8 @@ MGC_HD void mgcw26_discharge_tile(W& w, const MgcLattice& L, int tile, uint32_t 
         else if constexpr (H == 1) ra[D].set(l, K, v);
         else r[D](l, K) = v;
     };
-    typename W::template Reg<int, 1> cnd, epos, satl, nbm, cmv, newh;
+    typename W::template Reg<int, 1> cnd, epos, satl, nbm, cmv, newh, ob;
+    typename W::template Reg<int, 8> m8; /* the residual masks of the lane's column: updated in registers while the steps run, in LDS (w.S.m) for the passes over the labels */
 
     double* const t_excess = L.excess + (int64_t)tile * MGC_TV;
     double* const t_sink = L.sink + (int64_t)tile * MGC_TV;
@@ -196,6 +197,7 @@ MGC_HD void mgcw26_discharge_tile(W& w, const MgcLattice& L, int tile, uint32_t 
             mgcw_static_for<8>([&](auto KK) MGCW_INL {
                 constexpr int K = decltype(KK)::value;
                 w.S.m[K * 64 + l] = (uint32_t)tm(l, K);
+                m8(l, K) = tm(l, K);
                 w.S.hs[mgcw_hs(l, K)] = th(l, K);
                 w.S.snk[K * 64 + l] = ts(l, K);
                 mgcw_static_for<MGC26_NDIR>([&](auto DD) MGCW_INL {
@@ -272,6 +274,7 @@ MGC_HD void mgcw26_discharge_tile(W& w, const MgcLattice& L, int tile, uint32_t 
      * the tile is handed to lane + 8 dy + dx, slot K + dz; what leaves it is parked in LDS for the flush of the slot */
     uint32_t OUT = 0; /* directions with parked outflow of the slot being processed */
     bool moved = false; /* some step of the current pass over the slots ran */
+    bool moved_slot = false; /* ... of the slot just processed */
     auto step = [&](auto KK, auto DD) MGCW_INL {
         constexpr int K = decltype(KK)::value;
         constexpr int D = decltype(DD)::value;
@@ -288,7 +291,7 @@ MGC_HD void mgcw26_discharge_tile(W& w, const MgcLattice& L, int tile, uint32_t 
             RSET(DD, KK, l, rd - delta); /* saturating push: rd - rd == 0.0 exactly */
             const bool sat = can && delta == rd;
             satl(l, 0) |= sat ? 1 : 0;
-            w.lds_and(&w.S.m[K * 64 + l], sat ? ~(1u << D) : ~0u);
+            m8(l, K) &= sat ? (int)~(1u << D) : -1;
             const bool inside = z_in && mgcw26_in_xy(l, dy, dx);
             stay(l, 0) = inside ? delta : 0.0;
             outv(l, 0) = inside ? 0.0 : delta;
@@ -305,25 +308,29 @@ MGC_HD void mgcw26_discharge_tile(W& w, const MgcLattice& L, int tile, uint32_t 
                     constexpr std::integral_constant<int, KR> KRC{};
                     e(l, KR) += d;
                     RSET(DR, KRC, l, RGET(DR, KRC, l) + d);
-                    w.lds_or(&w.S.m[KR * 64 + l], d > 0.0 ? (1u << (25 - D)) : 0u);
+                    m8(l, KR) |= d > 0.0 ? (int)(1u << (25 - D)) : 0;
                 }
             });
         }
-        if (w.any([&](int l) MGCW_INL -> bool { return outv(l, 0) != 0.0; })) {
-            w.lanes([&](int l) MGCW_INL { w.S.out[D][l] = outv(l, 0); });
-            OUT |= 1u << D;
+        /* what leaves the tile is parked unconditionally (a store nobody waits for) and flagged per lane: one OR over the wave per
+         * slot says which directions the flush has to look at (a vote per step was a compare -> branch round trip 200 times a sweep) */
+        if constexpr (!z_in || dy != 0 || dx != 0) {
+            w.lanes([&](int l) MGCW_INL {
+                w.S.out[D][l] = outv(l, 0);
+                ob(l, 0) |= outv(l, 0) != 0.0 ? (int)(1u << D) : 0;
+            });
         }
         w.mark(5); /* one step */
     };
     auto slot = [&](auto KK) MGCW_INL {
         constexpr int K = decltype(KK)::value;
-        w.lanes([&](int l) MGCW_INL { cnd(l, 0) = (int)(w.S.cand[K * 64 + l] & w.S.m[K * 64 + l]); }); /* (arcs saturated since pass A are out) */
+        w.lanes([&](int l) MGCW_INL { cnd(l, 0) = (int)w.S.cand[K * 64 + l] & m8(l, K); ob(l, 0) = 0; }); /* (arcs saturated since pass A are out) */
         /* the steps of this slot that run: the directions along which a voxel that holds excess NOW can push (what arrived from
          * the slots below during this sweep moves on at once); in a step that runs, every voxel pushes that can */
         const uint32_t CK = w.wave_or([&](int l) MGCW_INL -> uint32_t { return e(l, K) > 0.0 ? (uint32_t)cnd(l, 0) : 0u; });
+        moved_slot = CK != 0;
         if (!CK) return;
         moved = true;
-        OUT = 0;
         if (CK & MGC26_MASK_SINK) { /* push to the sink first: always admissible (label 1 -> 0) */
             w.lanes([&](int l) MGCW_INL {
                 const bool can = (((uint32_t)cnd(l, 0) >> 26) & 1u) != 0;
@@ -333,7 +340,7 @@ MGC_HD void mgcw26_discharge_tile(W& w, const MgcLattice& L, int tile, uint32_t 
                 w.S.snk[K * 64 + l] = sk - delta;
                 const bool sat = can && delta == sk;
                 satl(l, 0) |= sat ? 1 : 0;
-                w.lds_and(&w.S.m[K * 64 + l], sat ? ~MGC26_MASK_SINK : ~0u);
+                m8(l, K) &= sat ? (int)~MGC26_MASK_SINK : -1;
             });
         }
         mgcw_static_for<MGC26_NDIR>([&](auto DD) MGCW_INL {
@@ -396,8 +403,8 @@ MGC_HD void mgcw26_discharge_tile(W& w, const MgcLattice& L, int tile, uint32_t 
             mgcw_static_for<8>([&](auto KK) MGCW_INL {
                 constexpr int K = decltype(KK)::value;
                 if (!w.uget(cmv, K)) return; /* no voxel of the slot held excess when the sweep began: its masks were not computed */
-                OUT = 0;
                 slot(KK);
+                OUT = moved_slot ? w.wave_or([&](int l) MGCW_INL -> uint32_t { return (uint32_t)ob(l, 0); }) : 0u;
                 /* flush: the target voxel lives in an idle neighbour tile and nobody else writes it in this launch: its excess,
                  * reverse residual and mask are updated in place, direction by direction in a fixed order */
                 while (OUT) {
@@ -423,6 +430,7 @@ MGC_HD void mgcw26_discharge_tile(W& w, const MgcLattice& L, int tile, uint32_t 
             });
             if (!moved) break;
         }
+        if (anyc) w.lanes([&](int l) MGCW_INL { mgcw_static_for<8>([&](auto KK) MGCW_INL { w.S.m[decltype(KK)::value * 64 + l] = (uint32_t)m8(l, decltype(KK)::value); }); });
         w.mark(2); /* (the rest of the passes over the steps) */
 
         /* ---- pass R, the local relabel: a voxel that still holds excess rises to 1 + the lowest label behind a residual arc
@@ -480,7 +488,7 @@ MGC_HD void mgcw26_discharge_tile(W& w, const MgcLattice& L, int tile, uint32_t 
     if (SINK) {
         has_sink = w.any([&](int l) MGCW_INL -> bool {
             uint32_t m = 0;
-            mgcw_static_for<8>([&](auto KK) MGCW_INL { m |= w.S.m[decltype(KK)::value * 64 + l]; });
+            mgcw_static_for<8>([&](auto KK) MGCW_INL { m |= (uint32_t)m8(l, decltype(KK)::value); });
             return (m & MGC26_MASK_SINK) != 0;
         });
     }
@@ -505,7 +513,7 @@ MGC_HD void mgcw26_discharge_tile(W& w, const MgcLattice& L, int tile, uint32_t 
         mgcw_static_for<8>([&](auto KK) MGCW_INL {
             constexpr int K = decltype(KK)::value;
             w.st(t_excess, K * 64 + l, e(l, K));
-            w.st(t_rmask, K * 64 + l, w.S.m[K * 64 + l]);
+            w.st(t_rmask, K * 64 + l, (uint32_t)m8(l, K));
             if (SINK) w.st(t_sink, K * 64 + l, w.S.snk[K * 64 + l]);
             if (relabelled) w.st(t_height, K * 64 + l, w.S.hs[mgcw_hs(l, K)]);
         });
