@@ -1118,7 +1118,7 @@ __device__ __forceinline__ double mgc_block_sum(double v, double* scratch)
 }
 
 /* TERM: the boundary term as a compile-time constant (the kernel dispatches once), so g(.) is straight-line code */
-template <bool FULL, int TERM> /* FULL: 26-neighbourhood */
+template <bool FULL, int TERM, bool PRE6 = false> /* FULL: 26-neighbourhood; PRE6: the 6-neighbourhood instance with the pre-push (graphs with a regional term) */
 __device__ __forceinline__ void k_build_tiles(const MgcLattice& L, const MgcBuildArgs& A, double* img, double* scratch, double* wf, int* tflag_lds, double* pre_lds)
 {
     const int t = threadIdx.x;
@@ -1182,11 +1182,11 @@ __device__ __forceinline__ void k_build_tiles(const MgcLattice& L, const MgcBuil
             __syncthreads();
             tbits = *tflag_lds;
         };
-        if constexpr (FULL) {
+        if constexpr (FULL || PRE6) {
             __syncthreads(); /* the reset of the vote word above, before the votes */
             tlinks_and_vote();
         }
-        const bool pre = FULL && A.prepush && (tbits & 3) == 3; /* (uniform) the tile holds source links AND sink links */
+        const bool pre = (FULL || PRE6) && A.prepush && (tbits & 3) == 3; /* (uniform) the tile holds source links AND sink links */
         double exc_out = tr > 0.0 ? tr : 0.0, snk_out = tr < 0.0 ? -tr : 0.0; /* (the 6-neighbourhood path: after its tlinks_and_vote below) */
         uint32_t m = 0;
         if constexpr (!FULL) {
@@ -1213,6 +1213,65 @@ __device__ __forceinline__ void k_build_tiles(const MgcLattice& L, const MgcBuil
                 }
             }
             __syncthreads();
+            if constexpr (PRE6) {
+                /* the pre-push of the 26-neighbourhood path below, three pairs of opposite directions: voxels that hold excess push
+                 * min(excess, weight, what the neighbour's sink link still takes) to their neighbours inside the tile, the receiver hands
+                 * it on to the sink -- the first colour round of a graph with a regional term, settled while the weights are in LDS */
+                double w6[6];
+#pragma unroll
+                for (int d = 0; d < 6; ++d) {
+                    w6[d] = 0.0;
+                    if (TERM != MGC_TERM_NONE && valid) {
+                        const int c = ((d >> 1) == 0 ? lx : ((d >> 1) == 1 ? ly : lz)) + (d & 1);
+                        const int uv = (d >> 1) == 0 ? lz * 8 + ly : ((d >> 1) == 1 ? lz * 8 + lx : ly * 8 + lx);
+                        w6[d] = wf[(d >> 1) * 576 + c * 64 + uv];
+                    }
+                    if (L.cap0) L.cap0[((int64_t)tile * 6 + d) * MGC_TV + t] = w6[d]; /* (as built) */
+                }
+                if (pre) {
+                    double* const dfc = pre_lds; /* [512] what the voxels' sink links still take */
+                    double e = tr > 0.0 ? tr : 0.0;
+                    dfc[t] = tr < 0.0 ? -tr : 0.0;
+                    __syncthreads();
+#pragma unroll
+                    for (int ax = 0; ax < 3; ++ax) {
+                        double* const revA = pre_lds + MGC_TV * (1 + 2 * (ax & 1)); /* what arrived along the - direction (double-buffered over the pairs) */
+                        double* const revB = revA + MGC_TV;                           /* ... along the + direction */
+                        const int cl = ax == 0 ? lx : (ax == 1 ? ly : lz), st = ax == 0 ? 1 : (ax == 1 ? 8 : 64);
+                        const bool inA = cl > 0, inB = cl < 7; /* my neighbour along - / + lies in the tile */
+                        double pA = 0.0, pB = 0.0;
+                        if (inA) {
+                            if (e > 0.0 && w6[2 * ax] > 0.0) {
+                                const double q = dfc[t - st];
+                                pA = fmin(e, fmin(w6[2 * ax], q));
+                                if (pA > 0.0) { dfc[t - st] = q - pA; e -= pA; }
+                            }
+                            revA[t - st] = pA;
+                        }
+                        __syncthreads();
+                        if (inB) {
+                            if (e > 0.0 && w6[2 * ax + 1] > 0.0) {
+                                const double q = dfc[t + st];
+                                pB = fmin(e, fmin(w6[2 * ax + 1], q));
+                                if (pB > 0.0) { dfc[t + st] = q - pB; e -= pB; }
+                            }
+                            revB[t + st] = pB;
+                        }
+                        __syncthreads();
+                        w6[2 * ax] = (w6[2 * ax] - pA) + (inA ? revB[t] : 0.0); /* my - neighbour pushed back to me along + */
+                        w6[2 * ax + 1] = (w6[2 * ax + 1] - pB) + (inB ? revA[t] : 0.0);
+                    }
+                    __syncthreads();
+                    exc_out = e;
+                    snk_out = dfc[t];
+                    __syncthreads(); /* (dfc is rewritten by the next tile) */
+                }
+#pragma unroll
+                for (int d = 0; d < 6; ++d) {
+                    L.rcap[((int64_t)tile * 6 + d) * MGC_TV + t] = w6[d];
+                    if (w6[d] > 0.0) m |= 1u << d;
+                }
+            } else
 #pragma unroll
             for (int d = 0; d < 6; ++d) {
                 double w = 0.0;
@@ -1317,17 +1376,17 @@ __device__ __forceinline__ void k_build_tiles(const MgcLattice& L, const MgcBuil
                 });
             }
         }
-        if constexpr (!FULL) tlinks_and_vote();
+        if constexpr (!FULL && !PRE6) tlinks_and_vote();
         const int64_t v = (int64_t)tile * MGC_TV + t;
         const int any_sink = tbits & 2, any_exc = tbits & 1;
-        if constexpr (!FULL) { exc_out = tr > 0.0 ? tr : 0.0; snk_out = tr < 0.0 ? -tr : 0.0; }
+        if constexpr (!FULL && !PRE6) { exc_out = tr > 0.0 ? tr : 0.0; snk_out = tr < 0.0 ? -tr : 0.0; }
         L.excess[v] = exc_out;
         if constexpr (!FULL) {
             /* 6-neighbourhood: the merged t-links and the residual sink links of a tile are only READ where the tile holds a t-link
              * of the sign in question (A.tflags, status bit MGC_ST_SINK: k_discharge_w, k_cut_value6, k_validate ...), so they are only
              * written there: 16 of the 79 bytes per voxel this kernel writes, for 98 % of the tiles of a marker-seeded volume */
             if (tbits & 3) A.tr0[v] = tr;
-            if (any_sink) L.sink[v] = tr < 0.0 ? -tr : 0.0;
+            if (any_sink) L.sink[v] = snk_out; /* (what a pre-push left of it) */
         } else {
             A.tr0[v] = tr;       /* (as built: the cut value and the invariant check start from the merged t-link) */
             L.sink[v] = snk_out; /* (what the pre-push left of it) */
@@ -1337,7 +1396,7 @@ __device__ __forceinline__ void k_build_tiles(const MgcLattice& L, const MgcBuil
             const uint32_t need = (gx > 0 ? 1u : 0u) | (gx + 1 < L.dx ? 2u : 0u) | (gy > 0 ? 4u : 0u) | (gy + 1 < L.dy ? 8u : 0u) |
                                   (gz > 0 ? 16u : 0u) | (gz + 1 < L.dz ? 32u : 0u);
             if (__ballot(valid && (m & need) != need) != 0ull && (t & 63) == 0) atomicAdd(&L.count[MGC_CNT_NOT_FULL], 1);
-            if (tr < 0.0) m |= MGC_MASK_SINK;
+            if (snk_out > 0.0) m |= MGC_MASK_SINK;
             L.rmask[v] = (uint8_t)m;
         } else {
             if (snk_out > 0.0) m |= MGC26_MASK_SINK;
@@ -1377,20 +1436,37 @@ __device__ __forceinline__ void k_build_tiles(const MgcLattice& L, const MgcBuil
 #ifndef MGC_BUILD_WAVES26
 #define MGC_BUILD_WAVES26 4 /* two workgroups per CU: 128 VGPRs */
 #endif
-template <bool FULL, int TERM> /* FULL: 26-neighbourhood */
-__global__ __launch_bounds__(MGC_TV, FULL ? MGC_BUILD_WAVES26 : MGC_BUILD_WAVES6) void k_build(MgcLattice L, MgcBuildArgs A)
+template <bool FULL, int TERM, bool PRE6 = false> /* FULL: 26-neighbourhood; PRE6: 6-neighbourhood with the pre-push (regional term) */
+__global__ __launch_bounds__(MGC_TV, FULL ? MGC_BUILD_WAVES26 : (PRE6 ? 4 : MGC_BUILD_WAVES6)) void k_build(MgcLattice L, MgcBuildArgs A)
 {
     __shared__ double img[1000]; /* 10x10x10: tile + one-voxel halo, already |.|'d for the maximum terms */
     __shared__ double scratch[MGC_TV];
     __shared__ double wf[FULL ? 1 : 3 * 576]; /* 6-neighbourhood: the forward n-link weights of the tile and its lower faces */
     __shared__ int tflag;
-    __shared__ double pre_lds[FULL ? 5 * MGC_TV : 1]; /* pre-push: residual sink capacities + two double-buffered hand-off planes */
-    k_build_tiles<FULL, TERM>(L, A, img, scratch, wf, &tflag, pre_lds);
+    __shared__ double pre_lds[(FULL || PRE6) ? 5 * MGC_TV : 1]; /* pre-push: residual sink capacities + two double-buffered hand-off planes */
+    k_build_tiles<FULL, TERM, PRE6>(L, A, img, scratch, wf, &tflag, pre_lds);
 }
 
 template <bool FULL>
 static void mgc_launch_build(int term, int grid, hipStream_t stream, const MgcLattice& L, const MgcBuildArgs& A)
 {
+    if constexpr (!FULL) {
+        if (A.prepush && A.prob) { /* a regional term: the instance with the pre-push */
+            switch (term) {
+#define MGC_BUILD_CASE6(T) case T: hipLaunchKernelGGL((k_build<false, T, true>), dim3(grid), dim3(MGC_TV), 0, stream, L, A); return;
+            MGC_BUILD_CASE6(MGC_TERM_NONE)
+            MGC_BUILD_CASE6(MGC_TERM_DIFFERENCE_LINEAR)
+            MGC_BUILD_CASE6(MGC_TERM_DIFFERENCE_EXPONENTIAL)
+            MGC_BUILD_CASE6(MGC_TERM_DIFFERENCE_DIVISION)
+            MGC_BUILD_CASE6(MGC_TERM_DIFFERENCE_POWER)
+            MGC_BUILD_CASE6(MGC_TERM_MAXIMUM_LINEAR)
+            MGC_BUILD_CASE6(MGC_TERM_MAXIMUM_EXPONENTIAL)
+            MGC_BUILD_CASE6(MGC_TERM_MAXIMUM_DIVISION)
+            default: hipLaunchKernelGGL((k_build<false, MGC_TERM_MAXIMUM_POWER, true>), dim3(grid), dim3(MGC_TV), 0, stream, L, A); return;
+#undef MGC_BUILD_CASE6
+            }
+        }
+    }
     switch (term) {
 #define MGC_BUILD_CASE(T) case T: hipLaunchKernelGGL((k_build<FULL, T>), dim3(grid), dim3(MGC_TV), 0, stream, L, A); break;
     MGC_BUILD_CASE(MGC_TERM_NONE)
@@ -1541,7 +1617,8 @@ __global__ __launch_bounds__(MGC_TV) void k_cut_value(MgcLattice L, MgcBuildArgs
     }
 }
 
-/* 26-neighbourhood form of k_cut_value, one WAVE per tile (four tiles per workgroup, no barrier).  With a regional term EVERY
+/* the form of k_cut_value for graphs with a regional term (and every 26-neighbourhood graph), one WAVE per tile (four tiles per
+ * workgroup, no barrier).  With a regional term EVERY
  * voxel pays a t-link, so no tile can be skipped; but only the tiles the cut passes through pay n-links.  A tile whose label
  * summary (tsum, k_labels8) says "all on one side" and whose 26 neighbour tiles say the same pays t-links only: one coalesced
  * read of the merged t-links -- no label volume, no 26 byte loads per voxel.  Every other tile takes the general path.
@@ -1567,6 +1644,7 @@ __global__ __launch_bounds__(256) void k_cut_value26(MgcLattice L, MgcBuildArgs 
             }
         }
         const bool general = __ballot(differs) != 0ull;
+        const bool has_tlinks = L.ndir != 6 || A.tflags[tile] != 0; /* (6-neighbourhood: k_build writes tr0 only for tiles that hold a t-link) */
         const int ly = lane >> 3, lx = lane & 7;
         const int64_t gy = (int64_t)ty * 8 + ly, gx = (int64_t)tx * 8 + lx;
         double s = 0.0;
@@ -1575,7 +1653,7 @@ __global__ __launch_bounds__(256) void k_cut_value26(MgcLattice L, MgcBuildArgs 
             const int64_t gz = (int64_t)tz * 8 + lz;
             const int t = lz * 64 + lane;
             if (!(gz < L.dz && gy < L.dy && gx < L.dx)) continue;
-            const double tr = tr0[(int64_t)tile * MGC_TV + t];
+            const double tr = has_tlinks ? tr0[(int64_t)tile * MGC_TV + t] : 0.0;
             if (!general) {
                 if (side == 1) { if (tr < 0.0) s += -tr; } /* source side: pays its sink link (no n-link leaves the 27 tiles' common side) */
                 else if (tr > 0.0) s += tr;                /* sink side: pays its source link */
@@ -1583,9 +1661,15 @@ __global__ __launch_bounds__(256) void k_cut_value26(MgcLattice L, MgcBuildArgs 
                 const int64_t id = (gz * L.dy + gy) * L.dx + gx;
                 if (labels[id]) { /* source side: pays its sink link and every n-link into T */
                     if (tr < 0.0) s += -tr;
-                    for (int d = 0; d < MGC26_NDIR; ++d) {
+                    for (int d = 0; d < L.ndir; ++d) {
                         int dz, dy, dx;
-                        mgc26_offset(d, dz, dy, dx);
+                        if (L.ndir == 6) {
+                            dz = (d >> 1) == 2 ? ((d & 1) ? 1 : -1) : 0;
+                            dy = (d >> 1) == 1 ? ((d & 1) ? 1 : -1) : 0;
+                            dx = (d >> 1) == 0 ? ((d & 1) ? 1 : -1) : 0;
+                        } else {
+                            mgc26_offset(d, dz, dy, dx);
+                        }
                         const int64_t nz = gz + dz, ny = gy + dy, nx = gx + dx;
                         if (nz >= 0 && nz < L.dz && ny >= 0 && ny < L.dy && nx >= 0 && nx < L.dx && !labels[(nz * L.dy + ny) * L.dx + nx])
                             s += mgc_built_capacity(L, A, tile, t, gz, gy, gx, d);
@@ -2427,7 +2511,12 @@ static int mgc_launch_readout(mgc_handle h, int slot, hipEvent_t after_labels)
     MGC_HIP(h, hipGetLastError());
     if (after_labels) MGC_HIP(h, hipEventRecord(after_labels, h->stream));
     const int grid = L.ntiles < h->grid_cap * 4 ? L.ntiles : h->grid_cap * 4;
-    if (L.ndir == 6) {
+    if (L.ndir == 6 && h->d_prob && h->d_tr0 && !L.cap0 && L.nshard == 1) {
+        /* a regional term: every tile pays t-links (the tile filter below would list them all, and k_cut_value6 sums a tile behind ten
+         * barriers); 6-neighbourhood tiles write tr0 only where they hold t-links -- with a regional term that is everywhere */
+        hipLaunchKernelGGL(k_cut_value26, dim3((grid + 3) / 4 < 8192 ? (grid + 3) / 4 : 8192), dim3(256), 0, h->stream, L, h->build_args, (const double*)h->d_tr0, (const uint8_t*)h->d_labels, rows8 ? (const uint8_t*)h->d_tsum : (const uint8_t*)nullptr, h->d_part);
+    }
+    else if (L.ndir == 6) {
         const int fg = (L.ntiles + 255) / 256;
         HipDev dev;
         dev.h = h;
@@ -3378,7 +3467,9 @@ int mgc_maxflow(mgc_handle h, double* flow)
         dev.h = dev26.h = h;
         int rc;
         if (L.ndir == 6) {
-            rc = mgc_solve(dev, L, h->params, st);
+            MgcSolveParams P = h->params;
+            if (h->prepush && h->d_prob && !h->rounds_set) P.rounds_per_relabel = 2; /* (a pre-pushed graph, see the 26-neighbourhood branch; 512^3 + regional map: 19.0 ms at 3, 17.8 at 2, 20.1 at 4; without the pre-push 21.4) */
+            rc = mgc_solve(dev, L, P, st);
         } else {
             /* A graph whose source -> u -> v -> sink paths k_build settled (regional term + pre-push) starts with a sixth of its tiles
              * active and most of their excess enclosed: it pays to look at the labels again after three colour rounds instead of six,
