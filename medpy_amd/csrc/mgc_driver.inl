@@ -36,6 +36,7 @@ struct MgcSolveParams {
     int check_rounds;       /* colour rounds launched between two counter read-backs      */
     int incremental_relabel;/* 1: later global relabels touch suspect tiles only          */
     int stop_below;         /* the colour rounds of a cycle end early when no more than this many tiles are queued (0: only when none are) */
+    int trace;              /* 1: one stderr line per global relabel (tile visits of the relabel, discharges since the one before) */
     int adaptive_rounds;    /* k > 0: the number of rounds between two relabels doubles (up to 4x) while a relabel visits more
                                than k times as many tiles as the discharges of the cycle before it did                   */
 };
@@ -80,6 +81,7 @@ static inline MgcSolveParams mgc_default_params(int ndir = 6)
     p.check_rounds = 4;
     p.incremental_relabel = 1;
     p.stop_below = 0;
+    p.trace = 0;
     p.adaptive_rounds = ndir == 26 ? 9 : 2; /* a tile visit of a relabel costs 1/3 of a discharge (8 vs 25 ns), 1/9 in the full neighbourhood (20 vs 175 ns);
                                                measured at 512^3 (round 3): weak contrast 68.7 ms at 3, 66.3 at 2, 66.3 at 1; headline volume 35.9 at 3 and 2, 39.8 at 1 */
     return p;
@@ -119,6 +121,10 @@ int mgc_solve(Dev& dev, const MgcLattice& L, const MgcSolveParams& P, MgcSolveSt
                 if (cnt[MGC_CNT_CHANGED] == 0) break;
             }
             dev.reset_suspect(rep + 1, lay.rl_base + (int)((rep + 1) & 1u));
+            if (P.trace) {
+                dev.read_counts(cnt);
+                fprintf(stderr, "[mgc] relabel %d: %d suspect tiles\n", outer, cnt[lay.rl_base + (int)((rep + 1) & 1u)]);
+            }
         }
         st.relabel_passes++;
         if (by_transform) {
@@ -181,6 +187,7 @@ int mgc_solve(Dev& dev, const MgcLattice& L, const MgcSolveParams& P, MgcSolveSt
         {
             const int64_t d_dis = (int64_t)cnt[lay.cnt_dis] - prev_dis; /* discharges since the relabel before this one */
             const int64_t d_rel = (int64_t)cnt[lay.cnt_rel] - prev_rel; /* tile visits of the relabel that just ended  */
+            if (P.trace) fprintf(stderr, "[mgc] relabel %d: %lld tile visits in %lld passes so far, %lld discharges before it, %d active tiles\n", outer, (long long)d_rel, (long long)st.relabel_passes, (long long)d_dis, cnt[lay.cnt_active]);
             if (P.adaptive_rounds > 0 && outer > 0 && d_rel > (int64_t)P.adaptive_rounds * d_dis && rounds < 4 * P.rounds_per_relabel) rounds *= 2;
             prev_dis = cnt[lay.cnt_dis];
             prev_rel = cnt[lay.cnt_rel];

@@ -3701,6 +3701,7 @@ int mgc_set_param(mgc_handle h, const char* name, int64_t value)
     else if (!strcmp(name, "check_rounds") && value > 0) h->params.check_rounds = (int)value;
     else if (!strcmp(name, "stop_below") && value >= 0) h->params.stop_below = (int)value;
     else if (!strcmp(name, "incremental_relabel")) h->params.incremental_relabel = value != 0;
+    else if (!strcmp(name, "trace")) h->params.trace = value != 0;
     else if (!strcmp(name, "adaptive_rounds") && value >= 0) h->params.adaptive_rounds = (int)value; /* 0 = off, k = threshold */
     else if (!strcmp(name, "use_filters")) h->use_filters = (int)value;
     else if (!strcmp(name, "wave_kernels")) { h->wave_kernels = (int)value; h->wave_set = true; }

@@ -363,7 +363,7 @@ MGC_HD void mgc_discharge_tile(X& x, const MgcLattice& L, int tile, uint32_t pha
      * in LDS (x.S.r): that keeps the kernel under 64 VGPRs, i.e. 4 workgroups (32 waves) per CU, which is what
      * hides the HBM latency of the load / store phases of the neighbouring workgroups. */
     typename X::template Reg<double> e, snk, ob0, ob1, ob2;
-    typename X::template Reg<int> hme, msk;
+    typename X::template Reg<int> hme, msk, lostarc; /* (lostarc: this voxel saturated an arc or its sink link) */
     /* per-tile (wave-uniform) base pointers + 32-bit lane offsets: SGPR-base addressing, fewer VGPRs */
     double* const t_excess = L.excess + (int64_t)tile * MGC_TV;
     double* const t_sink = L.sink + (int64_t)tile * MGC_TV;
@@ -386,6 +386,7 @@ MGC_HD void mgc_discharge_tile(X& x, const MgcLattice& L, int tile, uint32_t pha
         mgc_load_nbrs(x, L, tile, t);
         mgc_load_halo_inbox(x, L, tile, t);
         ob0[t] = ob1[t] = ob2[t] = 0.0;
+        lostarc[t] = 0;
         if (!(st_now & MGC_ST_SINK)) snk[t] = 0.0; /* the build writes the sink plane only where a tile has a sink link */
         x.async_wait(); /* the DMA must have landed before the barrier that ends this step */
     });
@@ -446,7 +447,10 @@ MGC_HD void mgc_discharge_tile(X& x, const MgcLattice& L, int tile, uint32_t pha
                     e[t] -= delta;
                     x.S.r[d][t] = rd - delta; /* saturating push: rd - rd == 0.0 exactly */
                     x.S.flag[fl] = 1;
-                    if (delta == rd) x.S.satflag = 1;
+                    if (delta == rd) {
+                        if (stored_labels) lostarc[t] = 1; /* (looked at once, behind the sweeps) */
+                        else x.S.satflag = 1;
+                    }
                 }
                 return delta;
             };
@@ -474,7 +478,10 @@ MGC_HD void mgc_discharge_tile(X& x, const MgcLattice& L, int tile, uint32_t pha
                     e[t] -= delta;
                     snk[t] -= delta;
                     x.S.flag[fl] = 1;
-                    if (snk[t] == 0.0) x.S.satflag = 1;
+                    if (snk[t] == 0.0) {
+                        if (stored_labels) lostarc[t] = 1;
+                        else x.S.satflag = 1;
+                    }
                 }
                 din[t] = 0.0;
             });
@@ -521,6 +528,7 @@ MGC_HD void mgc_discharge_tile(X& x, const MgcLattice& L, int tile, uint32_t pha
                     if (cand > hme[t]) {
                         hme[t] = cand;
                         x.S.hs[me] = cand;
+                        x.S.satflag = 1; /* a label rose: whoever stood on it has to be looked at */
                         if (cand < MGC_HINF) x.S.flag[fl] = 1; /* it can push again next sweep */
                     }
                 }
@@ -532,6 +540,20 @@ MGC_HD void mgc_discharge_tile(X& x, const MgcLattice& L, int tile, uint32_t pha
     if (active) {
         /* cycle budget exhausted: is there still something to do with the current labels? */
         active = x.any([&](int t) -> bool { return e[t] > 0.0 && hme[t] < MGC_HINF; });
+    }
+    /* DIRTY (the next global relabel recomputes the tile and whoever depends on it) iff a label rose, or a voxel that saturated an
+     * arc has no residual arc one label down left: a voxel that keeps one of its supports keeps its distance.  (With an exact
+     * in-tile labelling per discharge the stored labels are not what the pushes followed: any saturation counts there.) */
+    if (stored_labels) {
+        x.par([&](int t) {
+            if (lostarc[t] && hme[t] < MGC_HINF) {
+                const int me = mgc_hs_index(t >> 6, (t >> 3) & 7, t & 7);
+                bool kept = snk[t] > 0.0; /* (a label of 1 stands on the sink link) */
+#pragma unroll
+                for (int d = 0; d < 6; ++d) kept = kept || (x.S.r[d][t] > 0.0 && x.S.hs[me + mgc_hs_step(d)] == hme[t] - 1);
+                if (!kept) x.S.satflag = 1;
+            }
+        });
     }
     const bool has_sink = x.any([&](int t) -> bool { return snk[t] > 0.0; });
     x.mark(L, 4); /* tail votes */

@@ -360,7 +360,10 @@ MGC_HD void mgc26_discharge_tile(X& x, const MgcLattice& L, int tile, uint32_t p
                         e[t] -= delta;
                         R(d, t) -= delta;
                         x.S.flag[fl] = 1;
-                        if (R(d, t) == 0.0) x.S.satflag = 1;
+                        if (R(d, t) == 0.0) {
+                            if (stored_labels) pushed[t] |= 0x80000000u; /* (looked at once, behind the sweeps) */
+                            else x.S.satflag = 1;
+                        }
                         if (!((pushed[t] >> d) & 1u)) { /* (the lane's own copy spares the atomic on every further push) */
                             pushed[t] |= 1u << d;
                             x.atomic_or(&x.S.pushmask, 1u << d);
@@ -400,7 +403,10 @@ MGC_HD void mgc26_discharge_tile(X& x, const MgcLattice& L, int tile, uint32_t p
                             e[t] -= delta;
                             snk[t] -= delta;
                             x.S.flag[fl] = 1;
-                            if (snk[t] == 0.0) x.S.satflag = 1;
+                            if (snk[t] == 0.0) {
+                                if (stored_labels) pushed[t] |= 0x80000000u;
+                                else x.S.satflag = 1;
+                            }
                         }
                     } else {
                         if ((M >> q) & 1u) receive(t, std::integral_constant<int, q>{}, (q & 1) * 2);
@@ -430,6 +436,7 @@ MGC_HD void mgc26_discharge_tile(X& x, const MgcLattice& L, int tile, uint32_t p
                     if (cand > hme[t]) {
                         hme[t] = cand;
                         x.S.hs[me] = cand;
+                        x.S.satflag = 1; /* a label rose: whoever stood on it has to be looked at */
                         if (cand < MGC_HINF) x.S.flag[fl] = 1;
                     }
                 }
@@ -439,6 +446,21 @@ MGC_HD void mgc26_discharge_tile(X& x, const MgcLattice& L, int tile, uint32_t p
         }
     }
     if (active) active = x.any([&](int t) -> bool { return e[t] > 0.0 && hme[t] < MGC_HINF; });
+    /* DIRTY (the next global relabel recomputes the tile and whoever depends on it) iff a label rose, or a voxel that saturated an
+     * arc has no residual arc one label down left.  A voxel that keeps one of its supports keeps its distance: with 26 neighbours
+     * most do, and the tiles a small flow merely passes through stay clean.  (With an exact in-tile labelling per discharge the
+     * stored labels are not what the pushes followed: any saturation counts there.) */
+    if (stored_labels) {
+        x.par([&](int t) {
+            if ((pushed[t] >> 31) && hme[t] < MGC_HINF) {
+                const int me = mgc_hs_index(t >> 6, (t >> 3) & 7, t & 7);
+                bool kept = snk[t] > 0.0; /* (a label of 1 stands on the sink link) */
+#pragma unroll
+                for (int d = 0; d < MGC26_NDIR; ++d) kept = kept || (R(d, t) > 0.0 && x.S.hs[me + mgc26_hs_step(d)] == hme[t] - 1);
+                if (!kept) x.S.satflag = 1;
+            }
+        });
+    }
     const bool has_sink = x.any([&](int t) -> bool { return snk[t] > 0.0; });
 
     /* a residual plane changed iff somebody pushed along it or along its opposite (the receiver's reverse arc): the others --

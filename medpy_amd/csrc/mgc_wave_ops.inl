@@ -371,7 +371,7 @@ MGC_HD void mgcw_discharge_impl(W& w, const MgcLattice& L, int tile, uint32_t ph
     typename W::template Reg<double, 2> obz;      /* ... across the -z / +z faces */
     typename W::template Reg<int, 16> hn;         /* in-plane neighbour labels of the four slots being swept */
     typename W::template Reg<int, 2> hz;          /* halo labels below slot 0 / above slot 7 (frozen) */
-    typename W::template Reg<int, 1> sat;         /* this lane saturated an arc (or its sink link) */
+    typename W::template Reg<int, 1> sat;         /* bit K: this lane's voxel of slot K saturated an arc (or its sink link); bit 8: a label of the lane rose */
     w.lanes([&](int l) MGCW_INL {
         mgcw_static_for<8>([&](auto KK) MGCW_INL {
             constexpr int K = decltype(KK)::value;
@@ -393,7 +393,7 @@ MGC_HD void mgcw_discharge_impl(W& w, const MgcLattice& L, int tile, uint32_t ph
         const double delta = can ? fmin(e(l, K), rd) : 0.0;
         e(l, K) -= delta;
         r[D](l, K) = rd - delta; /* saturating push: rd - rd == 0.0 exactly */
-        sat(l, 0) |= (can && delta == rd) ? 1 : 0;
+        sat(l, 0) |= (can && delta == rd) ? (1 << K) : 0;
         return delta;
     };
     auto slot_mask = [&]() MGCW_INL -> uint32_t { /* bit K: some voxel of slot K holds excess that can reach the sink */
@@ -446,7 +446,7 @@ MGC_HD void mgcw_discharge_impl(W& w, const MgcLattice& L, int tile, uint32_t ph
                     const double delta = can ? fmin(e(l, K), sk) : 0.0;
                     e(l, K) -= delta;
                     w.S.snk[K * 64 + l] = sk - delta;
-                    sat(l, 0) |= (can && delta == sk) ? 1 : 0;
+                    sat(l, 0) |= (can && delta == sk) ? (1 << K) : 0;
                 });
             }
             mgcw_static_for<4>([&](auto DD) MGCW_INL {
@@ -536,7 +536,9 @@ MGC_HD void mgcw_discharge_impl(W& w, const MgcLattice& L, int tile, uint32_t ph
                     const int cd = r[D](l, K) > 0.0 ? hv + 1 : MGC_HINF; /* hv == MGC_HINF gives a value above every candidate */
                     c = cd < c ? cd : c;
                 });
-                h(l, K) = (e(l, K) > 0.0 && h(l, K) < c) ? c : h(l, K);
+                const bool rises = e(l, K) > 0.0 && h(l, K) < c;
+                sat(l, 0) |= rises ? 256 : 0;
+                h(l, K) = rises ? c : h(l, K);
                 w.S.hs[mgcw_hs(l, K)] = h(l, K);
             });
         });
@@ -602,7 +604,31 @@ MGC_HD void mgcw_discharge_impl(W& w, const MgcLattice& L, int tile, uint32_t ph
             has_sink = has_sink || w.any([&](int l) MGCW_INL -> bool { return w.S.snk[K * 64 + l] > 0.0; });
         });
     }
-    const bool saturated = w.any([&](int l) MGCW_INL -> bool { return sat(l, 0) != 0; });
+    /* DIRTY (the tile's labels may no longer be exact distances: the next global relabel recomputes it and whoever depends on it)
+     * iff a label rose or was recomputed, or a voxel that saturated an arc has no residual arc one label down left.  A voxel that
+     * keeps one of its supports keeps its distance, and the tiles a small flow merely passes through stay clean. */
+    bool saturated = (flags & MGCW_BFS) ? w.any([&](int l) MGCW_INL -> bool { return sat(l, 0) != 0; })
+                                        : w.any([&](int l) MGCW_INL -> bool { return (sat(l, 0) & 256) != 0; });
+    if (!saturated && w.any([&](int l) MGCW_INL -> bool { return sat(l, 0) != 0; })) {
+        mgcw_static_for<8>([&](auto KK) MGCW_INL {
+            constexpr int K = decltype(KK)::value;
+            if (saturated || !w.any([&](int l) MGCW_INL -> bool { return ((sat(l, 0) >> K) & 1) != 0; })) return;
+            saturated = w.any([&](int l) MGCW_INL -> bool {
+                const int hk = h(l, K);
+                bool kept = false;
+                if constexpr (SINK) kept = w.S.snk[K * 64 + l] > 0.0; /* (a label of 1 stands on the sink link) */
+                mgcw_static_for<6>([&](auto DD) MGCW_INL {
+                    constexpr int D = decltype(DD)::value;
+                    int hv;
+                    if constexpr (D < 4) hv = w.S.hs[mgcw_hs(l, K) + mgc_hs_step(D)];
+                    else if constexpr (D == 4) { if constexpr (K > 0) hv = h(l, K - 1); else hv = hz(l, 0); }
+                    else { if constexpr (K < 7) hv = h(l, K + 1); else hv = hz(l, 1); }
+                    kept = kept || (r[D](l, K) > 0.0 && hv == hk - 1);
+                });
+                return ((sat(l, 0) >> K) & 1) && hk < MGC_HINF && !kept;
+            });
+        });
+    }
     w.lanes([&](int l) MGCW_INL { /* outbox staged through LDS (face order: the neighbours read 64 consecutive doubles per face) */
         const int y = l >> 3, x = l & 7;
         mgcw_static_for<8>([&](auto KK) MGCW_INL {

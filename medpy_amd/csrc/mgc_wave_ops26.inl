@@ -290,7 +290,7 @@ MGC_HD void mgcw26_discharge_tile(W& w, const MgcLattice& L, int tile, uint32_t 
             e(l, K) -= delta;
             RSET(DD, KK, l, rd - delta); /* saturating push: rd - rd == 0.0 exactly */
             const bool sat = can && delta == rd;
-            satl(l, 0) |= sat ? 1 : 0;
+            satl(l, 0) |= sat ? (1 << K) : 0;
             m8(l, K) &= sat ? (int)~(1u << D) : -1;
             const bool inside = z_in && mgcw26_in_xy(l, dy, dx);
             stay(l, 0) = inside ? delta : 0.0;
@@ -339,7 +339,7 @@ MGC_HD void mgcw26_discharge_tile(W& w, const MgcLattice& L, int tile, uint32_t 
                 e(l, K) -= delta;
                 w.S.snk[K * 64 + l] = sk - delta;
                 const bool sat = can && delta == sk;
-                satl(l, 0) |= sat ? 1 : 0;
+                satl(l, 0) |= sat ? (1 << K) : 0;
                 m8(l, K) &= sat ? (int)~MGC26_MASK_SINK : -1;
             });
         }
@@ -483,7 +483,29 @@ MGC_HD void mgcw26_discharge_tile(W& w, const MgcLattice& L, int tile, uint32_t 
 
     /* ---- tail: wake-ups first (two dependent returning atomics per woken tile), the write-back behind them ---- */
     const uint32_t NB = w.wave_or([&](int l) MGCW_INL -> uint32_t { return (uint32_t)nbm(l, 0); });
-    const bool saturated = w.any([&](int l) MGCW_INL -> bool { return satl(l, 0) != 0; });
+    /* DIRTY (the tile's labels may no longer be exact distances; the next global relabel recomputes it and whoever depends on it)
+     * iff a label rose, or a voxel that saturated an arc has no residual arc one label down left.  A voxel that keeps one of its
+     * supports keeps its distance: with 26 neighbours most do, and the tiles a small flow merely passes through stay clean. */
+    bool saturated = relabelled;
+    if (!saturated && w.any([&](int l) MGCW_INL -> bool { return satl(l, 0) != 0; })) {
+#if defined(__HIP_DEVICE_COMPILE__)
+#pragma unroll 1
+#endif
+        for (int K = 0; K < 8 && !saturated; ++K) {
+            if (!w.any([&](int l) MGCW_INL -> bool { return ((satl(l, 0) >> K) & 1) != 0; })) continue;
+            saturated = w.any([&](int l) MGCW_INL -> bool {
+                const int me = mgcw_hs(l, K);
+                const int h = w.S.hs[me];
+                const uint32_t m = w.S.m[K * 64 + l];
+                bool kept = (m & MGC26_MASK_SINK) != 0; /* (a label of 1 stands on the sink link) */
+                mgcw_static_for<MGC26_NDIR>([&](auto DD) MGCW_INL {
+                    constexpr int D = decltype(DD)::value;
+                    kept = kept || (((m >> D) & 1u) && w.S.hs[me + mgc26_hs_step(D)] == h - 1);
+                });
+                return ((satl(l, 0) >> K) & 1) && h < MGC_HINF && !kept;
+            });
+        }
+    }
     bool has_sink = false;
     if (SINK) {
         has_sink = w.any([&](int l) MGCW_INL -> bool {

@@ -225,6 +225,7 @@ static int g_wave_mode = 0;
 static int g_w26_passes = 2, g_w26_raises = 1, g_w26_flags = 0; /* hostsim_set_w26: step passes / relabel rounds per sweep of the 26-neighbourhood wave discharge */
 static int g_act_exact_max = 4096; /* hostsim_set_act_exact: see mgcw_activate_tile */
 static FILE* g_trace = NULL; /* one line per wave-form discharge: phase, tile, sweeps (hostsim_trace; tools/sim_launch_model.py) */
+static int g_check_exact = 0; /* hostsim_set_check_exact: labels after a global relabel vs exact distances (g_prof[40], [41]) */
 static int g_use_dt = 1; /* the first global relabel may be a distance transform (hostsim_set_dt) */
 
 typedef HostBlockT<MgcTileShared> HostBlock;
@@ -320,6 +321,38 @@ struct HostDev {
             else mgc_relabel_tile(x, L, L.list[lst][i], epoch, next, false);
         }
     }
+    /* hostsim_set_check_exact: after every global relabel the labels are compared with the exact distances to the sink in the
+     * residual graph (plain relaxation over the whole volume; everything pushed has been absorbed by then): g_prof[40] relabels
+     * checked, g_prof[41] voxels that differ.  (A single device only: a slab would need its neighbours' residuals.) */
+    void check_exact_labels()
+    {
+        const int64_t N = L.nvox;
+        std::vector<int32_t> dist((size_t)N, MGC_HINF), tl((size_t)N), lc((size_t)N);
+        for (int64_t id = 0; id < N; ++id) {
+            int tile, loc;
+            mgc_node_to_tile(L, id, tile, loc);
+            tl[id] = tile; lc[id] = loc;
+            if ((L.status[tile] & MGC_ST_SINK) && L.sink[(int64_t)tile * MGC_TV + loc] > 0.0) dist[id] = 1;
+        }
+        static const int off[6][3] = {{0, 0, -1}, {0, 0, 1}, {0, -1, 0}, {0, 1, 0}, {-1, 0, 0}, {1, 0, 0}}; /* (dz, dy, dx) of direction d */
+        for (bool changed = true; changed;) {
+            changed = false;
+            for (int64_t id = 0; id < N; ++id) {
+                const int64_t x0 = id % L.dx, y0 = (id / L.dx) % L.dy, z0 = id / (L.dx * L.dy);
+                int32_t best = dist[id];
+                for (int d = 0; d < 6; ++d) {
+                    if (!(L.rcap[((int64_t)tl[id] * 6 + d) * MGC_TV + lc[id]] > 0.0)) continue;
+                    const int64_t z = z0 + off[d][0], y = y0 + off[d][1], xx = x0 + off[d][2];
+                    if (z < 0 || z >= L.dz || y < 0 || y >= L.dy || xx < 0 || xx >= L.dx) continue;
+                    const int32_t hv = dist[(z * L.dy + y) * L.dx + xx];
+                    if (hv < MGC_HINF && hv + 1 < best) best = hv + 1;
+                }
+                if (best < dist[id]) { dist[id] = best; changed = true; }
+            }
+        }
+        g_prof[40]++;
+        for (int64_t id = 0; id < N; ++id) g_prof[41] += L.height[(int64_t)tl[id] * MGC_TV + lc[id]] != dist[id];
+    }
     /* work profile: what does an incremental relabel change?  labels of the tiles it reset, before and after */
     std::vector<std::pair<int, std::vector<int32_t> > > reset_snapshot;
     void activate_all(uint32_t phase)
@@ -339,6 +372,7 @@ struct HostDev {
             g_prof[27] += changed;              /* voxels whose label changed                          */
         }
         reset_snapshot.clear();
+        if (g_check_exact) check_exact_labels();
         HostBlock x(S);
         HostWave w(WS);
         int candidates = 0; /* what the library's tile filter would list */
@@ -470,6 +504,7 @@ extern "C" {
 void hostsim_set_wave_mode(int mode) { g_wave_mode = mode; }
 void hostsim_set_w26(int passes, int raises, int flags) { g_w26_passes = passes; g_w26_raises = raises; g_w26_flags = flags; }
 void hostsim_set_dt(int on) { g_use_dt = on; }
+void hostsim_set_check_exact(int on) { g_check_exact = on; }
 void hostsim_trace(const char* path) { if (g_trace) fclose(g_trace); g_trace = path && *path ? fopen(path, "w") : NULL; }
 void hostsim_set_bricks(int on) { g_bricks = on; }
 /* record slots of a compacted border message (MgcLattice::halo_max_rec); which: 6 or 26 */
@@ -639,6 +674,18 @@ struct HostDev26 {
     void reset_suspect(uint32_t epoch, int list)
     {
         HostBlock26 x(S);
+        if (getenv("HOSTSIM_TRACE26")) {
+            int sus = 0, dirty = 0;
+            for (int t = 0; t < L.ntiles; ++t) { sus += (L.status[t] & MGC_ST_SUSPECT) != 0; dirty += (L.status[t] & MGC_ST_DIRTY) != 0; }
+            fprintf(stderr, "\n[relabel: %d of %d tiles suspect, %d dirty] ", sus, L.ntiles, dirty);
+            int hd[16] = {0}, hs[16] = {0}, ha[16] = {0};
+            for (int t = 0; t < L.ntiles; ++t) {
+                int tx = t % L.gx, ty = (t / L.gx) % L.gy, tz = t / (L.gx * L.gy);
+                int sh = std::min(std::min(std::min(tx, L.gx - 1 - tx), std::min(ty, L.gy - 1 - ty)), std::min(tz, L.gz - 1 - tz));
+                ha[sh]++; hd[sh] += (L.status[t] & MGC_ST_DIRTY) != 0; hs[sh] += (L.status[t] & MGC_ST_SUSPECT) != 0;
+            }
+            for (int i = 0; i < 16 && ha[i]; ++i) fprintf(stderr, "{shell %d: %d tiles, %d dirty, %d suspect} ", i, ha[i], hd[i], hs[i]);
+        }
         for (int t = 0; t < L.ntiles; ++t) mgc26_reset_suspect_tile(x, L, t, epoch, list);
     }
     void relabel_all(uint32_t epoch, int next)
@@ -656,8 +703,42 @@ struct HostDev26 {
         L.count[MGC26_CNT_REL] += n;
         for (int i = 0; i < n; ++i) mgc26_relabel_tile(x, L, L.list[lst][i], epoch, next, false);
     }
+    /* hostsim_set_check_exact: after every global relabel the labels are compared with the exact distances to the sink in the
+     * residual graph (plain relaxation over the whole volume): g_prof[40] relabels checked, g_prof[41] voxels that differ.
+     * (A single device only: a slab would need its neighbours' residuals.) */
+    void check_exact_labels()
+    {
+        const int64_t N = L.nvox;
+        std::vector<int32_t> dist((size_t)N, MGC_HINF), tl((size_t)N), lc((size_t)N);
+        for (int64_t id = 0; id < N; ++id) {
+            int tile, loc;
+            mgc_node_to_tile(L, id, tile, loc);
+            tl[id] = tile; lc[id] = loc;
+            if (L.sink[(int64_t)tile * MGC_TV + loc] > 0.0) dist[id] = 1;
+        }
+        for (bool changed = true; changed;) {
+            changed = false;
+            for (int64_t id = 0; id < N; ++id) {
+                const int64_t x0 = id % L.dx, y0 = (id / L.dx) % L.dy, z0 = id / (L.dx * L.dy);
+                int32_t best = dist[id];
+                for (int d = 0; d < 26; ++d) {
+                    if (!(L.rcap[((int64_t)tl[id] * 26 + d) * MGC_TV + lc[id]] > 0.0)) continue;
+                    int dz, dy, dx;
+                    mgc26_offset(d, dz, dy, dx);
+                    const int64_t z = z0 + dz, y = y0 + dy, xx = x0 + dx;
+                    if (z < 0 || z >= L.dz || y < 0 || y >= L.dy || xx < 0 || xx >= L.dx) continue;
+                    const int32_t hv = dist[(z * L.dy + y) * L.dx + xx];
+                    if (hv < MGC_HINF && hv + 1 < best) best = hv + 1;
+                }
+                if (best < dist[id]) { dist[id] = best; changed = true; }
+            }
+        }
+        g_prof[40]++;
+        for (int64_t id = 0; id < N; ++id) g_prof[41] += L.height[(int64_t)tl[id] * MGC_TV + lc[id]] != dist[id];
+    }
     void activate_all(uint32_t phase)
     {
+        if (g_check_exact) check_exact_labels();
         HostBlock26 x(S);
         for (int t = 0; t < L.ntiles; ++t)
             if (mgc26_activate_tile(x, L, t, phase)) L.count[MGC26_CNT_ACTIVE]++;

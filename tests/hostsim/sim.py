@@ -50,6 +50,21 @@ def set_wave_mode(mode):
     lib().hostsim_set_wave_mode(int(mode))
 
 
+def set_check_exact(on):
+    """after every global relabel, compare the labels with the exact distances to the sink in the residual graph (a plain
+    relaxation over the volume); read the result with prof(): [40] relabels checked, [41] voxels whose label differs"""
+    lib().hostsim_set_check_exact(int(bool(on)))
+
+
+def prof():
+    """the simulator's work counters (copied and cleared)"""
+    out = np.zeros(64, np.int64)
+    L = lib()
+    L.hostsim_prof.argtypes = [np.ctypeslib.ndpointer(np.int64), C.c_void_p, C.c_int]
+    L.hostsim_prof(out, None, 0)
+    return out
+
+
 def solve(shape, weights, trcap, rounds=0, cycles=0, sweeps=0, max_outer=0, wave_mode=None):
     """weights: per-axis arrays for a 3-D shape (oracle layout); returns (labels[bool array], stats dict)."""
     if wave_mode is not None:

@@ -186,6 +186,42 @@ def test_hostsim_full_neighbourhood_incremental_relabel(gen, shape, rounds, cycl
     np.testing.assert_array_equal(lab, g.labels().reshape(shape))
 
 
+@pytest.mark.parametrize("conn,gen,shape,kw", [
+    (6, "hard", (32, 32, 32), dict(rounds=1, cycles=-1, sweeps=2)),
+    (6, "hard", (32, 32, 32), dict(rounds=1, cycles=1, sweeps=2)),
+    (6, "ties", (24, 24, 24), dict(rounds=2, cycles=-1, sweeps=4)),
+    (6, "sphere", (24, 40, 17), dict(rounds=1, cycles=-1, sweeps=2, wave_mode=3)),
+    (6, "hard", (32, 32, 32), dict(rounds=1, cycles=-1, sweeps=2, wave_mode=7)),
+    (26, "hard", (32, 32, 32), dict(rounds=1, cycles=-1, sweeps=2)),
+    (26, "hard", (32, 32, 32), dict(rounds=1, cycles=1, sweeps=1)),
+    (26, "ties", (24, 24, 24), dict(rounds=2, cycles=-1, sweeps=4)),
+    (26, "sphere", (24, 40, 17), dict(rounds=1, cycles=-1, sweeps=2, wave_mode=16)),
+    (26, "hard", (32, 32, 32), dict(rounds=1, cycles=-1, sweeps=2, wave_mode=16)),
+])
+def test_hostsim_incremental_relabels_leave_exact_distances(conn, gen, shape, kw):
+    """A tile is recomputed by an incremental global relabel only if a label of it rose or one of its voxels lost its last
+    residual arc one label down (or it stands on such a tile): after EVERY global relabel of a solve driven through many of them
+    the labels must be the exact distances to the sink in the residual graph, in every form of the discharge."""
+    import sim
+    from medpy_amd import synthetic
+    from oracle import energy_numpy
+    s = getattr(synthetic, gen)(shape)
+    tr = (np.where(s["fg"], 65535.0, 0.0) - np.where(s["bg"], 65535.0, 0.0)).ravel()
+    sim.set_check_exact(1)
+    sim.prof()
+    try:
+        if conn == 6:
+            _, st = sim.solve(shape, energy_numpy.boundary_weights(s["term"], s["image"], s["sigma"]), tr, **kw)
+        else:
+            w = energy_numpy.boundary_weights_offsets(s["term"], s["image"], energy_numpy.forward_offsets(3, 26), s["sigma"])
+            _, st = sim.solve26(shape, w, tr, **kw)
+        p = sim.prof()
+    finally:
+        sim.set_check_exact(0)
+    assert st["converged"] == 1 and st["outer"] >= 5
+    assert p[40] == st["outer"] and p[41] == 0
+
+
 def test_dimacs_writer_text_equals_the_reference_layout():
     """reference medpy/graphcut/write.py:29-76 on the dict Graph (graph.py:31-264); expected text written out by hand from
     the reference's format strings"""
