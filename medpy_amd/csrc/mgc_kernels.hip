@@ -2097,7 +2097,7 @@ struct mgc_graph {
     int wave_grid_dis = 0, wave_grid_rel = 0; /* persistent grids of the wave kernels (waves resident on the device) */
     int tk_dis = MGC_CNT_TICKET_DIS, tk_rel = MGC_CNT_TICKET_REL; /* ticket slot of the next wave launch (alternates) */
     int est_phase_tiles = 1 << 30; /* length of the discharge lists at the last counter read-back */
-    int sweeps_sparse26 = 8;       /* 26-neighbourhood: sweep budget of a discharge while fewer than 20 % of a colour's tiles are active */
+    int sweeps_sparse26 = 5;       /* 26-neighbourhood: sweep budget of a discharge while fewer than 20 % of a colour's tiles are active (8 until incremental relabels got cheap; 512^3 markers only 285 ms at 8, 265 at 5 and 4, 287 at 3: profiles/r4_sched26_sparse_sweeps.jsonl) */
     int wave_grid26 = 0;           /* persistent grid of k26_discharge_w: one wave per SIMD (it needs the whole register file) */
     int relabel_exchange_every = 4; /* slabs: relabel passes between two exchanges of the border labels (0: iterate to the local fixpoint first, round 3's schedule) */
     bool rounds_set = false, sparse26_set = false, wave_set = false;
