@@ -26,5 +26,11 @@ python bench.py --config 3 --no-cpu 2>>gpurun_out/r4_bench.err | tail -1 > gpuru
 python bench.py --config 2 --no-cpu 2>>gpurun_out/r4_bench.err | tail -1 > gpurun_out/r4_bench_config2.json
 timeout 300 python tools/gpu_workloads.py 512 > gpurun_out/r4_workloads.jsonl 2>&1
 ( timeout 300 python tools/gpu_ab.py --n 512 --conn 26 --reps 2 base; timeout 300 python tools/gpu_ab.py --n 512 --conn 26 --regional --reps 2 base prepush=0; timeout 300 python tools/gpu_ab.py --n 512 --conn 26 --wl hard --reps 2 base ) > gpurun_out/r4_workloads26.jsonl 2>&1
+OUT=$ROOT/gpurun_out/prof26n; rm -rf $OUT; mkdir -p $OUT; cd /tmp
+timeout 600 rocprofv3 --kernel-trace --stats -d $OUT/trace -- python $ROOT/tools/gpu_ab.py --n 512 --conn 26 --reps 1 base > $OUT/trace.log 2>&1
+cd $ROOT; T=$(find $OUT/trace -name "*.db" | head -1); [ -n "$T" ] && python tools/rocpd_summary.py stats $T > gpurun_out/r4_26conn_noreg_trace.csv; rm -rf $OUT
+( timeout 300 python tools/gpu_ab.py --n 512 --regional --reps 3 base prepush=0 ) > gpurun_out/r4_regional_6conn.jsonl 2>&1
+( timeout 300 python tools/gpu_ab.py --n 512 --conn 26 --reps 1 trace=1 ) > /dev/null 2> gpurun_out/r4_relabel_trace26.txt
+MEDPY_HIP_LIB=$ROOT/build/lib_prof.so timeout 200 python tools/gpu_sections26.py 512 0 2>&1 | grep -v Warn | tail -6 > gpurun_out/r4_discharge26_sections_noreg.txt
 MEDPY_HIP_LIB=$ROOT/build/lib_prof.so timeout 200 python tools/gpu_sections.py 512 2>&1 | grep -v Warn | tail -14 > gpurun_out/r4_discharge_sections.txt
 cat gpurun_out/r4_pytest.txt | tail -2; cut -c1-600 gpurun_out/r4_bench_n1.json; cut -c1-300 gpurun_out/r4_bench_config3.json; cut -c1-200 gpurun_out/r4_workloads.jsonl; cut -c1-300 gpurun_out/r4_workloads26.jsonl
