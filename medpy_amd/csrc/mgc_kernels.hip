@@ -163,6 +163,11 @@ struct GpuBlockT {
     __device__ __forceinline__ void wave_fence() { __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront"); __builtin_amdgcn_wave_barrier(); }
     /* development aid: cycles spent since the previous mark go to section `id` (count in id + 8).  Accumulated in
      * lane 0's registers and flushed once per workgroup (flush_marks), so the probe does not perturb the kernel. */
+    /* += / |= on global memory as atomics WITHOUT return: the value is not needed, so nothing waits for the trip to HBM (a load +
+     * add + store in the middle of a step cost the whole workgroup that trip at its next barrier).  One writer per address and
+     * step, and an f64 atomic add is the IEEE sum (tools/probes/atomic_f64_probe.hip): the result is what += gives. */
+    __device__ __forceinline__ void gadd(double* p, double v) { (void)__hip_atomic_fetch_add(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
+    __device__ __forceinline__ void gor(uint32_t* p, uint32_t v) { (void)__hip_atomic_fetch_or(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
     unsigned long long last = 0;
     unsigned long long acc[8] = {0, 0, 0, 0, 0, 0, 0, 0};
     unsigned int cnt[8] = {0, 0, 0, 0, 0, 0, 0, 0};
@@ -498,10 +503,11 @@ __global__ __launch_bounds__(MGCW_LANES) void k_relabel_w(MgcLattice L, int lst,
  * register file (excess + 26 residual planes of a z-column per lane = 432 registers); four tiles in flight per CU ---- */
 typedef GpuWaveT<MgcWaveShared26> GpuWave26;
 __global__ __launch_bounds__(MGCW_LANES) __attribute__((amdgpu_waves_per_eu(1, 1)))
-void k26_discharge_w(MgcLattice L, int lst, uint32_t phase, int sweeps, int passes, int raises, int flags, int tk)
+void k26_discharge_w(MgcLattice L, int lst, uint32_t phase, int sweeps, int passes, int raises, int flags, int tk, int zero_idx)
 {
     __shared__ MgcWaveShared26 S;
     GpuWave26 w(S);
+    mgc_clear_counter(L, zero_idx); /* the list the previous phase consumed (nobody appends to it for the next seven phases) */
     if (blockIdx.x == 0) {
         MgcListView view;
         const int n = mgc_list_view(L, lst, view);
@@ -579,6 +585,8 @@ struct GpuBlockV {
     __device__ __forceinline__ int atomic_add(int32_t* p, int v) { return atomicAdd(p, v); }
     __device__ __forceinline__ uint32_t atomic_exch(uint32_t* p, uint32_t v) { return atomicExch(p, v); }
     __device__ __forceinline__ void mark(const MgcLattice&, int) {}
+    __device__ __forceinline__ void gadd(double* p, double v) { (void)__hip_atomic_fetch_add(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
+    __device__ __forceinline__ void gor(uint32_t* p, uint32_t v) { (void)__hip_atomic_fetch_or(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
     __device__ __forceinline__ int shard(const MgcLattice& L) const { return (int)(blockIdx.x & (unsigned)(L.nshard - 1)); }
     __device__ __forceinline__ void atomic_or(uint32_t* p, uint32_t v) { atomicOr(p, v); }
     /* a value every lane of the workgroup holds alike (read from LDS after a barrier): scalar for the branches on it */
@@ -634,10 +642,11 @@ struct MgcTileShared26V : MgcTileShared26 { /* all 26 residuals in registers: rl
 };
 /* region discharge with two voxels per thread and all 26 residuals of both in registers (see mgc26_discharge_tile) */
 __global__ __launch_bounds__(MGC_TV / 2) __attribute__((amdgpu_waves_per_eu(2, 2)))
-void k26_discharge_v(MgcLattice L, int lst, uint32_t phase, int cycles, int sweeps)
+void k26_discharge_v(MgcLattice L, int lst, uint32_t phase, int cycles, int sweeps, int zero_idx)
 {
     __shared__ MgcTileShared26V S;
     GpuBlockV<2, MgcTileShared26V, true> x(S);
+    mgc_clear_counter(L, zero_idx);
     MgcListView view;
     const int n = mgc_list_view(L, lst, view);
     if (blockIdx.x == 0 && threadIdx.x == 0 && n) atomicAdd(&L.count[MGC26_CNT_DIS], n);
@@ -725,10 +734,11 @@ __global__ __launch_bounds__(256) void k26_activate_w(MgcLattice L, uint32_t pha
 #define MGC26_DISCHARGE_WAVES 4 /* waves per SIMD the register allocator leaves room for: 128 VGPRs, 2 workgroups per CU
                                    (13 of the 26 residuals live in LDS, see MgcTileShared26D) */
 #endif
-__global__ __launch_bounds__(MGC_TV, MGC26_DISCHARGE_WAVES) void k26_discharge(MgcLattice L, int lst, uint32_t phase, int cycles, int sweeps)
+__global__ __launch_bounds__(MGC_TV, MGC26_DISCHARGE_WAVES) void k26_discharge(MgcLattice L, int lst, uint32_t phase, int cycles, int sweeps, int zero_idx)
 {
     __shared__ MgcTileShared26D S;
     GpuBlock26D x(S);
+    mgc_clear_counter(L, zero_idx); /* the list the previous phase consumed (nobody appends to it for the next seven phases) */
     MgcListView view;
     const int n = mgc_list_view(L, lst, view);
     if (blockIdx.x == 0 && threadIdx.x == 0 && n) atomicAdd(&L.count[MGC26_CNT_DIS], n);
@@ -2198,7 +2208,7 @@ struct HipDevT {
     }
     void zero_count(int i)
     {
-        if (!FULL && i == last_discharged) { flush_zero(); h->pending_zero = i; last_discharged = -1; return; }
+        if (i == last_discharged) { flush_zero(); h->pending_zero = i; last_discharged = -1; return; }
         if (h->pending_zero >= 0) { h->zero_mask |= 1u << h->pending_zero; h->pending_zero = -1; }
         h->zero_mask |= 1u << i;
     }
@@ -2361,11 +2371,11 @@ struct HipDevT {
              * 6; markers only 494 ms at 3, 431 at 8. */
             if (h->sweeps_sparse26 > 0 && (int64_t)h->est_phase_tiles * 40 < h->L.ntiles) sweeps = h->sweeps_sparse26;
             if (((h->wave_kernels & 32) || h->w26_auto) && cycles < 0) { /* one wave per tile, the tile in registers (stored labels only) */
-                hipLaunchKernelGGL(k26_discharge_w, dim3(h->wave_grid26), dim3(MGCW_LANES), 0, h->stream, h->L, lst, phase, sweeps, h->w26_auto ? 1 : h->w26_passes, h->w26_raises, h->w26_flags, h->tk_dis);
+                hipLaunchKernelGGL(k26_discharge_w, dim3(h->wave_grid26), dim3(MGCW_LANES), 0, h->stream, h->L, lst, phase, sweeps, h->w26_auto ? 1 : h->w26_passes, h->w26_raises, h->w26_flags, h->tk_dis, zero_idx);
                 h->tk_dis ^= 1;
             }
-            else if (h->wave_kernels & 16) hipLaunchKernelGGL(k26_discharge_v, dim3(grid(h->L.ntiles)), dim3(MGC_TV / 2), 0, h->stream, h->L, lst, phase, cycles, sweeps);
-            else hipLaunchKernelGGL(k26_discharge, dim3(h->grid26_dis > 0 ? (h->grid26_dis < h->L.ntiles ? h->grid26_dis : h->L.ntiles) : grid(h->L.ntiles)), dim3(MGC_TV), 0, h->stream, h->L, lst, phase, cycles, sweeps);
+            else if (h->wave_kernels & 16) hipLaunchKernelGGL(k26_discharge_v, dim3(grid(h->L.ntiles)), dim3(MGC_TV / 2), 0, h->stream, h->L, lst, phase, cycles, sweeps, zero_idx);
+            else hipLaunchKernelGGL(k26_discharge, dim3(h->grid26_dis > 0 ? (h->grid26_dis < h->L.ntiles ? h->grid26_dis : h->L.ntiles) : grid(h->L.ntiles)), dim3(MGC_TV), 0, h->stream, h->L, lst, phase, cycles, sweeps, zero_idx);
         }
         /* one wave per tile has the higher throughput (2 048 tiles in flight, fewer instructions per tile), eight waves per tile
          * the shorter latency (36 us against 60 us for one tile): short lists -- small volumes, the tail of a solve -- are a

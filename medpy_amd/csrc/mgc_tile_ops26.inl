@@ -47,6 +47,10 @@ struct MgcTileShared26 {
     int32_t satflag;      /* discharge: some arc (or sink link) of the tile was saturated               */
     uint32_t dirmask[2];  /* discharge: directions along which some active voxel can push in this sweep  */
     uint32_t pushmask;    /* discharge: directions along which a voxel of the tile DID push               */
+    uint32_t pflag[MGC26_NDIR][8]; /* discharge: somebody pushed along direction d into z-layer k of the tile in the step before
+                                      (cleared at the top of a sweep).  A z-layer is a wave: in the sparse phases of a solve
+                                      most waves of most steps have nothing to receive and nothing to push, and skip both on
+                                      two words instead of reading 128 hand-off slots */
 };
 
 /* status word of a tile, full neighbourhood: bits 0..5 as in mgc_common.h (SINK, DIRTY, SUSPECT, EXCESS, ALLINF), bits 6..31 =
@@ -276,6 +280,9 @@ MGC_HD void mgc26_discharge_tile(X& x, const MgcLattice& L, int tile, uint32_t p
 #pragma unroll
         for (int d = 0; d < MGC26_NDIR; ++d) R(d, t) = L.rcap[((int64_t)tile * MGC26_NDIR + d) * MGC_TV + t];
         mgc26_load_halo(x, L, t);
+        /* hand-off slots are zero except between a push and its receive (the receiver clears what it took): a voxel that pushes
+         * nothing writes nothing */
+        x.S.out[0][t] = 0.0; x.S.out[1][t] = 0.0; x.S.out[2][t] = 0.0; x.S.out[3][t] = 0.0;
     });
     x.mark(L, 0); /* load */
 
@@ -311,6 +318,7 @@ MGC_HD void mgc26_discharge_tile(X& x, const MgcLattice& L, int tile, uint32_t p
              * (A voxel that receives excess during the sweep pushes on in the steps that run; its other directions wait for
              * the next sweep -- any order of admissible pushes is a valid discharge.) */
             x.par([&](int t) {
+                if (t < MGC26_NDIR * 8) (&x.S.pflag[0][0])[t] = 0; /* (the last receive of the sweep before lies behind a barrier) */
                 if (e[t] > 0.0 && hme[t] < MGC_HINF) {
                     const int me = mgc_hs_index(t >> 6, (t >> 3) & 7, t & 7);
                     uint32_t m = 0;
@@ -329,6 +337,7 @@ MGC_HD void mgc26_discharge_tile(X& x, const MgcLattice& L, int tile, uint32_t p
             const uint32_t M = x.uniform(x.S.dirmask[fl]);
 #endif
             MGC26_COUNT_STEPS(M);
+            x.mark(L, 5); /* which directions run */
             /* 14 steps: step p pushes along the OPPOSITE directions p and 25 - p (p < 13) after receiving what step p - 1
              * pushed.  Two directions share a barrier, and their LDS round trips overlap.  Opposite directions, because
              * pushes over the tile boundary update the idle neighbour tile in place, one writer per voxel and step: two
@@ -339,12 +348,15 @@ MGC_HD void mgc26_discharge_tile(X& x, const MgcLattice& L, int tile, uint32_t p
                 constexpr int d = decltype(dc)::value;
                 int dz, dy, dx;
                 mgc26_offset(d, dz, dy, dx);
+                if (!x.S.pflag[d][t >> 6]) return; /* nobody pushed into this z-layer along d */
                 const int sz = (t >> 6) - dz, sy = ((t >> 3) & 7) - dy, sx = (t & 7) - dx; /* the voxel that pushed towards me */
                 if (sz >= 0 && sz < 8 && sy >= 0 && sy < 8 && sx >= 0 && sx < 8) {
-                    const double din = x.S.out[buf][mgc_local(sz, sy, sx)];
+                    const int src = mgc_local(sz, sy, sx);
+                    const double din = x.S.out[buf][src];
                     if (din != 0.0) {
                         e[t] += din;
                         R(25 - d, t) += din;
+                        x.S.out[buf][src] = 0.0; /* (one receiver per slot and step) */
                     }
                 }
             };
@@ -373,18 +385,20 @@ MGC_HD void mgc26_discharge_tile(X& x, const MgcLattice& L, int tile, uint32_t p
                         }
                     }
                 }
+                if (delta == 0.0) return;
                 if (inside) {
                     x.S.out[buf][t] = delta;
-                } else if (delta != 0.0) {
+                    x.S.pflag[d][vz] = 1;
+                } else {
                     /* the target voxel lives in an idle neighbour tile and nobody else writes it in this step: update its
                      * excess and reverse residual in place */
                     const int ni = ((vz < 0 ? -1 : (vz > 7 ? 1 : 0)) + 1) * 9 + ((vy < 0 ? -1 : (vy > 7 ? 1 : 0)) + 1) * 3 +
                                    ((vx < 0 ? -1 : (vx > 7 ? 1 : 0)) + 1);
                     const int nt = x.S.nbr[ni];
                     const int lv = mgc_local(vz & 7, vy & 7, vx & 7);
-                    L.excess[(int64_t)nt * MGC_TV + lv] += delta;
-                    L.rcap[((int64_t)nt * MGC26_NDIR + (25 - d)) * MGC_TV + lv] += delta;
-                    L.rmask32[(int64_t)nt * MGC_TV + lv] |= 1u << (25 - d);
+                    x.gadd(&L.excess[(int64_t)nt * MGC_TV + lv], delta);
+                    x.gadd(&L.rcap[((int64_t)nt * MGC26_NDIR + (25 - d)) * MGC_TV + lv], delta);
+                    x.gor(&L.rmask32[(int64_t)nt * MGC_TV + lv], 1u << (25 - d));
                     x.S.nbrflag[ni] = 1;
                 }
             };
@@ -425,6 +439,7 @@ MGC_HD void mgc26_discharge_tile(X& x, const MgcLattice& L, int tile, uint32_t p
             MGC26_STEP(0) MGC26_STEP(1) MGC26_STEP(2) MGC26_STEP(3) MGC26_STEP(4) MGC26_STEP(5) MGC26_STEP(6) MGC26_STEP(7) MGC26_STEP(8)
             MGC26_STEP(9) MGC26_STEP(10) MGC26_STEP(11) MGC26_STEP(12) MGC26_STEP(13)
 #undef MGC26_STEP
+            x.mark(L, 6); /* the steps */
             /* local relabel of stuck active voxels (see mgc_discharge_tile): labels stay valid lower bounds */
             x.par([&](int t) {
                 if (e[t] > 0.0 && hme[t] < MGC_HINF) {
@@ -444,7 +459,7 @@ MGC_HD void mgc26_discharge_tile(X& x, const MgcLattice& L, int tile, uint32_t p
                     }
                 }
             });
-            x.mark(L, 2); /* one sweep */
+            x.mark(L, 2); /* one sweep (what is left of it: the local relabel) */
             if (!x.S.flag[fl]) break;
         }
     }

@@ -90,6 +90,8 @@ struct HostBlockT {
     uint32_t uniform(uint32_t v) const { return v; }
     void atomic_and(uint32_t* p, uint32_t v) { *p &= v; }
     void mark(const MgcLattice&, int id) { g_prof[id & 15]++; }
+    void gadd(double* p, double v) { *p += v; }
+    void gor(uint32_t* p, uint32_t v) { *p |= v; }
     void wave_fence() {}
     /* exact in-tile labels: reference implementation = chaotic relaxation from scratch (mgc_tile_bfs) */
     template <class MaskFn, class RegI>

@@ -17,7 +17,7 @@ t0 = time.perf_counter(); g._build(); g.maxflow(); plain = time.perf_counter() -
 g.set_param("profile_sections", 1)
 g._build(); t0 = time.perf_counter(); g.maxflow(); dt = time.perf_counter() - t0
 st = g.stats(); pr = g.profile()
-names = {"load": "load", "labels": "label set-up / between tiles", "sweep": "one sweep", "store": "tail votes + stores"}
+names = {"load": "load", "labels": "label set-up / between tiles", "faceflags": "sweep: direction mask", "s6": "sweep: the steps", "sweep": "sweep: local relabel", "store": "tail votes + stores"}
 tot = sum(pr[k]["cycles"] for k in names)
 print(json.dumps({"n": n, "regional": regional, "solve_ms": plain * 1e3, "profiled_ms": dt * 1e3, "discharge_tiles": st["discharge_tiles"], "discharge_ms": st["discharge_ms"],
                   "relabel_ms": st["relabel_ms"], "build_ms": st["build_ms"], "phases": st["phases"], "relabels": st["global_relabels"]}))
@@ -25,3 +25,5 @@ for k, label in names.items():
     v = pr[k]
     print("%-32s cycles %16d (%5.1f%%)  count %9d  avg %8.0f" % (label, v["cycles"], 100.0 * v["cycles"] / max(tot, 1), v["count"], v["cycles"] / max(v["count"], 1)))
 print("per tile discharge: %.0f clock64 ticks; sweeps per discharge %.2f" % (tot / max(st["discharge_tiles"], 1), pr["sweep"]["count"] / max(st["discharge_tiles"], 1)))
+if len(sys.argv) > 3:  # one more run with extra parameters, e.g. sweeps_sparse26=8
+    pass
