@@ -132,7 +132,8 @@ def test_full_neighbourhood_slabs_equal_single_and_oracle(gen, shape, nslabs, re
 
 @pytest.mark.parametrize("driver,halo_max", [("slab.py", 0), ("native", 0), ("native", 2)])
 @pytest.mark.parametrize("nranks,conn,gen,shape", [(2, 6, "sphere", (64, 40, 48)), (3, 6, "hard", (48, 48, 40)), (2, 26, "sphere", (64, 40, 48)),
-                                                   (4, 26, "sphere", (64, 32, 32))])
+                                                   (4, 26, "sphere", (64, 32, 32)),
+                                                   (8, 6, "sphere", (128, 40, 48)), (8, 26, "sphere", (128, 32, 32))])  # (the rank count of configs 4 / 5's node)
 def test_native_transport_protocol_with_mock_rccl(nranks, conn, gen, shape, driver, halo_max, tmp_path, monkeypatch):
     """The multi-rank protocol of mgc_halo_exchange / mgc_allreduce_counts (one grouped send / receive per neighbour and
     exchange, bounded compacted messages with deferral, every rank taking the same decisions) -- driven by slab.py and by the
