@@ -40,10 +40,14 @@
 #define MGC_ST_EXCESS 16u      /* some voxel of the tile holds excess under a finite label, as of build / absorb / its last discharge */
 #define MGC_ST_ALLINF 32u      /* every label of the tile is MGC_HINF: set when an incremental relabel resets the tile, cleared when a
                                   relabel pass lowers one of its labels (a clear bit promises nothing) */
+#define MGC_ST_SOURCE 64u      /* (6-neighbourhood) the tile held a source link (tr_cap > 0) when the graph was built: where the schedule looks for
+                                  "can excess of the source still reach the sink?" (mgc_source_open_tile) */
 #define MGC_ST_DEP_SHIFT 8
 /* counter slots no layout uses as a work list (6-neighbourhood: lists 0..7, totals 8 / 9; 26-neighbourhood: lists 0..17,
  * totals 18..20; tickets of the wave kernels 24..27) */
 #define MGC_CNT_SINK_TILES 13  /* (6-neighbourhood) k_build: tiles that hold a sink link */
+#define MGC_CNT_RADIAL_C 14    /* (6-neighbourhood) hop length of the shortest source -> sink path (mgc_dt_cmin_tile) or MGC_HINF */
+#define MGC_CNT_SOURCE_OPEN 15 /* (6-neighbourhood) source tiles whose excess still stands under a finite label (mgc_source_open_tile) */
 #define MGC_CNT_CHANGED 21     /* suspect-closure pass changed something */
 #define MGC_CNT_FILTER 22      /* length of the scratch list the tile filters fill (absorb / relabel seeding / suspect reset) */
 #define MGC_CNT_FILTER_ACT 23  /* ... of the activation filter */

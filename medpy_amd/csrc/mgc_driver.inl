@@ -21,6 +21,9 @@
  *   fill_heights_inf()  zero_count(i)  read_counts(int out[MGC_NCOUNT])   absorb_all()   suspect_pass()  suspect_batch()
  *   relabel_all(epoch, next_list)  relabel_list(list, epoch, next_list)  first_relabel_dt() -> bool
  *   activate_all(phase)  discharge(list, phase, max_cycles, max_sweeps)  range_push(name) / range_pop() (tracing ranges)
+ *   radial labels (mgc_dt_ops.inl; only after first_relabel_dt() returned true):
+ *   radial_begin(c_min) -> bool  (distance from the source, C into MGC_CNT_RADIAL_C, exact labels kept aside, labels lowered)
+ *   radial_restore_exact()  radial_save_exact()  radial_lower(c_min)  source_open() (counts into MGC_CNT_SOURCE_OPEN)  set_radial(bool)
  */
 #ifndef MGC_DRIVER_INL
 #define MGC_DRIVER_INL
@@ -39,6 +42,11 @@ struct MgcSolveParams {
     int trace;              /* 1: one stderr line per global relabel (tile visits of the relabel, discharges since the one before) */
     int adaptive_rounds;    /* k > 0: the number of rounds between two relabels doubles (up to 4x) while a relabel visits more
                                than k times as many tiles as the discharges of the cycle before it did                   */
+    int radial;             /* 1: the flood phase runs on RADIAL labels (mgc_dt_ops.inl): after a first relabel by distance transform
+                               the labels are min(exact, C - distance from the source) while excess of the source can still
+                               reach the sink; exact labels from the relabel that finds the source sealed in            */
+    int radial_min_c;       /* ... only when the shortest source -> sink path has at least this many hops               */
+    int radial_rounds0;     /* colour rounds of the first radial cycle (the following ones run rounds_per_relabel)       */
 };
 
 struct MgcSolveStats {
@@ -50,6 +58,7 @@ struct MgcSolveStats {
     int64_t converged;        /* 1 when the preflow is maximum                             */
     int64_t last_active;      /* active tiles found by the last activation pass            */
     int64_t readbacks;        /* counter read-backs (host syncs)                           */
+    int64_t radial_cycles;    /* cycles of colour phases that ran on radial labels         */
 };
 
 /* where a solver variant keeps its lists and counters (6-neighbourhood: 2 colours, lists 0..3 + 4,5;
@@ -84,6 +93,10 @@ static inline MgcSolveParams mgc_default_params(int ndir = 6)
     p.trace = 0;
     p.adaptive_rounds = ndir == 26 ? 9 : 2; /* a tile visit of a relabel costs 1/3 of a discharge (8 vs 25 ns), 1/9 in the full neighbourhood (20 vs 175 ns);
                                                measured at 512^3 (round 3): weak contrast 68.7 ms at 3, 66.3 at 2, 66.3 at 1; headline volume 35.9 at 3 and 2, 39.8 at 1 */
+    p.radial = ndir == 6 ? 1 : 0;
+    p.radial_min_c = 8;
+    p.radial_rounds0 = 4; /* a source whose cut hugs it is sealed in by then, and the exact labels take over before the flow that got through
+                             is sent astray (weak-contrast volume, host simulator 256^3: 4 rounds 127 k discharges, 8 rounds 173 k; exact labels 126 k) */
     return p;
 }
 
@@ -95,6 +108,8 @@ int mgc_solve(Dev& dev, const MgcLattice& L, const MgcSolveParams& P, MgcSolveSt
     int cnt[MGC_NCOUNT];
     int rounds = P.rounds_per_relabel;
     int64_t prev_dis = 0, prev_rel = 0, last_passes = 0;
+    bool radial = false; /* the labels in HBM are the radial ones: discharges mark every saturation, relabels start from the exact labels kept aside */
+    int radial_done = 0, radial_next = P.radial_rounds0, radial_budget = 0; /* colour rounds run on radial labels / length of the next radial cycle / most such rounds */
     st = MgcSolveStats();
     dev.zero_count(lay.cnt_dis);
     dev.zero_count(lay.cnt_rel);
@@ -108,6 +123,9 @@ int mgc_solve(Dev& dev, const MgcLattice& L, const MgcSolveParams& P, MgcSolveSt
         if (lay.rl_third >= 0) dev.zero_count(lay.rl_third); /* (all clears of this stretch go out together, see HipDevT::flush_zero) */
         const bool by_transform = outer == 0 && dev.first_relabel_dt(); /* exact labels in six streaming scans: no passes at all */
         if (by_transform) {
+            /* the flood phase on radial labels; whether the graph qualifies (C >= radial_min_c) is decided on the device, the host
+             * reads C with the counters of the activation below */
+            if (P.radial && lay.incremental && P.incremental_relabel) radial = dev.radial_begin(P.radial_min_c);
         } else if (outer == 0 || !lay.incremental || !P.incremental_relabel) {
             dev.fill_heights_inf();
             dev.relabel_all(rep + 1, lay.rl_base + (int)((rep + 1) & 1u));
@@ -120,6 +138,7 @@ int mgc_solve(Dev& dev, const MgcLattice& L, const MgcSolveParams& P, MgcSolveSt
                 st.readbacks++;
                 if (cnt[MGC_CNT_CHANGED] == 0) break;
             }
+            if (radial) dev.radial_restore_exact(); /* everybody back on the exact labels of the last relabel; the suspect tiles are reset and recomputed from them */
             dev.reset_suspect(rep + 1, lay.rl_base + (int)((rep + 1) & 1u));
             if (P.trace) {
                 dev.read_counts(cnt);
@@ -169,6 +188,11 @@ int mgc_solve(Dev& dev, const MgcLattice& L, const MgcSolveParams& P, MgcSolveSt
         }
         st.outer++;
         dev.range_pop();
+        if (radial && outer > 0) { /* the labels are exact now: keep them, and ask whether excess of the source still reaches the sink */
+            dev.radial_save_exact();
+            dev.zero_count(MGC_CNT_SOURCE_OPEN);
+            dev.source_open();
+        }
 
         /* ---- who can still push towards the sink? ---- */
         dev.range_push("activation");
@@ -188,7 +212,7 @@ int mgc_solve(Dev& dev, const MgcLattice& L, const MgcSolveParams& P, MgcSolveSt
             const int64_t d_dis = (int64_t)cnt[lay.cnt_dis] - prev_dis; /* discharges since the relabel before this one */
             const int64_t d_rel = (int64_t)cnt[lay.cnt_rel] - prev_rel; /* tile visits of the relabel that just ended  */
             if (P.trace) fprintf(stderr, "[mgc] relabel %d: %lld tile visits in %lld passes so far, %lld discharges before it, %d active tiles\n", outer, (long long)d_rel, (long long)st.relabel_passes, (long long)d_dis, cnt[lay.cnt_active]);
-            if (P.adaptive_rounds > 0 && outer > 0 && d_rel > (int64_t)P.adaptive_rounds * d_dis && rounds < 4 * P.rounds_per_relabel) rounds *= 2;
+            if (P.adaptive_rounds > 0 && outer > 0 && !radial && d_rel > (int64_t)P.adaptive_rounds * d_dis && rounds < 4 * P.rounds_per_relabel) rounds *= 2;
             prev_dis = cnt[lay.cnt_dis];
             prev_rel = cnt[lay.cnt_rel];
         }
@@ -197,10 +221,30 @@ int mgc_solve(Dev& dev, const MgcLattice& L, const MgcSolveParams& P, MgcSolveSt
             st.converged = 1;
             return 0;
         }
+        if (radial) {
+            if (outer == 0) {
+                if (cnt[MGC_CNT_RADIAL_C] >= MGC_HINF || cnt[MGC_CNT_RADIAL_C] < P.radial_min_c) radial = false; /* (the device left the labels alone for the same reason) */
+                /* a flood front moves a tile per colour phase, and nothing a shortest path's length away from the source is still
+                 * "behind the cut": five eighths of that many phases reach the far side of a cut that surrounds the source
+                 * (host simulator, headline volume: 8 rounds at 256^3, 16 at 512^3 close the surface; 4 resp. 8 do not) */
+                else radial_budget = (5 * cnt[MGC_CNT_RADIAL_C] / 8 + 7) / 8;
+            } else if (cnt[MGC_CNT_SOURCE_OPEN] == 0 || radial_done >= radial_budget) {
+                /* the source is sealed in -- or the flood has had its time, and what is still open are holes that only exact
+                 * labels find (radial labels lead past them: measured, a solve that re-lowers for ever) */
+                radial = false;
+            } else {
+                dev.radial_lower(P.radial_min_c);
+                radial_next = 2 * radial_next < radial_budget - radial_done ? 2 * radial_next : radial_budget - radial_done;
+            }
+            if (P.trace) fprintf(stderr, "[mgc] relabel %d: radial labels %s (shortest source -> sink path %d hops, %d source tiles open)\n", outer, radial ? "on" : "off", cnt[MGC_CNT_RADIAL_C], outer ? cnt[MGC_CNT_SOURCE_OPEN] : -1);
+        }
+        dev.set_radial(radial);
 
         /* ---- colour phases ---- */
         dev.range_push("colour phases");
-        for (int r = 0; r < rounds; ++r) {
+        const int rounds_now = radial ? radial_next : rounds;
+        if (radial) { st.radial_cycles++; radial_done += rounds_now; }
+        for (int r = 0; r < rounds_now; ++r) {
             for (int c = 0; c < lay.ncolours; ++c) {
                 const int lst = (int)(phase & (uint32_t)lay.list_mask);
                 dev.discharge(lst, phase, P.max_cycles, P.max_sweeps);
@@ -208,7 +252,7 @@ int mgc_solve(Dev& dev, const MgcLattice& L, const MgcSolveParams& P, MgcSolveSt
                 st.phases++;
                 phase++;
             }
-            if ((r + 1) % P.check_rounds == 0 && r + 1 < rounds) {
+            if ((r + 1) % P.check_rounds == 0 && r + 1 < rounds_now) {
                 dev.read_counts(cnt);
                 st.readbacks++;
                 int pending = 0;

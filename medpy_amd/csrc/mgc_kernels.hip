@@ -349,6 +349,7 @@ struct GpuWaveT {
     __device__ __forceinline__ int atomic_add(int32_t* p, int v) { return atomicAdd(p, v); }
     __device__ __forceinline__ uint32_t atomic_exch(uint32_t* p, uint32_t v) { return atomicExch(p, v); }
     __device__ __forceinline__ void atomic_or(uint32_t* p, uint32_t v) { atomicOr(p, v); }
+    __device__ __forceinline__ void atomic_min(int32_t* p, int v) { atomicMin(p, v); }
     __device__ __forceinline__ int shard(const MgcLattice& L) const { return (int)(blockIdx.x & (unsigned)(L.nshard - 1)); }
     /* a value every lane of the workgroup holds alike (read from LDS after a barrier): scalar for the branches on it */
     __device__ __forceinline__ uint32_t uniform(uint32_t v) const { return (uint32_t)__builtin_amdgcn_readfirstlane((int)v); }
@@ -954,7 +955,7 @@ __global__ __launch_bounds__(MGC_TV) void k_activate_list(MgcLattice L, int list
 }
 
 /* first global relabel as a distance transform (mgc_dt_ops.inl): one scan of every tile line along AXIS, one wave per line */
-template <int AXIS, bool BWD, bool SEED, bool FINAL>
+template <int AXIS, bool BWD, int SEED, bool FINAL> /* SEED 1: from the sink links (rmask), 2: from the voxels that hold excess (the radial labels), 0: a later pass */
 __global__ __launch_bounds__(256) void k_dt_scan(MgcLattice L, const void* in, void* out)
 {
     __shared__ MgcWaveShared S; /* (not touched: the executor wants one) */
@@ -974,6 +975,38 @@ __global__ __launch_bounds__(256) void k_dt_finish(MgcLattice L)
     for (int tile = (int)blockIdx.x * 4 + (int)(threadIdx.x >> 6); tile < L.ntiles; tile += (int)gridDim.x * 4) {
         w.new_tile();
         mgc_dt_finish_tile(w, L, __builtin_amdgcn_readfirstlane(tile));
+    }
+}
+
+/* radial labels of the flood phase (mgc_dt_ops.inl): C = hops of the shortest source -> sink path; the labels lowered to
+ * max(1, C - distance from the source); "does excess of the source still stand under a finite label?" -- one wave per tile */
+__global__ __launch_bounds__(256) void k_dt_cmin(MgcLattice L, const uint16_t* ds)
+{
+    __shared__ MgcWaveShared S;
+    GpuWave w(S);
+    for (int tile = (int)blockIdx.x * 4 + (int)(threadIdx.x >> 6); tile < L.ntiles; tile += (int)gridDim.x * 4) {
+        w.new_tile();
+        mgc_dt_cmin_tile(w, L, __builtin_amdgcn_readfirstlane(tile), ds);
+    }
+}
+
+__global__ __launch_bounds__(256) void k_dt_lower(MgcLattice L, const uint16_t* ds, int c_min)
+{
+    __shared__ MgcWaveShared S;
+    GpuWave w(S);
+    for (int tile = (int)blockIdx.x * 4 + (int)(threadIdx.x >> 6); tile < L.ntiles; tile += (int)gridDim.x * 4) {
+        w.new_tile();
+        mgc_dt_lower_tile(w, L, __builtin_amdgcn_readfirstlane(tile), ds, c_min);
+    }
+}
+
+__global__ __launch_bounds__(256) void k_source_open(MgcLattice L)
+{
+    __shared__ MgcWaveShared S;
+    GpuWave w(S);
+    for (int tile = (int)blockIdx.x * 4 + (int)(threadIdx.x >> 6); tile < L.ntiles; tile += (int)gridDim.x * 4) {
+        w.new_tile();
+        mgc_source_open_tile(w, L, __builtin_amdgcn_readfirstlane(tile));
     }
 }
 
@@ -1131,7 +1164,7 @@ __device__ __forceinline__ double mgc_block_sum(double v, double* scratch)
 template <bool FULL, int TERM, bool PRE6 = false> /* FULL: 26-neighbourhood; PRE6: the 6-neighbourhood instance with the pre-push (graphs with a regional term) */
 __device__ __forceinline__ void k_build_tiles(const MgcLattice& L, const MgcBuildArgs& A, double* img, double* scratch, double* wf, int* tflag_lds, double* pre_lds)
 {
-    const int t = threadIdx.x;
+    const int t_lane = threadIdx.x;
     const bool take_abs = (TERM == MGC_TERM_MAXIMUM_LINEAR || TERM == MGC_TERM_MAXIMUM_EXPONENTIAL || TERM == MGC_TERM_MAXIMUM_POWER);
     /* XCD-aware tile order: workgroups are dealt round-robin to the 8 XCDs, each with its own L2.  Workgroup b therefore
      * works inside the b % 8-th eighth of the tile range, consecutive workgroups of one XCD on consecutive tiles, so the
@@ -1143,6 +1176,12 @@ __device__ __forceinline__ void k_build_tiles(const MgcLattice& L, const MgcBuil
     for (int idx = (int)blockIdx.x / nx; idx < chunk; idx += stride) {
         const int tile = ((int)blockIdx.x % nx) * chunk + idx;
         if (tile >= L.ntiles) break;
+        /* the lane id is made opaque once per tile: everything derived from it (LDS slots of the weights, halo indices, the
+         * lane's coordinates) is then recomputed per tile -- a dozen integer operations -- instead of being hoisted out of the
+         * tile loop, where those values lived across the whole body and were spilled under the kernel's register cap (round 4:
+         * 64 B of scratch per lane for the exponential term, 140 - 144 B for the power terms, reloaded nine times per tile) */
+        int t = t_lane;
+        asm volatile("" : "+v"(t));
         int tz, ty, tx;
         mgc_tile_coords(L, tile, tz, ty, tx);
         const int64_t z0 = (int64_t)tz * 8, y0 = (int64_t)ty * 8, x0 = (int64_t)tx * 8;
@@ -1211,9 +1250,16 @@ __device__ __forceinline__ void k_build_tiles(const MgcLattice& L, const MgcBuil
                     if (A.has_spacing) w = w / A.inv_axis[axis]; /* energy_voxel.py:657-658 */
                     return w;
                 };
+                /* one g(.) at a time: left to itself the compiler interleaves the three evaluations (three exp / pow bodies in
+                 * flight) and spills under the kernel's register cap -- 64 B of scratch per lane for the exponential term,
+                 * 144 B for the power terms (round 4's resource remarks); the issue slots the interleaving would fill belong
+                 * to the other five waves of the SIMD anyway */
                 wf[0 * 576 + (lx + 1) * 64 + lz * 8 + ly] = pair_weight(0, me, valid && gx + 1 < L.dx);
+                asm volatile("" ::: "memory");
                 wf[1 * 576 + (ly + 1) * 64 + lz * 8 + lx] = pair_weight(1, me, valid && gy + 1 < L.dy);
+                asm volatile("" ::: "memory");
                 wf[2 * 576 + (lz + 1) * 64 + ly * 8 + lx] = pair_weight(2, me, valid && gz + 1 < L.dz);
+                asm volatile("" ::: "memory");
                 if (t < 192) { /* the pair that enters the tile through its lower face along `axis`: (halo voxel, voxel 0) */
                     const int axis = t >> 6, u = (t >> 3) & 7, v = t & 7;
                     const int lo = axis == 0 ? mgc_hs_index(u, v, -1) : (axis == 1 ? mgc_hs_index(u, -1, v) : mgc_hs_index(-1, u, v));
@@ -1419,7 +1465,7 @@ __device__ __forceinline__ void k_build_tiles(const MgcLattice& L, const MgcBuil
             L.oflags[tile] = 0;
             L.stamp[tile] = 0;
             L.rstamp[tile] = 0;
-            L.status[tile] = (any_sink ? MGC_ST_SINK : 0u) | (any_exc ? MGC_ST_EXCESS : 0u);
+            L.status[tile] = (any_sink ? MGC_ST_SINK : 0u) | (any_exc ? MGC_ST_EXCESS : 0u) | ((!FULL && (tbits & 1)) ? MGC_ST_SOURCE : 0u);
             A.tflags[tile] = (uint8_t)((any_exc ? 1 : 0) | (any_sink ? 2 : 0));
             sink_tiles += any_sink ? 1 : 0;
         }
@@ -1435,19 +1481,20 @@ __device__ __forceinline__ void k_build_tiles(const MgcLattice& L, const MgcBuil
         if constexpr (FULL) __syncthreads(); /* the weights above read the image tile in LDS, the next tile's load overwrites it (the
                                                 6-neighbourhood path has its vote barrier behind the weights) */
     }
-    if (!FULL && t == 0 && sink_tiles) atomicAdd(&L.count[MGC_CNT_SINK_TILES], sink_tiles); /* once per workgroup (mgc_build: exact_sink_tiles) */
+    if (!FULL && t_lane == 0 && sink_tiles) atomicAdd(&L.count[MGC_CNT_SINK_TILES], sink_tiles); /* once per workgroup (mgc_build: exact_sink_tiles) */
 }
 
 /* One kernel per (neighbourhood, boundary term): g(.) is straight-line code, and every instance gets the registers ITS term
  * needs (one kernel with a switch is allocated for the power terms: 151 VGPRs, one workgroup per CU for all nine). */
 #ifndef MGC_BUILD_WAVES6
-#define MGC_BUILD_WAVES6 6 /* three workgroups per CU: 80 VGPRs and 32 B of scratch for the exponential term; measured 3.74 ms vs 4.28 ms at 4 (and 4.35 at 5) for 512^3 */
+#define MGC_BUILD_WAVES6 6 /* three workgroups per CU: 80 VGPRs (73 used, no scratch, for the exponential term; the power terms -- pow() is the largest g(.) -- get
+                              two waves less and 128); measured 3.74 ms vs 4.28 ms at 4 (and 4.35 at 5) for 512^3 */
 #endif
 #ifndef MGC_BUILD_WAVES26
 #define MGC_BUILD_WAVES26 4 /* two workgroups per CU: 128 VGPRs */
 #endif
 template <bool FULL, int TERM, bool PRE6 = false> /* FULL: 26-neighbourhood; PRE6: 6-neighbourhood with the pre-push (regional term) */
-__global__ __launch_bounds__(MGC_TV, FULL ? MGC_BUILD_WAVES26 : (PRE6 ? 4 : MGC_BUILD_WAVES6)) void k_build(MgcLattice L, MgcBuildArgs A)
+__global__ __launch_bounds__(MGC_TV, FULL ? MGC_BUILD_WAVES26 : (PRE6 ? 4 : ((TERM == MGC_TERM_DIFFERENCE_POWER || TERM == MGC_TERM_MAXIMUM_POWER) ? MGC_BUILD_WAVES6 - 2 : MGC_BUILD_WAVES6))) void k_build(MgcLattice L, MgcBuildArgs A)
 {
     __shared__ double img[1000]; /* 10x10x10: tile + one-voxel halo, already |.|'d for the maximum terms */
     __shared__ double scratch[MGC_TV];
@@ -2079,6 +2126,9 @@ struct mgc_graph {
     bool labels_valid = false; /* the distance labels belong to this build (set by the first label fill of a solve, cleared by mgc_build) */
     void* d_vout = nullptr;    /* MgcValidateOut of mgc_validate */
     uint16_t* d_dt16 = nullptr; /* scratch of the distance-transform relabel (uint16 per voxel, tile-major), allocated on first use */
+    uint16_t* d_ds16 = nullptr; /* radial labels: 1 + L1 distance from the nearest voxel that held excess when the solve began (allocated on first use) */
+    int32_t* d_hexact = nullptr; /* radial labels: the exact labels of the last global relabel, kept aside while the labels in L.height are the radial ones */
+    bool radial_on = false;      /* the discharges run on radial labels (every saturation marks the tile DIRTY) */
     bool all_residual = false; /* k_build found every n-link inside the volume residual */
     int exact_sink_tiles = 1;  /* k_discharge_w: exact in-tile labels per visit for the tiles that hold a sink link (MGCW_BFS_SINK; parameter
                                   exact_sink_tiles): 0 never, 2 always, 1 when most tiles of the volume hold one (markers scattered over the
@@ -2179,6 +2229,7 @@ struct HipDevT {
     int64_t discharge_launches = 0, relabel_launches = 0, readbacks = 0;
     int last_discharged = -1; /* list consumed by the discharge launched last (see pending_zero) */
     int suspect_batch() const { return 2; } /* closure passes between two looks at the "changed" flag: a pass settles a brick */
+    bool labels_inexact() const { return false; }
     void range_push(const char* name) { mgc_range_push(name); } /* roctx range around a stretch of the schedule (mgc_driver.inl) */
     void range_pop() { mgc_range_pop(); }
     struct Span { int a, b, kind; };
@@ -2291,17 +2342,77 @@ struct HipDevT {
         void* const T = h->d_dt16;
         const dim3 blk(256);
         auto g = [&](int lines) { return dim3(grid((lines + 3) / 4)); };
-        hipLaunchKernelGGL((k_dt_scan<0, false, true, false>), g(L.gz * L.gy), blk, 0, h->stream, L, (const void*)L.rmask, T);
-        hipLaunchKernelGGL((k_dt_scan<0, true, false, false>), g(L.gz * L.gy), blk, 0, h->stream, L, (const void*)T, T);
-        hipLaunchKernelGGL((k_dt_scan<1, false, false, false>), g(L.gz * L.gx), blk, 0, h->stream, L, (const void*)T, T);
-        hipLaunchKernelGGL((k_dt_scan<1, true, false, false>), g(L.gz * L.gx), blk, 0, h->stream, L, (const void*)T, T);
-        hipLaunchKernelGGL((k_dt_scan<2, false, false, false>), g(L.gy * L.gx), blk, 0, h->stream, L, (const void*)T, T);
-        hipLaunchKernelGGL((k_dt_scan<2, true, false, true>), g(L.gy * L.gx), blk, 0, h->stream, L, (const void*)T, (void*)L.height);
+        hipLaunchKernelGGL((k_dt_scan<0, false, 1, false>), g(L.gz * L.gy), blk, 0, h->stream, L, (const void*)L.rmask, T);
+        hipLaunchKernelGGL((k_dt_scan<0, true, 0, false>), g(L.gz * L.gy), blk, 0, h->stream, L, (const void*)T, T);
+        hipLaunchKernelGGL((k_dt_scan<1, false, 0, false>), g(L.gz * L.gx), blk, 0, h->stream, L, (const void*)T, T);
+        hipLaunchKernelGGL((k_dt_scan<1, true, 0, false>), g(L.gz * L.gx), blk, 0, h->stream, L, (const void*)T, T);
+        hipLaunchKernelGGL((k_dt_scan<2, false, 0, false>), g(L.gy * L.gx), blk, 0, h->stream, L, (const void*)T, T);
+        hipLaunchKernelGGL((k_dt_scan<2, true, 0, true>), g(L.gy * L.gx), blk, 0, h->stream, L, (const void*)T, (void*)L.height);
         hipLaunchKernelGGL(k_dt_finish, g(L.ntiles), blk, 0, h->stream, L);
         check(hipGetLastError());
         time_end(id);
         relabel_launches += 7;
         return true;
+    }
+    /* ---- radial labels of the flood phase (mgc_dt_ops.inl; the schedule: mgc_driver.inl) ---- */
+    void set_radial(bool on) { h->radial_on = on; }
+    bool radial_begin(int c_min)
+    {
+        if (FULL) return false;
+        const size_t nv = (size_t)h->L.ntiles * MGC_TV;
+        if (!h->d_ds16) {
+            if (hipMalloc((void**)&h->d_ds16, nv * sizeof(uint16_t)) != hipSuccess) { (void)hipGetLastError(); return false; }
+            h->device_bytes += (int64_t)(nv * sizeof(uint16_t));
+        }
+        if (!h->d_hexact) {
+            if (hipMalloc((void**)&h->d_hexact, nv * sizeof(int32_t)) != hipSuccess) { (void)hipGetLastError(); return false; }
+            h->device_bytes += (int64_t)(nv * sizeof(int32_t));
+        }
+        flush_zero();
+        const int id = time_begin(2);
+        const MgcLattice& L = h->L;
+        void* const T = h->d_ds16;
+        const dim3 blk(256);
+        auto g = [&](int lines) { return dim3(grid((lines + 3) / 4)); };
+        check(hipMemsetAsync(L.count + MGC_CNT_RADIAL_C, 0x3f, sizeof(int32_t), h->stream)); /* MGC_HINF */
+        hipLaunchKernelGGL((k_dt_scan<0, false, 2, false>), g(L.gz * L.gy), blk, 0, h->stream, L, (const void*)L.excess, T);
+        hipLaunchKernelGGL((k_dt_scan<0, true, 0, false>), g(L.gz * L.gy), blk, 0, h->stream, L, (const void*)T, T);
+        hipLaunchKernelGGL((k_dt_scan<1, false, 0, false>), g(L.gz * L.gx), blk, 0, h->stream, L, (const void*)T, T);
+        hipLaunchKernelGGL((k_dt_scan<1, true, 0, false>), g(L.gz * L.gx), blk, 0, h->stream, L, (const void*)T, T);
+        hipLaunchKernelGGL((k_dt_scan<2, false, 0, false>), g(L.gy * L.gx), blk, 0, h->stream, L, (const void*)T, T);
+        hipLaunchKernelGGL((k_dt_scan<2, true, 0, false>), g(L.gy * L.gx), blk, 0, h->stream, L, (const void*)T, T);
+        hipLaunchKernelGGL(k_dt_cmin, g(L.ntiles), blk, 0, h->stream, L, (const uint16_t*)h->d_ds16);
+        check(hipMemcpyAsync(h->d_hexact, L.height, nv * sizeof(int32_t), hipMemcpyDeviceToDevice, h->stream));
+        hipLaunchKernelGGL(k_dt_lower, g(L.ntiles), blk, 0, h->stream, L, (const uint16_t*)h->d_ds16, c_min);
+        check(hipGetLastError());
+        time_end(id);
+        relabel_launches += 9;
+        return true;
+    }
+    void radial_save_exact()
+    {
+        flush_zero();
+        check(hipMemcpyAsync(h->d_hexact, h->L.height, (size_t)h->L.ntiles * MGC_TV * sizeof(int32_t), hipMemcpyDeviceToDevice, h->stream));
+    }
+    void radial_restore_exact()
+    {
+        flush_zero();
+        check(hipMemcpyAsync(h->L.height, h->d_hexact, (size_t)h->L.ntiles * MGC_TV * sizeof(int32_t), hipMemcpyDeviceToDevice, h->stream));
+    }
+    void radial_lower(int c_min)
+    {
+        flush_zero();
+        const int id = time_begin(2);
+        hipLaunchKernelGGL(k_dt_lower, dim3(grid((h->L.ntiles + 3) / 4)), dim3(256), 0, h->stream, h->L, (const uint16_t*)h->d_ds16, c_min);
+        check(hipGetLastError());
+        time_end(id);
+        relabel_launches++;
+    }
+    void source_open()
+    {
+        flush_zero();
+        hipLaunchKernelGGL(k_source_open, dim3(grid((h->L.ntiles + 3) / 4)), dim3(256), 0, h->stream, h->L);
+        check(hipGetLastError());
     }
     void relabel_list(int lst, uint32_t epoch, int next, int zero_list = -1)
     {
@@ -2384,11 +2495,11 @@ struct HipDevT {
             const bool exact_sink = h->exact_sink_tiles == 2 || (h->exact_sink_tiles == 1 && 2 * (int64_t)h->sink_tiles > h->L.ntiles);
             /* a visit that starts from exact in-tile labels needs fewer sweeps to move what it can (tie-heavy 512^3: 796 ms at 12, 731 at 8, 788 at 6) */
             if (exact_sink && h->exact_sink_tiles == 1 && sweeps > h->sink_sweeps) sweeps = h->sink_sweeps;
-            hipLaunchKernelGGL(k_discharge_w, dim3(h->wave_grid_dis), dim3(MGCW_LANES), 0, h->stream, h->L, lst, phase, sweeps, ((h->wave_kernels & 4) ? MGCW_BFS : 0) | (exact_sink ? MGCW_BFS_SINK : 0), h->tk_dis, zero_idx, h->wave_stagger);
+            hipLaunchKernelGGL(k_discharge_w, dim3(h->wave_grid_dis), dim3(MGCW_LANES), 0, h->stream, h->L, lst, phase, sweeps, ((h->wave_kernels & 4) ? MGCW_BFS : 0) | (exact_sink ? MGCW_BFS_SINK : 0) | (h->radial_on ? MGCW_SAT_DIRTY : 0), h->tk_dis, zero_idx, h->wave_stagger);
             h->tk_dis ^= 1;
         }
         else hipLaunchKernelGGL(k_discharge, dim3(grid(h->L.ntiles)), dim3(MGC_TV), 0, h->stream, h->L, lst, phase,
-                                (h->wave_kernels & 1) && !(h->wave_kernels & 4) ? -1 : cycles, sweeps, zero_idx); /* same labelling policy as the wave form */
+                                (h->wave_kernels & 1) && !(h->wave_kernels & 4) ? (h->radial_on ? -2 : -1) : cycles, sweeps, zero_idx); /* same labelling policy as the wave form (-2: radial labels, any saturation marks the tile) */
         check(hipGetLastError());
         time_end(id);
         discharge_launches++;
@@ -3143,7 +3254,7 @@ int mgc_destroy(mgc_handle h)
     void* ptrs[] = {L.rcap, L.cap0, L.excess, L.sink, L.height, L.rmask, L.rmask32, L.obox, L.oflags, L.list[0], L.list[1], L.list[2],
                     L.list[3], L.list[4], L.list[5], L.list[6], L.list[7], L.list[8], L.list[9], L.list[10], L.list[11], L.list[12],
                     L.list[13], L.list[14], L.list[15], L.list[16], L.list[17], L.count, L.stamp, L.rstamp, L.status, h->d_tr0, h->d_part, h->d_part2, h->d_scalar,
-                    h->d_labels, h->d_tflags, h->d_tsum, h->d_image, h->d_lut, h->d_prob, h->d_fg, h->d_bg, h->d_tr_in, h->d_eslot, h->d_eval, h->d_erun, L.hshadow[0], L.hshadow[1], h->d_vout, h->d_dt16, h->d_halo, h->d_xchg[0], h->d_xchg[1], h->d_xchg[2], h->d_xchg[3], h->d_cnt64};
+                    h->d_labels, h->d_tflags, h->d_tsum, h->d_image, h->d_lut, h->d_prob, h->d_fg, h->d_bg, h->d_tr_in, h->d_eslot, h->d_eval, h->d_erun, L.hshadow[0], L.hshadow[1], h->d_vout, h->d_dt16, h->d_ds16, h->d_hexact, h->d_halo, h->d_xchg[0], h->d_xchg[1], h->d_xchg[2], h->d_xchg[3], h->d_cnt64};
     for (void* p : ptrs)
         if (p) (void)hipFree(p);
     if (h->h_count) (void)hipHostFree(h->h_count);
@@ -3533,6 +3644,7 @@ int mgc_maxflow(mgc_handle h, double* flow)
         h->stats.discharge_launches = dev.discharge_launches;
         h->stats.relabel_launches = dev.relabel_launches;
         h->stats.reserved[0] = dev.readbacks;
+        h->stats.reserved[1] = st.radial_cycles;
         h->stats.discharge_tiles = st.discharge_tiles;
         h->stats.discharge_wave_tiles = L.ndir == 6 ? h->h_count[MGC_CNT_WAVE_TILES] : st.discharge_tiles; /* (as of the solve's last counter read-back) */
         h->stats.relabel_tiles = st.relabel_tiles;
@@ -3713,6 +3825,9 @@ int mgc_set_param(mgc_handle h, const char* name, int64_t value)
     else if (!strcmp(name, "incremental_relabel")) h->params.incremental_relabel = value != 0;
     else if (!strcmp(name, "trace")) h->params.trace = value != 0;
     else if (!strcmp(name, "adaptive_rounds") && value >= 0) h->params.adaptive_rounds = (int)value; /* 0 = off, k = threshold */
+    else if (!strcmp(name, "radial") && value >= 0) h->params.radial = (int)value;                 /* flood phase on radial labels (mgc_dt_ops.inl) */
+    else if (!strcmp(name, "radial_min_c") && value >= 1) h->params.radial_min_c = (int)value;
+    else if (!strcmp(name, "radial_rounds0") && value >= 1) h->params.radial_rounds0 = (int)value;
     else if (!strcmp(name, "use_filters")) h->use_filters = (int)value;
     else if (!strcmp(name, "wave_kernels")) { h->wave_kernels = (int)value; h->wave_set = true; }
     else if (!strcmp(name, "wave_min_tiles") && value >= 0) h->wave_min_tiles = (int)value;

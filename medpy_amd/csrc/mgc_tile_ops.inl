@@ -409,6 +409,7 @@ MGC_HD void mgc_discharge_tile(X& x, const MgcLattice& L, int tile, uint32_t pha
     /* max_cycles < 0: no exact in-tile labelling -- the stored labels are valid lower bounds (distances only grow) and the
      * local relabel at the end of every sweep raises the voxels that are stuck (what the one-wave-per-tile form does) */
     const bool stored_labels = max_cycles < 0;
+    const bool any_saturation = max_cycles == -2; /* the stored labels are RADIAL labels (mgc_dt_ops.inl), not distances: every saturated arc marks the tile DIRTY */
     if (stored_labels) max_cycles = 1;
     for (int cyc = 0; cyc < max_cycles; ++cyc) {
         if (stored_labels) {
@@ -551,7 +552,7 @@ MGC_HD void mgc_discharge_tile(X& x, const MgcLattice& L, int tile, uint32_t pha
                 bool kept = snk[t] > 0.0; /* (a label of 1 stands on the sink link) */
 #pragma unroll
                 for (int d = 0; d < 6; ++d) kept = kept || (x.S.r[d][t] > 0.0 && x.S.hs[me + mgc_hs_step(d)] == hme[t] - 1);
-                if (!kept) x.S.satflag = 1;
+                if (!kept || any_saturation) x.S.satflag = 1;
             }
         });
     }

@@ -67,6 +67,8 @@
                                  labelling per visit saves visits (tie-heavy volume, markers everywhere, 512^3 on MI355X: 1077 -> 710 ms);
                                  elsewhere labels come from far away and the stored ones are as good (weak contrast: 69 -> 80 ms with
                                  MGCW_BFS on every tile) */
+#define MGCW_SAT_DIRTY 4      /* ... the visit runs on RADIAL labels (mgc_dt_ops.inl): any saturated arc marks the tile DIRTY -- whether a voxel
+                                 keeps "a residual arc one label down" says nothing about its distance when the labels are not distances */
 
 
 struct alignas(16) MgcWaveShared {
@@ -607,7 +609,7 @@ MGC_HD void mgcw_discharge_impl(W& w, const MgcLattice& L, int tile, uint32_t ph
     /* DIRTY (the tile's labels may no longer be exact distances: the next global relabel recomputes it and whoever depends on it)
      * iff a label rose or was recomputed, or a voxel that saturated an arc has no residual arc one label down left.  A voxel that
      * keeps one of its supports keeps its distance, and the tiles a small flow merely passes through stay clean. */
-    bool saturated = (flags & MGCW_BFS) ? w.any([&](int l) MGCW_INL -> bool { return sat(l, 0) != 0; })
+    bool saturated = (flags & (MGCW_BFS | MGCW_SAT_DIRTY)) ? w.any([&](int l) MGCW_INL -> bool { return sat(l, 0) != 0; })
                                         : w.any([&](int l) MGCW_INL -> bool { return (sat(l, 0) & 256) != 0; });
     if (!saturated && w.any([&](int l) MGCW_INL -> bool { return sat(l, 0) != 0; })) {
         mgcw_static_for<8>([&](auto KK) MGCW_INL {

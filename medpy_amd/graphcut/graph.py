@@ -20,6 +20,17 @@ class termtype(enum.IntEnum):
     SINK = 1
 
 
+def _holds_whole_numbers(image, block=1 << 20):
+    """every value of a float array is a whole number (NaN / inf: no) -- in blocks, leaving at the first block that holds
+    anything else: a 512^3 float32 volume of noise is turned away after 4 MB, and no volume-sized temporary is made"""
+    flat = image.reshape(-1) if image.flags.c_contiguous else image.ravel()
+    for start in range(0, flat.size, block):
+        part = flat[start:start + block]
+        if not numpy.array_equal(part, numpy.floor(part)):   # (NaN != NaN, inf == floor(inf): caught by the range check below)
+            return False
+    return True
+
+
 def boundary_table(term, image, sigma, limit=65536):
     """The exponential / power boundary function of an INTEGER-VALUED image by table, or None.
 
@@ -39,10 +50,8 @@ def boundary_table(term, image, sigma, limit=65536):
         return None
     if image.dtype.kind not in "iuf":
         return None
-    if image.dtype.kind == "f":
-        probe = image.ravel()[:4096]
-        if not numpy.array_equal(probe, numpy.rint(probe)) or not numpy.array_equal(image, numpy.rint(image)):
-            return None
+    if image.dtype.kind == "f" and not _holds_whole_numbers(image):
+        return None
     lo, hi = float(image.min()), float(image.max())
     if not (math.isfinite(lo) and math.isfinite(hi)):
         return None
@@ -234,17 +243,42 @@ class SparseGraph(object):
     library's sparse-graph solver (C ABI ``msg_*``).  Returned by ``graph_from_labels``, by ``graph_from_voxels`` for
     images of more than three dimensions and by ``GCGraph.get_graph()`` for graphs that plug-in terms assemble edge by
     edge.  Besides the facade hooks (``_add_*``) it takes the raw GraphDouble calls ``add_node``, ``add_edge``,
-    ``sum_edge`` and ``add_tweights``; edges are buffered and uploaded in batches."""
+    ``sum_edge``, ``add_tweights``, ``get_edge`` and ``reset`` with the reference's semantics (graph.h:428-498,
+    graph.cpp:46-60): ``add_edge`` creates a PARALLEL arc pair per call (the flow sees the summed capacity; ``get_edge``
+    reports the arc the reference's list walk meets first, i.e. the pair added last), ``sum_edge`` adds to that arc.
+    Edges are buffered and uploaded in batches.
+
+    ``_cast`` is the capacity type of the instance (``GraphDouble``: float64; the subclasses ``GraphFloat`` / ``GraphInt``
+    quantise every capacity, every running sum and the returned flow to float32 / int, instances.inc:12-15)."""
 
     termtype = termtype
+    _captype = "double"
+
+    @staticmethod
+    def _cast(v):
+        """a capacity handed in by the caller, in the graph's capacity type"""
+        return float(v)
+
+    @classmethod
+    def _out(cls, v):
+        """a value read back from the device, in the graph's capacity type"""
+        return cls._cast(v)
 
     def __init__(self, nodes, edges=0, device=0):
         lib = _lib.load()
         if _lib.device_count() < 1:
             raise _lib.MedpyHipError(_lib.ERR_NO_DEVICE, "no HIP device visible; medpy_amd has no CPU fallback")
         self._nodes = max(int(nodes), 1)
+        self._device = int(device)
+        self._h = None
+        self._open()
+
+    def _open(self):
+        """a fresh, empty solver graph in HBM (``__init__`` and ``reset``)"""
+        lib = _lib.load()
+        self.close()
         h = C.c_void_p()
-        rc = lib.msg_create(self._nodes, int(device), C.byref(h))
+        rc = lib.msg_create(self._nodes, self._device, C.byref(h))
         self._h = h if h.value else None
         if rc != _lib.OK:
             msg = (lib.msg_last_error(self._h) or b"").decode()
@@ -253,8 +287,17 @@ class SparseGraph(object):
         self._labels = None
         self._pending = ([], [], [], [])
         self._tr = None
-        self._flow_const = 0.0
+        self._flow_const = self._cast(0)
         self._declared = 0
+        self._first_arc = {}   # (i, j) -> capacity of the arc get_arc(i, j) meets first (raw add_edge / sum_edge calls only)
+        self._raw_pairs = set()
+        self._host_arcs = {}   # GraphFloat / GraphInt: (i, j) -> [capacity of the front arc, sum of the parallel arcs behind it]
+        self._host_sent = False
+
+    def reset(self):
+        """Graph::reset, reference graph.cpp:46-60 (wrapper.cpp:68): back to the state just after construction -- no nodes
+        declared, no arcs, no t-links, flow 0."""
+        self._open()
 
     def close(self):
         if getattr(self, "_h", None):
@@ -326,42 +369,120 @@ class SparseGraph(object):
 
     # -- raw GraphDouble calls (graph.h:388-480)
     def add_node(self, num=1):
+        """Graph::add_node, reference graph.h:388-413: declares ``num`` more nodes, returns the id of the first.  Going beyond
+        the constructor's node count grows the graph (the reference reallocates, graph.cpp:62-85): a larger graph is
+        created in HBM and what was uploaded so far moves over."""
         first = self._declared
         self._declared += int(num)
+        if self._declared > self._nodes:
+            self._grow(self._declared)
         return first
 
-    def sum_edge(self, i, j, cap, rev_cap):
+    def _grow(self, nodes):
+        self._flush()
+        tail, head, cap = self.arcs()
+        lib = _lib.load()
+        old = self._h
+        h = C.c_void_p()
+        rc = lib.msg_create(int(nodes), self._device, C.byref(h))
+        if rc != _lib.OK:
+            msg = (lib.msg_last_error(h if h.value else None) or b"").decode()
+            if h.value:
+                lib.msg_destroy(h)
+            raise _lib.MedpyHipError(rc, msg)
+        self._h, self._nodes = h, int(nodes)
+        lib.msg_destroy(old)
+        if tail.size:
+            self._add_edges(tail, head, cap, numpy.zeros(cap.size))
+        if self._tr is not None:
+            self._tr = numpy.concatenate([self._tr, numpy.zeros(self._nodes - self._tr.size)])
+        self._labels = None
+
+    def _queue(self, i, j, cap, rev_cap):
         p = self._pending
-        p[0].append(int(i)); p[1].append(int(j)); p[2].append(float(cap)); p[3].append(float(rev_cap))
+        p[0].append(i); p[1].append(j); p[2].append(float(cap)); p[3].append(float(rev_cap))
+        self._labels = None
         if len(p[0]) >= 1 << 20:
             self._flush()
 
-    add_edge = sum_edge  # parallel arcs carry the same flow as one arc with the summed capacity
+    def _check_ids(self, i, j):
+        n = max(self._declared, self._nodes) if self._declared else self._nodes
+        if not (0 <= i < n and 0 <= j < n) or i == j:   # the reference asserts (graph.h:430-432); here an exception
+            raise ValueError("edge ({}, {}): node ids must differ and lie in [0, {})".format(i, j, n))
+
+    def add_edge(self, i, j, cap, rev_cap):
+        """Graph::add_edge, reference graph.h:428-454: a NEW pair of arcs i->j / j->i per call, prepended to both adjacency
+        lists.  Parallel arcs carry the flow of one arc with the summed capacity (that is what goes to the device);
+        ``get_edge`` afterwards sees the pair added LAST, as the reference's ``get_arc`` walk does (graph.h:500-509)."""
+        i, j, cap, rev_cap = int(i), int(j), self._cast(cap), self._cast(rev_cap)
+        self._check_ids(i, j)
+        if self._captype != "double":
+            for key, c in (((i, j), cap), ((j, i), rev_cap)):
+                front = self._host_arcs.get(key)
+                self._host_arcs[key] = [c, 0.0] if front is None else [c, front[1] + front[0]]
+            self._labels = None
+            return
+        if (i, j) in self._raw_pairs or (j, i) in self._raw_pairs:
+            self._first_arc[(i, j)], self._first_arc[(j, i)] = cap, rev_cap   # a parallel pair now hides the older ones
+        self._raw_pairs.add((i, j))
+        self._queue(i, j, cap, rev_cap)
+
+    def sum_edge(self, i, j, cap, rev_cap):
+        """Graph::sum_edge, reference graph.h:457-480: adds to the arc ``get_arc(i, j)`` finds (and to its sister), or
+        creates the pair."""
+        i, j, cap, rev_cap = int(i), int(j), self._cast(cap), self._cast(rev_cap)
+        self._check_ids(i, j)
+        if self._captype != "double":   # float32 / int arcs: the running sum is rounded per call, in the arc's type (host side)
+            if (i, j) not in self._host_arcs:
+                return self.add_edge(i, j, cap, rev_cap)
+            a, r = self._host_arcs[(i, j)], self._host_arcs[(j, i)]
+            a[0], r[0] = self._cast(a[0] + cap), self._cast(r[0] + rev_cap)
+            self._labels = None
+            return
+        if (i, j) in self._first_arc:   # parallel pairs exist: the one in front takes the sum
+            self._first_arc[(i, j)] = self._first_arc[(i, j)] + cap
+            self._first_arc[(j, i)] = self._first_arc[(j, i)] + rev_cap
+        self._raw_pairs.add((i, j))
+        self._queue(i, j, cap, rev_cap)
 
     def add_tweights(self, i, cap_source, cap_sink):
         if self._tr is None:
             self._tr = numpy.zeros(self._nodes, dtype=numpy.float64)
-        cs, ck = float(cap_source), float(cap_sink)
-        delta = self._tr[i]
+        cs, ck = self._cast(cap_source), self._cast(cap_sink)
+        delta = self._cast(self._tr[i])
         if delta > 0:
-            cs += delta
+            cs = self._cast(cs + delta)
         else:
-            ck -= delta
-        self._flow_const += cs if cs < ck else ck
-        self._tr[i] = cs - ck
+            ck = self._cast(ck - delta)
+        self._flow_const = self._cast(self._flow_const + (cs if cs < ck else ck))
+        self._tr[i] = self._cast(cs - ck)
         self._labels = None
 
     # -- GraphDouble surface
     def maxflow(self):
         """GraphDouble.maxflow(), reference maxflow.cpp:472-604"""
         self._flush()
+        self._send_host_arcs()
         if self._tr is not None:
             tr = numpy.ascontiguousarray(self._tr, dtype=numpy.float64)
-            self._call("msg_set_tweights_merged", _lib.ptr(tr), self._flow_const)
+            self._call("msg_set_tweights_merged", _lib.ptr(tr), float(self._flow_const))
         flow = C.c_double(0.0)
         self._call("msg_maxflow", C.byref(flow))
         self._labels = None
-        return flow.value
+        return self._out(flow.value)
+
+    def _send_host_arcs(self):
+        """GraphFloat / GraphInt: the arcs accumulated on the host go to the device once, parallel arcs summed (exactly: float32
+        values and integers add without rounding in float64)"""
+        if not self._host_arcs or self._host_sent:
+            return
+        keys = [k for k in self._host_arcs if k[0] < k[1]]
+        i = numpy.array([k[0] for k in keys], dtype=numpy.int64)
+        j = numpy.array([k[1] for k in keys], dtype=numpy.int64)
+        cap = numpy.array([float(self._host_arcs[k][0]) + float(self._host_arcs[k][1]) for k in keys], dtype=numpy.float64)
+        rev = numpy.array([float(self._host_arcs[(k[1], k[0])][0]) + float(self._host_arcs[(k[1], k[0])][1]) for k in keys], dtype=numpy.float64)
+        self._add_edges(i, j, cap, rev)
+        self._host_sent = True
 
     def labels(self):
         """every node at once: bool array, False where what_segment == SINK"""
@@ -377,19 +498,29 @@ class SparseGraph(object):
         return termtype(seg.value)
 
     def get_edge(self, i, j):
+        """Graph::get_edge, reference graph.h:482-498: the capacity of the first arc i->j of i's adjacency list (the pair
+        added last when ``add_edge`` created parallel ones), 0 when there is none"""
+        i, j = int(i), int(j)
+        if self._captype != "double":
+            a = self._host_arcs.get((i, j))
+            return self._cast(0) if a is None else a[0]
+        if (i, j) in self._first_arc:
+            return self._first_arc[(i, j)]
         self._flush()
         out = C.c_double(0.0)
-        self._call("msg_get_edge", int(i), int(j), C.byref(out))
-        return out.value
+        self._call("msg_get_edge", i, j, C.byref(out))
+        return self._out(out.value)
 
     def get_trcap(self, i):
-        return 0.0 if self._tr is None else float(self._tr[int(i)])
+        return self._cast(0) if self._tr is None else self._cast(self._tr[int(i)])
 
     def get_node_num(self):
-        return self._nodes
+        """nodes declared with ``add_node`` so far (graph.h:413), or the constructor's count when the facade filled the graph"""
+        return self._declared if (self._declared or self._raw_pairs) else self._nodes
 
     def get_arc_num(self):
         self._flush()
+        self._send_host_arcs()
         n = C.c_int64(0)
         self._call("msg_get_counts", None, None, C.byref(n))
         return n.value
@@ -409,6 +540,43 @@ class SparseGraph(object):
         st = _lib.SparseStats()
         self._call("msg_get_stats", C.byref(st))
         return st.as_dict()
+
+
+class GraphFloat(SparseGraph):
+    """``maxflow.GraphFloat`` = ``Graph<float,float,float>`` (reference instances.inc:14, wrapper.cpp:27-57): capacities,
+    t-links, their running sums and the returned flow are float32 values.  The solve itself runs in the library's float64
+    arithmetic on those float32-valued capacities (sums of float32 numbers are exact in float64 far beyond any graph's
+    size), so the cut is the exact minimum cut of the float32 graph; the reference's float32 augmentations can differ
+    from it only where its own rounding decides a tie."""
+
+    _captype = "float"
+
+    @staticmethod
+    def _cast(v):
+        return float(numpy.float32(v))
+
+
+class GraphInt(SparseGraph):
+    """``maxflow.GraphInt`` = ``Graph<int,int,int>`` (reference instances.inc:12, wrapper.cpp:93-134): integer capacities
+    and flow.  Whole numbers below 2**53 are exact in float64, so the device solve is exact integer arithmetic; like the
+    Boost.Python binding, a capacity that is not an integer is a ``TypeError`` (there is no implicit float -> int
+    conversion at that boundary)."""
+
+    _captype = "int"
+
+    @staticmethod
+    def _cast(v):
+        if isinstance(v, (bool, numpy.bool_)):
+            return int(v)
+        if isinstance(v, (int, numpy.integer)):
+            return int(v)
+        if isinstance(v, numpy.floating) and float(v).is_integer():
+            return int(v)   # (the host copy of the t-links is a float64 array that holds whole numbers)
+        raise TypeError("GraphInt: capacity %r is not an integer" % (v,))
+
+    @staticmethod
+    def _out(v):
+        return int(round(v))
 
 
 def region_sums(label_image, values, nregions, device=0):
@@ -529,20 +697,20 @@ class Graph(object):
         return self._terminal
 
     def inconsistent(self):
-        """``False`` for a well-formed graph, otherwise one message per defect: a node id above the node count in the
-        t-weights, the markers or an edge, and every edge whose reverse is stored as an edge of its own (the weights of
-        both directions belong into ONE entry)."""
+        """``False`` for a well-formed graph, otherwise one message per defect, in the reference's wording and order
+        (reference graph.py:227-264): a node id above the node count in the t-weights, the markers or an edge, and every
+        edge whose reverse is stored as an edge of its own (the weights of both directions belong into ONE entry)."""
         def unknown(node):
-            return node > self._count
+            return not node <= self._count
 
-        problems = ["t-weights name node {}, the graph has {} nodes".format(n, self._count) for n in self._terminal if unknown(n)]
-        for side in ("source", "sink"):
-            problems += ["{} marker on node {}, the graph has {} nodes".format(side, n, self._count) for n in self._markers[side] if unknown(n)]
+        messages = ["Node {} in t-weights but not in nodes.".format(n) for n in self._terminal if unknown(n)]
+        messages += ["Node {} in s-nodes but not in nodes.".format(n) for n in self._markers["source"] if unknown(n)]
+        messages += ["Node {} in t-nodes but not in nodes.".format(n) for n in self._markers["sink"] if unknown(n)]
         for edge in self._edges:
-            problems += ["edge {} ends in node {}, the graph has {} nodes".format(edge, n, self._count) for n in edge if unknown(n)]
-            if tuple(reversed(edge)) in self._edges:
-                problems.append("edge {} is stored in both directions".format(edge))
-        return problems or False
+            messages += ["Node {} in edge {} but not in nodes.".format(n, edge) for n in edge if unknown(n)]
+            if (edge[1], edge[0]) in self._edges:
+                messages.append("The reversed edges of {} is also in the n-weights.".format(edge))
+        return messages or False
 
 
 class GCGraph(object):

@@ -87,7 +87,7 @@ def install(force_shim=False):
         sys.modules["medpy.graphcut." + sub] = importlib.import_module("medpy_amd.graphcut." + sub)
     # the compiled module the reference's graph.py imports (from .maxflow import GraphDouble, GraphFloat, GraphInt)
     sys.modules["medpy.graphcut.maxflow"] = _module("medpy.graphcut.maxflow", GraphDouble=graphcut.GraphDouble,
-                                                    GraphFloat=graphcut.GraphDouble, GraphInt=graphcut.GraphDouble)
+                                                    GraphFloat=graphcut.GraphFloat, GraphInt=graphcut.GraphInt)
     return "shim" if real is None else "patched"
 
 

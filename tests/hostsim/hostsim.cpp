@@ -183,6 +183,7 @@ struct HostWaveT {
     int atomic_add(int32_t* p, int v) { int o = *p; *p += v; return o; }
     uint32_t atomic_exch(uint32_t* p, uint32_t v) { uint32_t o = *p; *p = v; return o; }
     void atomic_or(uint32_t* p, uint32_t v) { *p |= v; }
+    void atomic_min(int32_t* p, int v) { if (v < *p) *p = v; }
     uint32_t uniform(uint32_t v) const { return v; }
     void atomic_and(uint32_t* p, uint32_t v) { *p &= v; }
     void mark(int id) { g_prof[id & 15]++; }
@@ -244,7 +245,6 @@ struct HostDev {
     std::vector<uint8_t> rmask;
     std::vector<uint32_t> oflags, stamp, rstamp, status;
     std::vector<int32_t> hshadow[2];
-
     void fill_heights_inf()
     {
         for (int64_t i = 0; i < (int64_t)L.ntiles * MGC_TV; ++i) L.height[i] = MGC_HINF;
@@ -293,16 +293,62 @@ struct HostDev {
                 }
         std::vector<uint16_t> T((size_t)L.ntiles * MGC_TV);
         HostWave w(WS);
-        for (int i = 0; i < L.gz * L.gy; ++i) mgc_dt_scan_line<0, false, true, false>(w, L, i, L.rmask, T.data());
-        for (int i = 0; i < L.gz * L.gy; ++i) mgc_dt_scan_line<0, true, false, false>(w, L, i, T.data(), T.data());
-        for (int i = 0; i < L.gz * L.gx; ++i) mgc_dt_scan_line<1, false, false, false>(w, L, i, T.data(), T.data());
-        for (int i = 0; i < L.gz * L.gx; ++i) mgc_dt_scan_line<1, true, false, false>(w, L, i, T.data(), T.data());
-        for (int i = 0; i < L.gy * L.gx; ++i) mgc_dt_scan_line<2, false, false, false>(w, L, i, T.data(), T.data());
-        for (int i = 0; i < L.gy * L.gx; ++i) mgc_dt_scan_line<2, true, false, true>(w, L, i, T.data(), L.height);
+        for (int i = 0; i < L.gz * L.gy; ++i) mgc_dt_scan_line<0, false, 1, false>(w, L, i, L.rmask, T.data());
+        for (int i = 0; i < L.gz * L.gy; ++i) mgc_dt_scan_line<0, true, 0, false>(w, L, i, T.data(), T.data());
+        for (int i = 0; i < L.gz * L.gx; ++i) mgc_dt_scan_line<1, false, 0, false>(w, L, i, T.data(), T.data());
+        for (int i = 0; i < L.gz * L.gx; ++i) mgc_dt_scan_line<1, true, 0, false>(w, L, i, T.data(), T.data());
+        for (int i = 0; i < L.gy * L.gx; ++i) mgc_dt_scan_line<2, false, 0, false>(w, L, i, T.data(), T.data());
+        for (int i = 0; i < L.gy * L.gx; ++i) mgc_dt_scan_line<2, true, 0, true>(w, L, i, T.data(), L.height);
         for (int t = 0; t < L.ntiles; ++t) mgc_dt_finish_tile(w, L, t);
         L.count[9] += L.ntiles;
         g_prof[28]++;
         return true;
+    }
+    /* ---- radial labels of the flood phase (mgc_dt_ops.inl), the library's HipDevT ops on host arrays ---- */
+    std::vector<uint16_t> ds16;      /* 1 + L1 distance from the nearest voxel that held excess when the solve began */
+    std::vector<int32_t> hexact;     /* the exact labels of the last global relabel */
+    bool radial_on = false, lowered = false;
+    void set_radial(bool on) { radial_on = on; }
+    bool radial_begin(int c_min)
+    {
+        HostWave w(WS);
+        ds16.assign((size_t)L.ntiles * MGC_TV, 0);
+        uint16_t* const T = ds16.data();
+        for (int i = 0; i < L.gz * L.gy; ++i) mgc_dt_scan_line<0, false, 2, false>(w, L, i, L.excess, T);
+        for (int i = 0; i < L.gz * L.gy; ++i) mgc_dt_scan_line<0, true, 0, false>(w, L, i, T, T);
+        for (int i = 0; i < L.gz * L.gx; ++i) mgc_dt_scan_line<1, false, 0, false>(w, L, i, T, T);
+        for (int i = 0; i < L.gz * L.gx; ++i) mgc_dt_scan_line<1, true, 0, false>(w, L, i, T, T);
+        for (int i = 0; i < L.gy * L.gx; ++i) mgc_dt_scan_line<2, false, 0, false>(w, L, i, T, T);
+        for (int i = 0; i < L.gy * L.gx; ++i) mgc_dt_scan_line<2, true, 0, false>(w, L, i, T, T);
+        L.count[MGC_CNT_RADIAL_C] = MGC_HINF;
+        for (int t = 0; t < L.ntiles; ++t) mgc_dt_cmin_tile(w, L, t, T);
+        radial_save_exact();
+        radial_lower(c_min);
+        return true;
+    }
+    void radial_save_exact() { hexact.assign(L.height, L.height + (size_t)L.ntiles * MGC_TV); }
+    void radial_restore_exact() { memcpy(L.height, hexact.data(), hexact.size() * sizeof(int32_t)); lowered = false; }
+    void radial_lower(int c_min)
+    {
+        HostWave w(WS);
+        lowered = L.count[MGC_CNT_RADIAL_C] < MGC_HINF && L.count[MGC_CNT_RADIAL_C] >= c_min; /* (what mgc_dt_lower_tile decides by) */
+        for (int t = 0; t < L.ntiles; ++t) mgc_dt_lower_tile(w, L, t, ds16.data(), c_min);
+    }
+    void source_open()
+    {
+        HostWave w(WS);
+        if (getenv("HOSTSIM_TRACE")) { /* development aid: how saturated are the tiles the flood touched? */
+            int64_t dirty = 0, arcs = 0, gone = 0, exc_tiles = 0, exc_clean = 0;
+            for (int t = 0; t < L.ntiles; ++t) {
+                const bool d = (L.status[t] & MGC_ST_DIRTY) != 0, e = (L.status[t] & MGC_ST_EXCESS) != 0;
+                exc_tiles += e; exc_clean += e && !d;
+                if (!e) continue;
+                dirty++;
+                for (int v = 0; v < MGC_TV; ++v) { arcs += 6; gone += 6 - __builtin_popcount(rmask[(int64_t)t * MGC_TV + v] & 63); }
+            }
+            fprintf(stderr, "[sim] dirty tiles %lld: %.1f%% of their arcs are saturated; tiles with excess %lld, of them clean %lld\n", (long long)dirty, 100.0 * gone / (arcs ? arcs : 1), (long long)exc_tiles, (long long)exc_clean);
+        }
+        for (int t = 0; t < L.ntiles; ++t) mgc_source_open_tile(w, L, t);
     }
     void relabel_list(int lst, uint32_t epoch, int next, int zero_list = -1)
     {
@@ -353,10 +399,13 @@ struct HostDev {
             }
         }
         g_prof[40]++;
-        for (int64_t id = 0; id < N; ++id) g_prof[41] += L.height[(int64_t)tl[id] * MGC_TV + lc[id]] != dist[id];
+        /* (right after radial_begin the labels in L.height are the radial ones: the exact labels are the copy kept aside) */
+        const int32_t* const lab = lowered ? hexact.data() : L.height;
+        for (int64_t id = 0; id < N; ++id) g_prof[41] += lab[(int64_t)tl[id] * MGC_TV + lc[id]] != dist[id];
     }
     /* work profile: what does an incremental relabel change?  labels of the tiles it reset, before and after */
     std::vector<std::pair<int, std::vector<int32_t> > > reset_snapshot;
+    std::vector<char> weak0;
     void activate_all(uint32_t phase)
     {
         for (auto& sn : reset_snapshot) {
@@ -375,6 +424,13 @@ struct HostDev {
         }
         reset_snapshot.clear();
         if (g_check_exact) check_exact_labels();
+        if (getenv("HOSTSIM_WEAK")) { /* development aid: how many of the weak arcs (capacity as loaded < 1e-9) are saturated by now, how many voxels hold excess */
+            int64_t weak = 0, sat = 0, exc = 0, excfin = 0;
+            if (weak0.empty()) { weak0.resize(rcap.size()); for (size_t i = 0; i < rcap.size(); ++i) weak0[i] = rcap[i] > 0.0 && rcap[i] < 1e-9; }
+            for (size_t i = 0; i < rcap.size(); ++i) if (weak0[i]) { weak++; sat += rcap[i] == 0.0; }
+            for (size_t i = 0; i < excess.size(); ++i) if (excess[i] > 0.0) { exc++; excfin += height[i] < MGC_HINF; }
+            fprintf(stderr, "[sim] weak arcs %lld, saturated %lld (%.1f%%); voxels with excess %lld, with a finite label %lld\n", (long long)weak, (long long)sat, 100.0 * sat / (weak ? weak : 1), (long long)exc, (long long)excfin);
+        }
         HostBlock x(S);
         HostWave w(WS);
         int candidates = 0; /* what the library's tile filter would list */
@@ -419,15 +475,38 @@ struct HostDev {
         const int n = L.count[lst];
         L.count[8] += n;
         HostWave w(WS);
+        if (getenv("HOSTSIM_DUMP")) { /* development aid: labels, excess and "a weak arc of this voxel is saturated" of the middle z-plane, before every phase */
+            char path[512];
+            snprintf(path, sizeof(path), "%s/phase_%04u.bin", getenv("HOSTSIM_DUMP"), phase);
+            FILE* f = fopen(path, "wb");
+            if (f) {
+                const int64_t z = L.dz / 2;
+                for (int64_t y = 0; y < L.dy; ++y)
+                    for (int64_t xx = 0; xx < L.dx; ++xx) {
+                        int tile, loc;
+                        mgc_node_to_tile(L, (z * L.dy + y) * L.dx + xx, tile, loc);
+                        const int64_t i = (int64_t)tile * MGC_TV + loc;
+                        double rec[3] = {(double)height[i], excess[i], 0.0};
+                        for (int d = 0; d < 6; ++d) if (!weak0.empty() && weak0[((int64_t)tile * 6 + d) * MGC_TV + loc] && rcap[((int64_t)tile * 6 + d) * MGC_TV + loc] == 0.0) rec[2] += 1.0;
+                        fwrite(rec, sizeof(double), 3, f);
+                    }
+                fclose(f);
+            }
+        }
+        if (getenv("HOSTSIM_WEAK") && atoi(getenv("HOSTSIM_WEAK")) > 1 && !weak0.empty()) {
+            int64_t sat = 0;
+            for (size_t i = 0; i < rcap.size(); ++i) sat += weak0[i] && rcap[i] == 0.0;
+            fprintf(stderr, "[sim]   phase %u: %d tiles, weak arcs saturated so far %lld\n", phase, n, (long long)sat);
+        }
         for (int i = 0; i < n; ++i) {
             if ((int)g_tile_discharges.size() == L.ntiles) g_tile_discharges[L.list[lst][i]]++;
             if (g_wave_mode & 1) {
                 const int64_t sweeps_before = g_prof[2];
-                mgcw_discharge_tile(w, L, L.list[lst][i], phase, sweeps, ((g_wave_mode & 4) ? MGCW_BFS : 0) | ((g_wave_mode & 8) ? MGCW_BFS_SINK : 0));
+                mgcw_discharge_tile(w, L, L.list[lst][i], phase, sweeps, ((g_wave_mode & 4) ? MGCW_BFS : 0) | ((g_wave_mode & 8) ? MGCW_BFS_SINK : 0) | (radial_on ? MGCW_SAT_DIRTY : 0));
                 if (g_trace) fprintf(g_trace, "%u %d %d\n", phase, L.list[lst][i], (int)(g_prof[2] - sweeps_before));
                 g_prof[3]++;
             } else {
-                mgc_discharge_tile(x, L, L.list[lst][i], phase, cycles, sweeps);
+                mgc_discharge_tile(x, L, L.list[lst][i], phase, radial_on && cycles < 0 ? -2 : cycles, sweeps);
             }
         }
     }
@@ -484,7 +563,7 @@ struct HostDev {
                     }
                     const double tr = trcap[id];
                     excess[(int64_t)tile * MGC_TV + loc] = tr > 0 ? tr : 0.0;
-                    if (tr > 0) status[tile] |= MGC_ST_EXCESS;
+                    if (tr > 0) status[tile] |= MGC_ST_EXCESS | MGC_ST_SOURCE;
                     sink[(int64_t)tile * MGC_TV + loc] = tr < 0 ? -tr : 0.0;
                     if (tr < 0) { m |= MGC_MASK_SINK; status[tile] |= 2u; }
                     rmask[(int64_t)tile * MGC_TV + loc] = (uint8_t)m;
@@ -613,6 +692,11 @@ int hostsim_solve(const int64_t* shape, const double* w0, const double* w1, cons
     if (sweeps > 0) P.max_sweeps = sweeps;
     if (max_outer > 0) P.max_outer = max_outer;
     P.incremental_relabel = incremental;
+    if (getenv("HOSTSIM_TRACE")) P.trace = atoi(getenv("HOSTSIM_TRACE")); /* one stderr line per global relabel (tools/sim_workprofile.py) */
+    if (getenv("HOSTSIM_ADAPTIVE")) P.adaptive_rounds = atoi(getenv("HOSTSIM_ADAPTIVE"));
+    if (getenv("HOSTSIM_RADIAL")) P.radial = atoi(getenv("HOSTSIM_RADIAL"));
+    if (getenv("HOSTSIM_RADIAL_ROUNDS0")) P.radial_rounds0 = atoi(getenv("HOSTSIM_RADIAL_ROUNDS0"));
+    if (getenv("HOSTSIM_RADIAL_MIN_C")) P.radial_min_c = atoi(getenv("HOSTSIM_RADIAL_MIN_C"));
     MgcSolveStats st;
     const int rc = mgc_solve(*d, d->L, P, st);
     memcpy(stats_out, &st, sizeof(st));
@@ -629,10 +713,13 @@ int hostsim_first_relabel(const int64_t* shape, const double* w0, const double* 
     HostDev* d = (HostDev*)hostsim_create(shape, 0, 1);
     d->load(w0, w1, w2, trcap);
     const int keep = g_use_dt;
-    g_use_dt = use_dt;
+    g_use_dt = use_dt & 1;
     MgcSolveParams P = mgc_default_params();
     P.max_outer = 1; /* one global relabel + the activation, then the rounds of colour phases: stop before them */
     P.rounds_per_relabel = 0;
+    P.radial = (use_dt & 2) ? 1 : 0; /* bit 1: the radial labels of the flood phase on top of the transform (mgc_dt_ops.inl) */
+    P.radial_rounds0 = 0;
+    if (use_dt & 4) P.radial_min_c = 1;
     MgcSolveStats st;
     g_prof[28] = 0;
     (void)mgc_solve(*d, d->L, P, st);
@@ -657,6 +744,12 @@ struct HostDev26 {
     std::vector<int32_t> height, lists, count;
     std::vector<uint32_t> rmask32, stamp, rstamp, status;
     bool first_relabel_dt() { return false; } /* (an L-infinity distance is not separable) */
+    bool radial_begin(int) { return false; }
+    void radial_save_exact() {}
+    void radial_restore_exact() {}
+    void radial_lower(int) {}
+    void source_open() {}
+    void set_radial(bool) {}
     void fill_heights_inf()
     {
         for (int64_t i = 0; i < (int64_t)L.ntiles * MGC_TV; ++i) L.height[i] = MGC_HINF;

@@ -40,7 +40,7 @@ def lib():
     return _lib
 
 
-STAT_NAMES = ("outer", "relabel_passes", "relabel_tiles", "phases", "discharge_tiles", "converged", "last_active", "reserved")
+STAT_NAMES = ("outer", "relabel_passes", "relabel_tiles", "phases", "discharge_tiles", "converged", "last_active", "reserved", "radial_cycles")
 
 
 def set_wave_mode(mode):
@@ -79,7 +79,7 @@ def solve(shape, weights, trcap, rounds=0, cycles=0, sweeps=0, max_outer=0, wave
     ws = [w if w.size else np.zeros(1) for w in ws]
     tr = np.ascontiguousarray(trcap, dtype=np.float64).ravel()
     labels = np.empty(int(np.prod(shape)), np.uint8)
-    stats = np.zeros(8, np.int64)
+    stats = np.zeros(16, np.int64)
     rc = lib().hostsim_solve(shape, ws[0], ws[1], ws[2], tr, rounds, cycles, sweeps, max_outer, labels, stats)
     st = dict(zip(STAT_NAMES, stats.tolist()))
     st["rc"] = rc
@@ -87,7 +87,9 @@ def solve(shape, weights, trcap, rounds=0, cycles=0, sweeps=0, max_outer=0, wave
 
 
 def first_relabel(shape, weights, trcap, use_dt):
-    """the first global relabel alone: (ran_as_distance_transform, labels[tiles, 512] int32, status[tiles] uint32)"""
+    """the first global relabel alone: (ran_as_distance_transform, labels[tiles, 512] int32, status[tiles] uint32);
+    use_dt: 0 relaxation passes, 1 distance transform, 3 transform + the radial labels of the flood phase (7: whatever the
+    length of the shortest source -> sink path)"""
     shape = np.asarray(shape, dtype=np.int64)
     ws = [np.ascontiguousarray(w, dtype=np.float64).ravel() for w in weights]
     ws = [w if w.size else np.zeros(1) for w in ws]
@@ -99,7 +101,7 @@ def first_relabel(shape, weights, trcap, use_dt):
     L.hostsim_first_relabel.restype = C.c_int
     L.hostsim_first_relabel.argtypes = [np.ctypeslib.ndpointer(np.int64), pf, pf, pf, pf, C.c_int,
                                         np.ctypeslib.ndpointer(np.int32), np.ctypeslib.ndpointer(np.uint32)]
-    ran = L.hostsim_first_relabel(shape, ws[0], ws[1], ws[2], tr, int(bool(use_dt)), h, st)
+    ran = L.hostsim_first_relabel(shape, ws[0], ws[1], ws[2], tr, int(use_dt), h, st)
     return bool(ran), h, st
 
 
@@ -218,7 +220,7 @@ def solve26(shape, weights_by_offset, trcap, rounds=0, cycles=0, sweeps=0, max_o
     n = int(np.prod(shape))
     w = weights26(shape, weights_by_offset)
     labels = np.empty(n, np.uint8)
-    stats = np.zeros(8, np.int64)
+    stats = np.zeros(16, np.int64)
     rc = L.hostsim_solve26(np.asarray(shape, np.int64), np.ascontiguousarray(w).ravel(), np.ascontiguousarray(trcap, dtype=np.float64).ravel(),
                            rounds, cycles, sweeps, max_outer, labels, stats)
     st = dict(zip(STAT_NAMES, stats.tolist()))

@@ -201,3 +201,123 @@ def test_dimacs_export_of_device_graphs_round_trips():
     oflow, olabels = _solve_dimacs(f.getvalue())
     np.testing.assert_array_equal(g.labels().astype(np.uint8), olabels)
     np.testing.assert_array_equal(olabels, GOLD[case + "/stawiaski_directed_neg/segments"])
+
+
+# ---- maxflow.GraphDouble / GraphFloat / GraphInt as the reference binds them (wrapper.cpp:27-134) ----
+def _graph_types():
+    from medpy_amd import graphcut
+    return [graphcut.GraphDouble, graphcut.GraphFloat, graphcut.GraphInt]
+
+
+@pytest.mark.parametrize("kind", [0, 1, 2])
+def test_get_edge_kat_of_the_reference(kind):
+    """reference lib/maxflow/src/get_edge_test.py:17-59 (FIRST, SECOND, THIRD: RANDOM), on all three graph types: the graph
+    grows past its constructor's node count, get_edge reads both directions, absent arcs read 0"""
+    import random
+    G = _graph_types()[kind]
+    g = G(2, 1)
+    g.add_node(3)
+    g.add_edge(0, 1, 2, 2)
+    g.add_edge(0, 2, 4, 5)
+    assert [g.get_edge(0, 1), g.get_edge(1, 0), g.get_edge(0, 2), g.get_edge(2, 0), g.get_edge(1, 2), g.get_edge(2, 1)] == [2, 2, 4, 5, 0, 0]
+    assert g.get_node_num() == 3
+    g = G(2, 1)
+    g.add_node(2)
+    g.add_edge(0, 1, 2, 3)
+    assert g.get_edge(0, 1) == 2 and g.get_edge(1, 0) == 3
+    rnd = random.Random(5)
+    nodes = 40
+    g = G(nodes, nodes * (nodes - 1))
+    g.add_node(nodes)
+    want = {}
+    for fr in range(nodes):
+        for to in range(fr + 1, nodes):
+            want[(fr, to)] = (rnd.randint(1, 10), rnd.randint(1, 10))
+            g.add_edge(fr, to, want[(fr, to)][0], want[(fr, to)][1])
+    for (fr, to), (c, r) in want.items():
+        assert g.get_edge(fr, to) == c and g.get_edge(to, fr) == r
+    if kind == 2:
+        assert isinstance(g.get_edge(0, 1), int)
+
+
+@pytest.mark.skipif(not bk.available("ref"), reason="oracle/_ref not built")
+@pytest.mark.parametrize("kind", [0, 1, 2])
+def test_parallel_arcs_like_the_compiled_reference(kind):
+    """add_edge creates PARALLEL arcs (graph.h:428-454): get_edge reports the pair added last (the first the list walk meets,
+    graph.h:500-509), sum_edge adds to that pair, and the flow sees the sum of all of them -- every read-back and the cut
+    compared with the unmodified reference driven through the same calls"""
+    G = _graph_types()[kind]
+    rng = np.random.default_rng(3 + kind)
+    n = 30
+    o = bk.BKGraph(n, 16, "ref")
+    g = G(n, 16)
+    assert g.add_node(n) == 0
+    calls = []
+    for k in range(400):
+        a, b = (int(v) for v in rng.choice(n, 2, replace=False))
+        c, r = (float(v) for v in rng.integers(0, 9, 2)) if kind else (float(rng.random()), float(rng.random()))
+        which = "add" if rng.random() < 0.5 else "sum"
+        calls.append((which, a, b, c, r))
+    for which, a, b, c, r in calls:
+        cc, rr = (int(c), int(r)) if kind == 2 else (c, r)
+        if which == "add":
+            o.add_edges([a], [b], [c], [r]); g.add_edge(a, b, cc, rr)
+        else:
+            o.sum_edges([a], [b], [c], [r]); g.sum_edge(a, b, cc, rr)
+    for a in range(n):
+        for b in range(n):
+            if a != b:
+                assert g.get_edge(a, b) == o.get_edge(a, b), (a, b)
+    src = np.where(rng.random(n) < 0.3, rng.integers(1, 20, n), 0).astype(float)
+    snk = np.where(rng.random(n) < 0.3, rng.integers(1, 20, n), 0).astype(float)
+    o.add_tweights(None, src, snk)
+    for u in range(n):
+        if src[u] or snk[u]:
+            g.add_tweights(u, int(src[u]) if kind == 2 else float(src[u]), int(snk[u]) if kind == 2 else float(snk[u]))
+    oflow, flow = o.maxflow(), g.maxflow()
+    assert flow == pytest.approx(oflow, rel=1e-6 if kind == 1 else 1e-12)
+    np.testing.assert_array_equal(g.labels().astype(np.uint8), o.labels())  # the minimal sink set is unique, ties or not
+
+
+def test_reset_returns_an_empty_graph():
+    """Graph::reset, graph.cpp:46-60: no nodes, no arcs, no t-links, flow 0 -- and the object is usable again"""
+    from medpy_amd.graphcut import GraphDouble
+    g = GraphDouble(4, 4)
+    g.add_node(4)
+    g.add_edge(0, 1, 3.0, 1.0)
+    g.add_tweights(0, 5.0, 0.0)
+    g.add_tweights(1, 0.0, 5.0)
+    assert g.maxflow() == 3.0
+    g.reset()
+    assert g.get_node_num() == 0 and g.get_arc_num() == 0 and g.get_trcap(0) == 0.0
+    assert g.add_node(3) == 0
+    g.add_edge(0, 2, 2.0, 2.0)
+    g.add_tweights(0, 7.0, 0.0)
+    g.add_tweights(2, 0.0, 1.5)
+    assert g.maxflow() == 1.5 and g.get_edge(0, 1) == 0.0
+    assert list(g.labels()[:3]) == [True, True, False]
+
+
+def test_graph_float_and_int_compute_in_their_type():
+    """instances.inc:12-15: GraphFloat keeps float32 capacities and running sums, GraphInt integers; non-integers are refused
+    by GraphInt as the Boost.Python signature would"""
+    from medpy_amd.graphcut import GraphFloat, GraphInt
+    f = GraphFloat(3, 2)
+    f.add_node(3)
+    f.sum_edge(0, 1, 0.1, 0.1)
+    assert f.get_edge(0, 1) == float(np.float32(0.1))
+    f.sum_edge(0, 1, 0.2, 0.0)
+    assert f.get_edge(0, 1) == float(np.float32(np.float32(0.1) + np.float32(0.2)))
+    f.add_tweights(0, 1.0, 0.0)
+    f.add_tweights(1, 0.0, 1.0)
+    assert f.maxflow() == float(np.float32(np.float32(0.1) + np.float32(0.2)))
+    g = GraphInt(3, 2)
+    g.add_node(3)
+    g.add_edge(0, 1, 3, 0)
+    g.add_edge(1, 2, 2, 0)
+    g.add_tweights(0, 9, 0)
+    g.add_tweights(2, 0, 9)
+    flow = g.maxflow()
+    assert flow == 2 and isinstance(flow, int)
+    with pytest.raises(TypeError):
+        g.add_edge(0, 2, 1.5, 0)

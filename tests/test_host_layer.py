@@ -241,7 +241,8 @@ def test_dimacs_writer_text_equals_the_reference_layout():
                             "a 1 3 65535\na 5 2 65535\na 1 4 0.125\nc inter-node arcs (n-weights)\n"
                             "a 3 4 0.5\na 4 3 0.25\na 4 5 2\nc end-of-file")
     g.set_nweights({(1, 2): (1, 1), (2, 1): (1, 1), (1, 9): (1, 1)})
-    assert len(g.inconsistent()) == 3
+    assert g.inconsistent() == ["The reversed edges of (1, 2) is also in the n-weights.", "The reversed edges of (2, 1) is also in the n-weights.",
+                                "Node 9 in edge (1, 9) but not in nodes."]  # the reference's wording (graph.py:241-264)
 
 
 def test_merge_tweights_equals_call_by_call_add_tweights():
@@ -278,6 +279,35 @@ def test_graph_from_labels_argument_checks():
         graph_from_labels(good, m, m, boundary_term=lambda g, args: None)
     with pytest.raises(AttributeError):
         graph_from_labels(good, m, m, regional_term=lambda g, l, a, extra: None)
+
+
+@pytest.mark.parametrize("gen,shape", [("sphere", (40, 40, 40)), ("sphere", (24, 40, 17)), ("hard", (32, 32, 32)), ("ties", (24, 16, 16))])
+def test_radial_labels_are_a_valid_labelling(gen, shape):
+    """mgc_dt_ops.inl, radial labels of the flood phase: d = min(exact, max(1, C - hops from the source)) must be a VALID
+    push-relabel labelling -- never above the exact distance, at most 1 on sink-linked voxels, and d(u) <= d(v) + 1 along every
+    lattice arc (all arcs are residual when the transform runs) -- and below the exact labels somewhere, or it does nothing."""
+    import sim
+    from medpy_amd import synthetic
+    from oracle import energy_numpy
+    s = getattr(synthetic, gen)(shape)
+    w = energy_numpy.boundary_weights(s["term"], s["image"], s["sigma"])
+    tr = (np.where(s["fg"], 65535.0, 0.0) - np.where(s["bg"], 65535.0, 0.0)).ravel()
+    _, h_exact, _ = sim.first_relabel(shape, w, tr, 1)
+    _, h_rad, _ = sim.first_relabel(shape, w, tr, 7)
+    g = [(d + 7) // 8 for d in shape]
+
+    def untile(h):  # [tiles, 512] -> padded volume
+        v = h.reshape(g[0], g[1], g[2], 8, 8, 8).transpose(0, 3, 1, 4, 2, 5).reshape(g[0] * 8, g[1] * 8, g[2] * 8)
+        return v[:shape[0], :shape[1], :shape[2]].astype(np.int64)
+    ex, rd = untile(h_exact), untile(h_rad)
+    assert (rd <= ex).all() and (rd >= 1).all()
+    assert (rd[s["bg"]] == 1).all()
+    for ax in range(3):
+        assert np.abs(np.diff(rd, axis=ax)).max() <= 1
+    if gen == "sphere":
+        assert (rd < ex).mean() > 0.5  # everywhere off the shortest source -> sink paths
+        c = np.unravel_index(np.argmax(rd), rd.shape)  # the highest label sits on the source
+        assert s["fg"][c]
 
 
 def test_relabel_first_appearance_order():
