@@ -42,10 +42,17 @@
                                   relabel pass lowers one of its labels (a clear bit promises nothing) */
 #define MGC_ST_SOURCE 64u      /* (6-neighbourhood) the tile held a source link (tr_cap > 0) when the graph was built: where the schedule looks for
                                   "can excess of the source still reach the sink?" (mgc_source_open_tile) */
+/* A "wall": a tile in which at least MGC_WALL_VOXELS voxels hold an n-link below MGC_WALL_WEIGHT -- the patch of a closed surface of
+ * weak arcs (an intensity edge under an exponential / power term: exp(-44) ~ 1e-19 on the headline volume) that crosses the tile.
+ * Isolated weak arcs of a noisy image do not qualify (weak-contrast volume: ~2 per tile).  mgc_build counts the wall tiles; the
+ * flood phase of the solve runs on radial labels (mgc_dt_ops.inl) only when there are walls to flood against. */
+#define MGC_WALL_WEIGHT 9.313225746154785e-10 /* 2^-30 */
+#define MGC_WALL_VOXELS 24
 #define MGC_ST_DEP_SHIFT 8
 /* counter slots no layout uses as a work list (6-neighbourhood: lists 0..7, totals 8 / 9; 26-neighbourhood: lists 0..17,
  * totals 18..20; tickets of the wave kernels 24..27) */
 #define MGC_CNT_SINK_TILES 13  /* (6-neighbourhood) k_build: tiles that hold a sink link */
+#define MGC_CNT_WALL_TILES 12  /* (6-neighbourhood) k_build: tiles a surface of weak arcs passes through (MGC_WALL_*), read by mgc_build */
 #define MGC_CNT_RADIAL_C 14    /* (6-neighbourhood) hop length of the shortest source -> sink path (mgc_dt_cmin_tile) or MGC_HINF */
 #define MGC_CNT_SOURCE_OPEN 15 /* (6-neighbourhood) source tiles whose excess still stands under a finite label (mgc_source_open_tile) */
 #define MGC_CNT_CHANGED 21     /* suspect-closure pass changed something */

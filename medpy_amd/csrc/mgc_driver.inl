@@ -46,7 +46,8 @@ struct MgcSolveParams {
                                the labels are min(exact, C - distance from the source) while excess of the source can still
                                reach the sink; exact labels from the relabel that finds the source sealed in            */
     int radial_min_c;       /* ... only when the shortest source -> sink path has at least this many hops               */
-    int radial_rounds0;     /* colour rounds of the first radial cycle (the following ones run rounds_per_relabel)       */
+    int radial_rounds0;     /* colour rounds of the first radial cycle; 0: one cycle of the whole budget                 */
+    int radial_budget_x8;   /* most colour rounds on radial labels, in eighths of (tiles on the shortest source -> sink path) */
 };
 
 struct MgcSolveStats {
@@ -93,10 +94,13 @@ static inline MgcSolveParams mgc_default_params(int ndir = 6)
     p.trace = 0;
     p.adaptive_rounds = ndir == 26 ? 9 : 2; /* a tile visit of a relabel costs 1/3 of a discharge (8 vs 25 ns), 1/9 in the full neighbourhood (20 vs 175 ns);
                                                measured at 512^3 (round 3): weak contrast 68.7 ms at 3, 66.3 at 2, 66.3 at 1; headline volume 35.9 at 3 and 2, 39.8 at 1 */
-    p.radial = ndir == 6 ? 1 : 0;
+    p.radial = ndir == 6 ? 2 : 0; /* 2: decided per graph by whoever calls mgc_solve (mgc_maxflow: wall tiles counted by k_build); the host simulator treats 2 as 1 */
     p.radial_min_c = 8;
-    p.radial_rounds0 = 4; /* a source whose cut hugs it is sealed in by then, and the exact labels take over before the flow that got through
-                             is sent astray (weak-contrast volume, host simulator 256^3: 4 rounds 127 k discharges, 8 rounds 173 k; exact labels 126 k) */
+    p.radial_budget_x8 = 5;
+    p.radial_rounds0 = 0; /* 0: ONE radial cycle as long as the flood may take (radial_budget below).  Measured on MI355X, headline volume 512^3:
+                             35.9 ms on exact labels; first radial cycle of 4 rounds (then 8, then 4, a relabel in between) 26.1 ms, 6: 23.4,
+                             8: 24.4, 16 (= the budget, one cycle): 22.0 ms; 256^3: 9.5 / 5.3 (4) / 4.8 (8 = the budget).  A short first cycle
+                             only pays where a cut hugs the source, and such graphs hold no walls to flood against (parameter radial = 2) */
     return p;
 }
 
@@ -109,7 +113,7 @@ int mgc_solve(Dev& dev, const MgcLattice& L, const MgcSolveParams& P, MgcSolveSt
     int rounds = P.rounds_per_relabel;
     int64_t prev_dis = 0, prev_rel = 0, last_passes = 0;
     bool radial = false; /* the labels in HBM are the radial ones: discharges mark every saturation, relabels start from the exact labels kept aside */
-    int radial_done = 0, radial_next = P.radial_rounds0, radial_budget = 0; /* colour rounds run on radial labels / length of the next radial cycle / most such rounds */
+    int radial_done = 0, radial_next = P.radial_rounds0 > 0 ? P.radial_rounds0 : 1 << 20, radial_budget = 0; /* colour rounds run on radial labels / length of the next radial cycle / most such rounds */
     st = MgcSolveStats();
     dev.zero_count(lay.cnt_dis);
     dev.zero_count(lay.cnt_rel);
@@ -227,7 +231,10 @@ int mgc_solve(Dev& dev, const MgcLattice& L, const MgcSolveParams& P, MgcSolveSt
                 /* a flood front moves a tile per colour phase, and nothing a shortest path's length away from the source is still
                  * "behind the cut": five eighths of that many phases reach the far side of a cut that surrounds the source
                  * (host simulator, headline volume: 8 rounds at 256^3, 16 at 512^3 close the surface; 4 resp. 8 do not) */
-                else radial_budget = (5 * cnt[MGC_CNT_RADIAL_C] / 8 + 7) / 8;
+                else {
+                    radial_budget = (P.radial_budget_x8 * cnt[MGC_CNT_RADIAL_C] / 8 + 7) / 8;
+                    if (radial_next > radial_budget) radial_next = radial_budget;
+                }
             } else if (cnt[MGC_CNT_SOURCE_OPEN] == 0 || radial_done >= radial_budget) {
                 /* the source is sealed in -- or the flood has had its time, and what is still open are holes that only exact
                  * labels find (radial labels lead past them: measured, a solve that re-lowers for ever) */

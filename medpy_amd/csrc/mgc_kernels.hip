@@ -1173,6 +1173,7 @@ __device__ __forceinline__ void k_build_tiles(const MgcLattice& L, const MgcBuil
     const int nx = gridDim.x >= 8 ? 8 : 1;
     const int chunk = (L.ntiles + nx - 1) / nx, stride = (int)gridDim.x / nx;
     int sink_tiles = 0; /* (thread 0) tiles of this workgroup that hold a sink link */
+    int wall_tiles = 0; /* (thread 0) ... that a surface of weak arcs passes through (MGC_WALL_*) */
     for (int idx = (int)blockIdx.x / nx; idx < chunk; idx += stride) {
         const int tile = ((int)blockIdx.x % nx) * chunk + idx;
         if (tile >= L.ntiles) break;
@@ -1206,7 +1207,8 @@ __device__ __forceinline__ void k_build_tiles(const MgcLattice& L, const MgcBuil
          * word) where three barrier-reductions stood.  The 26-neighbourhood path runs this BEFORE its weights (the pre-push needs the
          * t-links), the 6-neighbourhood path behind them (its weight hand-over barrier separates the reset of the vote word from the votes). */
         double tr = 0.0, fc = 0.0;
-        int tbits = 0;
+        int tbits = 0, weak_voxels = 0;
+        bool weak_voxel = false; /* one of this voxel's n-links is below MGC_WALL_WEIGHT (6-neighbourhood, markers only: set before the vote) */
         auto tlinks_and_vote = [&]() __attribute__((always_inline)) {
             if (valid) {
                 if (A.tr_in) tr = A.tr_in[id];
@@ -1227,9 +1229,14 @@ __device__ __forceinline__ void k_build_tiles(const MgcLattice& L, const MgcBuil
                 if (A.bg && A.bg[id]) mgc_add_tweights(tr, fc, 0.0, MGC_MARKER_MAX);
             }
             const int bits = (__ballot(tr < 0.0) != 0ull ? 2 : 0) | (__ballot(tr > 0.0) != 0ull ? 1 : 0) | (__ballot(fc != 0.0) != 0ull ? 4 : 0);
+            /* bits 8..: how many voxels of the tile hold a weak n-link (the same word, one atomic per wave: the count never carries into the vote bits) */
+            const int weak_here = __popcll(__ballot(weak_voxel));
+            if ((t & 63) == 0 && weak_here) atomicAdd(tflag_lds, weak_here << 8);
             if ((t & 63) == 0 && bits) atomicOr(tflag_lds, bits);
             __syncthreads();
             tbits = *tflag_lds;
+            weak_voxels = tbits >> 8;
+            tbits &= 7;
         };
         if constexpr (FULL || PRE6) {
             __syncthreads(); /* the reset of the vote word above, before the votes */
@@ -1342,6 +1349,7 @@ __device__ __forceinline__ void k_build_tiles(const MgcLattice& L, const MgcBuil
                 L.rcap[o] = w;
                 if (L.cap0) L.cap0[o] = w;
                 if (w > 0.0) m |= 1u << d; /* NaN (0/0 of the linear terms on a constant image) is not residual */
+                weak_voxel = weak_voxel || (w > 0.0 && w < MGC_WALL_WEIGHT);
             }
         } else {
             /* full neighbourhood: same g(.) on all 26 offsets (oracle/energy_numpy.py:boundary_weights_offsets).  Unrolled: the
@@ -1468,6 +1476,7 @@ __device__ __forceinline__ void k_build_tiles(const MgcLattice& L, const MgcBuil
             L.status[tile] = (any_sink ? MGC_ST_SINK : 0u) | (any_exc ? MGC_ST_EXCESS : 0u) | ((!FULL && (tbits & 1)) ? MGC_ST_SOURCE : 0u);
             A.tflags[tile] = (uint8_t)((any_exc ? 1 : 0) | (any_sink ? 2 : 0));
             sink_tiles += any_sink ? 1 : 0;
+            wall_tiles += weak_voxels >= MGC_WALL_VOXELS ? 1 : 0;
         }
         /* flow constant: only voxels whose t-links were merged more than once contribute (regional term + marker, fg and bg
          * marker on one voxel): most tiles skip the ten barriers of the tree sum */
@@ -1482,6 +1491,7 @@ __device__ __forceinline__ void k_build_tiles(const MgcLattice& L, const MgcBuil
                                                 6-neighbourhood path has its vote barrier behind the weights) */
     }
     if (!FULL && t_lane == 0 && sink_tiles) atomicAdd(&L.count[MGC_CNT_SINK_TILES], sink_tiles); /* once per workgroup (mgc_build: exact_sink_tiles) */
+    if (!FULL && t_lane == 0 && wall_tiles) atomicAdd(&L.count[MGC_CNT_WALL_TILES], wall_tiles);
 }
 
 /* One kernel per (neighbourhood, boundary term): g(.) is straight-line code, and every instance gets the registers ITS term
@@ -2135,6 +2145,8 @@ struct mgc_graph {
                                   volume: 512^3 tie-heavy volume 1081 -> 790 ms; sink links only on the faces, as in the headline volume: the
                                   few visits of those tiles cost 0.7 ms of 36 more with it) */
     int sink_tiles = 0;        /* tiles holding a sink link, as built */
+    int wall_tiles = 0;        /* tiles a surface of weak arcs passes through, as built (MGC_WALL_*) */
+    int radial_min_walls = 16; /* parameter radial = 2 (the default): radial labels only when the graph holds at least this many wall tiles */
     int sink_sweeps = 8;       /* sweep budget of a visit while exact_sink_tiles = 1 has switched the exact labelling on (parameter sink_sweeps) */
     int use_bricks = 0;        /* incremental global relabels run their passes over bricks of 2 x 2 x 2 tiles (parameter relabel_bricks).  Measured on MI355X
                                   at 512^3: a third fewer passes (318 -> 202 launches) but 67 us instead of 31 us per pass -- 118 VGPRs allow two
@@ -3552,9 +3564,10 @@ int mgc_build(mgc_handle h)
     /* every n-link of the volume residual (and nothing added on top that the mask refresh could have changed): the first
      * global relabel of the solve is a distance transform (mgc_dt_ops.inl) */
     h->sink_tiles = L.ndir == 6 ? h->h_count[MGC_CNT_SINK_TILES] : 0;
+    h->wall_tiles = L.ndir == 6 ? h->h_count[MGC_CNT_WALL_TILES] : 0;
     /* the two build counters are read: their slots (MGC_CNT_NOT_FULL is MGC_CNT_DEFERRED during a solve) are cleared with the next
      * batch of counter clears, whichever schedule drives the solve */
-    h->zero_mask |= (1u << MGC_CNT_NOT_FULL) | (1u << MGC_CNT_SINK_TILES);
+    h->zero_mask |= (1u << MGC_CNT_NOT_FULL) | (1u << MGC_CNT_SINK_TILES) | (1u << MGC_CNT_WALL_TILES);
     h->all_residual = L.ndir == 6 && A.term != MGC_TERM_NONE && h->h_count[MGC_CNT_NOT_FULL] == 0 && !h->n_edges && h->nranks == 1 &&
                       L.dz + L.dy + L.dx < MGC_DT_INF - 8;
     float ms = 0.f;
@@ -3589,6 +3602,10 @@ int mgc_maxflow(mgc_handle h, double* flow)
         int rc;
         if (L.ndir == 6) {
             MgcSolveParams P = h->params;
+            /* radial = 2: the flood phase runs on radial labels where there are walls to flood against (a closed surface of weak arcs
+             * takes many cycles of exact labels to saturate: 35.9 -> 23.7 ms on the headline volume); on a weak-contrast volume, where
+             * what leaves the source mostly reaches the sink, exact labels are the better guide (66 vs 104 ms at 512^3) */
+            if (P.radial == 2) P.radial = h->wall_tiles >= h->radial_min_walls ? 1 : 0;
             if (h->prepush && h->d_prob && !h->rounds_set) P.rounds_per_relabel = 2; /* (a pre-pushed graph, see the 26-neighbourhood branch; 512^3 + regional map: 19.0 ms at 3, 17.8 at 2, 20.1 at 4; without the pre-push 21.4) */
             rc = mgc_solve(dev, L, P, st);
         } else {
@@ -3825,9 +3842,11 @@ int mgc_set_param(mgc_handle h, const char* name, int64_t value)
     else if (!strcmp(name, "incremental_relabel")) h->params.incremental_relabel = value != 0;
     else if (!strcmp(name, "trace")) h->params.trace = value != 0;
     else if (!strcmp(name, "adaptive_rounds") && value >= 0) h->params.adaptive_rounds = (int)value; /* 0 = off, k = threshold */
-    else if (!strcmp(name, "radial") && value >= 0) h->params.radial = (int)value;                 /* flood phase on radial labels (mgc_dt_ops.inl) */
+    else if (!strcmp(name, "radial") && value >= 0 && value <= 2) h->params.radial = (int)value;   /* flood phase on radial labels (mgc_dt_ops.inl): 0 never, 1 always, 2 when the graph holds walls */
+    else if (!strcmp(name, "radial_min_walls") && value >= 0) h->radial_min_walls = (int)value;
+    else if (!strcmp(name, "radial_budget_x8") && value >= 1) h->params.radial_budget_x8 = (int)value;
     else if (!strcmp(name, "radial_min_c") && value >= 1) h->params.radial_min_c = (int)value;
-    else if (!strcmp(name, "radial_rounds0") && value >= 1) h->params.radial_rounds0 = (int)value;
+    else if (!strcmp(name, "radial_rounds0") && value >= 0) h->params.radial_rounds0 = (int)value; /* 0: one radial cycle of the whole budget */
     else if (!strcmp(name, "use_filters")) h->use_filters = (int)value;
     else if (!strcmp(name, "wave_kernels")) { h->wave_kernels = (int)value; h->wave_set = true; }
     else if (!strcmp(name, "wave_min_tiles") && value >= 0) h->wave_min_tiles = (int)value;

@@ -271,6 +271,7 @@ class SparseGraph(object):
         self._nodes = max(int(nodes), 1)
         self._device = int(device)
         self._h = None
+        self._raw = False   # driven through the raw GraphDouble calls (add_node / add_edge / sum_edge / reset) rather than the facade hooks
         self._open()
 
     def _open(self):
@@ -297,6 +298,7 @@ class SparseGraph(object):
     def reset(self):
         """Graph::reset, reference graph.cpp:46-60 (wrapper.cpp:68): back to the state just after construction -- no nodes
         declared, no arcs, no t-links, flow 0."""
+        self._raw = True
         self._open()
 
     def close(self):
@@ -373,6 +375,7 @@ class SparseGraph(object):
         the constructor's node count grows the graph (the reference reallocates, graph.cpp:62-85): a larger graph is
         created in HBM and what was uploaded so far moves over."""
         first = self._declared
+        self._raw = True
         self._declared += int(num)
         if self._declared > self._nodes:
             self._grow(self._declared)
@@ -416,6 +419,7 @@ class SparseGraph(object):
         ``get_edge`` afterwards sees the pair added LAST, as the reference's ``get_arc`` walk does (graph.h:500-509)."""
         i, j, cap, rev_cap = int(i), int(j), self._cast(cap), self._cast(rev_cap)
         self._check_ids(i, j)
+        self._raw = True
         if self._captype != "double":
             for key, c in (((i, j), cap), ((j, i), rev_cap)):
                 front = self._host_arcs.get(key)
@@ -516,7 +520,7 @@ class SparseGraph(object):
 
     def get_node_num(self):
         """nodes declared with ``add_node`` so far (graph.h:413), or the constructor's count when the facade filled the graph"""
-        return self._declared if (self._declared or self._raw_pairs) else self._nodes
+        return self._declared if self._raw else self._nodes
 
     def get_arc_num(self):
         self._flush()

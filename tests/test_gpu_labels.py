@@ -293,8 +293,8 @@ def test_reset_returns_an_empty_graph():
     assert g.add_node(3) == 0
     g.add_edge(0, 2, 2.0, 2.0)
     g.add_tweights(0, 7.0, 0.0)
-    g.add_tweights(2, 0.0, 1.5)
-    assert g.maxflow() == 1.5 and g.get_edge(0, 1) == 0.0
+    g.add_tweights(2, 0.0, 5.0)
+    assert g.maxflow() == 2.0 and g.get_edge(0, 1) == 0.0  # the new arc is the bottleneck; the arc of the old graph is gone
     assert list(g.labels()[:3]) == [True, True, False]
 
 
