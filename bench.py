@@ -1,7 +1,7 @@
 #!/usr/bin/env python3
 """bench.py -- Mvoxels/s of the voxel graph cut (build + solve) on MI355X.
 
-    python bench.py [--gpus N] [--steps K] [--warmup W] [--config C] [--strong] [--no-cpu] [--cpu-full]
+    python bench.py [--gpus N] [--steps K] [--warmup W] [--config C] [--strong] [--no-cpu] [--no-extras] [--cpu-full]
 
 A "step" = one pass of the hot path over one synthetic volume: n-link / t-link construction (mgc_build) + max-flow solve
 with image and markers already resident in HBM and the label array left in HBM (SURVEY.md 8(d) "headline,
@@ -140,6 +140,112 @@ def cpu_baseline(n):
     return out
 
 
+def labels_sha256(labels):
+    """the hash tests/golden/reference_large.json holds for the reference's label volumes (oracle/gen_golden.py large): SHA-256 of the packed bits"""
+    return hashlib.sha256(np.packbits(np.asarray(labels).astype(np.uint8).ravel()).tobytes()).hexdigest()
+
+
+def golden_large():
+    p = os.path.join(ROOT, "tests", "golden", "reference_large.json")
+    return json.load(open(p)) if os.path.exists(p) else {}
+
+
+def parity_relaxation_summary():
+    """how many comparisons of the last GPU test tier needed the equivalence checker instead of strict label equality (exact ties
+    between minimum cuts; profiles/r5_parity_relaxations.jsonl, written by tests/conftest.py on the GPU box and committed)"""
+    for name in ("r5_parity_relaxations.jsonl", "r4_parity_relaxations.jsonl"):
+        p = os.path.join(ROOT, "profiles", name)
+        if os.path.exists(p):
+            rows = [json.loads(ln) for ln in open(p) if ln.strip().startswith("{")]
+            return {"file": "profiles/" + name, "relaxed_comparisons": len(rows), "most_voxels_differing": max([r.get("differing", 0) for r in rows] or [0]),
+                    "all_equivalent": all(r.get("verdict") == "equivalent" for r in rows),
+                    "note": "labels are bit-exact with the reference except inside its own ambiguity set on exact ties between minimum cuts (b0: 7 of 1 048 576 voxels)"}
+    return None
+
+
+def also_case(name, n, conn, regional, steps=3, warmup=1, golden_key=None):
+    """one more BASELINE config inside the driver's run: a fresh handle, `steps` timed build + solve steps (median), the dominant
+    kernel's roofline fraction by the headline's formula, the device-side invariants, and the label hash against the
+    reference's (tests/golden/reference_large.json) where the oracle reaches the size"""
+    from medpy_amd import _lib, synthetic
+    from medpy_amd.graphcut.graph import VoxelGraph
+    shape = (n, n, n)
+    s = synthetic.sphere(shape, seed=0)
+    g = VoxelGraph(shape, device=0, connectivity=conn if conn != 6 else None)
+    g._set_boundary("difference_exponential", s["image"], s["sigma"], False)
+    g._set_markers(s["fg"], s["bg"])
+    if regional:
+        r = synthetic.regional(shape)
+        g._set_regional(r["prob"], r["alpha"])
+    times, flow, st = [], 0.0, None
+    acc = {"discharge_ms": 0.0, "discharge_launches": 0, "discharge_tiles": 0, "discharge_wave_ms": 0.0, "discharge_wave_launches": 0, "discharge_wave_tiles": 0,
+           "build_ms": 0.0, "relabel_ms": 0.0, "global_relabels": 0, "phases": 0}
+    for i in range(warmup + steps):
+        t0 = time.perf_counter()
+        g._build()
+        flow = g.maxflow()
+        dt = time.perf_counter() - t0
+        if i >= warmup:
+            times.append(dt)
+            st = g.stats()
+            for k in acc:
+                acc[k] += st[k]
+    ms = float(np.median(times)) * 1e3
+    b_alg = B_ALG[conn] + (4.0 if regional else 0.0)
+    wave = conn == 6 and acc["discharge_wave_launches"] > 0
+    launches = max(acc["discharge_wave_launches"] if wave else acc["discharge_launches"], 1)
+    avg_ms = (acc["discharge_wave_ms"] if wave else acc["discharge_ms"]) / launches
+    vox = (acc["discharge_wave_tiles"] if wave else acc["discharge_tiles"]) * 512.0 / launches
+    achieved = (b_alg * vox) / (avg_ms * 1e-3) / 1e9 if avg_ms > 0 else 0.0
+    v = g.validate()
+    counts = ("negative_values", "active_excess", "residual_arcs_across", "sink_links_across", "pair_violations", "node_violations", "pending_outbox")
+    out = {"workload": "%d^3 sphere volume, %d-conn%s" % (n, conn, " + regional_probability_map" if regional else ""),
+           "ms_per_step": round(ms, 3), "mvoxels_s": round(n ** 3 / (ms * 1e-3) / 1e6, 1), "steps": steps, "flow": flow,
+           "kernel": "k_discharge_w" if conn == 6 else ("k26_discharge_w" if regional else "k26_discharge"), "frac": round(achieved / HBM_PEAK_GBS, 5),
+           "job_roofline_frac": round(n ** 3 / (ms * 1e-3) * b_alg / (HBM_PEAK_GBS * 1e9), 6),
+           "build_ms": round(acc["build_ms"] / steps, 3), "discharge_kernels_ms": round(acc["discharge_ms"] / steps, 3), "relabel_kernels_ms": round(acc["relabel_ms"] / steps, 3),
+           "global_relabels": acc["global_relabels"] / steps, "colour_phases": acc["phases"] / steps,
+           "validation_all_zero": all(int(v[k]) == 0 for k in counts), "cut_capacity": v["cut_capacity"]}
+    ref = golden_large().get(golden_key) if golden_key else None
+    if ref is not None:
+        sha = labels_sha256(g.labels())
+        out["labels_sha256"] = sha
+        out["labels_match_reference"] = bool(sha == ref["sha256_packed_labels"])
+        out["reference"] = "tests/golden/reference_large.json:%s (unmodified reference BK, oracle/gen_golden.py large)" % golden_key
+    g.close()
+    return out
+
+
+def api_end_to_end(n=BLOCK, reps=3):
+    """The public path from HOST arrays: graph_from_voxels(fg, bg, boundary_term, args) -> maxflow() -> labels(), wall clock per volume
+    (H2D of image + markers, build, solve, read-out, D2H of the labels), median of `reps`; the reference's own call sequence
+    (bin/medpy_graphcut_voxel.py:163-182) with the per-voxel what_segment loop replaced by the bulk read-out."""
+    from medpy_amd import graphcut, synthetic
+    s = synthetic.sphere((n, n, n), seed=0)
+    times, parts, labels = [], None, None
+    for _ in range(reps + 1):
+        t0 = time.perf_counter()
+        g = graphcut.graph_from_voxels(s["fg"], s["bg"], boundary_term=graphcut.energy_voxel.boundary_difference_exponential,
+                                       boundary_term_args=(s["image"], s["sigma"], False))
+        t1 = time.perf_counter()
+        flow = g.maxflow()
+        t2 = time.perf_counter()
+        labels = g.labels()
+        t3 = time.perf_counter()
+        times.append(t3 - t0)
+        parts = (t1 - t0, t2 - t1, t3 - t2)
+        g.close()
+    times = times[1:]  # (the first call pays the handle's first allocations)
+    ms = float(np.median(times)) * 1e3
+    ref = golden_large().get("sphere_512_6") if n == 512 else None
+    out = {"ms_per_volume": round(ms, 2), "mvoxels_s": round(n ** 3 / (ms * 1e-3) / 1e6, 1), "reps": reps,
+           "last_call_ms": {"graph_from_voxels (H2D + build)": round(parts[0] * 1e3, 2), "maxflow": round(parts[1] * 1e3, 2), "labels (read-out + D2H)": round(parts[2] * 1e3, 2)},
+           "flow": flow, "path": "medpy_amd.graphcut.graph_from_voxels(...).maxflow(); .labels() from host arrays (float32 image, bool markers)"}
+    if ref is not None:
+        out["labels_match_reference"] = bool(labels_sha256(labels) == ref["sha256_packed_labels"])
+    return out
+
+
 def block_volume(planes0, planes1, nz_blocks, xy_blocks, block):
     """the local planes [planes0, planes1) of a (nz_blocks x xy_blocks x xy_blocks) grid of sphere blocks: image, fg, bg.
     Every block carries its own bright ball and foreground seed; exactly the outer shell of the WHOLE volume is
@@ -182,6 +288,7 @@ def main():
     ap.add_argument("--cpu-full", action="store_true", help="(default when the host has the memory) the CPU leg runs the whole 512^3")
     ap.add_argument("--cpu-sample-only", action="store_true", help="CPU leg on the bounded sample whatever the host")
     ap.add_argument("--no-cpu", action="store_true")
+    ap.add_argument("--no-extras", action="store_true", help="headline only: no `also` (configs 2 / 3) and no `api_end_to_end` block (profiling runs)")
     ap.add_argument("--cpu-only", type=int, default=0, help=argparse.SUPPRESS)  # child process of cpu_baseline_in_run
     args = ap.parse_args()
     if args.cpu_only:
@@ -217,6 +324,7 @@ def main():
     flow = 0.0
     step_s = []  # wall time of every timed step (N > 1: the slowest rank's)
     end_to_end = None
+    head_sha = None
     slab_stats = validation = None
     transport = None
     if world == 1 and not args.strong:
@@ -257,6 +365,12 @@ def main():
                       "note": "image + markers (+ probability map) from pageable host arrays into HBM, labels back; measured once, outside the timed steps; never part of `value`"}
         validation = g.validate()
         _lib.assert_valid(validation)
+        head_sha = None
+        ref = golden_large().get("sphere_512_6") if (n == 512 and conn == 6 and not regional) else (golden_large().get("sphere_256_6") if (n == 256 and conn == 6 and not regional) else None)
+        if ref is not None:
+            head_sha = {"labels_sha256": labels_sha256(lab), "reference": ref["sha256_packed_labels"]}
+            head_sha["labels_match_reference"] = bool(head_sha["labels_sha256"] == head_sha["reference"])
+        g.close()
         gshape = shape
         workload = "%d^3 sphere volume (float32), %d-conn, boundary_difference_exponential sigma=15%s, fg=inner ball, bg=6 faces" % (
             n, conn, " + regional_probability_map (float32, alpha 0.5)" if regional else "")
@@ -423,6 +537,15 @@ def main():
             if not timed:
                 out["roofline"]["timing"] = ("not available in this run: the launches of a slab are timed by the library's own schedule (mgc_solve_slab over "
                                              "RCCL); this run drove the schedule from Python over the development transport")
+        if world == 1 and not args.strong and head_sha is not None:
+            out["config"].update(head_sha)
+        out["parity"] = parity_relaxation_summary()
+        if world == 1 and not args.config and not args.strong and not args.no_extras and not args.size:
+            # the other single-GPU BASELINE configs and the public API path, inside the driver's run
+            out["also"] = {"config2": also_case("config2", 256, 6, False, golden_key="sphere_256_6"),
+                           "config3": also_case("config3", 512, 26, True),
+                           "config3_at_256": also_case("config3_at_256", 256, 26, True, steps=1, warmup=1, golden_key="config3_256_26_regional")}
+            out["api_end_to_end"] = api_end_to_end()
         if not args.no_cpu and world == 1 and not args.config and not args.strong:
             out["cpu_baseline"] = cpu_baseline_in_run(args.cpu_sample, not args.cpu_sample_only)
         else:

@@ -47,7 +47,7 @@ struct MgcSolveParams {
                                reach the sink; exact labels from the relabel that finds the source sealed in            */
     int radial_min_c;       /* ... only when the shortest source -> sink path has at least this many hops               */
     int radial_rounds0;     /* colour rounds of the first radial cycle; 0: one cycle of the whole budget                 */
-    int radial_budget_x8;   /* most colour rounds on radial labels, in eighths of (tiles on the shortest source -> sink path) */
+    int radial_budget_x16;  /* most colour rounds on radial labels, in sixteenths of (tiles on the shortest source -> sink path) */
 };
 
 struct MgcSolveStats {
@@ -96,7 +96,7 @@ static inline MgcSolveParams mgc_default_params(int ndir = 6)
                                                measured at 512^3 (round 3): weak contrast 68.7 ms at 3, 66.3 at 2, 66.3 at 1; headline volume 35.9 at 3 and 2, 39.8 at 1 */
     p.radial = ndir == 6 ? 2 : 0; /* 2: decided per graph by whoever calls mgc_solve (mgc_maxflow: wall tiles counted by k_build); the host simulator treats 2 as 1 */
     p.radial_min_c = 8;
-    p.radial_budget_x8 = 5;
+    p.radial_budget_x16 = 8;
     p.radial_rounds0 = 0; /* 0: ONE radial cycle as long as the flood may take (radial_budget below).  Measured on MI355X, headline volume 512^3:
                              35.9 ms on exact labels; first radial cycle of 4 rounds (then 8, then 4, a relabel in between) 26.1 ms, 6: 23.4,
                              8: 24.4, 16 (= the budget, one cycle): 22.0 ms; 256^3: 9.5 / 5.3 (4) / 4.8 (8 = the budget).  A short first cycle
@@ -229,10 +229,12 @@ int mgc_solve(Dev& dev, const MgcLattice& L, const MgcSolveParams& P, MgcSolveSt
             if (outer == 0) {
                 if (cnt[MGC_CNT_RADIAL_C] >= MGC_HINF || cnt[MGC_CNT_RADIAL_C] < P.radial_min_c) radial = false; /* (the device left the labels alone for the same reason) */
                 /* a flood front moves a tile per colour phase, and nothing a shortest path's length away from the source is still
-                 * "behind the cut": five eighths of that many phases reach the far side of a cut that surrounds the source
-                 * (host simulator, headline volume: 8 rounds at 256^3, 16 at 512^3 close the surface; 4 resp. 8 do not) */
+                 * "behind the cut": half that many ROUNDS (two phases each) reach the far side of a cut that surrounds the source.
+                 * Measured on MI355X, headline volume (C = 206 hops = 26 tiles): budget 13 rounds 19.7 ms, 16: 22.5, 20: 22.2, 23: 24.3,
+                 * 26: 25.2; 256^3 (C = 103): 7 rounds 4.44 ms, 8: 4.79, 10: 5.31, 13: 6.0 -- what the flood has not closed by then
+                 * are holes the exact labels find faster */
                 else {
-                    radial_budget = (P.radial_budget_x8 * cnt[MGC_CNT_RADIAL_C] / 8 + 7) / 8;
+                    radial_budget = (P.radial_budget_x16 * cnt[MGC_CNT_RADIAL_C] / 16 + 7) / 8;
                     if (radial_next > radial_budget) radial_next = radial_budget;
                 }
             } else if (cnt[MGC_CNT_SOURCE_OPEN] == 0 || radial_done >= radial_budget) {

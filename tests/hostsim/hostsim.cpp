@@ -718,7 +718,7 @@ int hostsim_first_relabel(const int64_t* shape, const double* w0, const double* 
     P.max_outer = 1; /* one global relabel + the activation, then the rounds of colour phases: stop before them */
     P.rounds_per_relabel = 0;
     P.radial = (use_dt & 2) ? 1 : 0; /* bit 1: the radial labels of the flood phase on top of the transform (mgc_dt_ops.inl) */
-    P.radial_budget_x8 = 0; /* (no colour rounds on the radial labels either) */
+    P.radial_budget_x16 = 0; /* (no colour rounds on the radial labels either) */
     if (use_dt & 4) P.radial_min_c = 1;
     MgcSolveStats st;
     g_prof[28] = 0;

@@ -41,6 +41,10 @@ rows = list(csv.DictReader(open("$G/${TAG}_timeline.csv")))
 # the last bench step = the dispatches after the last k_build
 last = max(i for i, r in enumerate(rows) if r["kernel"].startswith("k_build"))
 step = rows[last:]
+for i, r in enumerate(step[1:], 1):  # the step ends where the host takes over (validation, read-out to the host: a gap of milliseconds)
+    if float(r["gap_us"]) > 5000.0:
+        step = step[:i]
+        break
 gaps = [float(r["gap_us"]) for r in step[1:]]
 print("dispatches in the step: %d; gaps > 5 us: %d, > 20 us: %d; idle between dispatches %.2f ms" % (len(step), sum(g > 5 for g in gaps), sum(g > 20 for g in gaps), sum(g for g in gaps if g > 0) / 1e3))
 PY
