@@ -32,6 +32,7 @@
 #include <algorithm>
 #include <map>
 #include <string>
+#include <mutex>
 #include <thread>
 #include <vector>
 
@@ -2137,8 +2138,6 @@ struct mgc_graph {
     bool labels_valid = false; /* the distance labels belong to this build (set by the first label fill of a solve, cleared by mgc_build) */
     void* d_vout = nullptr;    /* MgcValidateOut of mgc_validate */
     uint16_t* d_dt16 = nullptr; /* scratch of the distance-transform relabel (uint16 per voxel, tile-major), allocated on first use */
-    void* stage = nullptr;            /* pinned staging of mgc_staged_copy (allocated on first use) */
-    hipStream_t stage_stream[8] = {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};
     uint16_t* d_ds16 = nullptr; /* radial labels: 1 + L1 distance from the nearest voxel that held excess when the solve began (allocated on first use) */
     int32_t* d_hexact = nullptr; /* radial labels: the exact labels of the last global relabel, kept aside while the labels in L.height are the radial ones */
     bool radial_on = false;      /* the discharges run on radial labels (every saturation marks the tile DIRTY) */
@@ -3272,8 +3271,6 @@ int mgc_destroy(mgc_handle h)
                     h->d_labels, h->d_tflags, h->d_tsum, h->d_image, h->d_lut, h->d_prob, h->d_fg, h->d_bg, h->d_tr_in, h->d_eslot, h->d_eval, h->d_erun, L.hshadow[0], L.hshadow[1], h->d_vout, h->d_dt16, h->d_ds16, h->d_hexact, h->d_halo, h->d_xchg[0], h->d_xchg[1], h->d_xchg[2], h->d_xchg[3], h->d_cnt64};
     for (void* p : ptrs)
         if (p) (void)hipFree(p);
-    if (h->stage) (void)hipHostFree(h->stage);
-    for (hipStream_t st : h->stage_stream) if (st) (void)hipStreamDestroy(st);
     if (h->h_count) (void)hipHostFree(h->h_count);
     if (h->h_scalar) (void)hipHostFree(h->h_scalar);
     free(h->h_labels);
@@ -3294,24 +3291,46 @@ int mgc_destroy(mgc_handle h)
  * the threads copy chunk k + 1: the PCIe link, not a memcpy, sets the pace.  Blocks until the whole transfer is done (the boundary's
  * contract: the caller's buffer may be freed on return).  Falls back to the plain copy for small transfers or if no pinned memory is to be had. */
 #ifndef MGC_STAGE_THREADS
-#define MGC_STAGE_THREADS 4
+#define MGC_STAGE_THREADS 4    /* device -> host */
+#define MGC_STAGE_THREADS_UP 4 /* host -> device.  tools/gpu_transfer_probe.py on the GPU box, 805 MB up / 134 MB down, warm: the runtime's own
+                                  staging 22.7 ms (35 GB/s) / 22.5 ms; 2 threads 16.6 / 20.5; 4 threads 16.0 ms (50 GB/s) / 19.2; 8: 16.4 / 19.6 */
 #endif
 #define MGC_STAGE_CHUNK ((size_t)8 << 20)
+struct MgcStage { /* one per process and device: pinning memory costs tens of milliseconds, a handle per volume must not pay it again */
+    std::mutex lock;
+    void* pinned = nullptr;
+    hipStream_t stream[8] = {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};
+    bool failed = false;
+};
+static MgcStage g_stage[16];
+
 static hipError_t mgc_staged_copy(mgc_handle h, void* dev, void* host, size_t bytes, bool to_device)
 {
     if (bytes < 4 * MGC_STAGE_CHUNK) {
         hipError_t e = to_device ? hipMemcpyAsync(dev, host, bytes, hipMemcpyHostToDevice, h->stream) : hipMemcpyAsync(host, dev, bytes, hipMemcpyDeviceToHost, h->stream);
         return e != hipSuccess ? e : hipStreamSynchronize(h->stream);
     }
-    const int NT = MGC_STAGE_THREADS, SLOTS = 2; /* two chunks per thread: one being filled / drained by the host, one on the wire */
-    if (!h->stage) {
-        if (hipHostMalloc(&h->stage, (size_t)NT * SLOTS * MGC_STAGE_CHUNK, hipHostMallocDefault) != hipSuccess) {
+    static const int env_threads = getenv("MEDPY_HIP_STAGE_THREADS") ? atoi(getenv("MEDPY_HIP_STAGE_THREADS")) : -1; /* 0: the runtime's own staging; n: n threads (at most 8) */
+    const int want = env_threads >= 0 ? env_threads : (to_device ? MGC_STAGE_THREADS_UP : MGC_STAGE_THREADS);
+    if (want == 0) {
+        hipError_t e = to_device ? hipMemcpyAsync(dev, host, bytes, hipMemcpyHostToDevice, h->stream) : hipMemcpyAsync(host, dev, bytes, hipMemcpyDeviceToHost, h->stream);
+        return e != hipSuccess ? e : hipStreamSynchronize(h->stream);
+    }
+    const int NT = want > 8 ? 8 : want, SLOTS = 2; /* two chunks per thread: one being filled / drained by the host, one on the wire */
+    MgcStage& G = g_stage[h->device & 15];
+    std::lock_guard<std::mutex> guard(G.lock); /* (one staged transfer per device at a time: they would share the link anyway) */
+    if (!G.pinned && !G.failed) {
+        if (hipHostMalloc(&G.pinned, (size_t)8 * SLOTS * MGC_STAGE_CHUNK, hipHostMallocDefault) != hipSuccess) {
             (void)hipGetLastError();
-            h->stage = nullptr;
-            hipError_t e = to_device ? hipMemcpyAsync(dev, host, bytes, hipMemcpyHostToDevice, h->stream) : hipMemcpyAsync(host, dev, bytes, hipMemcpyDeviceToHost, h->stream);
-            return e != hipSuccess ? e : hipStreamSynchronize(h->stream);
+            G.pinned = nullptr;
+            G.failed = true;
+        } else {
+            for (int i = 0; i < 8; ++i) if (hipStreamCreateWithFlags(&G.stream[i], hipStreamNonBlocking) != hipSuccess) G.stream[i] = nullptr;
         }
-        for (int i = 0; i < NT; ++i) if (hipStreamCreateWithFlags(&h->stage_stream[i], hipStreamNonBlocking) != hipSuccess) h->stage_stream[i] = nullptr;
+    }
+    if (!G.pinned) {
+        hipError_t e = to_device ? hipMemcpyAsync(dev, host, bytes, hipMemcpyHostToDevice, h->stream) : hipMemcpyAsync(host, dev, bytes, hipMemcpyDeviceToHost, h->stream);
+        return e != hipSuccess ? e : hipStreamSynchronize(h->stream);
     }
     hipError_t first = hipStreamSynchronize(h->stream); /* what the transfer reads / overwrites is settled */
     if (first != hipSuccess) return first;
@@ -3320,10 +3339,10 @@ static hipError_t mgc_staged_copy(mgc_handle h, void* dev, void* host, size_t by
     std::vector<hipError_t> err((size_t)NT, hipSuccess);
     const int device = h->device;
     for (int t = 0; t < NT; ++t) {
-        th.emplace_back([=, &err]() {
+        th.emplace_back([=, &err, &G]() {
             (void)hipSetDevice(device);
-            hipStream_t st = h->stage_stream[t] ? h->stage_stream[t] : h->stream;
-            char* const base = (char*)h->stage + (size_t)t * SLOTS * MGC_STAGE_CHUNK;
+            hipStream_t st = G.stream[t] ? G.stream[t] : h->stream;
+            char* const base = (char*)G.pinned + (size_t)t * SLOTS * MGC_STAGE_CHUNK;
             hipEvent_t ev[SLOTS];
             for (int k = 0; k < SLOTS; ++k) if (hipEventCreateWithFlags(&ev[k], hipEventDisableTiming) != hipSuccess) { err[t] = hipErrorUnknown; return; }
             bool used[SLOTS] = {false, false};

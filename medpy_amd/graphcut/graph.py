@@ -147,8 +147,8 @@ class VoxelGraph(object):
             if m is None:
                 return None
             m = numpy.asarray(m)
-            if m.dtype == numpy.bool_ and m.flags.c_contiguous:
-                return m.view(numpy.uint8)
+            if m.dtype in (numpy.bool_, numpy.uint8, numpy.int8) and m.flags.c_contiguous:
+                return m.view(numpy.uint8)   # (the library reads "non-zero")
             return numpy.ascontiguousarray(m, dtype=numpy.bool_).view(numpy.uint8)
         fg8, bg8 = as_bytes(fg), as_bytes(bg)
         self._call("mgc_set_markers", None if fg8 is None else _lib.ptr(fg8), None if bg8 is None else _lib.ptr(bg8))
@@ -191,7 +191,7 @@ class VoxelGraph(object):
         if self._labels is None:
             out = numpy.empty(self._nodes, dtype=numpy.uint8)
             self._call("mgc_labels", _lib.ptr(out))
-            self._labels = out.astype(numpy.bool_).reshape(self._shape)
+            self._labels = out.view(numpy.bool_).reshape(self._shape)   # (the library writes 0 / 1: the bytes ARE the bool array, no second pass over the volume)
         return self._labels
 
     def what_segment(self, i):
@@ -804,6 +804,24 @@ class GCGraph(object):
         self.__regional = (pm.reshape(self.__shape), alpha)
 
     # -- reference API
+    def record_markers(self, fg_mask, bg_mask):
+        """fast path of ``graph_from_voxels``: the marker MASKS (bool arrays of the volume's shape) instead of id lists --
+        what ``set_source_nodes(flatnonzero(fg))`` / ``set_sink_nodes(flatnonzero(bg))`` would leave, without the lists"""
+        for mask, side in ((fg_mask, "fg"), (bg_mask, "bg")):
+            mask = numpy.ascontiguousarray(mask, dtype=numpy.bool_)
+            if mask.size != self.__nodes:
+                raise ValueError("marker mask of {} voxels on a graph of {} nodes".format(mask.size, self.__nodes))
+            if not mask.any():
+                continue
+            flat = mask.reshape(-1).view(numpy.uint8)
+            have = self.__fg if side == "fg" else self.__bg
+            if have is not None:   # ids were wired before (a plug-in called set_*_nodes): repeated ids accumulate, the explicit path keeps that
+                (self.set_source_nodes if side == "fg" else self.set_sink_nodes)(numpy.flatnonzero(flat))
+            elif side == "fg":
+                self.__fg = flat
+            else:
+                self.__bg = flat
+
     def set_source_nodes(self, source_nodes):
         source_nodes = numpy.asarray(source_nodes)
         if source_nodes.size == 0:
@@ -813,6 +831,8 @@ class GCGraph(object):
                 source_nodes.max(), source_nodes.min(), self.__nodes - 1))
         if self.__fg is None:
             self.__fg = numpy.zeros(self.__nodes, dtype=numpy.uint8)
+        elif not self.__fg.flags.owndata:
+            self.__fg = self.__fg.copy()   # (a view of the caller's mask, record_markers: never written through)
         if numpy.unique(source_nodes).size != source_nodes.size or self.__fg[source_nodes].any():
             for s in source_nodes:  # repeated ids accumulate in the reference; keep that via the explicit path
                 self.set_tweight(int(s), self.MAX, 0)
@@ -828,6 +848,8 @@ class GCGraph(object):
                 sink_nodes.max(), sink_nodes.min(), self.__nodes - 1))
         if self.__bg is None:
             self.__bg = numpy.zeros(self.__nodes, dtype=numpy.uint8)
+        elif not self.__bg.flags.owndata:
+            self.__bg = self.__bg.copy()
         if numpy.unique(sink_nodes).size != sink_nodes.size or self.__bg[sink_nodes].any():
             for s in sink_nodes:
                 self.set_tweight(int(s), 0, self.MAX)
