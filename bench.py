@@ -20,7 +20,9 @@ The multi-GPU volume is a grid of 512^3 sphere blocks sharing one connected medi
 volume are background); no CPU oracle reaches these sizes, so every N > 1 run ends with the device-side invariant check
 (mgc_validate over all slabs: conservation, no residual arc across the cut, no active excess, flow == cut) and FAILS if it
 does not hold.  After every relabel pass / colour phase the packed slab borders travel to the neighbour ranks with RCCL
-send/recv over xGMI (medpy_amd/slab.py); tiny all-reduces decide termination.
+send/recv over xGMI (medpy_amd/slab.py); tiny all-reduces decide termination.  The launcher of the build contract
+(one process per GPU) only hands out RANK / LOCAL_RANK / WORLD_SIZE: bench.py and the package import no ML framework; the ranks meet in
+a private directory of files (medpy_amd/rendezvous.py).
 
 Prints ONE JSON line (rank 0) with `roofline` (dominant kernel k_discharge_w, HIP-event timed on the launch stream inside
 the library) and `cpu_baseline` (the reference's own BK solver, compiled in place as oracle/_ref, timed on a bounded sample
@@ -375,18 +377,20 @@ def main():
         workload = "%d^3 sphere volume (float32), %d-conn, boundary_difference_exponential sigma=15%s, fg=inner ball, bg=6 faces" % (
             n, conn, " + regional_probability_map (float32, alpha 0.5)" if regional else "")
     else:
-        import torch
-        import torch.distributed as dist  # out-of-band channel only (gloo): RCCL id broadcast, barriers, host scalars
-        from medpy_amd.slab import DistExchange, HipSlab, LoopbackExchange, RcclExchange, solve_slabs, validate_slabs
-        # MEDPY_DIST_BACKEND=gloo: development aid -- the borders travel through host buffers and the ranks may share a GPU
-        # (exercises this code path on a 1-GPU box).  Default: RCCL over xGMI, driven by the library itself; if it cannot be
-        # brought up, or there are fewer GPUs than ranks, the run FAILS rather than print a number that is not an RCCL number.
+        from medpy_amd.rendezvous import FileStore
+        from medpy_amd.slab import HipSlab, LoopbackExchange, RcclExchange, StoreExchange, solve_slabs, validate_slabs
+        # The launcher of the contract only provides RANK / LOCAL_RANK / WORLD_SIZE / MASTER_*; nothing here imports an ML framework.  Out-of-band channel (the RCCL id, barriers, a few host scalars): a private directory of files
+        # (medpy_amd/rendezvous.py).  MEDPY_DIST_BACKEND=host: development aid -- the borders travel through host buffers and that
+        # directory, the ranks may share a GPU (exercises this code path on a 1-GPU box).  Default: RCCL over xGMI, driven by the
+        # library itself; if it cannot be brought up, or there are fewer GPUs than ranks, the run FAILS rather than print a
+        # number that is not an RCCL number.
         backend = os.environ.get("MEDPY_DIST_BACKEND", "nccl")
+        if backend == "gloo":
+            backend = "host"  # (the name rounds 1 - 4 used for the development transport)
         if world > ndev and backend == "nccl":
-            raise SystemExit("bench.py: %d ranks but %d GPUs visible (MEDPY_DIST_BACKEND=gloo shares GPUs for development runs)" % (world, ndev))
+            raise SystemExit("bench.py: %d ranks but %d GPUs visible (MEDPY_DIST_BACKEND=host shares GPUs for development runs)" % (world, ndev))
         dev_index = local_rank % ndev
-        if world > 1:
-            dist.init_process_group("gloo", rank=rank, world_size=world)
+        store = FileStore(rank, world, timeout=float(os.environ.get("MEDPY_RENDEZVOUS_TIMEOUT", "900"))) if world > 1 else None
         xy, blk = args.xy, args.block
         if xy % blk:
             raise SystemExit("bench.py: --xy must be a multiple of --block")
@@ -409,7 +413,7 @@ def main():
 
             def bring_up():
                 try:
-                    e = RcclExchange(slab)
+                    e = RcclExchange(slab, store)
                     slab.build()
                     e.exchange(0, 1, 4)
                     e.global_counts()
@@ -420,15 +424,15 @@ def main():
             th = threading.Thread(target=bring_up, daemon=True)
             th.start()
             th.join(float(os.environ.get("MEDPY_RCCL_TIMEOUT", "300")))
-            ok = torch.tensor([1 if "ex" in box else 0], dtype=torch.int32)
-            dist.all_reduce(ok, op=dist.ReduceOp.MIN)
+            # (the other ranks' verdict comes through files of their own names: a rank stalled inside RCCL does not block this)
+            ok = store.allreduce([1.0 if "ex" in box else 0.0], "min")
             if int(ok[0]) != 1:
                 sys.stderr.write("[bench rank %d] RCCL bring-up %s -- no result\n" % (rank, "stalled" if th.is_alive() else "failed: %s" % box.get("err", "on another rank")))
                 sys.stderr.flush()
                 os._exit(3)
             ex, transport = box["ex"], "RCCL (grouped ncclSend/ncclRecv between neighbour slabs, ncclAllReduce of the counters)"
         else:
-            ex, transport = DistExchange(slab), "gloo, host-staged borders (MEDPY_DIST_BACKEND=gloo: development run, not an RCCL number)"
+            ex, transport = StoreExchange(slab, store), "host-staged borders through files (MEDPY_DIST_BACKEND=host: development run, not an RCCL number)"
 
         wall = {"build": 0.0, "solve": 0.0}
 
@@ -437,6 +441,8 @@ def main():
             slab.build()
             t_b = time.perf_counter()
             st = solve_slabs([slab], ex)
+            if not st.get("converged", 1):  # (the library's schedule hands back the stats of a run that exhausted max_outer)
+                raise SystemExit("bench.py: the slab schedule did not reach a maximum preflow: %r" % (st,))
             part_flow = slab.finish_device()
             wall["build"], wall["solve"] = (t_b - t_a) * 1e3, (time.perf_counter() - t_b) * 1e3  # (the last step's, this rank's)
             return st, part_flow
@@ -444,18 +450,17 @@ def main():
         for _ in range(args.warmup):
             step()
         if world > 1:
-            dist.barrier()  # every library call above returned after its stream drained (device synchronised)
+            store.barrier()  # every library call above returned after its stream drained (device synchronised)
         t0 = time.perf_counter()
         for _ in range(args.steps):
             ts = time.perf_counter()
             slab_stats, part = step()  # finish_device() synchronises the stream
             step_s.append(time.perf_counter() - ts)
         if world > 1:
-            dist.barrier()
+            store.barrier()
         elapsed = time.perf_counter() - t0
         if world > 1:
-            t = torch.tensor([elapsed] + step_s, dtype=torch.float64)
-            dist.all_reduce(t, op=dist.ReduceOp.MAX)  # a step ends when its slowest rank is done (every exchange synchronises neighbours)
+            t = store.allreduce([elapsed] + step_s, "max")  # a step ends when its slowest rank is done (every exchange synchronises neighbours)
             elapsed, step_s = float(t[0]), [float(v) for v in t[1:]]
         flow = float(ex.allreduce_sum([part]))
         lab, _ = slab.finish()
@@ -464,7 +469,7 @@ def main():
         _lib.assert_valid(validation)
         assert abs((validation["cut_capacity"] + validation["flow_constant"]) - flow) <= 1e-9 * max(abs(flow), 1e-300)
         if world > 1:
-            dist.barrier()
+            store.barrier()
         workload = "%dx%dx%d volume (%dx%dx%d sphere blocks of %d^3, float32, one connected medium), %d-conn, boundary_difference_exponential sigma=15, bg=outer faces" % (
             gshape[0], gshape[1], gshape[2], gshape[0] // blk, xy // blk, xy // blk, blk, conn)
 
@@ -552,8 +557,7 @@ def main():
             out["cpu_baseline"] = None
         print(json.dumps(out))
     if world > 1:
-        import torch.distributed as dist
-        dist.destroy_process_group()
+        store.close()
 
 
 if __name__ == "__main__":

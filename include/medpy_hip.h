@@ -108,6 +108,9 @@ typedef struct mgc_validation {
 
 /* number of usable devices (0 => every other call fails with MGC_ERR_NO_DEVICE) */
 int mgc_device_count(int* count);
+/* free / total HBM of a device in bytes (hipMemGetInfo): callers that size work by memory -- tests that need tens of GB skip instead
+ * of failing on a smaller device; no reference counterpart (the reference malloc()s and exit(1)s, graph.cpp:19-23) */
+int mgc_device_memory(int device, int64_t* free_bytes, int64_t* total_bytes);
 
 /* Replaces GCGraph.__init__ -> GraphDouble(nodes, edges) + add_node (graph.py:294-308,
  * graph.cpp:12-31).  ndim 1..3; connectivity = 2*ndim (the only neighbourhood the reference supports,

@@ -99,6 +99,7 @@ LABEL_TERM_IDS = {"stawiaski": 1, "stawiaski_directed": 2, "difference_of_means"
 _VP, _I64, _DBL, _INT = C.c_void_p, C.c_int64, C.c_double, C.c_int
 SIGNATURES = {
     "mgc_device_count": (_INT, [C.POINTER(_INT)]),
+    "mgc_device_memory": (_INT, [_INT, C.POINTER(C.c_int64), C.POINTER(C.c_int64)]),
     "mgc_create": (_INT, [_INT, C.POINTER(_I64), _INT, _INT, C.POINTER(_VP)]),
     "mgc_destroy": (_INT, [_VP]),
     "mgc_last_error": (C.c_char_p, [_VP]),
@@ -188,6 +189,12 @@ def device_count():
     n = C.c_int(0)
     load().mgc_device_count(C.byref(n))
     return n.value
+
+
+def device_free_bytes(device=0):
+    """free HBM of a device in bytes, or None when it cannot be asked"""
+    f, t = C.c_int64(0), C.c_int64(0)
+    return f.value if load().mgc_device_memory(int(device), C.byref(f), C.byref(t)) == OK else None
 
 
 def check(handle, rc):

@@ -47,9 +47,12 @@ MGC_HD int mgc_dt_lines(const MgcLattice& L) { return AXIS == 0 ? L.gz * L.gy : 
  * towards the SINK; SEED 2: `in` is the excess plane (f64) and the scan starts the transform away from the SOURCE (voxels
  * that hold excess, mgc_dt_lower_tile); SEED 0: `in` holds uint16 distances.  BWD: back to front.  FINAL: `out` is the
  * int32 label array (MGC_HINF for "no seed anywhere" and for the padding voxels of a partial tile), otherwise uint16. */
-template <int AXIS, bool BWD, int SEED, bool FINAL, class W>
-MGC_HD void mgc_dt_scan_line(W& w, const MgcLattice& L, int line, const void* in, void* out)
+template <int AXIS, bool BWD, int SEED, int FINAL, class W> /* FINAL 2: the last scan of the distance FROM THE SOURCE -- uint16 out as for 0, and the labels
+                                                               in L.height lowered to max(1, C - (distance - 1)) on the way (mgc_dt_lower_tile without a pass of its own) */
+MGC_HD void mgc_dt_scan_line(W& w, const MgcLattice& L, int line, const void* in, void* out, int c_min = 0)
 {
+    int C = MGC_HINF;
+    if (FINAL == 2) { C = L.count[MGC_CNT_RADIAL_C]; if (C < c_min) C = MGC_HINF; }
     const int na = AXIS == 0 ? L.gx : (AXIS == 1 ? L.gy : L.gz);
     const int64_t len = AXIS == 0 ? L.dx : (AXIS == 1 ? L.dy : L.dz);
     w.lanes([&](int l) MGCW_INL {
@@ -95,8 +98,14 @@ MGC_HD void mgc_dt_scan_line(W& w, const MgcLattice& L, int line, const void* in
 #pragma unroll
                 for (int i = 0; i < 8; ++i) {
                     const int loc = mgc_dt_loc<AXIS>(l, i);
-                    if (FINAL) ((int32_t*)out)[base + loc] = v[g][i] < MGC_DT_INF ? v[g][i] : MGC_HINF;
+                    if (FINAL == 1) ((int32_t*)out)[base + loc] = v[g][i] < MGC_DT_INF ? v[g][i] : MGC_HINF;
                     else ((uint16_t*)out)[base + loc] = (uint16_t)v[g][i];
+                    if (FINAL == 2 && C < MGC_HINF && v[g][i] < MGC_DT_INF) {
+                        const int hv = L.height[base + loc];
+                        int gl = C - (v[g][i] - 1);
+                        gl = gl < 1 ? 1 : gl;
+                        if (hv < MGC_HINF && gl < hv) L.height[base + loc] = gl;
+                    }
                 }
             }
         }
@@ -158,19 +167,21 @@ MGC_HD void mgc_dt_finish_tile(W& w, const MgcLattice& L, int tile)
  * that can reach the sink does not).
  * ------------------------------------------------------------------------------------------------------------------- */
 
-/* C = min over sink-linked voxels of their hop distance from the source (ds holds 1 + distance, seeds 1), one wave per tile
- * that holds a sink link: atomicMin into counter slot MGC_CNT_RADIAL_C (the host presets it to MGC_HINF) */
+/* C = hop length of the shortest source -> sink path = the smallest EXACT label a voxel that holds excess carries (the labels count
+ * the hop into the sink, as the distance from the source counts its seed): known as soon as the transform towards the sink is done,
+ * from the few tiles that hold a source link -- so that the last scan of the transform away from the source can lower the labels
+ * on its way.  One wave per tile; atomicMin into counter slot MGC_CNT_RADIAL_C (the host presets it to MGC_HINF). */
 template <class W>
-MGC_HD void mgc_dt_cmin_tile(W& w, const MgcLattice& L, int tile, const uint16_t* ds)
+MGC_HD void mgc_dt_cmin_tile(W& w, const MgcLattice& L, int tile)
 {
-    if (!(L.status[tile] & MGC_ST_SINK)) return;
+    if (!(L.status[tile] & MGC_ST_SOURCE)) return;
     typename W::template Reg<int, 1> best;
     w.lanes([&](int l) MGCW_INL {
         int b = MGC_HINF;
         for (int k = 0; k < 8; ++k) {
             const int64_t i = (int64_t)tile * MGC_TV + k * 64 + l;
-            const int d = (int)ds[i];
-            if ((L.rmask[i] & MGC_MASK_SINK) && d < MGC_DT_INF && d < b) b = d;
+            const int hv = L.height[i];
+            if (L.excess[i] > 0.0 && hv < b) b = hv;
         }
         best(l, 0) = b;
     });

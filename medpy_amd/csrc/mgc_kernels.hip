@@ -957,15 +957,15 @@ __global__ __launch_bounds__(MGC_TV) void k_activate_list(MgcLattice L, int list
 }
 
 /* first global relabel as a distance transform (mgc_dt_ops.inl): one scan of every tile line along AXIS, one wave per line */
-template <int AXIS, bool BWD, int SEED, bool FINAL> /* SEED 1: from the sink links (rmask), 2: from the voxels that hold excess (the radial labels), 0: a later pass */
-__global__ __launch_bounds__(256) void k_dt_scan(MgcLattice L, const void* in, void* out)
+template <int AXIS, bool BWD, int SEED, int FINAL> /* SEED 1: from the sink links (rmask), 2: from the voxels that hold excess (the radial labels), 0: a later pass */
+__global__ __launch_bounds__(256) void k_dt_scan(MgcLattice L, const void* in, void* out, int c_min)
 {
     __shared__ MgcWaveShared S; /* (not touched: the executor wants one) */
     GpuWave w(S);
     const int n = mgc_dt_lines<AXIS>(L);
     for (int line = (int)blockIdx.x * 4 + (int)(threadIdx.x >> 6); line < n; line += (int)gridDim.x * 4) {
         w.new_tile();
-        mgc_dt_scan_line<AXIS, BWD, SEED, FINAL>(w, L, __builtin_amdgcn_readfirstlane(line), in, out);
+        mgc_dt_scan_line<AXIS, BWD, SEED, FINAL>(w, L, __builtin_amdgcn_readfirstlane(line), in, out, c_min);
     }
 }
 
@@ -982,13 +982,13 @@ __global__ __launch_bounds__(256) void k_dt_finish(MgcLattice L)
 
 /* radial labels of the flood phase (mgc_dt_ops.inl): C = hops of the shortest source -> sink path; the labels lowered to
  * max(1, C - distance from the source); "does excess of the source still stand under a finite label?" -- one wave per tile */
-__global__ __launch_bounds__(256) void k_dt_cmin(MgcLattice L, const uint16_t* ds)
+__global__ __launch_bounds__(256) void k_dt_cmin(MgcLattice L)
 {
     __shared__ MgcWaveShared S;
     GpuWave w(S);
     for (int tile = (int)blockIdx.x * 4 + (int)(threadIdx.x >> 6); tile < L.ntiles; tile += (int)gridDim.x * 4) {
         w.new_tile();
-        mgc_dt_cmin_tile(w, L, __builtin_amdgcn_readfirstlane(tile), ds);
+        mgc_dt_cmin_tile(w, L, __builtin_amdgcn_readfirstlane(tile));
     }
 }
 
@@ -2356,12 +2356,12 @@ struct HipDevT {
         void* const T = h->d_dt16;
         const dim3 blk(256);
         auto g = [&](int lines) { return dim3(grid((lines + 3) / 4)); };
-        hipLaunchKernelGGL((k_dt_scan<0, false, 1, false>), g(L.gz * L.gy), blk, 0, h->stream, L, (const void*)L.rmask, T);
-        hipLaunchKernelGGL((k_dt_scan<0, true, 0, false>), g(L.gz * L.gy), blk, 0, h->stream, L, (const void*)T, T);
-        hipLaunchKernelGGL((k_dt_scan<1, false, 0, false>), g(L.gz * L.gx), blk, 0, h->stream, L, (const void*)T, T);
-        hipLaunchKernelGGL((k_dt_scan<1, true, 0, false>), g(L.gz * L.gx), blk, 0, h->stream, L, (const void*)T, T);
-        hipLaunchKernelGGL((k_dt_scan<2, false, 0, false>), g(L.gy * L.gx), blk, 0, h->stream, L, (const void*)T, T);
-        hipLaunchKernelGGL((k_dt_scan<2, true, 0, true>), g(L.gy * L.gx), blk, 0, h->stream, L, (const void*)T, (void*)L.height);
+        hipLaunchKernelGGL((k_dt_scan<0, false, 1, 0>), g(L.gz * L.gy), blk, 0, h->stream, L, (const void*)L.rmask, T, 0);
+        hipLaunchKernelGGL((k_dt_scan<0, true, 0, 0>), g(L.gz * L.gy), blk, 0, h->stream, L, (const void*)T, T, 0);
+        hipLaunchKernelGGL((k_dt_scan<1, false, 0, 0>), g(L.gz * L.gx), blk, 0, h->stream, L, (const void*)T, T, 0);
+        hipLaunchKernelGGL((k_dt_scan<1, true, 0, 0>), g(L.gz * L.gx), blk, 0, h->stream, L, (const void*)T, T, 0);
+        hipLaunchKernelGGL((k_dt_scan<2, false, 0, 0>), g(L.gy * L.gx), blk, 0, h->stream, L, (const void*)T, T, 0);
+        hipLaunchKernelGGL((k_dt_scan<2, true, 0, 1>), g(L.gy * L.gx), blk, 0, h->stream, L, (const void*)T, (void*)L.height, 0);
         hipLaunchKernelGGL(k_dt_finish, g(L.ntiles), blk, 0, h->stream, L);
         check(hipGetLastError());
         time_end(id);
@@ -2389,18 +2389,17 @@ struct HipDevT {
         const dim3 blk(256);
         auto g = [&](int lines) { return dim3(grid((lines + 3) / 4)); };
         check(hipMemsetAsync(L.count + MGC_CNT_RADIAL_C, 0x3f, sizeof(int32_t), h->stream)); /* MGC_HINF */
-        hipLaunchKernelGGL((k_dt_scan<0, false, 2, false>), g(L.gz * L.gy), blk, 0, h->stream, L, (const void*)L.excess, T);
-        hipLaunchKernelGGL((k_dt_scan<0, true, 0, false>), g(L.gz * L.gy), blk, 0, h->stream, L, (const void*)T, T);
-        hipLaunchKernelGGL((k_dt_scan<1, false, 0, false>), g(L.gz * L.gx), blk, 0, h->stream, L, (const void*)T, T);
-        hipLaunchKernelGGL((k_dt_scan<1, true, 0, false>), g(L.gz * L.gx), blk, 0, h->stream, L, (const void*)T, T);
-        hipLaunchKernelGGL((k_dt_scan<2, false, 0, false>), g(L.gy * L.gx), blk, 0, h->stream, L, (const void*)T, T);
-        hipLaunchKernelGGL((k_dt_scan<2, true, 0, false>), g(L.gy * L.gx), blk, 0, h->stream, L, (const void*)T, T);
-        hipLaunchKernelGGL(k_dt_cmin, g(L.ntiles), blk, 0, h->stream, L, (const uint16_t*)h->d_ds16);
-        check(hipMemcpyAsync(h->d_hexact, L.height, nv * sizeof(int32_t), hipMemcpyDeviceToDevice, h->stream));
-        hipLaunchKernelGGL(k_dt_lower, g(L.ntiles), blk, 0, h->stream, L, (const uint16_t*)h->d_ds16, c_min);
+        hipLaunchKernelGGL(k_dt_cmin, g(L.ntiles), blk, 0, h->stream, L); /* C from the exact labels of the source voxels */
+        check(hipMemcpyAsync(h->d_hexact, L.height, nv * sizeof(int32_t), hipMemcpyDeviceToDevice, h->stream)); /* the exact labels, kept aside */
+        hipLaunchKernelGGL((k_dt_scan<0, false, 2, 0>), g(L.gz * L.gy), blk, 0, h->stream, L, (const void*)L.excess, T, 0);
+        hipLaunchKernelGGL((k_dt_scan<0, true, 0, 0>), g(L.gz * L.gy), blk, 0, h->stream, L, (const void*)T, T, 0);
+        hipLaunchKernelGGL((k_dt_scan<1, false, 0, 0>), g(L.gz * L.gx), blk, 0, h->stream, L, (const void*)T, T, 0);
+        hipLaunchKernelGGL((k_dt_scan<1, true, 0, 0>), g(L.gz * L.gx), blk, 0, h->stream, L, (const void*)T, T, 0);
+        hipLaunchKernelGGL((k_dt_scan<2, false, 0, 0>), g(L.gy * L.gx), blk, 0, h->stream, L, (const void*)T, T, 0);
+        hipLaunchKernelGGL((k_dt_scan<2, true, 0, 2>), g(L.gy * L.gx), blk, 0, h->stream, L, (const void*)T, T, c_min); /* ... and the labels lowered on the way */
         check(hipGetLastError());
         time_end(id);
-        relabel_launches += 9;
+        relabel_launches += 8;
         return true;
     }
     void radial_save_exact()
@@ -2676,6 +2675,15 @@ int mgc_device_count(int* count)
     hipError_t e = hipGetDeviceCount(&n);
     if (e != hipSuccess) n = 0;
     if (count) *count = n;
+    return MGC_OK;
+}
+
+int mgc_device_memory(int device, int64_t* free_bytes, int64_t* total_bytes)
+{
+    size_t f = 0, t = 0;
+    if (hipSetDevice(device) != hipSuccess || hipMemGetInfo(&f, &t) != hipSuccess) { (void)hipGetLastError(); return MGC_ERR_NO_DEVICE; }
+    if (free_bytes) *free_bytes = (int64_t)f;
+    if (total_bytes) *total_bytes = (int64_t)t;
     return MGC_OK;
 }
 
@@ -3097,6 +3105,8 @@ static int mgc_solve_slab_on(mgc_handle h, const MgcLayout lay, mgc_slab_stats* 
     uint32_t phase = 2 * (uint32_t)(lmask + 1), rep = 2;
     dev.zero_count(lay.cnt_dis);
     dev.zero_count(lay.cnt_rel);
+    int rounds = P.rounds_per_relabel;
+    int64_t prev_dis = 0, prev_rel = 0;
     dev.zero_count(MGC_CNT_DEFERRED);
     for (int outer = 0; outer < P.max_outer; ++outer) {
         mgc_range_push("global relabel");
@@ -3184,6 +3194,15 @@ static int mgc_solve_slab_on(mgc_handle h, const MgcLayout lay, mgc_slab_stats* 
             st.converged = 1;
             break;
         }
+        /* the rule of mgc_solve (mgc_driver.inl): a relabel that visits several times the tiles the discharges before it did is paid
+         * too often -- the rounds between two relabels double, up to four times the setting.  Decided on the GLOBAL counters (the
+         * reduce above), so every rank runs the same number of rounds. */
+        {
+            const int64_t d_dis = g[lay.cnt_dis] - prev_dis, d_rel = g[lay.cnt_rel] - prev_rel;
+            if (P.adaptive_rounds > 0 && st.outer > 1 && d_rel > (int64_t)P.adaptive_rounds * d_dis && rounds < 4 * P.rounds_per_relabel) rounds *= 2;
+            prev_dis = g[lay.cnt_dis];
+            prev_rel = g[lay.cnt_rel];
+        }
 
         /* ---- colour phases.  Border labels + outbox flow are exchanged once per ROUND of the two colours (6-neighbourhood): what a
          * tile of the first colour pushed over the slab border waits in its outbox one phase longer -- region discharge only
@@ -3191,7 +3210,7 @@ static int mgc_solve_slab_on(mgc_handle h, const MgcLayout lay, mgc_slab_stats* 
          * 26-neighbourhood pushes into the ghost tiles in place and exchanges after every phase. */
         mgc_range_push("colour phases");
         dev.zero_count(MGC_CNT_DEFERRED);
-        for (int r = 0; r < P.rounds_per_relabel; ++r) {
+        for (int r = 0; r < rounds; ++r) {
             for (int c = 0; c < lay.ncolours; ++c) {
                 const int lst = (int)(phase & (uint32_t)lmask);
                 dev.discharge(lst, phase, P.max_cycles, P.max_sweeps);
@@ -3200,7 +3219,7 @@ static int mgc_solve_slab_on(mgc_handle h, const MgcLayout lay, mgc_slab_stats* 
                 st.phases++;
                 phase++;
             }
-            if ((r + 1) % P.check_rounds == 0 && r + 1 < P.rounds_per_relabel) {
+            if ((r + 1) % P.check_rounds == 0 && r + 1 < rounds) {
                 MGC_SLAB_TRY(reduce());
                 int64_t pending = g[MGC_CNT_DEFERRED];
                 for (int i = 0; i <= lmask; ++i) pending += g[i];

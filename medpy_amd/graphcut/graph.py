@@ -31,29 +31,27 @@ def _holds_whole_numbers(image, block=1 << 20):
     return True
 
 
-def boundary_table(term, image, sigma, limit=65536):
-    """The exponential / power boundary function of an INTEGER-VALUED image by table, or None.
+def image_table_facts(term, image):
+    """what ``boundary_table`` needs to know about an image (or about one slab of it, medpy_amd/slab.py:sync_boundary_table):
+    (holds whole numbers only, min, max) -- or None when the term has no table or the image no finite range"""
+    import math
+    if not (term.endswith("exponential") or term.endswith("power")):
+        return None
+    image = numpy.asarray(image)
+    if image.size == 0 or image.dtype.kind not in "iuf":
+        return None
+    whole = image.dtype.kind != "f" or _holds_whole_numbers(image)
+    lo, hi = float(image.min()), float(image.max())
+    if not (math.isfinite(lo) and math.isfinite(hi)):
+        return None
+    return whole, lo, hi
 
-    On such images (CT / MR data: uint8, uint16, int16; floats that hold whole numbers) the reference's term functions see
-    only whole-number arguments d = |I_p - I_q| (difference terms) or max(|I_p|, |I_q|) (maximum terms), because
-    ``__skeleton_base`` casts the image to float64 first (reference energy_voxel.py:633-634).  Evaluating the term ONCE per
-    possible d with the very NumPy operations the reference applies to its arrays (energy_voxel.py:226-236 / 290-300:
-    power(x, 2), /= pow(sigma, 2), *= -1, exp, floor at float_info.min; 444-452 / 506-513: 1 / (x + 1), power(x, sigma), floor)
-    makes the n-link weights bit-identical to the reference's -- the device's own exp / pow (OCML) is up to 2 ulp away, which
-    is enough to flip a tie.  The linear and division terms are IEEE-basic arithmetic and need no table."""
+
+def boundary_table_for_range(term, sigma, lo, hi, limit=65536):
+    """the table of ``boundary_table`` for an image known to hold whole numbers in [lo, hi]"""
     import math
     import sys
     if not (term.endswith("exponential") or term.endswith("power")) or sigma is None:
-        return None
-    image = numpy.asarray(image)
-    if image.size == 0:
-        return None
-    if image.dtype.kind not in "iuf":
-        return None
-    if image.dtype.kind == "f" and not _holds_whole_numbers(image):
-        return None
-    lo, hi = float(image.min()), float(image.max())
-    if not (math.isfinite(lo) and math.isfinite(hi)):
         return None
     top = max(abs(lo), abs(hi)) if term.startswith("maximum") else hi - lo
     if top + 1 > limit:
@@ -69,6 +67,24 @@ def boundary_table(term, image, sigma, limit=65536):
         x = numpy.power(x, sigma)
     x[x <= 0] = sys.float_info.min
     return numpy.ascontiguousarray(x, dtype=numpy.float64)
+
+
+def boundary_table(term, image, sigma, limit=65536):
+    """The exponential / power boundary function of an INTEGER-VALUED image by table, or None.
+
+    On such images (CT / MR data: uint8, uint16, int16; floats that hold whole numbers) the reference's term functions see
+    only whole-number arguments d = |I_p - I_q| (difference terms) or max(|I_p|, |I_q|) (maximum terms), because
+    ``__skeleton_base`` casts the image to float64 first (reference energy_voxel.py:633-634).  Evaluating the term ONCE per
+    possible d with the very NumPy operations the reference applies to its arrays (energy_voxel.py:226-236 / 290-300:
+    power(x, 2), /= pow(sigma, 2), *= -1, exp, floor at float_info.min; 444-452 / 506-513: 1 / (x + 1), power(x, sigma), floor)
+    makes the n-link weights bit-identical to the reference's -- the device's own exp / pow (OCML) is up to 2 ulp away, which
+    is enough to flip a tie.  The linear and division terms are IEEE-basic arithmetic and need no table."""
+    if sigma is None:
+        return None
+    facts = image_table_facts(term, image)
+    if facts is None or not facts[0]:
+        return None
+    return boundary_table_for_range(term, sigma, facts[1], facts[2], limit)
 
 
 class VoxelGraph(object):

@@ -1,0 +1,154 @@
+"""Out-of-band channel for the ranks of ONE node: a directory of small files.
+
+What the slab schedule needs besides RCCL is tiny and rare -- rank 0's 128-byte RCCL id once, a barrier around the timed region,
+a few float64 scalars summed at the end.  ``FileStore`` provides exactly that over a directory every rank of the job can see
+(``/tmp`` by default: one process per GPU of one node, as the launch contract has it), so that nothing in this package needs
+PyTorch.  No sockets, no pickling: every value is raw bytes of a length both sides know or a ``numpy`` array of float64; the
+directory is created with mode 0700 and named after things only the ranks of one launch share (the launcher's pid and the
+rendezvous port), so two jobs -- or two runs of the same job -- never read each other's files.
+
+(Round 4 withdrew a TCP channel that unpickled what it received on a port open to the node's network; this is the replacement the
+review asked for: loopback-free, token-free because there is no listener at all, fixed framing.)
+"""
+import os
+import time
+
+import numpy as np
+
+
+def default_directory():
+    """a directory name every rank of one launch computes alike: ranks started by one launcher share its pid (the launcher of
+    the multi-process contract, a test's subprocess loop) and the rendezvous port"""
+    key = "%s_%s_%s" % (os.environ.get("MASTER_PORT", "0"), os.environ.get("TORCHELASTIC_RUN_ID", "none"), os.getppid())
+    base = os.environ.get("MEDPY_RENDEZVOUS_DIR") or os.path.join(os.environ.get("TMPDIR", "/tmp"), "medpy_amd_rdv_%d_%s" % (os.getuid(), key))
+    return base
+
+
+class FileStore(object):
+    def __init__(self, rank, world, directory=None, timeout=600.0):
+        self.rank, self.world, self.timeout = int(rank), int(world), float(timeout)
+        self.dir = directory or default_directory()
+        os.makedirs(self.dir, mode=0o700, exist_ok=True)
+        st = os.stat(self.dir)
+        if st.st_uid != os.getuid() or (st.st_mode & 0o077):
+            raise RuntimeError("rendezvous directory %s is not private to this user" % self.dir)
+        self._seq = 0
+        self._p2p = {}
+
+    # -- primitives: one file per (sequence number, name, rank); written under a temporary name and renamed (atomic on POSIX)
+    def _path(self, tag, rank):
+        return os.path.join(self.dir, "%s.%d" % (tag, rank))
+
+    def _put(self, tag, data):
+        p = self._path(tag, self.rank)
+        tmp = p + ".tmp%d" % os.getpid()
+        with open(tmp, "wb") as f:
+            f.write(data)
+        os.rename(tmp, p)
+
+    def _get(self, tag, rank, nbytes=None):
+        p, t0, pause = self._path(tag, rank), time.monotonic(), 1e-4
+        while True:
+            try:
+                with open(p, "rb") as f:
+                    data = f.read()
+                if nbytes is None or len(data) == nbytes:
+                    return data
+            except FileNotFoundError:
+                pass
+            if time.monotonic() - t0 > self.timeout:
+                raise TimeoutError("rank %d waited %.0f s for %s" % (self.rank, self.timeout, p))
+            time.sleep(pause)
+            pause = min(pause * 2, 0.01)
+
+    def _next(self, name):
+        self._seq += 1
+        return "%06d_%s" % (self._seq, name)
+
+    # -- collectives (every rank calls them in the same order)
+    def allgather(self, data, nbytes=None):
+        """every rank's bytes, in rank order; ``nbytes``: the length every contribution must have (fixed framing)"""
+        tag = self._next("ag")
+        self._put(tag, bytes(data))
+        out = [self._get(tag, r, nbytes) for r in range(self.world)]
+        self._retire(tag)
+        return out
+
+    def broadcast(self, data, src=0, nbytes=None):
+        tag = self._next("bc")
+        if self.rank == src:
+            self._put(tag, bytes(data))
+        out = self._get(tag, src, nbytes)
+        self.barrier()  # (everybody has read it: the file may go)
+        if self.rank == src:
+            self._unlink(self._path(tag, src))
+        return out
+
+    def barrier(self):
+        self.allgather(b"\x01", 1)
+
+    def allreduce(self, values, op="sum"):
+        a = np.ascontiguousarray(values, dtype=np.float64).reshape(-1)
+        parts = [np.frombuffer(b, dtype=np.float64) for b in self.allgather(a.tobytes(), a.nbytes)]
+        return np.sum(parts, axis=0) if op == "sum" else (np.max(parts, axis=0) if op == "max" else np.min(parts, axis=0))
+
+    # -- point to point (development transport of the slab borders, medpy_amd.slab.StoreExchange): one file per message, read once
+    def send(self, dst, data):
+        k = self._p2p.get(("s", dst), 0)
+        self._p2p[("s", dst)] = k + 1
+        p = os.path.join(self.dir, "p2p_%d_%d_%06d" % (self.rank, dst, k))
+        tmp = p + ".tmp%d" % os.getpid()
+        with open(tmp, "wb") as f:
+            f.write(data)
+        os.rename(tmp, p)
+
+    def recv(self, src, nbytes=None):
+        k = self._p2p.get(("r", src), 0)
+        self._p2p[("r", src)] = k + 1
+        p, t0, pause = os.path.join(self.dir, "p2p_%d_%d_%06d" % (src, self.rank, k)), time.monotonic(), 1e-4
+        while True:
+            try:
+                with open(p, "rb") as f:
+                    data = f.read()
+                if nbytes is None or len(data) == nbytes:
+                    self._unlink(p)
+                    return data
+            except FileNotFoundError:
+                pass
+            if time.monotonic() - t0 > self.timeout:
+                raise TimeoutError("rank %d waited %.0f s for a message from rank %d" % (self.rank, self.timeout, src))
+            time.sleep(pause)
+            pause = min(pause * 2, 0.005)
+
+    # -- housekeeping: a rank removes its own file of step k once every rank has published step k + 1 (so nobody still reads k)
+    def _retire(self, tag):
+        prev = getattr(self, "_prev", None)
+        if prev is not None:
+            self._unlink(self._path(prev, self.rank))
+        self._prev = tag
+
+    @staticmethod
+    def _unlink(p):
+        try:
+            os.unlink(p)
+        except OSError:
+            pass
+
+    def close(self):
+        """last call of a job: a final barrier, then every rank says goodbye with a file of its own and rank 0 -- the only one that
+        waits for those -- removes the directory (nobody reads anything after its goodbye)"""
+        try:
+            self.barrier()
+            if self.rank != 0:
+                self._put("bye", b"\x01")
+                return
+            for r in range(1, self.world):
+                self._get("bye", r, 1)
+        except TimeoutError:
+            return
+        for f in os.listdir(self.dir):
+            self._unlink(os.path.join(self.dir, f))
+        try:
+            os.rmdir(self.dir)
+        except OSError:
+            pass

@@ -6,7 +6,7 @@ label-based.  Here the split is exact: the volume is cut along axis 0 into slabs
 8-plane tile layers, one slab per GPU; a slab boundary is an ordinary tile face whose neighbour
 lives on another GPU.  After every relabel pass / colour phase each slab packs the labels of
 its border voxels and the flow it pushed across the boundary (``mgc_halo_pack``), the packed
-border travels to the neighbour rank (RCCL send/recv over xGMI through ``torch.distributed``,
+border travels to the neighbour rank (RCCL send/recv over xGMI, driven by the library itself,
 or an in-process loopback), and is unpacked into the ghost tiles there (``mgc_halo_unpack``).
 Because region discharge only ever reads a neighbour tile's labels and outbox as of that
 tile's last discharge, the distributed run performs exactly the single-GPU computation:
@@ -14,7 +14,7 @@ labels are bit-identical to the single-GPU (and hence the reference's) labels.
 
 This module holds the schedule (a mirror of ``medpy_amd/csrc/mgc_driver.inl`` with exchanges
 and all-reduces added) and the two transports.  It is backend-agnostic: the CPU test tier runs
-the same code over the host simulator with gloo (tests/test_slab_*.py).
+the same code over the host simulator, two processes over gloo or over a directory of files (tests/test_slab_*.py).
 """
 import numpy as np
 
@@ -69,84 +69,52 @@ class LoopbackExchange(object):
         return np.sum([s.read_counts().astype(np.int64) for s in self.slabs], axis=0)
 
 
-class DistExchange(object):
-    """One slab per process; neighbours are rank-1 / rank+1 of ``torch.distributed``; the packed borders
-    travel as torch tensors.  Used with "gloo" (host buffers): the CPU test tier over the host simulator,
-    and a development mode of bench.py.  The production transport is RcclExchange below -- PyTorch's ROCm
-    wheel bundles its own HIP runtime, which cannot share a process with the system runtime this library
-    is linked against, so torch.cuda tensors are deliberately not used here."""
+class StoreExchange(object):
+    """One slab per process; the packed borders travel through host buffers and the out-of-band store
+    (medpy_amd.rendezvous.FileStore: a file per message).  A DEVELOPMENT transport -- ranks may share one GPU, nothing here is
+    fast -- that exercises the multi-process schedule where no second GPU (or no RCCL) is to be had: the CPU test tier over the
+    host simulator and the reduced-size multi-rank run of bench.py.  The production transport is RcclExchange below."""
 
-    def __init__(self, slab, group=None):
-        import torch
-        import torch.distributed as dist
-        self.torch, self.dist = torch, dist
-        self.slabs = [slab]
-        self.rank, self.world = dist.get_rank(group), dist.get_world_size(group)
-        self.group = group
-        self.on_device = dist.get_backend(group) == "nccl"
-        self.dev = torch.device("cuda", torch.cuda.current_device()) if self.on_device else torch.device("cpu")
-        self._bufs = {}
-
-    def _buf(self, key, nbytes):
-        b = self._bufs.get(key)
-        if b is None or b.numel() != nbytes:
-            b = self.torch.zeros(nbytes, dtype=self.torch.uint8, device=self.dev)
-            self._bufs[key] = b
-        return b
-
-    def _raw(self, t):
-        return t.data_ptr() if self.on_device else t.numpy()
+    def __init__(self, slab, store):
+        self.store, self.slabs = store, [slab]
+        self.rank, self.world = store.rank, store.world
 
     def exchange(self, kind, epoch, lst):
-        slab, dist = self.slabs[0], self.dist
+        slab = self.slabs[0]
         nb = slab.halo_bytes(kind)
-        ops, recvs = [], []
-        for side, peer in ((0, self.rank - 1), (1, self.rank + 1)):
-            if peer < 0 or peer >= self.world:
-                continue
-            snd, rcv = self._buf((side, "s", kind), nb), self._buf((side, "r", kind), nb)
-            slab.halo_pack(side, kind, self._raw(snd), on_device=self.on_device)
-            ops.append(dist.P2POp(dist.isend, snd, peer, self.group))
-            ops.append(dist.P2POp(dist.irecv, rcv, peer, self.group))
-            recvs.append((side, rcv))
-        if ops:
-            for w in dist.batch_isend_irecv(ops):
-                w.wait()
-            if self.on_device:
-                self.torch.cuda.synchronize()
-        for side, rcv in recvs:
-            slab.halo_unpack(side, kind, self._raw(rcv), epoch, lst, on_device=self.on_device)
+        peers = [(side, peer) for side, peer in ((0, self.rank - 1), (1, self.rank + 1)) if 0 <= peer < self.world]
+        for side, peer in peers:
+            buf = np.zeros(nb, dtype=np.uint8)
+            slab.halo_pack(side, kind, buf, on_device=False)
+            self.store.send(peer, buf.tobytes())
+        for side, peer in peers:
+            buf = np.frombuffer(self.store.recv(peer, nb), dtype=np.uint8).copy()
+            slab.halo_unpack(side, kind, buf, epoch, lst, on_device=False)
 
     def allreduce_sum(self, values):
-        t = self.torch.as_tensor(np.sum(np.asarray(values, dtype=np.float64), axis=0), dtype=self.torch.float64).reshape(-1).to(self.dev)
-        self.dist.all_reduce(t, group=self.group)
-        out = t.cpu().numpy()
+        out = self.store.allreduce(np.sum(np.asarray(values, dtype=np.float64), axis=0), "sum")
         return out if out.size > 1 else float(out[0])
 
     def allreduce_max(self, values):
-        t = self.torch.as_tensor(np.max(np.asarray(values, dtype=np.float64), axis=0), dtype=self.torch.float64).reshape(-1).to(self.dev)
-        self.dist.all_reduce(t, op=self.dist.ReduceOp.MAX, group=self.group)
-        return t.cpu().numpy()
+        return self.store.allreduce(np.max(np.asarray(values, dtype=np.float64), axis=0), "max")
 
     def global_counts(self):
-        return self.allreduce_sum([self.slabs[0].read_counts().astype(np.float64)]).astype(np.int64)
+        return np.asarray(self.allreduce_sum([self.slabs[0].read_counts().astype(np.float64)])).astype(np.int64)
 
 
 class RcclExchange(object):
     """One slab per process, borders moved by the library itself: pack -> grouped ncclSend/ncclRecv with
     rank-1 / rank+1 -> unpack, stream-ordered in HBM (``mgc_halo_exchange``); counters summed with
-    ncclAllReduce (``mgc_allreduce_counts``).  ``torch.distributed`` (gloo, CPU) is only the out-of-band
-    channel that hands rank 0's RCCL id to the other ranks and sums a few host scalars at the end."""
+    ncclAllReduce (``mgc_allreduce_counts``).  ``store`` (medpy_amd.rendezvous.FileStore, or anything with ``rank``, ``world``,
+    ``broadcast(bytes, src, nbytes)`` and ``allreduce(array, op)``) is only the out-of-band channel that hands rank 0's
+    128-byte RCCL id to the other ranks and sums a few host scalars at the end -- no PyTorch anywhere."""
 
-    def __init__(self, slab, group=None):
-        import torch
-        import torch.distributed as dist
-        self.torch, self.dist, self.group = torch, dist, group
+    def __init__(self, slab, store):
+        self.store = store
         self.slabs = [slab]
-        self.rank, self.world = dist.get_rank(group), dist.get_world_size(group)
-        box = [slab.comm_unique_id() if self.rank == 0 else None]
-        dist.broadcast_object_list(box, src=0, group=group)
-        slab.comm_init(box[0])
+        self.rank, self.world = store.rank, store.world
+        uid = slab.comm_unique_id() if self.rank == 0 else b""
+        slab.comm_init(store.broadcast(uid, src=0, nbytes=128))
 
     native = True  # solve_slabs hands the whole schedule to the library (mgc_solve_slab)
 
@@ -157,15 +125,11 @@ class RcclExchange(object):
         return self.slabs[0].allreduce_counts()
 
     def allreduce_sum(self, values):
-        t = self.torch.as_tensor(np.sum(np.asarray(values, dtype=np.float64), axis=0), dtype=self.torch.float64).reshape(-1)
-        self.dist.all_reduce(t, group=self.group)
-        out = t.numpy()
+        out = self.store.allreduce(np.sum(np.asarray(values, dtype=np.float64), axis=0), "sum")
         return out if out.size > 1 else float(out[0])
 
     def allreduce_max(self, values):
-        t = self.torch.as_tensor(np.max(np.asarray(values, dtype=np.float64), axis=0), dtype=self.torch.float64).reshape(-1)
-        self.dist.all_reduce(t, op=self.dist.ReduceOp.MAX, group=self.group)
-        return t.numpy()
+        return self.store.allreduce(np.max(np.asarray(values, dtype=np.float64), axis=0), "max")
 
 
 def sync_image_range(slabs, ex):
@@ -181,6 +145,24 @@ def sync_image_range(slabs, ex):
     g = np.asarray(ex.allreduce_max(local), dtype=np.float64).reshape(-1)
     for s in slabs:
         s.set_image_range(-g[0], g[1], g[2])
+
+
+def sync_boundary_table(slabs, ex):
+    """One decision for the whole volume: the exponential / power term goes by table iff EVERY slab holds whole numbers only and the
+    GLOBAL value range is small enough (graph.py:boundary_table, reference energy_voxel.py:226-236, 290-300, 444-452, 506-513).
+    Call between set_boundary() and build(), like sync_image_range(); a no-op for slabs without images (the host simulator)."""
+    facts = []
+    for s in slabs:
+        if not hasattr(s, "table_facts"):
+            return
+        f = s.table_facts()
+        facts.append([0.0, -np.inf, -np.inf] if f is None else [1.0 if f[0] else 0.0, -f[1], f[2]])
+    # min over "whole numbers only" = -max(-x); max over (-min) and max
+    g = np.asarray(ex.allreduce_max([[-f[0], f[1], f[2]] for f in facts]), dtype=np.float64).reshape(-1)
+    if -g[0] < 1.0 or not np.isfinite(g[1]) or not np.isfinite(g[2]):
+        return
+    for s in slabs:
+        s.set_boundary_table(-g[1], g[2])
 
 
 def solve_slabs(slabs, ex, rounds_per_relabel=None, max_cycles=None, max_sweeps=None, max_outer=100000, check_rounds=4, relabel_batch=8,
@@ -386,10 +368,23 @@ class HipSlab(object):
         sp = (C.c_double * 3)(*[float(v) for v in spacing]) if spacing else None
         self._call("mgc_set_boundary", _lib.TERM_IDS[term], _lib.ptr(image), _lib.DTYPE_IDS[image.dtype],
                    float(sigma) if sigma is not None else 0.0, sp)
-        from .graphcut.graph import boundary_table
-        table = boundary_table(term, image, sigma)  # integer-valued planes: the term by table (a function of d alone: the same on every slab)
+        # The term by table (integer-valued images, graph.py:boundary_table) is decided for the WHOLE volume, not per slab: one slab
+        # on the table and its neighbour on the device's own exp / pow would put weights up to 2 ulp apart on either side of the
+        # border, and the slab labels would no longer be those of the single handle.  sync_boundary_table() hands out the table
+        # after every rank has said what its planes hold; until then the device functions stand.
+        self._term, self._sigma = term, sigma
+        from .graphcut.graph import image_table_facts
+        self._table_facts = image_table_facts(term, image)
+
+    def table_facts(self):
+        """(whole numbers only?, min, max) of the local planes, or None when the term has no table"""
+        return getattr(self, "_table_facts", None)
+
+    def set_boundary_table(self, lo, hi):
+        from .graphcut.graph import boundary_table_for_range
+        table = boundary_table_for_range(self._term, self._sigma, lo, hi)
         if table is not None:
-            self._call("mgc_set_boundary_lut", _lib.ptr(table), table.size)
+            self._call("mgc_set_boundary_lut", self._lib.ptr(table), table.size)
 
     def image_range(self):
         out = np.zeros(3, dtype=np.float64)
@@ -401,8 +396,10 @@ class HipSlab(object):
         self._call("mgc_set_image_range", self._lib.ptr(v))
 
     def set_markers(self, fg_local, bg_local):
-        fg = np.ascontiguousarray(fg_local, dtype=np.uint8)
-        bg = np.ascontiguousarray(bg_local, dtype=np.uint8)
+        def as_bytes(m):  # (a contiguous bool / byte array IS what the library reads: no copy)
+            m = np.asarray(m)
+            return m.view(np.uint8) if (m.dtype in (np.bool_, np.uint8) and m.flags.c_contiguous) else np.ascontiguousarray(m, dtype=np.bool_).view(np.uint8)
+        fg, bg = as_bytes(fg_local), as_bytes(bg_local)
         self._call("mgc_set_markers", self._lib.ptr(fg), self._lib.ptr(bg))
 
     def set_regional(self, prob_local, alpha):
@@ -526,9 +523,14 @@ def graphcut_voxel_slabs(image, fg, bg, term="difference_exponential", sigma=Non
     ex = LoopbackExchange(slabs)
     if term.endswith("linear"):
         sync_image_range(slabs, ex)
+    sync_boundary_table(slabs, ex)
     for s in slabs:
         s.build()
     st = solve_slabs(slabs, ex, **schedule)
+    if not st.get("converged", 1):  # (solve_native hands back the stats of a run that exhausted max_outer instead of raising)
+        for s in slabs:
+            s.close()
+        raise RuntimeError("graphcut_voxel_slabs: the slab schedule did not reach a maximum preflow within max_outer global relabels: %r" % (st,))
     parts = [s.finish() for s in slabs]
     labels = np.concatenate([p[0] for p in parts], axis=0)
     flow = float(sum(p[1] for p in parts))

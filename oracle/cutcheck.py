@@ -139,6 +139,12 @@ def assert_labels_equivalent(labels, ref_cut, max_differing=None, exact=None, to
     if exact is not None:
         a, b = exact_cut_value(labels, *exact), exact_cut_value(ref, *exact)
         entry["cut_capacity_exact_equal"] = float(a) == float(b)
+        # the difference of the two cuts AS RATIONALS, not only whether they round to the same double: 0 on a true tie, a few
+        # 1e-308 where a flipped voxel sits next to DBL_MIN-floored weights -- and the cut's own size next to it, for scale
+        d = a - b
+        entry["cut_capacity_rational_equal"] = bool(d == 0)
+        entry["cut_capacity_rational_difference"] = "0" if d == 0 else "%s (= %.6e)" % (str(d) if len(str(d)) <= 80 else "p/q with %d-digit q" % len(str(d.denominator)), float(d))
+        entry["cut_capacity_relative_difference"] = 0.0 if d == 0 or b == 0 else abs(float(d / b))
         if float(a) != float(b):
             _record(dict(entry, verdict="FAIL: cut capacities differ"))
         assert float(a) == float(b), "cut capacities differ: %r vs %r (by %r)" % (float(a), float(b), float(a - b))

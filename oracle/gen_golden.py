@@ -175,6 +175,21 @@ def main_b0():
         store[term + "/flow"] = r["flow"]
         store[term + "/sigma"] = np.float64(sigma)
         print(term, "flow", r["flow"], "fg fraction", r["labels"].mean())
+    # the notebook's two LITERAL invocations (notebooks/scripts/medpy_graphcut_voxel.py.ipynb):
+    #   medpy_gradient.py b0 gradient ; medpy_graphcut_voxel.py 10 gradient b0markers out --boundary diff_pow
+    #   medpy_graphcut_voxel.py 1 b0 b0markers out --boundary=max_div
+    # The gradient image is what bin/medpy_gradient.py:77-83 computes (float32 Prewitt gradient magnitude); the test recomputes
+    # it with the same SciPy call, only labels and flow are stored.
+    from scipy.ndimage import generic_gradient_magnitude, prewitt
+    grad = np.zeros(img.shape, dtype=np.float32)
+    generic_gradient_magnitude(img, prewitt, output=grad)
+    for key, term, image, sigma in (("notebook_gradient_diff_pow", "difference_power", grad, 10.0), ("notebook_b0_max_div", "maximum_division", img, 1.0)):
+        r = run_reference(gc, fg, bg, term, image, sigma)
+        store[key + "/labels"] = np.packbits(r["labels"])
+        store[key + "/flow"] = r["flow"]
+        store[key + "/sigma"] = np.float64(sigma)
+        store[key + "/term"] = np.asarray(term)
+        print(key, "flow", r["flow"], "fg fraction", r["labels"].mean())
     np.savez_compressed(os.path.join(OUT, "reference_b0.npz"), **store)
     print("reference_b0.npz", os.path.getsize(os.path.join(OUT, "reference_b0.npz")))
 

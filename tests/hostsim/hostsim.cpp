@@ -293,12 +293,12 @@ struct HostDev {
                 }
         std::vector<uint16_t> T((size_t)L.ntiles * MGC_TV);
         HostWave w(WS);
-        for (int i = 0; i < L.gz * L.gy; ++i) mgc_dt_scan_line<0, false, 1, false>(w, L, i, L.rmask, T.data());
-        for (int i = 0; i < L.gz * L.gy; ++i) mgc_dt_scan_line<0, true, 0, false>(w, L, i, T.data(), T.data());
-        for (int i = 0; i < L.gz * L.gx; ++i) mgc_dt_scan_line<1, false, 0, false>(w, L, i, T.data(), T.data());
-        for (int i = 0; i < L.gz * L.gx; ++i) mgc_dt_scan_line<1, true, 0, false>(w, L, i, T.data(), T.data());
-        for (int i = 0; i < L.gy * L.gx; ++i) mgc_dt_scan_line<2, false, 0, false>(w, L, i, T.data(), T.data());
-        for (int i = 0; i < L.gy * L.gx; ++i) mgc_dt_scan_line<2, true, 0, true>(w, L, i, T.data(), L.height);
+        for (int i = 0; i < L.gz * L.gy; ++i) mgc_dt_scan_line<0, false, 1, 0>(w, L, i, L.rmask, T.data());
+        for (int i = 0; i < L.gz * L.gy; ++i) mgc_dt_scan_line<0, true, 0, 0>(w, L, i, T.data(), T.data());
+        for (int i = 0; i < L.gz * L.gx; ++i) mgc_dt_scan_line<1, false, 0, 0>(w, L, i, T.data(), T.data());
+        for (int i = 0; i < L.gz * L.gx; ++i) mgc_dt_scan_line<1, true, 0, 0>(w, L, i, T.data(), T.data());
+        for (int i = 0; i < L.gy * L.gx; ++i) mgc_dt_scan_line<2, false, 0, 0>(w, L, i, T.data(), T.data());
+        for (int i = 0; i < L.gy * L.gx; ++i) mgc_dt_scan_line<2, true, 0, 1>(w, L, i, T.data(), L.height);
         for (int t = 0; t < L.ntiles; ++t) mgc_dt_finish_tile(w, L, t);
         L.count[9] += L.ntiles;
         g_prof[28]++;
@@ -314,16 +314,16 @@ struct HostDev {
         HostWave w(WS);
         ds16.assign((size_t)L.ntiles * MGC_TV, 0);
         uint16_t* const T = ds16.data();
-        for (int i = 0; i < L.gz * L.gy; ++i) mgc_dt_scan_line<0, false, 2, false>(w, L, i, L.excess, T);
-        for (int i = 0; i < L.gz * L.gy; ++i) mgc_dt_scan_line<0, true, 0, false>(w, L, i, T, T);
-        for (int i = 0; i < L.gz * L.gx; ++i) mgc_dt_scan_line<1, false, 0, false>(w, L, i, T, T);
-        for (int i = 0; i < L.gz * L.gx; ++i) mgc_dt_scan_line<1, true, 0, false>(w, L, i, T, T);
-        for (int i = 0; i < L.gy * L.gx; ++i) mgc_dt_scan_line<2, false, 0, false>(w, L, i, T, T);
-        for (int i = 0; i < L.gy * L.gx; ++i) mgc_dt_scan_line<2, true, 0, false>(w, L, i, T, T);
         L.count[MGC_CNT_RADIAL_C] = MGC_HINF;
-        for (int t = 0; t < L.ntiles; ++t) mgc_dt_cmin_tile(w, L, t, T);
+        for (int t = 0; t < L.ntiles; ++t) mgc_dt_cmin_tile(w, L, t); /* C from the exact labels of the source voxels */
         radial_save_exact();
-        radial_lower(c_min);
+        for (int i = 0; i < L.gz * L.gy; ++i) mgc_dt_scan_line<0, false, 2, 0>(w, L, i, L.excess, T);
+        for (int i = 0; i < L.gz * L.gy; ++i) mgc_dt_scan_line<0, true, 0, 0>(w, L, i, T, T);
+        for (int i = 0; i < L.gz * L.gx; ++i) mgc_dt_scan_line<1, false, 0, 0>(w, L, i, T, T);
+        for (int i = 0; i < L.gz * L.gx; ++i) mgc_dt_scan_line<1, true, 0, 0>(w, L, i, T, T);
+        for (int i = 0; i < L.gy * L.gx; ++i) mgc_dt_scan_line<2, false, 0, 0>(w, L, i, T, T);
+        lowered = L.count[MGC_CNT_RADIAL_C] < MGC_HINF && L.count[MGC_CNT_RADIAL_C] >= c_min;
+        for (int i = 0; i < L.gy * L.gx; ++i) mgc_dt_scan_line<2, true, 0, 2>(w, L, i, T, T, c_min); /* ... and the labels lowered on the way */
         return true;
     }
     void radial_save_exact() { hexact.assign(L.height, L.height + (size_t)L.ntiles * MGC_TV); }

@@ -94,7 +94,8 @@ SHIPPED_SCRIPT = os.path.join(ROOT, "oracle", "_ref", "bin", "medpy_graphcut_vox
 
 @pytest.mark.gpu
 @pytest.mark.skipif(not os.path.exists(SHIPPED_SCRIPT), reason="oracle/_ref/bin/medpy_graphcut_voxel.py did not travel (run __graft_entry__.build() where /root/reference exists)")
-@pytest.mark.parametrize("flag,term", [("diff_exp", "difference_exponential"), ("diff_div", "difference_division")])
+@pytest.mark.parametrize("flag,term", [("diff_exp", "difference_exponential"), ("diff_div", "difference_division"),
+                                       ("diff_pow", "notebook_gradient_diff_pow"), ("max_div", "notebook_b0_max_div")])
 def test_reference_voxel_script_unmodified_on_the_hip_path(tmp_path, flag, term):
     """The reference's bin/medpy_graphcut_voxel.py, byte for byte (shipped to the GPU box as a build product), run by
     medpy_amd.overlay over libmedpyhip.so on the reference's notebook image b0 (1024 x 1024): its argument parsing, its
@@ -112,16 +113,28 @@ def test_reference_voxel_script_unmodified_on_the_hip_path(tmp_path, flag, term)
         img = z["image"].astype(np.dtype(str(z["image_dtype"])))
         markers = z["markers"]
         sigma = float(z[term + "/sigma"])
+        key = term
+        if term.startswith("notebook_"):
+            # the notebook's two literal command lines (reference notebooks/scripts/medpy_graphcut_voxel.py.ipynb):
+            #   medpy_graphcut_voxel.py 10 gradient.nii.gz b0markers.nii.gz out --boundary diff_pow -f    (gradient = medpy_gradient.py b0)
+            #   medpy_graphcut_voxel.py 1 b0.nii.gz b0markers.nii.gz out --boundary=max_div -f
+            term = str(z[key + "/term"])
+            if "gradient" in key:  # bin/medpy_gradient.py:77-83
+                from scipy.ndimage import generic_gradient_magnitude, prewitt
+                grad = np.zeros(img.shape, dtype=np.float32)
+                generic_gradient_magnitude(img, prewitt, output=grad)
+                img = grad
         hdr = io.Header((1.0, 1.0))
         io.save(img, str(tmp_path / "b0.nii.gz"), hdr, True)
         io.save(markers, str(tmp_path / "b0markers.nii.gz"), hdr, True)
         out = str(tmp_path / "seg.nii.gz")
-        overlay.run(SHIPPED_SCRIPT, [str(sigma), str(tmp_path / "b0.nii.gz"), str(tmp_path / "b0markers.nii.gz"), out, "--boundary", flag, "-f"])
+        argv = [("%g" % sigma), str(tmp_path / "b0.nii.gz"), str(tmp_path / "b0markers.nii.gz"), out] + (["--boundary=" + flag] if key == "notebook_b0_max_div" else ["--boundary", flag]) + ["-f"]
+        overlay.run(SHIPPED_SCRIPT, argv)
         import medpy.graphcut
         import medpy_amd.graphcut
         assert medpy.graphcut is medpy_amd.graphcut  # the script's `from medpy import graphcut` got this package
         seg, _ = io.load(out)
-        ref = np.unpackbits(z[term + "/labels"])[: img.size].reshape(img.shape)
+        ref = np.unpackbits(z[key + "/labels"])[: img.size].reshape(img.shape)
         assert seg.shape == img.shape and seg.dtype == np.uint8
         nbad = int((seg != ref).sum())
         print(term, "voxels differing from the reference's output:", nbad)

@@ -118,7 +118,8 @@ dist.init_process_group("gloo")
 rank, world = dist.get_rank(), dist.get_world_size()
 import sim
 from medpy_amd import synthetic
-from medpy_amd.slab import DistExchange, solve_slabs
+from medpy_amd.slab import solve_slabs
+from dist_exchange import DistExchange
 from oracle import energy_numpy, pipeline
 shape = (40, 24, 24)
 conn = int(sys.argv[3]) if len(sys.argv) > 3 else 6
@@ -237,3 +238,66 @@ def test_full_neighbourhood_incremental_relabel_across_slabs(gen, shape, nslabs,
     st = solve_slabs(slabs, LoopbackExchange(slabs), rounds_per_relabel=1, max_sweeps=2, incremental_relabel=incremental)
     assert st["converged"] == 1 and st["outer"] >= 3
     np.testing.assert_array_equal(np.concatenate([sl.finish()[0] for sl in slabs], axis=0), ref)
+
+
+STORE_WORKER = r'''
+import os, sys
+import numpy as np
+ROOT = sys.argv[1]; out = sys.argv[2]; rank = int(sys.argv[3]); world = int(sys.argv[4])
+sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, "tests", "hostsim"))
+assert "torch" not in sys.modules
+import sim
+from medpy_amd import synthetic
+from medpy_amd.rendezvous import FileStore
+from medpy_amd.slab import StoreExchange, solve_slabs
+from oracle import energy_numpy, pipeline
+store = FileStore(rank, world, directory=os.path.join(out, "rdv"), timeout=120)
+shape = (40, 24, 24)
+s = synthetic.sphere(shape)
+w = energy_numpy.boundary_weights(s["term"], s["image"], s["sigma"])
+g = pipeline.build_graph(s["fg"], s["bg"], weights=w)
+tr = np.array([g.get_trcap(i) for i in range(s["fg"].size)])
+slab = sim.SimSlab(shape, rank, world)
+slab.load(w, tr)
+got = store.broadcast(bytes(range(128)) if rank == 0 else b"", src=0, nbytes=128)
+assert got == bytes(range(128))
+assert store.allreduce([rank + 1.0, 2.0], "sum").tolist() == [world * (world + 1) / 2.0, 2.0 * world]
+assert store.allreduce([float(rank)], "max").tolist() == [world - 1.0]
+st = solve_slabs([slab], StoreExchange(slab, store))
+lab, _ = slab.finish()
+np.save(os.path.join(out, "labels_%d.npy" % rank), lab)
+np.save(os.path.join(out, "range_%d.npy" % rank), np.array([slab.own0, slab.own1, st["converged"], st["exchanges"]]))
+store.close()
+assert "torch" not in sys.modules
+'''
+
+
+@pytest.mark.timeout(300)
+@pytest.mark.parametrize("world", [2, 3])
+def test_multi_process_slabs_over_the_file_store(tmp_path, world):
+    """The out-of-band channel of the package (medpy_amd/rendezvous.py: a private directory of files, fixed framing, no sockets, no
+    pickle, no PyTorch) and the development transport on top of it: broadcast of a 128-byte id as RcclExchange does it, sums and
+    maxima of host scalars, a barrier, and a whole slab solve with the borders travelling through it -- one process per slab."""
+    script = tmp_path / "worker.py"
+    script.write_text(STORE_WORKER)
+    env = dict(os.environ, OMP_NUM_THREADS="1")
+    procs = [subprocess.Popen([sys.executable, str(script), ROOT, str(tmp_path), str(r), str(world)], env=env, stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True)
+             for r in range(world)]
+    for p in procs:
+        out, err = p.communicate(timeout=280)
+        assert p.returncode == 0, err[-3000:]
+    _, _, ref = _problem("sphere", (40, 24, 24))
+    parts = [np.load(tmp_path / ("labels_%d.npy" % r)) for r in range(world)]
+    ranges = [np.load(tmp_path / ("range_%d.npy" % r)) for r in range(world)]
+    assert all(rg[2] == 1 and rg[3] > 0 for rg in ranges)
+    np.testing.assert_array_equal(np.concatenate(parts, axis=0), ref)
+    assert not os.path.exists(tmp_path / "rdv")  # the store cleaned up after itself
+
+
+def test_file_store_refuses_a_directory_others_can_write(tmp_path):
+    from medpy_amd.rendezvous import FileStore
+    d = tmp_path / "open"
+    d.mkdir(mode=0o777)
+    os.chmod(d, 0o777)
+    with pytest.raises(RuntimeError):
+        FileStore(0, 1, directory=str(d))
