@@ -218,7 +218,7 @@ def also_case(name, n, conn, regional, steps=3, warmup=1, golden_key=None):
     return out
 
 
-def api_end_to_end(n=BLOCK, reps=3):
+def api_end_to_end(n=BLOCK, reps=5):
     """The public path from HOST arrays: graph_from_voxels(fg, bg, boundary_term, args) -> maxflow() -> labels(), wall clock per volume
     (H2D of image + markers, build, solve, read-out, D2H of the labels), median of `reps`; the reference's own call sequence
     (bin/medpy_graphcut_voxel.py:163-182) with the per-voxel what_segment loop replaced by the bulk read-out."""
@@ -240,7 +240,7 @@ def api_end_to_end(n=BLOCK, reps=3):
     times = times[1:]  # (the first call pays the handle's first allocations)
     ms = float(np.median(times)) * 1e3
     ref = golden_large().get("sphere_512_6") if n == 512 else None
-    out = {"ms_per_volume": round(ms, 2), "mvoxels_s": round(n ** 3 / (ms * 1e-3) / 1e6, 1), "reps": reps,
+    out = {"ms_per_volume": round(ms, 2), "mvoxels_s": round(n ** 3 / (ms * 1e-3) / 1e6, 1), "reps": reps, "each_ms": [round(t * 1e3, 2) for t in times],
            "last_call_ms": {"graph_from_voxels (H2D + build)": round(parts[0] * 1e3, 2), "maxflow": round(parts[1] * 1e3, 2), "labels (read-out + D2H)": round(parts[2] * 1e3, 2)},
            "flow": flow, "path": "medpy_amd.graphcut.graph_from_voxels(...).maxflow(); .labels() from host arrays (float32 image, bool markers)"}
     if ref is not None:
@@ -547,10 +547,10 @@ def main():
         out["parity"] = parity_relaxation_summary()
         if world == 1 and not args.config and not args.strong and not args.no_extras and not args.size:
             # the other single-GPU BASELINE configs and the public API path, inside the driver's run
+            out["api_end_to_end"] = api_end_to_end()
             out["also"] = {"config2": also_case("config2", 256, 6, False, golden_key="sphere_256_6"),
                            "config3": also_case("config3", 512, 26, True),
                            "config3_at_256": also_case("config3_at_256", 256, 26, True, steps=1, warmup=1, golden_key="config3_256_26_regional")}
-            out["api_end_to_end"] = api_end_to_end()
         if not args.no_cpu and world == 1 and not args.config and not args.strong:
             out["cpu_baseline"] = cpu_baseline_in_run(args.cpu_sample, not args.cpu_sample_only)
         else:

@@ -1188,6 +1188,18 @@ __device__ __forceinline__ void k_build_tiles(const MgcLattice& L, const MgcBuil
         int tz, ty, tx;
         mgc_tile_coords(L, tile, tz, ty, tx);
         const int64_t z0 = (int64_t)tz * 8, y0 = (int64_t)ty * 8, x0 = (int64_t)tx * 8;
+        /* the marker bytes of this lane's voxel are asked for HERE, together with the image tile: they are needed behind the weights,
+         * and fetched there they were a second full memory latency per tile (two dependent trips to HBM where one does) */
+        uint8_t pre_fg = 0, pre_bg = 0;
+        {
+            const int plz = t >> 6, ply = (t >> 3) & 7, plx = t & 7;
+            const int64_t pz = z0 + plz, py = y0 + ply, px = x0 + plx;
+            if (pz < L.dz && py < L.dy && px < L.dx) {
+                const int64_t pid = (pz * L.dy + py) * L.dx + px;
+                if (A.fg) pre_fg = A.fg[pid];
+                if (A.bg) pre_bg = A.bg[pid];
+            }
+        }
         if (TERM != MGC_TERM_NONE) {
             for (int k = t; k < 1000; k += MGC_TV) {
                 const int64_t gz = z0 + k / 100 - 1, gy = y0 + (k / 10) % 10 - 1, gx = x0 + k % 10 - 1;
@@ -1227,8 +1239,8 @@ __device__ __forceinline__ void k_build_tiles(const MgcLattice& L, const MgcBuil
                     }
                     mgc_add_tweights(tr, fc, cs, ck);
                 }
-                if (A.fg && A.fg[id]) mgc_add_tweights(tr, fc, MGC_MARKER_MAX, 0.0);
-                if (A.bg && A.bg[id]) mgc_add_tweights(tr, fc, 0.0, MGC_MARKER_MAX);
+                if (pre_fg) mgc_add_tweights(tr, fc, MGC_MARKER_MAX, 0.0);
+                if (pre_bg) mgc_add_tweights(tr, fc, 0.0, MGC_MARKER_MAX);
             }
             const int bits = (__ballot(tr < 0.0) != 0ull ? 2 : 0) | (__ballot(tr > 0.0) != 0ull ? 1 : 0) | (__ballot(fc != 0.0) != 0ull ? 4 : 0);
             /* bits 8..: how many voxels of the tile hold a weak n-link (the same word, one atomic per wave: the count never carries into the vote bits) */
@@ -2242,7 +2254,8 @@ struct HipDevT {
     float discharge_ms = 0.f, relabel_ms = 0.f, once_ms = 0.f;
     int64_t discharge_launches = 0, relabel_launches = 0, readbacks = 0;
     int last_discharged = -1; /* list consumed by the discharge launched last (see pending_zero) */
-    int suspect_batch() const { return 2; } /* closure passes between two looks at the "changed" flag: a pass settles a brick */
+    int suspect_batch() const { return 4; } /* closure passes between two looks at the "changed" flag: a pass settles a brick (a pass is 5 - 12 us, a look a
+                                               stream drain of ~25 us: 2 passes per look until round 5) */
     bool labels_inexact() const { return false; }
     void range_push(const char* name) { mgc_range_push(name); } /* roctx range around a stretch of the schedule (mgc_driver.inl) */
     void range_pop() { mgc_range_pop(); }
