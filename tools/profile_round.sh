@@ -8,9 +8,9 @@ ROOT=$PWD
 OUT=$ROOT/gpurun_out/prof_$TAG
 mkdir -p $OUT
 cd /tmp && export TMPDIR=/tmp
-timeout 600 rocprofv3 --kernel-trace --stats -d $OUT/trace -- python $ROOT/bench.py --steps 2 --warmup 1 --no-cpu > $OUT/trace.log 2>&1
-timeout 600 rocprofv3 --kernel-trace --pmc FETCH_SIZE -d $OUT/fetch -- python $ROOT/bench.py --steps 1 --warmup 0 --no-cpu > $OUT/fetch.log 2>&1
-timeout 600 rocprofv3 --kernel-trace --pmc WRITE_SIZE -d $OUT/write -- python $ROOT/bench.py --steps 1 --warmup 0 --no-cpu > $OUT/write.log 2>&1
+timeout 600 rocprofv3 --kernel-trace --stats -d $OUT/trace -- python $ROOT/bench.py --steps 2 --warmup 1 --no-cpu --no-extras > $OUT/trace.log 2>&1
+timeout 600 rocprofv3 --kernel-trace --pmc FETCH_SIZE -d $OUT/fetch -- python $ROOT/bench.py --steps 1 --warmup 0 --no-cpu --no-extras > $OUT/fetch.log 2>&1
+timeout 600 rocprofv3 --kernel-trace --pmc WRITE_SIZE -d $OUT/write -- python $ROOT/bench.py --steps 1 --warmup 0 --no-cpu --no-extras > $OUT/write.log 2>&1
 cd $ROOT
 T=$(find $OUT/trace -name "*.db" | head -1); F=$(find $OUT/fetch -name "*.db" | head -1); W=$(find $OUT/write -name "*.db" | head -1)
 python tools/rocpd_summary.py stats $T > gpurun_out/${TAG}_kernel_stats.csv
@@ -22,7 +22,7 @@ rm -rf $OUT/trace $OUT/fetch $OUT/write
 cd /tmp
 for C in "SQ_INSTS_VALU SQ_INSTS_SALU" "SQ_INSTS_LDS SQ_INSTS_SMEM" "SQ_WAVE_CYCLES SQ_BUSY_CYCLES" "SQ_INSTS_VMEM_RD SQ_INSTS_VMEM_WR"; do
   N=$(echo $C | tr ' ' '_')
-  timeout 600 rocprofv3 --kernel-trace --pmc $C -d $OUT/$N -- python $ROOT/bench.py --steps 1 --warmup 0 --no-cpu > $OUT/$N.log 2>&1
+  timeout 600 rocprofv3 --kernel-trace --pmc $C -d $OUT/$N -- python $ROOT/bench.py --steps 1 --warmup 0 --no-cpu --no-extras > $OUT/$N.log 2>&1
   D=$(find $OUT/$N -name "*.db" | head -1)
   [ -n "$D" ] && python $ROOT/tools/rocpd_summary.py pmc $D > $ROOT/gpurun_out/${TAG}_pmc_$N.csv
   rm -rf $OUT/$N
