@@ -364,9 +364,17 @@ def main():
         fg_fraction = float(lab.mean())
         h2d_bytes = s["image"].nbytes + s["fg"].size + s["bg"].size + (r["prob"].nbytes if regional else 0)
         end_to_end = {"h2d_ms": round(t_h2d * 1e3, 2), "h2d_bytes": int(h2d_bytes), "d2h_ms": round(t_d2h * 1e3, 2), "d2h_bytes": int(lab.size),
-                      "note": "image + markers (+ probability map) from pageable host arrays into HBM, labels back; measured once, outside the timed steps; never part of `value`"}
+                      "note": "image + markers (+ probability map) from pageable host arrays into HBM (pinned staging, four host threads), labels back; outside the timed steps; never part of `value`"}
         validation = g.validate()
         _lib.assert_valid(validation)
+        t_h2d_cold = t_h2d  # (the first upload of the process also pins the staging buffers; the inputs go up once more, warm)
+        t_h2d = time.perf_counter()
+        g._set_boundary("difference_exponential", s["image"], s["sigma"], False)
+        g._set_markers(s["fg"], s["bg"])
+        if regional:
+            g._set_regional(r["prob"], r["alpha"])
+        t_h2d = time.perf_counter() - t_h2d
+        end_to_end["h2d_ms"], end_to_end["h2d_first_call_ms"] = round(t_h2d * 1e3, 2), round(t_h2d_cold * 1e3, 2)
         head_sha = None
         ref = golden_large().get("sphere_512_6") if (n == 512 and conn == 6 and not regional) else (golden_large().get("sphere_256_6") if (n == 256 and conn == 6 and not regional) else None)
         if ref is not None:
