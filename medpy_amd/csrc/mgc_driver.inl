@@ -192,6 +192,7 @@ int mgc_solve(Dev& dev, const MgcLattice& L, const MgcSolveParams& P, MgcSolveSt
         }
         st.outer++;
         dev.range_pop();
+        if (radial && outer > 0 && radial_done >= radial_budget) radial = false; /* the flood has had its rounds: the exact labels of this relabel stay (nothing to keep aside, nobody to ask) */
         if (radial && outer > 0) { /* the labels are exact now: keep them, and ask whether excess of the source still reaches the sink */
             dev.radial_save_exact();
             dev.zero_count(MGC_CNT_SOURCE_OPEN);
