@@ -192,6 +192,7 @@ int mgc_solve(Dev& dev, const MgcLattice& L, const MgcSolveParams& P, MgcSolveSt
         }
         st.outer++;
         dev.range_pop();
+        const bool after_flood = radial && outer > 0; /* (this relabel followed a cycle on radial labels: its size says nothing about the relabels to come) */
         if (radial && outer > 0 && radial_done >= radial_budget) radial = false; /* the flood has had its rounds: the exact labels of this relabel stay (nothing to keep aside, nobody to ask) */
         if (radial && outer > 0) { /* the labels are exact now: keep them, and ask whether excess of the source still reaches the sink */
             dev.radial_save_exact();
@@ -217,7 +218,7 @@ int mgc_solve(Dev& dev, const MgcLattice& L, const MgcSolveParams& P, MgcSolveSt
             const int64_t d_dis = (int64_t)cnt[lay.cnt_dis] - prev_dis; /* discharges since the relabel before this one */
             const int64_t d_rel = (int64_t)cnt[lay.cnt_rel] - prev_rel; /* tile visits of the relabel that just ended  */
             if (P.trace) fprintf(stderr, "[mgc] relabel %d: %lld tile visits in %lld passes so far, %lld discharges before it, %d active tiles\n", outer, (long long)d_rel, (long long)st.relabel_passes, (long long)d_dis, cnt[lay.cnt_active]);
-            if (P.adaptive_rounds > 0 && outer > 0 && !radial && d_rel > (int64_t)P.adaptive_rounds * d_dis && rounds < 4 * P.rounds_per_relabel) rounds *= 2;
+            if (P.adaptive_rounds > 0 && outer > 0 && !radial && !after_flood && d_rel > (int64_t)P.adaptive_rounds * d_dis && rounds < 4 * P.rounds_per_relabel) rounds *= 2;
             prev_dis = cnt[lay.cnt_dis];
             prev_rel = cnt[lay.cnt_rel];
         }
