@@ -72,7 +72,7 @@ typedef struct mgc_stats {
     int64_t ntiles;
     int64_t nvox;
     int64_t device_bytes;      /* HBM held by the handle                                   */
-    int64_t reserved[3];       /* [0]: counter read-backs (host syncs) of the solve         */
+    int64_t reserved[3];       /* [0]: counter read-backs (host syncs) of the solve; [1]: cycles of colour phases that ran on radial labels */
     /* the dominant kernel by itself: discharge_ms / _launches / _tiles pool the one-wave-per-tile kernel (k_discharge_w) and the
      * workgroup-per-tile kernel that takes the short lists; these three are k_discharge_w alone */
     double  discharge_wave_ms;

@@ -38,6 +38,7 @@ class Stats(C.Structure):
     def as_dict(self):
         d = {k: getattr(self, k) for k, _ in self._fields_ if k != "reserved"}
         d["readbacks"] = self.reserved[0]
+        d["radial_cycles"] = self.reserved[1]  # cycles of colour phases that ran on radial labels (mgc_driver.inl)
         return d
 
 

@@ -233,6 +233,41 @@ def test_synthetic_vs_oracle(gen, shape):
     assert flow == pytest.approx(inj.flow, rel=1e-9)
 
 
+@pytest.mark.parametrize("radial", [0, 1, 2])
+@pytest.mark.parametrize("gen,shape,kw", [("sphere", (64, 64, 64), {}), ("sphere", (96, 128, 80), {}), ("hard", (96, 96, 96), {}), ("ties", (48, 48, 48), {}),
+                                          ("sphere", (128, 128, 128), dict(radial_budget_x16=3)), ("sphere", (128, 128, 128), dict(radial_rounds0=2)),
+                                          ("sphere", (40, 40, 40), dict(radial_min_c=1, radial_min_walls=0))])
+def test_flood_phase_on_radial_labels_reaches_the_same_cut(gen, shape, kw, radial):
+    """mgc_dt_ops.inl / mgc_driver.inl, round 5: whether the flood phase of a solve runs on exact labels (radial = 0), on radial labels
+    (1: whenever the first relabel is the distance transform) or decides by the walls k_build counted (2, the default) -- and however the
+    radial phase is cut (a budget too short to close the surface, several radial cycles with a look at the source tiles in between,
+    sources next to sinks) -- the maximum preflow differs and the labels do not: the reference BK's, voxel for voxel."""
+    from medpy_amd import graphcut, synthetic
+    s = getattr(synthetic, gen)(shape)
+    ref = pipeline.graphcut_voxel(s["fg"], s["bg"], term=s["term"], image=s["image"], sigma=s["sigma"])
+    g = graphcut.graph_from_voxels(s["fg"], s["bg"], boundary_term=getattr(graphcut.energy_voxel, "boundary_" + s["term"]),
+                                   boundary_term_args=(s["image"], s["sigma"], False))
+    g.set_param("radial", radial)
+    for k, v in kw.items():
+        g.set_param(k, v)
+    flow = g.maxflow()
+    st = g.stats()
+    print(gen, shape, kw, "radial", radial, "->", {k: st[k] for k in ("global_relabels", "phases", "discharge_tiles", "relabel_tiles")}, "radial cycles", st["radial_cycles"])
+    if radial == 0:
+        assert st["radial_cycles"] == 0
+    if radial == 1 and gen == "sphere" and not kw.get("radial_budget_x16"):
+        assert st["radial_cycles"] >= 1
+    if gen == "ties":  # exact ties between minimum cuts: equivalent, not identical (oracle/cutcheck.py)
+        i, j, ww = cutcheck.lattice_edges(shape, energy_numpy.boundary_weights(s["term"], s["image"], s["sigma"]))
+        tr = np.where(s["fg"], 65535.0, 0.0) - np.where(s["bg"], 65535.0, 0.0)
+        cutcheck.assert_labels_equivalent(g.labels(), ref, exact=(i, j, ww, ww, tr))
+    else:
+        np.testing.assert_array_equal(g.labels(), ref.labels)
+    assert flow == pytest.approx(ref.flow, rel=1e-9)
+    v = g.validate()
+    assert not any(v[k] for k in ("negative_values", "active_excess", "residual_arcs_across", "sink_links_across", "pair_violations", "node_violations", "pending_outbox"))
+
+
 @pytest.mark.parametrize("gen,shape", [("sphere", (128, 128, 128)), ("hard", (96, 96, 96)), ("sphere", (20, 33, 47))])
 def test_cpu_capacities_into_the_gpu_solver(gen, shape):
     """SURVEY Appendix B "cross-inject", the direction round 2 lacked at scale: the ORACLE's capacities (NumPy energies,
