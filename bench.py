@@ -528,7 +528,7 @@ def main():
                                "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBS, 5), "traffic": traffic,
                                "traffic_source": traffic_info, "avg_launch_ms": round(avg_ms, 4), "launches_per_step": launches / args.steps,
                                "voxels_per_launch": round(vox_per_launch, 1), "bytes_per_voxel": b_alg,
-                               "timing": "HIP event pairs on the launch stream around every %d-th launch of the kernel, mean x launches" % max(int(st.get("timing_stride", 1)), 1),
+                               "timing": "HIP event pairs on the launch stream around every %d-th launch of the kernel (the timed residue rotates from step to step), mean x launches" % max(int(st.get("timing_stride", 1)), 1),
                                "other_discharge_launches_per_step": (acc["discharge_launches"] - launches) / args.steps if wave else 0.0}
         else:
             out["slab_schedule"] = slab_stats

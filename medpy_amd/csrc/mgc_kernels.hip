@@ -2204,7 +2204,11 @@ struct mgc_graph {
     int64_t device_bytes = 0;
     std::string err;
     bool timing = true;
-    int timing_stride = 3; /* HIP event pairs around every n-th solver launch of a kind (see HipDevT::time_begin) */
+    int timing_stride = 7; /* HIP event pairs around every n-th solver launch of a kind (see HipDevT::time_begin).  3 until round 5: with ~140 solver launches
+                              per 512^3 step left, a pair around every third cost 0.65 ms of 19.6 (kernel_timing 0: 18.9 ms, stride 7: 19.0) */
+    uint32_t timing_offset = 0; /* which residue of the stride is timed rotates from solve to solve: the launches of a solve have a shape (the flood grows, the
+                                   leak shrinks), and a fixed residue samples the same few launches every time -- at stride 7 that read 8 % low on the headline
+                                   volume; over seven steps every launch is timed once */
 };
 
 static int mgc_fail(mgc_handle h, int code, const char* fmt, ...)
@@ -2541,7 +2545,7 @@ struct HipDevT {
          * a pair around each of the ~450 solver launches of a 512^3 step costs 3 ms of its 47); the kernel time of the
          * kind is the mean of the timed launches times the number of launches.  An odd stride samples both tile colours. */
         if (kind != 2) { /* (kind 2 = a one-off stretch, always timed, never extrapolated: the distance-transform relabel) */
-            if ((seen[kind]++ % h->timing_stride) != 0) return -1;
+            if (((seen[kind]++ + h->timing_offset) % (uint32_t)h->timing_stride) != 0) return -1;
             timed[kind]++;
         }
         const size_t need = 2 * spans.size() + 2;
@@ -3730,6 +3734,7 @@ int mgc_maxflow(mgc_handle h, double* flow)
         HipDev dev;
         HipDev26 dev26;
         dev.h = dev26.h = h;
+        h->timing_offset++;
         int rc;
         if (L.ndir == 6) {
             MgcSolveParams P = h->params;
