@@ -3,7 +3,7 @@
 Follows reference medpy/graphcut/energy_voxel.py operation by operation (same ufuncs, same
 order, same dtypes) but returns whole arrays instead of driving ``GCGraph.set_nweight`` once
 per edge (energy_voxel.py:660-664).  Pinned against the reference itself (run through
-``oracle/overlay.py`` with a recording graph) by ``tests/test_oracle_energy_vs_ref.py`` and
+``oracle/overlay.py`` with a recording graph) by ``tests/test_oracle_golden.py`` (where /root/reference exists) and
 by the fixtures under ``tests/golden/``.
 
 ``boundary_weights`` returns, for every axis ``d``, the array the reference calls
