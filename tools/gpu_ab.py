@@ -18,6 +18,7 @@ ap.add_argument("--reps", type=int, default=3)
 ap.add_argument("--lib", default=None)
 ap.add_argument("--tag", default="")
 ap.add_argument("--regional", action="store_true", help="add the regional_probability_map term of BASELINE config 3")
+ap.add_argument("--term", default=None, help="boundary term instead of the workload's own (e.g. difference_division: what k_build costs without exp)")
 ap.add_argument("variants", nargs="*")
 a = ap.parse_args()
 if a.lib:
@@ -32,7 +33,7 @@ s = getattr(synthetic, a.wl)((n, n, n))
 ref = None
 for v in (a.variants or ["base"]):
     g = VoxelGraph((n, n, n), connectivity=a.conn)  # a fresh handle per variant: defaults restored
-    g._set_boundary(s["term"], s["image"], s["sigma"], False)
+    g._set_boundary(a.term or s["term"], s["image"], s["sigma"], False)
     if a.regional:
         rg = synthetic.regional((n, n, n))
         g._set_regional(rg["prob"], rg["alpha"])
