@@ -1223,7 +1223,13 @@ __device__ __forceinline__ void k_build_tiles(const MgcLattice& L, const MgcBuil
         double tr = 0.0, fc = 0.0;
         int tbits = 0, weak_voxels = 0;
         bool weak_voxel = false; /* one of this voxel's n-links is below MGC_WALL_WEIGHT (6-neighbourhood, markers only: set before the vote) */
-        auto tlinks_and_vote = [&]() __attribute__((always_inline)) {
+        /* Two halves.  tlinks(): everything that WAITS for memory (the marker bytes asked for at the top of the tile, the explicit t-links,
+         * the probability map) and the merge; vote(): ballots and the barrier.  The 6-neighbourhood path runs tlinks() in FRONT of its
+         * plane stores: a wave's vector memory operations retire in issue order, so a wait for a marker byte placed behind the six plane
+         * stores -- where the whole lambda stood until round 5 -- was a wait for those stores to be acknowledged, once per tile
+         * (diagnostic builds: the kernel without its image loads, whose wait has the same effect on the tile before, ran 2.4 ms
+         * instead of 3.15). */
+        auto tlinks = [&]() __attribute__((always_inline)) {
             if (valid) {
                 if (A.tr_in) tr = A.tr_in[id];
                 if (A.prob) {
@@ -1242,6 +1248,8 @@ __device__ __forceinline__ void k_build_tiles(const MgcLattice& L, const MgcBuil
                 if (pre_fg) mgc_add_tweights(tr, fc, MGC_MARKER_MAX, 0.0);
                 if (pre_bg) mgc_add_tweights(tr, fc, 0.0, MGC_MARKER_MAX);
             }
+        };
+        auto vote = [&]() __attribute__((always_inline)) {
             const int bits = (__ballot(tr < 0.0) != 0ull ? 2 : 0) | (__ballot(tr > 0.0) != 0ull ? 1 : 0) | (__ballot(fc != 0.0) != 0ull ? 4 : 0);
             /* bits 8..: how many voxels of the tile hold a weak n-link (the same word, one atomic per wave: the count never carries into the vote bits) */
             const int weak_here = __popcll(__ballot(weak_voxel));
@@ -1254,7 +1262,8 @@ __device__ __forceinline__ void k_build_tiles(const MgcLattice& L, const MgcBuil
         };
         if constexpr (FULL || PRE6) {
             __syncthreads(); /* the reset of the vote word above, before the votes */
-            tlinks_and_vote();
+            tlinks();
+            vote();
         }
         const bool pre = (FULL || PRE6) && A.prepush && (tbits & 3) == 3; /* (uniform) the tile holds source links AND sink links */
         double exc_out = tr > 0.0 ? tr : 0.0, snk_out = tr < 0.0 ? -tr : 0.0; /* (the 6-neighbourhood path: after its tlinks_and_vote below) */
@@ -1348,7 +1357,8 @@ __device__ __forceinline__ void k_build_tiles(const MgcLattice& L, const MgcBuil
                     L.rcap[((int64_t)tile * 6 + d) * MGC_TV + t] = w6[d];
                     if (w6[d] > 0.0) m |= 1u << d;
                 }
-            } else
+            } else {
+            tlinks(); /* (in front of the stores: see above) */
 #pragma unroll
             for (int d = 0; d < 6; ++d) {
                 double w = 0.0;
@@ -1364,6 +1374,7 @@ __device__ __forceinline__ void k_build_tiles(const MgcLattice& L, const MgcBuil
                 if (L.cap0) L.cap0[o] = w;
                 if (w > 0.0) m |= 1u << d; /* NaN (0/0 of the linear terms on a constant image) is not residual */
                 weak_voxel = weak_voxel || (w > 0.0 && w < MGC_WALL_WEIGHT);
+            }
             }
         } else {
             /* full neighbourhood: same g(.) on all 26 offsets (oracle/energy_numpy.py:boundary_weights_offsets).  Unrolled: the
@@ -1454,7 +1465,7 @@ __device__ __forceinline__ void k_build_tiles(const MgcLattice& L, const MgcBuil
                 });
             }
         }
-        if constexpr (!FULL && !PRE6) tlinks_and_vote();
+        if constexpr (!FULL && !PRE6) vote();
         const int64_t v = (int64_t)tile * MGC_TV + t;
         const int any_sink = tbits & 2, any_exc = tbits & 1;
         if constexpr (!FULL && !PRE6) { exc_out = tr > 0.0 ? tr : 0.0; snk_out = tr < 0.0 ? -tr : 0.0; }
