@@ -49,8 +49,9 @@ MGC_HD int mgc_dt_lines(const MgcLattice& L) { return AXIS == 0 ? L.gz * L.gy : 
  * int32 label array (MGC_HINF for "no seed anywhere" and for the padding voxels of a partial tile), otherwise uint16. */
 template <int AXIS, bool BWD, int SEED, int FINAL, class W> /* FINAL 2: the last scan of the distance FROM THE SOURCE -- uint16 out as for 0, and the labels
                                                                in L.height lowered to max(1, C - (distance - 1)) on the way (mgc_dt_lower_tile without a pass of its own) */
-MGC_HD void mgc_dt_scan_line(W& w, const MgcLattice& L, int line, const void* in, void* out, int c_min = 0)
-{
+MGC_HD void mgc_dt_scan_line(W& w, const MgcLattice& L, int line, const void* in, void* out, int c_min = 0, int32_t* hout = nullptr)
+{   /* hout (FINAL 2): where the lowered labels go -- EVERY label, lowered or not, so that the caller can swap the two arrays instead of copying
+     * the exact labels aside first (HipDevT::radial_begin); nullptr: in place, only what changed */
     int C = MGC_HINF;
     if (FINAL == 2) { C = L.count[MGC_CNT_RADIAL_C]; if (C < c_min) C = MGC_HINF; }
     const int na = AXIS == 0 ? L.gx : (AXIS == 1 ? L.gy : L.gz);
@@ -67,6 +68,14 @@ MGC_HD void mgc_dt_scan_line(W& w, const MgcLattice& L, int line, const void* in
          * flight; the scan itself is a register chain) */
         for (int s0 = 0; s0 < na; s0 += 4) {
             int v[4][8];
+            bool src[4] = {true, true, true, true};
+            if (SEED == 2) { /* excess as built sits in the tiles k_build marked (MGC_ST_SOURCE, what mgc_dt_cmin_tile goes by): the others' 4 KiB stay where they are */
+#pragma unroll
+                for (int g = 0; g < 4; ++g) {
+                    const int s = s0 + g < na ? s0 + g : na - 1;
+                    src[g] = (L.status[mgc_dt_tile<AXIS>(L, line, BWD ? na - 1 - s : s)] & MGC_ST_SOURCE) != 0u; /* (uniform over the wave) */
+                }
+            }
 #pragma unroll
             for (int g = 0; g < 4; ++g) {
                 const int s = s0 + g < na ? s0 + g : na - 1; /* (a short last group re-reads the last tile) */
@@ -76,7 +85,7 @@ MGC_HD void mgc_dt_scan_line(W& w, const MgcLattice& L, int line, const void* in
                 for (int i = 0; i < 8; ++i) {
                     const int loc = mgc_dt_loc<AXIS>(l, i);
                     if (SEED == 1) v[g][i] = (((const uint8_t*)in)[base + loc] & MGC_MASK_SINK) ? 1 : MGC_DT_INF;
-                    else if (SEED == 2) v[g][i] = ((const double*)in)[base + loc] > 0.0 ? 1 : MGC_DT_INF;
+                    else if (SEED == 2) v[g][i] = src[g] && ((const double*)in)[base + loc] > 0.0 ? 1 : MGC_DT_INF;
                     else v[g][i] = ((const uint16_t*)in)[base + loc];
                 }
             }
@@ -100,11 +109,16 @@ MGC_HD void mgc_dt_scan_line(W& w, const MgcLattice& L, int line, const void* in
                     const int loc = mgc_dt_loc<AXIS>(l, i);
                     if (FINAL == 1) ((int32_t*)out)[base + loc] = v[g][i] < MGC_DT_INF ? v[g][i] : MGC_HINF;
                     else ((uint16_t*)out)[base + loc] = (uint16_t)v[g][i];
-                    if (FINAL == 2 && C < MGC_HINF && v[g][i] < MGC_DT_INF) {
+                    if (FINAL == 2 && (hout || (C < MGC_HINF && v[g][i] < MGC_DT_INF))) {
                         const int hv = L.height[base + loc];
-                        int gl = C - (v[g][i] - 1);
-                        gl = gl < 1 ? 1 : gl;
-                        if (hv < MGC_HINF && gl < hv) L.height[base + loc] = gl;
+                        int nv = hv;
+                        if (C < MGC_HINF && v[g][i] < MGC_DT_INF) {
+                            int gl = C - (v[g][i] - 1);
+                            gl = gl < 1 ? 1 : gl;
+                            if (hv < MGC_HINF && gl < hv) nv = gl;
+                        }
+                        if (hout) hout[base + loc] = nv;
+                        else if (nv != hv) L.height[base + loc] = nv;
                     }
                 }
             }

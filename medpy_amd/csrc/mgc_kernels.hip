@@ -958,14 +958,14 @@ __global__ __launch_bounds__(MGC_TV) void k_activate_list(MgcLattice L, int list
 
 /* first global relabel as a distance transform (mgc_dt_ops.inl): one scan of every tile line along AXIS, one wave per line */
 template <int AXIS, bool BWD, int SEED, int FINAL> /* SEED 1: from the sink links (rmask), 2: from the voxels that hold excess (the radial labels), 0: a later pass */
-__global__ __launch_bounds__(256) void k_dt_scan(MgcLattice L, const void* in, void* out, int c_min)
+__global__ __launch_bounds__(256) void k_dt_scan(MgcLattice L, const void* in, void* out, int c_min, int32_t* hout)
 {
     __shared__ MgcWaveShared S; /* (not touched: the executor wants one) */
     GpuWave w(S);
     const int n = mgc_dt_lines<AXIS>(L);
     for (int line = (int)blockIdx.x * 4 + (int)(threadIdx.x >> 6); line < n; line += (int)gridDim.x * 4) {
         w.new_tile();
-        mgc_dt_scan_line<AXIS, BWD, SEED, FINAL>(w, L, __builtin_amdgcn_readfirstlane(line), in, out, c_min);
+        mgc_dt_scan_line<AXIS, BWD, SEED, FINAL>(w, L, __builtin_amdgcn_readfirstlane(line), in, out, c_min, hout);
     }
 }
 
@@ -1163,7 +1163,10 @@ __device__ __forceinline__ double mgc_block_sum(double v, double* scratch)
 }
 
 /* TERM: the boundary term as a compile-time constant (the kernel dispatches once), so g(.) is straight-line code */
-template <bool FULL, int TERM, bool PRE6 = false> /* FULL: 26-neighbourhood; PRE6: the 6-neighbourhood instance with the pre-push (graphs with a regional term) */
+/* TABLE false: an instance without the term-by-table of integer-valued images (mgc_set_boundary_lut).  Not a micro-saving: a table load's wait sits
+ * where the table path and the arithmetic path of g(.) merge, so every tile runs into it, table or not -- and on this hardware it is a wait for
+ * ALL of the wave's memory operations in flight, the previous tile's stores and the next tile's image block included. */
+template <bool FULL, int TERM, bool PRE6 = false, bool TABLE = true> /* FULL: 26-neighbourhood; PRE6: the 6-neighbourhood instance with the pre-push (graphs with a regional term) */
 __device__ __forceinline__ void k_build_tiles(const MgcLattice& L, const MgcBuildArgs& A, double* img, double* scratch, double* wf, int* tflag_lds, double* pre_lds)
 {
     const int t_lane = threadIdx.x;
@@ -1176,6 +1179,40 @@ __device__ __forceinline__ void k_build_tiles(const MgcLattice& L, const MgcBuil
     const int chunk = (L.ntiles + nx - 1) / nx, stride = (int)gridDim.x / nx;
     int sink_tiles = 0; /* (thread 0) tiles of this workgroup that hold a sink link */
     int wall_tiles = 0; /* (thread 0) ... that a surface of weak arcs passes through (MGC_WALL_*) */
+    /* float32 images (the usual case): the 10 x 10 x 10 block of a tile is asked for ONE TILE AHEAD -- right behind the first barrier of the tile
+     * before -- and put into LDS behind that tile's stores.  A wave's vector memory operations retire in issue order: a tile that begins by
+     * waiting for its own image loads waits for every store of the tile before to be acknowledged (diagnostic builds, round 5: the kernel
+     * without its image loads 2.4 ms instead of 3.15).  Loaded this way the block has the whole evaluation of g(.) to arrive in. */
+    const bool ahead = TERM != MGC_TERM_NONE && !FULL && !PRE6 && A.img_dtype == MGC_F32; /* (uniform) */
+    float raw_a = 0.f, raw_b = 0.f;
+    auto fetch_f32 = [&](int tile_n, int tl) __attribute__((always_inline)) {
+        int nz, ny, nxx;
+        mgc_tile_coords(L, tile_n, nz, ny, nxx);
+        const int64_t bz = (int64_t)nz * 8, by = (int64_t)ny * 8, bx = (int64_t)nxx * 8;
+        const float* const im = (const float*)A.image;
+        raw_a = raw_b = 0.f;
+        {
+            const int k = tl;
+            const int64_t gz = bz + k / 100 - 1, gy = by + (k / 10) % 10 - 1, gx = bx + k % 10 - 1;
+            if (gz >= 0 && gz < L.dz && gy >= 0 && gy < L.dy && gx >= 0 && gx < L.dx) raw_a = im[(gz * L.dy + gy) * L.dx + gx];
+        }
+        if (tl + MGC_TV < 1000) {
+            const int k = tl + MGC_TV;
+            const int64_t gz = bz + k / 100 - 1, gy = by + (k / 10) % 10 - 1, gx = bx + k % 10 - 1;
+            if (gz >= 0 && gz < L.dz && gy >= 0 && gy < L.dy && gx >= 0 && gx < L.dx) raw_b = im[(gz * L.dy + gy) * L.dx + gx];
+        }
+    };
+    auto stage_f32 = [&](int tl) __attribute__((always_inline)) {
+        img[tl] = take_abs ? fabs((double)raw_a) : (double)raw_a;
+        if (tl + MGC_TV < 1000) img[tl + MGC_TV] = take_abs ? fabs((double)raw_b) : (double)raw_b;
+    };
+    if (ahead) { /* the first tile's block */
+        const int first = ((int)blockIdx.x % nx) * chunk + (int)blockIdx.x / nx;
+        if ((int)blockIdx.x / nx < chunk && first < L.ntiles) {
+            fetch_f32(first, t_lane);
+            stage_f32(t_lane);
+        }
+    }
     for (int idx = (int)blockIdx.x / nx; idx < chunk; idx += stride) {
         const int tile = ((int)blockIdx.x % nx) * chunk + idx;
         if (tile >= L.ntiles) break;
@@ -1190,7 +1227,7 @@ __device__ __forceinline__ void k_build_tiles(const MgcLattice& L, const MgcBuil
         const int64_t z0 = (int64_t)tz * 8, y0 = (int64_t)ty * 8, x0 = (int64_t)tx * 8;
         /* the marker bytes of this lane's voxel are asked for HERE, together with the image tile: they are needed behind the weights,
          * and fetched there they were a second full memory latency per tile (two dependent trips to HBM where one does) */
-        uint8_t pre_fg = 0, pre_bg = 0;
+        uint32_t pre_fg = 0, pre_bg = 0; /* (whole registers: see the use in tlinks()) */
         {
             const int plz = t >> 6, ply = (t >> 3) & 7, plx = t & 7;
             const int64_t pz = z0 + plz, py = y0 + ply, px = x0 + plx;
@@ -1200,7 +1237,7 @@ __device__ __forceinline__ void k_build_tiles(const MgcLattice& L, const MgcBuil
                 if (A.bg) pre_bg = A.bg[pid];
             }
         }
-        if (TERM != MGC_TERM_NONE) {
+        if (TERM != MGC_TERM_NONE && !ahead) {
             for (int k = t; k < 1000; k += MGC_TV) {
                 const int64_t gz = z0 + k / 100 - 1, gy = y0 + (k / 10) % 10 - 1, gx = x0 + k % 10 - 1;
                 double v = 0.0;
@@ -1210,6 +1247,9 @@ __device__ __forceinline__ void k_build_tiles(const MgcLattice& L, const MgcBuil
             }
         }
         __syncthreads();
+        const int next = tile + stride;
+        const bool has_next = ahead && idx + stride < chunk && next < L.ntiles; /* (uniform) */
+        if (has_next) fetch_f32(next, t); /* in flight until the end of this tile */
         if (t == 0) *tflag_lds = 0; /* everybody is past the previous tile's look at it; this tile's votes come after the next barrier */
         const int lz = t >> 6, ly = (t >> 3) & 7, lx = t & 7;
         const int64_t gz = z0 + lz, gy = y0 + ly, gx = x0 + lx;
@@ -1230,6 +1270,9 @@ __device__ __forceinline__ void k_build_tiles(const MgcLattice& L, const MgcBuil
          * (diagnostic builds: the kernel without its image loads, whose wait has the same effect on the tile before, ran 2.4 ms
          * instead of 3.15). */
         auto tlinks = [&]() __attribute__((always_inline)) {
+            /* the bytes are looked at HERE and not where they were loaded: left alone the compiler turns "byte != 0" into a lane mask right
+             * behind the load, and the wait that goes with it -- at the top of the tile -- is a wait for the stores of the tile before */
+            asm volatile("" : "+v"(pre_fg), "+v"(pre_bg));
             if (valid) {
                 if (A.tr_in) tr = A.tr_in[id];
                 if (A.prob) {
@@ -1276,7 +1319,7 @@ __device__ __forceinline__ void k_build_tiles(const MgcLattice& L, const MgcBuil
             if (TERM != MGC_TERM_NONE) {
                 auto pair_weight = [&](int axis, int lo, bool ok) -> double { /* lo = img[] index of the lower voxel; ok = both voxels exist */
                     if (!ok) return 0.0;
-                    double w = mgc_boundary_g(TERM, img[lo], img[lo + (axis == 0 ? 1 : (axis == 1 ? 10 : 100))], A.p0, A.lut, A.lut_n);
+                    double w = mgc_boundary_g(TERM, img[lo], img[lo + (axis == 0 ? 1 : (axis == 1 ? 10 : 100))], A.p0, TABLE ? A.lut : nullptr, TABLE ? A.lut_n : 0);
                     if (A.has_spacing) w = w / A.inv_axis[axis]; /* energy_voxel.py:657-658 */
                     return w;
                 };
@@ -1370,7 +1413,7 @@ __device__ __forceinline__ void k_build_tiles(const MgcLattice& L, const MgcBuil
                 /* (16-byte stores -- two x-neighbours per lane, fetched from wf -- were measured on MI355X: 4.9 ms instead of
                  * 4.4 ms for this kernel at 512^3; the kernel is bound by instruction issue, not by the store width) */
                 const int64_t o = ((int64_t)tile * 6 + d) * MGC_TV + t;
-                L.rcap[o] = w;
+                __builtin_nontemporal_store(w, &L.rcap[o]); /* 6.4 GB at 512^3 that nothing reads before the caches have turned over many times (2.78 -> 2.70 ms) */
                 if (L.cap0) L.cap0[o] = w;
                 if (w > 0.0) m |= 1u << d; /* NaN (0/0 of the linear terms on a constant image) is not residual */
                 weak_voxel = weak_voxel || (w > 0.0 && w < MGC_WALL_WEIGHT);
@@ -1469,7 +1512,7 @@ __device__ __forceinline__ void k_build_tiles(const MgcLattice& L, const MgcBuil
         const int64_t v = (int64_t)tile * MGC_TV + t;
         const int any_sink = tbits & 2, any_exc = tbits & 1;
         if constexpr (!FULL && !PRE6) { exc_out = tr > 0.0 ? tr : 0.0; snk_out = tr < 0.0 ? -tr : 0.0; }
-        L.excess[v] = exc_out;
+        __builtin_nontemporal_store(exc_out, &L.excess[v]);
         if constexpr (!FULL) {
             /* 6-neighbourhood: the merged t-links and the residual sink links of a tile are only READ where the tile holds a t-link
              * of the sign in question (A.tflags, status bit MGC_ST_SINK: k_discharge_w, k_cut_value6, k_validate ...), so they are only
@@ -1514,6 +1557,7 @@ __device__ __forceinline__ void k_build_tiles(const MgcLattice& L, const MgcBuil
         }
         if constexpr (FULL) __syncthreads(); /* the weights above read the image tile in LDS, the next tile's load overwrites it (the
                                                 6-neighbourhood path has its vote barrier behind the weights) */
+        if (has_next) stage_f32(t); /* everybody is past this tile's reads of the block; this tile's stores are still on their way */
     }
     if (!FULL && t_lane == 0 && sink_tiles) atomicAdd(&L.count[MGC_CNT_SINK_TILES], sink_tiles); /* once per workgroup (mgc_build: exact_sink_tiles) */
     if (!FULL && t_lane == 0 && wall_tiles) atomicAdd(&L.count[MGC_CNT_WALL_TILES], wall_tiles);
@@ -1528,7 +1572,7 @@ __device__ __forceinline__ void k_build_tiles(const MgcLattice& L, const MgcBuil
 #ifndef MGC_BUILD_WAVES26
 #define MGC_BUILD_WAVES26 4 /* two workgroups per CU: 128 VGPRs */
 #endif
-template <bool FULL, int TERM, bool PRE6 = false> /* FULL: 26-neighbourhood; PRE6: 6-neighbourhood with the pre-push (regional term) */
+template <bool FULL, int TERM, bool PRE6 = false, bool TABLE = true> /* FULL: 26-neighbourhood; PRE6: 6-neighbourhood with the pre-push (regional term) */
 __global__ __launch_bounds__(MGC_TV, FULL ? MGC_BUILD_WAVES26 : (PRE6 ? 4 : ((TERM == MGC_TERM_DIFFERENCE_POWER || TERM == MGC_TERM_MAXIMUM_POWER) ? MGC_BUILD_WAVES6 - 2 : MGC_BUILD_WAVES6))) void k_build(MgcLattice L, MgcBuildArgs A)
 {
     __shared__ double img[1000]; /* 10x10x10: tile + one-voxel halo, already |.|'d for the maximum terms */
@@ -1536,7 +1580,7 @@ __global__ __launch_bounds__(MGC_TV, FULL ? MGC_BUILD_WAVES26 : (PRE6 ? 4 : ((TE
     __shared__ double wf[FULL ? 1 : 3 * 576]; /* 6-neighbourhood: the forward n-link weights of the tile and its lower faces */
     __shared__ int tflag;
     __shared__ double pre_lds[(FULL || PRE6) ? 5 * MGC_TV : 1]; /* pre-push: residual sink capacities + two double-buffered hand-off planes */
-    k_build_tiles<FULL, TERM, PRE6>(L, A, img, scratch, wf, &tflag, pre_lds);
+    k_build_tiles<FULL, TERM, PRE6, TABLE>(L, A, img, scratch, wf, &tflag, pre_lds);
 }
 
 template <bool FULL>
@@ -1560,6 +1604,19 @@ static void mgc_launch_build(int term, int grid, hipStream_t stream, const MgcLa
         }
     }
     switch (term) {
+    if constexpr (!FULL) {
+        if (!A.lut) { /* (only these four terms are ever evaluated by table: for the others the instances would be the same code twice) */
+            switch (term) {
+#define MGC_BUILD_CASE_NT(T) case T: hipLaunchKernelGGL((k_build<false, T, false, false>), dim3(grid), dim3(MGC_TV), 0, stream, L, A); return;
+            MGC_BUILD_CASE_NT(MGC_TERM_DIFFERENCE_EXPONENTIAL)
+            MGC_BUILD_CASE_NT(MGC_TERM_DIFFERENCE_POWER)
+            MGC_BUILD_CASE_NT(MGC_TERM_MAXIMUM_EXPONENTIAL)
+            MGC_BUILD_CASE_NT(MGC_TERM_MAXIMUM_POWER)
+#undef MGC_BUILD_CASE_NT
+            default: break;
+            }
+        }
+    }
 #define MGC_BUILD_CASE(T) case T: hipLaunchKernelGGL((k_build<FULL, T>), dim3(grid), dim3(MGC_TV), 0, stream, L, A); break;
     MGC_BUILD_CASE(MGC_TERM_NONE)
     MGC_BUILD_CASE(MGC_TERM_DIFFERENCE_LINEAR)
@@ -2384,12 +2441,12 @@ struct HipDevT {
         void* const T = h->d_dt16;
         const dim3 blk(256);
         auto g = [&](int lines) { return dim3(grid((lines + 3) / 4)); };
-        hipLaunchKernelGGL((k_dt_scan<0, false, 1, 0>), g(L.gz * L.gy), blk, 0, h->stream, L, (const void*)L.rmask, T, 0);
-        hipLaunchKernelGGL((k_dt_scan<0, true, 0, 0>), g(L.gz * L.gy), blk, 0, h->stream, L, (const void*)T, T, 0);
-        hipLaunchKernelGGL((k_dt_scan<1, false, 0, 0>), g(L.gz * L.gx), blk, 0, h->stream, L, (const void*)T, T, 0);
-        hipLaunchKernelGGL((k_dt_scan<1, true, 0, 0>), g(L.gz * L.gx), blk, 0, h->stream, L, (const void*)T, T, 0);
-        hipLaunchKernelGGL((k_dt_scan<2, false, 0, 0>), g(L.gy * L.gx), blk, 0, h->stream, L, (const void*)T, T, 0);
-        hipLaunchKernelGGL((k_dt_scan<2, true, 0, 1>), g(L.gy * L.gx), blk, 0, h->stream, L, (const void*)T, (void*)L.height, 0);
+        hipLaunchKernelGGL((k_dt_scan<0, false, 1, 0>), g(L.gz * L.gy), blk, 0, h->stream, L, (const void*)L.rmask, T, 0, (int32_t*)nullptr);
+        hipLaunchKernelGGL((k_dt_scan<0, true, 0, 0>), g(L.gz * L.gy), blk, 0, h->stream, L, (const void*)T, T, 0, (int32_t*)nullptr);
+        hipLaunchKernelGGL((k_dt_scan<1, false, 0, 0>), g(L.gz * L.gx), blk, 0, h->stream, L, (const void*)T, T, 0, (int32_t*)nullptr);
+        hipLaunchKernelGGL((k_dt_scan<1, true, 0, 0>), g(L.gz * L.gx), blk, 0, h->stream, L, (const void*)T, T, 0, (int32_t*)nullptr);
+        hipLaunchKernelGGL((k_dt_scan<2, false, 0, 0>), g(L.gy * L.gx), blk, 0, h->stream, L, (const void*)T, T, 0, (int32_t*)nullptr);
+        hipLaunchKernelGGL((k_dt_scan<2, true, 0, 1>), g(L.gy * L.gx), blk, 0, h->stream, L, (const void*)T, (void*)L.height, 0, (int32_t*)nullptr);
         hipLaunchKernelGGL(k_dt_finish, g(L.ntiles), blk, 0, h->stream, L);
         check(hipGetLastError());
         time_end(id);
@@ -2418,13 +2475,16 @@ struct HipDevT {
         auto g = [&](int lines) { return dim3(grid((lines + 3) / 4)); };
         check(hipMemsetAsync(L.count + MGC_CNT_RADIAL_C, 0x3f, sizeof(int32_t), h->stream)); /* MGC_HINF */
         hipLaunchKernelGGL(k_dt_cmin, g(L.ntiles), blk, 0, h->stream, L); /* C from the exact labels of the source voxels */
-        check(hipMemcpyAsync(h->d_hexact, L.height, nv * sizeof(int32_t), hipMemcpyDeviceToDevice, h->stream)); /* the exact labels, kept aside */
-        hipLaunchKernelGGL((k_dt_scan<0, false, 2, 0>), g(L.gz * L.gy), blk, 0, h->stream, L, (const void*)L.excess, T, 0);
-        hipLaunchKernelGGL((k_dt_scan<0, true, 0, 0>), g(L.gz * L.gy), blk, 0, h->stream, L, (const void*)T, T, 0);
-        hipLaunchKernelGGL((k_dt_scan<1, false, 0, 0>), g(L.gz * L.gx), blk, 0, h->stream, L, (const void*)T, T, 0);
-        hipLaunchKernelGGL((k_dt_scan<1, true, 0, 0>), g(L.gz * L.gx), blk, 0, h->stream, L, (const void*)T, T, 0);
-        hipLaunchKernelGGL((k_dt_scan<2, false, 0, 0>), g(L.gy * L.gx), blk, 0, h->stream, L, (const void*)T, T, 0);
-        hipLaunchKernelGGL((k_dt_scan<2, true, 0, 2>), g(L.gy * L.gx), blk, 0, h->stream, L, (const void*)T, T, c_min); /* ... and the labels lowered on the way */
+        hipLaunchKernelGGL((k_dt_scan<0, false, 2, 0>), g(L.gz * L.gy), blk, 0, h->stream, L, (const void*)L.excess, T, 0, (int32_t*)nullptr);
+        hipLaunchKernelGGL((k_dt_scan<0, true, 0, 0>), g(L.gz * L.gy), blk, 0, h->stream, L, (const void*)T, T, 0, (int32_t*)nullptr);
+        hipLaunchKernelGGL((k_dt_scan<1, false, 0, 0>), g(L.gz * L.gx), blk, 0, h->stream, L, (const void*)T, T, 0, (int32_t*)nullptr);
+        hipLaunchKernelGGL((k_dt_scan<1, true, 0, 0>), g(L.gz * L.gx), blk, 0, h->stream, L, (const void*)T, T, 0, (int32_t*)nullptr);
+        hipLaunchKernelGGL((k_dt_scan<2, false, 0, 0>), g(L.gy * L.gx), blk, 0, h->stream, L, (const void*)T, T, 0, (int32_t*)nullptr);
+        /* ... and the labels lowered on the way, INTO THE OTHER ARRAY: the last scan reads the exact labels anyway, so it writes every label
+         * (lowered or not) to the array that keeps the exact ones aside and the two trade places -- no copy of 4 bytes per voxel to keep them
+         * aside here (0.2 ms at 512^3), none to bring them back (radial_restore_exact) */
+        hipLaunchKernelGGL((k_dt_scan<2, true, 0, 2>), g(L.gy * L.gx), blk, 0, h->stream, L, (const void*)T, T, c_min, h->d_hexact);
+        std::swap(h->L.height, h->d_hexact); /* (kernels take the lattice by value at launch: everything from here on sees the lowered labels) */
         check(hipGetLastError());
         time_end(id);
         relabel_launches += 8;
@@ -2438,7 +2498,7 @@ struct HipDevT {
     void radial_restore_exact()
     {
         flush_zero();
-        check(hipMemcpyAsync(h->L.height, h->d_hexact, (size_t)h->L.ntiles * MGC_TV * sizeof(int32_t), hipMemcpyDeviceToDevice, h->stream));
+        std::swap(h->L.height, h->d_hexact); /* what the flood made of the radial labels is dropped as a whole: the arrays trade places again */
     }
     void radial_lower(int c_min)
     {

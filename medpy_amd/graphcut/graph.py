@@ -40,7 +40,9 @@ def image_table_facts(term, image):
     image = numpy.asarray(image)
     if image.size == 0 or image.dtype.kind not in "iuf":
         return None
-    whole = image.dtype.kind != "f" or _holds_whole_numbers(image)
+    if image.dtype.kind == "f" and not _holds_whole_numbers(image):
+        return False, 0.0, 0.0   # no table whatever the range: not worth two more passes over the volume (20 - 80 ms at 512^3)
+    whole = True
     lo, hi = float(image.min()), float(image.max())
     if not (math.isfinite(lo) and math.isfinite(hi)):
         return None
