@@ -1603,7 +1603,6 @@ static void mgc_launch_build(int term, int grid, hipStream_t stream, const MgcLa
             }
         }
     }
-    switch (term) {
     if constexpr (!FULL) {
         if (!A.lut) { /* (only these four terms are ever evaluated by table: for the others the instances would be the same code twice) */
             switch (term) {
@@ -1617,6 +1616,7 @@ static void mgc_launch_build(int term, int grid, hipStream_t stream, const MgcLa
             }
         }
     }
+    switch (term) {
 #define MGC_BUILD_CASE(T) case T: hipLaunchKernelGGL((k_build<FULL, T>), dim3(grid), dim3(MGC_TV), 0, stream, L, A); break;
     MGC_BUILD_CASE(MGC_TERM_NONE)
     MGC_BUILD_CASE(MGC_TERM_DIFFERENCE_LINEAR)
