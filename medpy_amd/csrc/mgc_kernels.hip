@@ -1183,7 +1183,7 @@ __device__ __forceinline__ void k_build_tiles(const MgcLattice& L, const MgcBuil
      * before -- and put into LDS behind that tile's stores.  A wave's vector memory operations retire in issue order: a tile that begins by
      * waiting for its own image loads waits for every store of the tile before to be acknowledged (diagnostic builds, round 5: the kernel
      * without its image loads 2.4 ms instead of 3.15).  Loaded this way the block has the whole evaluation of g(.) to arrive in. */
-    const bool ahead = TERM != MGC_TERM_NONE && !FULL && !PRE6 && A.img_dtype == MGC_F32; /* (uniform) */
+    const bool ahead = TERM != MGC_TERM_NONE && A.img_dtype == MGC_F32; /* (uniform; every path is past its reads of the block at the end of its tile: barriers behind the weights) */
     float raw_a = 0.f, raw_b = 0.f;
     auto fetch_f32 = [&](int tile_n, int tl) __attribute__((always_inline)) {
         int nz, ny, nxx;
@@ -1249,7 +1249,9 @@ __device__ __forceinline__ void k_build_tiles(const MgcLattice& L, const MgcBuil
         __syncthreads();
         const int next = tile + stride;
         const bool has_next = ahead && idx + stride < chunk && next < L.ntiles; /* (uniform) */
-        if (has_next) fetch_f32(next, t); /* in flight until the end of this tile */
+        if constexpr (!FULL && !PRE6) {
+            if (has_next) fetch_f32(next, t); /* in flight until the end of this tile */
+        }
         if (t == 0) *tflag_lds = 0; /* everybody is past the previous tile's look at it; this tile's votes come after the next barrier */
         const int lz = t >> 6, ly = (t >> 3) & 7, lx = t & 7;
         const int64_t gz = z0 + lz, gy = y0 + ly, gx = x0 + lx;
@@ -1307,6 +1309,7 @@ __device__ __forceinline__ void k_build_tiles(const MgcLattice& L, const MgcBuil
             __syncthreads(); /* the reset of the vote word above, before the votes */
             tlinks();
             vote();
+            if (has_next) fetch_f32(next, t); /* (behind the wait for the marker bytes: in front of it the block's whole latency would be waited for with them) */
         }
         const bool pre = (FULL || PRE6) && A.prepush && (tbits & 3) == 3; /* (uniform) the tile holds source links AND sink links */
         double exc_out = tr > 0.0 ? tr : 0.0, snk_out = tr < 0.0 ? -tr : 0.0; /* (the 6-neighbourhood path: after its tlinks_and_vote below) */
@@ -1436,7 +1439,9 @@ __device__ __forceinline__ void k_build_tiles(const MgcLattice& L, const MgcBuil
                 double w = 0.0;
                 if (has && TERM != MGC_TERM_NONE) {
                     const double other = img[me + dz * 100 + dy * 10 + dx];
-                    w = d >= 13 ? mgc_boundary_g(TERM, mine, other, A.p0, A.lut, A.lut_n) : mgc_boundary_g(TERM, other, mine, A.p0, A.lut, A.lut_n); /* g(lower, upper) */
+                    const double* const lut = TABLE ? A.lut : nullptr;
+                    const int lut_n = TABLE ? A.lut_n : 0;
+                    w = d >= 13 ? mgc_boundary_g(TERM, mine, other, A.p0, lut, lut_n) : mgc_boundary_g(TERM, other, mine, A.p0, lut, lut_n); /* g(lower, upper) */
                     if (A.has_spacing) w = w / A.div26[d];
                 }
                 if (L.cap0) L.cap0[((int64_t)tile * MGC26_NDIR + d) * MGC_TV + t] = w; /* (as built) */
@@ -1489,8 +1494,8 @@ __device__ __forceinline__ void k_build_tiles(const MgcLattice& L, const MgcBuil
                     __syncthreads();
                     wA = (wA - pA) + (inA ? revB[t] : 0.0); /* my neighbour along dA pushed back to me along dB */
                     wB = (wB - pB) + (inB ? revA[t] : 0.0);
-                    plane0[(int64_t)dA * MGC_TV] = wA;
-                    plane0[(int64_t)dB * MGC_TV] = wB;
+                    __builtin_nontemporal_store(wA, &plane0[(int64_t)dA * MGC_TV]);
+                    __builtin_nontemporal_store(wB, &plane0[(int64_t)dB * MGC_TV]);
                     if (wA > 0.0) m |= 1u << dA;
                     if (wB > 0.0) m |= 1u << dB;
                 });
@@ -1502,7 +1507,7 @@ __device__ __forceinline__ void k_build_tiles(const MgcLattice& L, const MgcBuil
                 mgcw_static_for<MGC26_NDIR>([&](auto dc) __attribute__((always_inline)) {
                     constexpr int d = decltype(dc)::value;
                     const double w = weight(dc);
-                    plane0[(int64_t)d * MGC_TV] = w;
+                    __builtin_nontemporal_store(w, &plane0[(int64_t)d * MGC_TV]);
                     if (w > 0.0) m |= 1u << d;
                     if (d % 4 == 3) asm volatile("" ::: "memory"); /* four weights in flight, not 26: 26 keep 151 VGPRs alive (one workgroup per CU) */
                 });
@@ -1586,34 +1591,34 @@ __global__ __launch_bounds__(MGC_TV, FULL ? MGC_BUILD_WAVES26 : (PRE6 ? 4 : ((TE
 template <bool FULL>
 static void mgc_launch_build(int term, int grid, hipStream_t stream, const MgcLattice& L, const MgcBuildArgs& A)
 {
-    if constexpr (!FULL) {
-        if (A.prepush && A.prob) { /* a regional term: the instance with the pre-push */
-            switch (term) {
-#define MGC_BUILD_CASE6(T) case T: hipLaunchKernelGGL((k_build<false, T, true>), dim3(grid), dim3(MGC_TV), 0, stream, L, A); return;
-            MGC_BUILD_CASE6(MGC_TERM_NONE)
-            MGC_BUILD_CASE6(MGC_TERM_DIFFERENCE_LINEAR)
-            MGC_BUILD_CASE6(MGC_TERM_DIFFERENCE_EXPONENTIAL)
-            MGC_BUILD_CASE6(MGC_TERM_DIFFERENCE_DIVISION)
-            MGC_BUILD_CASE6(MGC_TERM_DIFFERENCE_POWER)
-            MGC_BUILD_CASE6(MGC_TERM_MAXIMUM_LINEAR)
-            MGC_BUILD_CASE6(MGC_TERM_MAXIMUM_EXPONENTIAL)
-            MGC_BUILD_CASE6(MGC_TERM_MAXIMUM_DIVISION)
-            default: hipLaunchKernelGGL((k_build<false, MGC_TERM_MAXIMUM_POWER, true>), dim3(grid), dim3(MGC_TV), 0, stream, L, A); return;
-#undef MGC_BUILD_CASE6
-            }
+    const bool pre6 = !FULL && A.prepush && A.prob; /* a regional term on the 6-neighbourhood: the instance with the pre-push */
+    if (!A.lut) { /* no table set: the instances without one (only these four terms are ever evaluated by table: for the others they would be the same code twice) */
+        switch (term) {
+#define MGC_BUILD_CASE_NT(T) case T: \
+            if (pre6) hipLaunchKernelGGL((k_build<false, T, true, false>), dim3(grid), dim3(MGC_TV), 0, stream, L, A); \
+            else hipLaunchKernelGGL((k_build<FULL, T, false, false>), dim3(grid), dim3(MGC_TV), 0, stream, L, A); \
+            return;
+        MGC_BUILD_CASE_NT(MGC_TERM_DIFFERENCE_EXPONENTIAL)
+        MGC_BUILD_CASE_NT(MGC_TERM_DIFFERENCE_POWER)
+        MGC_BUILD_CASE_NT(MGC_TERM_MAXIMUM_EXPONENTIAL)
+        MGC_BUILD_CASE_NT(MGC_TERM_MAXIMUM_POWER)
+#undef MGC_BUILD_CASE_NT
+        default: break;
         }
     }
-    if constexpr (!FULL) {
-        if (!A.lut) { /* (only these four terms are ever evaluated by table: for the others the instances would be the same code twice) */
-            switch (term) {
-#define MGC_BUILD_CASE_NT(T) case T: hipLaunchKernelGGL((k_build<false, T, false, false>), dim3(grid), dim3(MGC_TV), 0, stream, L, A); return;
-            MGC_BUILD_CASE_NT(MGC_TERM_DIFFERENCE_EXPONENTIAL)
-            MGC_BUILD_CASE_NT(MGC_TERM_DIFFERENCE_POWER)
-            MGC_BUILD_CASE_NT(MGC_TERM_MAXIMUM_EXPONENTIAL)
-            MGC_BUILD_CASE_NT(MGC_TERM_MAXIMUM_POWER)
-#undef MGC_BUILD_CASE_NT
-            default: break;
-            }
+    if (pre6) {
+        switch (term) {
+#define MGC_BUILD_CASE6(T) case T: hipLaunchKernelGGL((k_build<false, T, true>), dim3(grid), dim3(MGC_TV), 0, stream, L, A); return;
+        MGC_BUILD_CASE6(MGC_TERM_NONE)
+        MGC_BUILD_CASE6(MGC_TERM_DIFFERENCE_LINEAR)
+        MGC_BUILD_CASE6(MGC_TERM_DIFFERENCE_EXPONENTIAL)
+        MGC_BUILD_CASE6(MGC_TERM_DIFFERENCE_DIVISION)
+        MGC_BUILD_CASE6(MGC_TERM_DIFFERENCE_POWER)
+        MGC_BUILD_CASE6(MGC_TERM_MAXIMUM_LINEAR)
+        MGC_BUILD_CASE6(MGC_TERM_MAXIMUM_EXPONENTIAL)
+        MGC_BUILD_CASE6(MGC_TERM_MAXIMUM_DIVISION)
+        default: hipLaunchKernelGGL((k_build<false, MGC_TERM_MAXIMUM_POWER, true>), dim3(grid), dim3(MGC_TV), 0, stream, L, A); return;
+#undef MGC_BUILD_CASE6
         }
     }
     switch (term) {
