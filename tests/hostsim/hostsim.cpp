@@ -316,18 +316,22 @@ struct HostDev {
         uint16_t* const T = ds16.data();
         L.count[MGC_CNT_RADIAL_C] = MGC_HINF;
         for (int t = 0; t < L.ntiles; ++t) mgc_dt_cmin_tile(w, L, t); /* C from the exact labels of the source voxels */
-        radial_save_exact();
+        hexact.assign((size_t)L.ntiles * MGC_TV, 0); /* (filled by the last scan: the library's HipDevT::radial_begin, array for array) */
         for (int i = 0; i < L.gz * L.gy; ++i) mgc_dt_scan_line<0, false, 2, 0>(w, L, i, L.excess, T);
         for (int i = 0; i < L.gz * L.gy; ++i) mgc_dt_scan_line<0, true, 0, 0>(w, L, i, T, T);
         for (int i = 0; i < L.gz * L.gx; ++i) mgc_dt_scan_line<1, false, 0, 0>(w, L, i, T, T);
         for (int i = 0; i < L.gz * L.gx; ++i) mgc_dt_scan_line<1, true, 0, 0>(w, L, i, T, T);
         for (int i = 0; i < L.gy * L.gx; ++i) mgc_dt_scan_line<2, false, 0, 0>(w, L, i, T, T);
         lowered = L.count[MGC_CNT_RADIAL_C] < MGC_HINF && L.count[MGC_CNT_RADIAL_C] >= c_min;
-        for (int i = 0; i < L.gy * L.gx; ++i) mgc_dt_scan_line<2, true, 0, 2>(w, L, i, T, T, c_min); /* ... and the labels lowered on the way */
+        /* ... and the labels lowered on the way, into the OTHER array -- every label, lowered or not -- and the two trade places: the exact labels
+         * are never copied aside */
+        for (int i = 0; i < L.gy * L.gx; ++i) mgc_dt_scan_line<2, true, 0, 2>(w, L, i, T, T, c_min, hexact.data());
+        std::swap(height, hexact);
+        L.height = height.data();
         return true;
     }
     void radial_save_exact() { hexact.assign(L.height, L.height + (size_t)L.ntiles * MGC_TV); }
-    void radial_restore_exact() { memcpy(L.height, hexact.data(), hexact.size() * sizeof(int32_t)); lowered = false; }
+    void radial_restore_exact() { std::swap(height, hexact); L.height = height.data(); lowered = false; } /* (what the flood made of the radial labels is dropped as a whole) */
     void radial_lower(int c_min)
     {
         HostWave w(WS);
