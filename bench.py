@@ -165,14 +165,14 @@ def parity_relaxation_summary():
     return None
 
 
-def also_case(name, n, conn, regional, steps=3, warmup=1, golden_key=None):
+def also_case(name, n, conn, regional, steps=3, warmup=1, golden_key=None, workload="sphere"):
     """one more BASELINE config inside the driver's run: a fresh handle, `steps` timed build + solve steps (median), the dominant
     kernel's roofline fraction by the headline's formula, the device-side invariants, and the label hash against the
     reference's (tests/golden/reference_large.json) where the oracle reaches the size"""
     from medpy_amd import _lib, synthetic
     from medpy_amd.graphcut.graph import VoxelGraph
     shape = (n, n, n)
-    s = synthetic.sphere(shape, seed=0)
+    s = getattr(synthetic, workload)(shape, seed=0)
     g = VoxelGraph(shape, device=0, connectivity=conn if conn != 6 else None)
     g._set_boundary("difference_exponential", s["image"], s["sigma"], False)
     g._set_markers(s["fg"], s["bg"])
@@ -201,12 +201,12 @@ def also_case(name, n, conn, regional, steps=3, warmup=1, golden_key=None):
     achieved = (b_alg * vox) / (avg_ms * 1e-3) / 1e9 if avg_ms > 0 else 0.0
     v = g.validate()
     counts = ("negative_values", "active_excess", "residual_arcs_across", "sink_links_across", "pair_violations", "node_violations", "pending_outbox")
-    out = {"workload": "%d^3 sphere volume, %d-conn%s" % (n, conn, " + regional_probability_map" if regional else ""),
+    out = {"workload": "%d^3 %s volume (%s), %d-conn%s" % (n, workload, s["image"].dtype.name, conn, " + regional_probability_map" if regional else ""),
            "ms_per_step": round(ms, 3), "mvoxels_s": round(n ** 3 / (ms * 1e-3) / 1e6, 1), "steps": steps, "flow": flow,
            "kernel": "k_discharge_w" if conn == 6 else ("k26_discharge_w" if regional else "k26_discharge"), "frac": round(achieved / HBM_PEAK_GBS, 5),
            "job_roofline_frac": round(n ** 3 / (ms * 1e-3) * b_alg / (HBM_PEAK_GBS * 1e9), 6),
            "build_ms": round(acc["build_ms"] / steps, 3), "discharge_kernels_ms": round(acc["discharge_ms"] / steps, 3), "relabel_kernels_ms": round(acc["relabel_ms"] / steps, 3),
-           "global_relabels": acc["global_relabels"] / steps, "colour_phases": acc["phases"] / steps,
+           "global_relabels": acc["global_relabels"] / steps, "colour_phases": acc["phases"] / steps, "radial_cycles": st.get("radial_cycles"), "wall_tiles": st.get("wall_tiles"),
            "validation_all_zero": all(int(v[k]) == 0 for k in counts), "cut_capacity": v["cut_capacity"]}
     ref = golden_large().get(golden_key) if golden_key else None
     if ref is not None:
@@ -218,13 +218,18 @@ def also_case(name, n, conn, regional, steps=3, warmup=1, golden_key=None):
     return out
 
 
+def _pool_info():
+    from medpy_amd import _lib
+    return _lib.pool_info(0)
+
+
 def api_end_to_end(n=BLOCK, reps=5):
     """The public path from HOST arrays: graph_from_voxels(fg, bg, boundary_term, args) -> maxflow() -> labels(), wall clock per volume
     (H2D of image + markers, build, solve, read-out, D2H of the labels), median of `reps`; the reference's own call sequence
     (bin/medpy_graphcut_voxel.py:163-182) with the per-voxel what_segment loop replaced by the bulk read-out."""
     from medpy_amd import graphcut, synthetic
     s = synthetic.sphere((n, n, n), seed=0)
-    times, parts, labels = [], None, None
+    times, parts, labels = [], [], None
     for _ in range(reps + 1):
         t0 = time.perf_counter()
         g = graphcut.graph_from_voxels(s["fg"], s["bg"], boundary_term=graphcut.energy_voxel.boundary_difference_exponential,
@@ -234,14 +239,20 @@ def api_end_to_end(n=BLOCK, reps=5):
         t2 = time.perf_counter()
         labels = g.labels()
         t3 = time.perf_counter()
-        times.append(t3 - t0)
-        parts = (t1 - t0, t2 - t1, t3 - t2)
         g.close()
-    times = times[1:]  # (the first call pays the handle's first allocations)
+        t4 = time.perf_counter()
+        times.append(t3 - t0)
+        parts.append((t1 - t0, t2 - t1, t3 - t2, t4 - t3))
+    times, parts = times[1:], parts[1:]  # (the first call pays the handle's first allocations: every later one is served by the library's pool, mgc_pool_*)
     ms = float(np.median(times)) * 1e3
+    slow = int(np.argmax(times))
+
+    def split(p):
+        return {"graph_from_voxels (handle + H2D + build)": round(p[0] * 1e3, 2), "maxflow": round(p[1] * 1e3, 2), "labels (read-out + D2H)": round(p[2] * 1e3, 2),
+                "close (not in each_ms)": round(p[3] * 1e3, 2)}
     ref = golden_large().get("sphere_512_6") if n == 512 else None
     out = {"ms_per_volume": round(ms, 2), "mvoxels_s": round(n ** 3 / (ms * 1e-3) / 1e6, 1), "reps": reps, "each_ms": [round(t * 1e3, 2) for t in times],
-           "last_call_ms": {"graph_from_voxels (H2D + build)": round(parts[0] * 1e3, 2), "maxflow": round(parts[1] * 1e3, 2), "labels (read-out + D2H)": round(parts[2] * 1e3, 2)},
+           "last_call_ms": split(parts[-1]), "slowest_call_ms": split(parts[slow]), "device_memory_pool": _pool_info(),
            "flow": flow, "path": "medpy_amd.graphcut.graph_from_voxels(...).maxflow(); .labels() from host arrays (float32 image, bool markers)"}
     if ref is not None:
         out["labels_match_reference"] = bool(labels_sha256(labels) == ref["sha256_packed_labels"])
@@ -558,7 +569,13 @@ def main():
             out["api_end_to_end"] = api_end_to_end()
             out["also"] = {"config2": also_case("config2", 256, 6, False, golden_key="sphere_256_6"),
                            "config3": also_case("config3", 512, 26, True),
-                           "config3_at_256": also_case("config3_at_256", 256, 26, True, steps=1, warmup=1, golden_key="config3_256_26_regional")}
+                           "config3_at_256": also_case("config3_at_256", 256, 26, True, steps=1, warmup=1, golden_key="config3_256_26_regional"),
+                           # the inputs the headline volume says nothing about: weak contrast, ties everywhere, the
+                           # 26-neighbourhood without a regional term (config 5's per-GPU workload), an integer-valued (CT-like, uint16) volume
+                           "hard": also_case("hard", 512, 6, False, steps=2, workload="hard"),
+                           "ties": also_case("ties", 512, 6, False, steps=2, warmup=0, workload="ties"),
+                           "conn26_markers": also_case("conn26_markers", 512, 26, False, steps=2, warmup=0),
+                           "ct_uint16": also_case("ct_uint16", 512, 6, False, steps=2, workload="ct")}
         if not args.no_cpu and world == 1 and not args.config and not args.strong:
             out["cpu_baseline"] = cpu_baseline_in_run(args.cpu_sample, not args.cpu_sample_only)
         else:

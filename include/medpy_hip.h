@@ -119,6 +119,13 @@ int mgc_device_memory(int device, int64_t* free_bytes, int64_t* total_bytes);
 int mgc_create(int ndim, const int64_t* shape, int connectivity, int device, mgc_handle* out);
 int mgc_destroy(mgc_handle h);
 const char* mgc_last_error(mgc_handle h); /* h may be NULL: error of the last failed mgc_create */
+/* Device memory of destroyed handles is kept in a per-device pool (blocks >= 1 MiB, by exact size, up to MEDPY_HIP_POOL_MB --
+ * default an eighth of the device's memory; 0 switches the pool off) and handed to the next handle that asks for the same sizes:
+ * the reference allocates per graph (graph.cpp:12-31, one graph per volume in bin/medpy_graphcut_voxel.py:163-182), and a 13 GB
+ * handle per 512^3 volume is 0.5 - 0.8 s of hipMalloc / hipFree on some boxes.  An allocation that fails empties the pool first.
+ * mgc_pool_trim returns everything to the driver; mgc_pool_info reports what is idle and how often the pool served a request. */
+int mgc_pool_trim(int device);
+int mgc_pool_info(int device, int64_t* idle_bytes, int64_t* hits, int64_t* misses);
 
 /* Replaces boundary_<term>(graph, (image, sigma, spacing)) -> __skeleton_base
  * (energy_voxel.py:611-664).  `image` has the handle's shape.  p0: sigma for

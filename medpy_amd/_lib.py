@@ -104,6 +104,8 @@ SIGNATURES = {
     "mgc_create": (_INT, [_INT, C.POINTER(_I64), _INT, _INT, C.POINTER(_VP)]),
     "mgc_destroy": (_INT, [_VP]),
     "mgc_last_error": (C.c_char_p, [_VP]),
+    "mgc_pool_trim": (_INT, [_INT]),
+    "mgc_pool_info": (_INT, [_INT, C.POINTER(C.c_int64), C.POINTER(C.c_int64), C.POINTER(C.c_int64)]),
     "mgc_set_boundary": (_INT, [_VP, _INT, _VP, _INT, _DBL, C.POINTER(_DBL)]),
     "mgc_set_boundary_lut": (_INT, [_VP, _VP, _I64]),
     "mgc_set_regional_probability": (_INT, [_VP, _VP, _INT, _DBL]),
@@ -194,8 +196,22 @@ def device_count():
 
 def device_free_bytes(device=0):
     """free HBM of a device in bytes, or None when it cannot be asked"""
-    f, t = C.c_int64(0), C.c_int64(0)
-    return f.value if load().mgc_device_memory(int(device), C.byref(f), C.byref(t)) == OK else None
+    f, t, idle = C.c_int64(0), C.c_int64(0), C.c_int64(0)
+    if load().mgc_device_memory(int(device), C.byref(f), C.byref(t)) != OK:
+        return None
+    load().mgc_pool_info(int(device), C.byref(idle), None, None)  # what the library's own pool holds gives way to any allocation that needs it
+    return f.value + idle.value
+
+
+def pool_trim(device=0):
+    """hand the device memory the library keeps for the next handle (mgc_pool_*) back to the driver"""
+    return load().mgc_pool_trim(int(device))
+
+
+def pool_info(device=0):
+    idle, hits, misses = C.c_int64(0), C.c_int64(0), C.c_int64(0)
+    load().mgc_pool_info(int(device), C.byref(idle), C.byref(hits), C.byref(misses))
+    return {"idle_bytes": idle.value, "hits": hits.value, "misses": misses.value}
 
 
 def check(handle, rc):

@@ -2304,10 +2304,96 @@ static int mgc_fail(mgc_handle h, int code, const char* fmt, ...)
                             #call, hipGetErrorString(e_), __FILE__, __LINE__);                                 \
     } while (0)
 
+
+/* ---- device memory of a handle comes from a small per-device POOL ----
+ * A MedPy user calls graph_from_voxels once per volume (bin/medpy_graphcut_voxel.py:163-182), and the reference allocates per graph
+ * (graph.cpp:12-31).  Here a 512^3 handle is 13 GB: hipMalloc maps it page by page and hipFree unmaps it -- 0.5 - 0.8 s per volume on
+ * some boxes of the pool (BENCH_r05: api_end_to_end 57 ... 845 ms, every other call slow), thirty times the solve.  Blocks of at
+ * least MGC_POOL_MIN bytes that a handle gives back are therefore kept (per device, by exact size: the next handle of the same shape
+ * asks for exactly these sizes) up to a byte budget -- MEDPY_HIP_POOL_MB, default an eighth of the device's memory -- and handed
+ * out again without a trip to the driver.  What does not fit the budget is freed as before; an allocation that fails empties the
+ * pool and tries again, so the pool never turns a volume that fits the device into MGC_ERR_OOM.  mgc_pool_trim() empties it. */
+#define MGC_POOL_MIN ((size_t)1 << 20)
+struct MgcPool {
+    std::mutex lock;
+    std::multimap<size_t, void*> idle[16];  /* per device: size -> block */
+    std::map<void*, std::pair<size_t, int>> live; /* blocks handed out through mgc_dmalloc: size, device */
+    size_t idle_bytes[16] = {0};
+    long long budget[16];
+    long long hits = 0, misses = 0;
+    MgcPool() { for (auto& b : budget) b = -1; }
+    long long budget_of(int dev)
+    {
+        if (budget[dev] < 0) {
+            const char* e = getenv("MEDPY_HIP_POOL_MB");
+            if (e && *e) budget[dev] = atoll(e) << 20;
+            else {
+                size_t f = 0, t = 0;
+                budget[dev] = hipMemGetInfo(&f, &t) == hipSuccess ? (long long)(t / 8) : 0;
+            }
+        }
+        return budget[dev];
+    }
+    void trim(int dev) /* (lock held) */
+    {
+        for (auto& kv : idle[dev]) (void)hipFree(kv.second);
+        idle[dev].clear();
+        idle_bytes[dev] = 0;
+    }
+};
+static MgcPool g_pool;
+
+static hipError_t mgc_dmalloc(void** p, size_t bytes)
+{
+    int dev = 0;
+    (void)hipGetDevice(&dev);
+    dev &= 15;
+    std::lock_guard<std::mutex> guard(g_pool.lock);
+    if (bytes >= MGC_POOL_MIN) {
+        auto it = g_pool.idle[dev].find(bytes);
+        if (it != g_pool.idle[dev].end()) {
+            *p = it->second;
+            g_pool.idle[dev].erase(it);
+            g_pool.idle_bytes[dev] -= bytes;
+            g_pool.live[*p] = {bytes, dev};
+            g_pool.hits++;
+            return hipSuccess;
+        }
+    }
+    hipError_t e = hipMalloc(p, bytes);
+    if (e == hipErrorOutOfMemory && g_pool.idle_bytes[dev]) { /* the pool gives way before the caller sees an error */
+        (void)hipGetLastError();
+        g_pool.trim(dev);
+        e = hipMalloc(p, bytes);
+    }
+    if (e == hipSuccess) { g_pool.live[*p] = {bytes, dev}; g_pool.misses++; }
+    return e;
+}
+
+static hipError_t mgc_dfree(void* p)
+{
+    if (!p) return hipSuccess;
+    std::lock_guard<std::mutex> guard(g_pool.lock);
+    auto it = g_pool.live.find(p);
+    if (it == g_pool.live.end()) return hipFree(p);
+    const size_t bytes = it->second.first;
+    const int dev = it->second.second;
+    g_pool.live.erase(it);
+    if (bytes >= MGC_POOL_MIN && (long long)(g_pool.idle_bytes[dev] + bytes) <= g_pool.budget_of(dev)) {
+        /* hipFree waits for the device; a block that goes back into the pool must be just as quiet before another handle (another
+         * stream) is given it */
+        (void)hipDeviceSynchronize();
+        g_pool.idle[dev].insert({bytes, p});
+        g_pool.idle_bytes[dev] += bytes;
+        return hipSuccess;
+    }
+    return hipFree(p);
+}
+
 template <class T>
 static int mgc_alloc(mgc_handle h, T** p, int64_t count)
 {
-    MGC_HIP(h, hipMalloc((void**)p, (size_t)count * sizeof(T)));
+    MGC_HIP(h, mgc_dmalloc((void**)p, (size_t)count * sizeof(T)));
     h->device_bytes += count * (int64_t)sizeof(T);
     return MGC_OK;
 }
@@ -2436,7 +2522,7 @@ struct HipDevT {
          * saturated arcs, and all_residual is what k_build counted (labels_valid: some solve of this build filled the labels already) */
         if (FULL || !h->use_dt || !h->all_residual || h->labels_valid) return false;
         if (!h->d_dt16) {
-            if (hipMalloc((void**)&h->d_dt16, (size_t)h->L.ntiles * MGC_TV * sizeof(uint16_t)) != hipSuccess) { (void)hipGetLastError(); return false; }
+            if (mgc_dmalloc((void**)&h->d_dt16, (size_t)h->L.ntiles * MGC_TV * sizeof(uint16_t)) != hipSuccess) { (void)hipGetLastError(); return false; }
             h->device_bytes += (int64_t)h->L.ntiles * MGC_TV * (int64_t)sizeof(uint16_t);
         }
         flush_zero();
@@ -2465,11 +2551,11 @@ struct HipDevT {
         if (FULL) return false;
         const size_t nv = (size_t)h->L.ntiles * MGC_TV;
         if (!h->d_ds16) {
-            if (hipMalloc((void**)&h->d_ds16, nv * sizeof(uint16_t)) != hipSuccess) { (void)hipGetLastError(); return false; }
+            if (mgc_dmalloc((void**)&h->d_ds16, nv * sizeof(uint16_t)) != hipSuccess) { (void)hipGetLastError(); return false; }
             h->device_bytes += (int64_t)(nv * sizeof(uint16_t));
         }
         if (!h->d_hexact) {
-            if (hipMalloc((void**)&h->d_hexact, nv * sizeof(int32_t)) != hipSuccess) { (void)hipGetLastError(); return false; }
+            if (mgc_dmalloc((void**)&h->d_hexact, nv * sizeof(int32_t)) != hipSuccess) { (void)hipGetLastError(); return false; }
             h->device_bytes += (int64_t)(nv * sizeof(int32_t));
         }
         flush_zero();
@@ -2782,6 +2868,25 @@ int mgc_device_memory(int device, int64_t* free_bytes, int64_t* total_bytes)
 
 const char* mgc_last_error(mgc_handle h) { return h ? h->err.c_str() : g_create_error.c_str(); }
 
+int mgc_pool_trim(int device)
+{
+    if (device < 0 || device > 15) return MGC_ERR_INVALID;
+    if (hipSetDevice(device) != hipSuccess) { (void)hipGetLastError(); return MGC_ERR_NO_DEVICE; }
+    std::lock_guard<std::mutex> guard(g_pool.lock);
+    g_pool.trim(device);
+    return MGC_OK;
+}
+
+int mgc_pool_info(int device, int64_t* idle_bytes, int64_t* hits, int64_t* misses)
+{
+    if (device < 0 || device > 15) return MGC_ERR_INVALID;
+    std::lock_guard<std::mutex> guard(g_pool.lock);
+    if (idle_bytes) *idle_bytes = (int64_t)g_pool.idle_bytes[device];
+    if (hits) *hits = g_pool.hits;
+    if (misses) *misses = g_pool.misses;
+    return MGC_OK;
+}
+
 static int mgc_create_impl(int ndim, const int64_t* shape, int connectivity, int device, const MgcSlabSpec* slab, mgc_handle* out)
 {
     if (!out) return mgc_fail(nullptr, MGC_ERR_INVALID, "mgc_create: out is NULL");
@@ -2946,9 +3051,9 @@ int mgc_halo_bytes(mgc_handle h, int kind, int64_t* bytes)
 static int mgc_halo_staging(mgc_handle h, int64_t bytes)
 {
     if (h->halo_cap >= bytes) return MGC_OK;
-    if (h->d_halo) (void)hipFree(h->d_halo);
+    if (h->d_halo) (void)mgc_dfree(h->d_halo);
     h->d_halo = nullptr;
-    MGC_HIP(h, hipMalloc(&h->d_halo, (size_t)bytes));
+    MGC_HIP(h, mgc_dmalloc(&h->d_halo, (size_t)bytes));
     h->halo_cap = bytes;
     return MGC_OK;
 }
@@ -3091,7 +3196,7 @@ int mgc_comm_init(mgc_handle h, const uint8_t* id128)
     ncclUniqueId id;
     memcpy(&id, id128, NCCL_UNIQUE_ID_BYTES);
     MGC_NCCL(h, g_rccl.CommInitRank(&h->comm, h->nranks, id, h->rank));
-    if (!h->d_cnt64) MGC_HIP(h, hipMalloc((void**)&h->d_cnt64, 2 * MGC_NCOUNT * sizeof(int64_t)));
+    if (!h->d_cnt64) MGC_HIP(h, mgc_dmalloc((void**)&h->d_cnt64, 2 * MGC_NCOUNT * sizeof(int64_t)));
     return MGC_OK;
 }
 
@@ -3130,9 +3235,9 @@ int mgc_halo_exchange(mgc_handle h, int kind, uint32_t epoch, int list)
     if (mgc_halo_bytes_nd(h->L, 0) > bytes) bytes = mgc_halo_bytes_nd(h->L, 0);
     if (h->xchg_cap < bytes) {
         for (int i = 0; i < 4; ++i) {
-            if (h->d_xchg[i]) (void)hipFree(h->d_xchg[i]);
+            if (h->d_xchg[i]) (void)mgc_dfree(h->d_xchg[i]);
             h->d_xchg[i] = nullptr;
-            MGC_HIP(h, hipMalloc(&h->d_xchg[i], (size_t)bytes));
+            MGC_HIP(h, mgc_dmalloc(&h->d_xchg[i], (size_t)bytes));
         }
         h->xchg_cap = bytes;
     }
@@ -3382,7 +3487,7 @@ int mgc_destroy(mgc_handle h)
                     L.list[13], L.list[14], L.list[15], L.list[16], L.list[17], L.count, L.stamp, L.rstamp, L.status, h->d_tr0, h->d_part, h->d_part2, h->d_scalar,
                     h->d_labels, h->d_tflags, h->d_tsum, h->d_image, h->d_lut, h->d_prob, h->d_fg, h->d_bg, h->d_tr_in, h->d_eslot, h->d_eval, h->d_erun, L.hshadow[0], L.hshadow[1], h->d_vout, h->d_dt16, h->d_ds16, h->d_hexact, h->d_halo, h->d_xchg[0], h->d_xchg[1], h->d_xchg[2], h->d_xchg[3], h->d_cnt64};
     for (void* p : ptrs)
-        if (p) (void)hipFree(p);
+        if (p) (void)mgc_dfree(p);
     if (h->h_count) (void)hipHostFree(h->h_count);
     if (h->h_scalar) (void)hipHostFree(h->h_scalar);
     free(h->h_labels);
@@ -3500,13 +3605,13 @@ static int mgc_upload(mgc_handle h, void** dst, const void* src, size_t bytes)
     size_t& cap = h->buf_cap[(const void*)dst];
     if (*dst && cap < bytes) {
         MGC_HIP(h, hipStreamSynchronize(h->stream));
-        MGC_HIP(h, hipFree(*dst));
+        MGC_HIP(h, mgc_dfree(*dst));
         h->device_bytes -= (int64_t)cap;
         *dst = nullptr;
         cap = 0;
     }
     if (!*dst) {
-        MGC_HIP(h, hipMalloc(dst, bytes));
+        MGC_HIP(h, mgc_dmalloc(dst, bytes));
         h->device_bytes += (int64_t)bytes;
         cap = bytes;
     }
@@ -3526,7 +3631,7 @@ int mgc_set_boundary(mgc_handle h, int term, const void* image, int dtype, doubl
     if (term == MGC_TERM_NONE) return MGC_OK;
     const size_t es = mgc_dtype_size(dtype);
     if (!image || !es) return mgc_fail(h, MGC_ERR_INVALID, "mgc_set_boundary: image NULL or bad dtype %d", dtype);
-    if (h->d_image && h->img_dtype != dtype) { (void)hipFree(h->d_image); h->d_image = nullptr; }
+    if (h->d_image && h->img_dtype != dtype) { (void)mgc_dfree(h->d_image); h->d_image = nullptr; }
     h->img_dtype = dtype;
     h->sigma = sigma;
     h->has_spacing = spacing ? 1 : 0;
@@ -3558,7 +3663,7 @@ int mgc_set_regional_probability(mgc_handle h, const void* pm, int dtype, double
     if (!h) return MGC_ERR_INVALID;
     if (!pm || (dtype != MGC_F32 && dtype != MGC_F64)) return mgc_fail(h, MGC_ERR_INVALID, "probability map must be float32 or float64");
     MGC_HIP(h, hipSetDevice(h->device));
-    if (h->d_prob && h->prob_dtype != dtype) { (void)hipFree(h->d_prob); h->d_prob = nullptr; }
+    if (h->d_prob && h->prob_dtype != dtype) { (void)mgc_dfree(h->d_prob); h->d_prob = nullptr; }
     h->prob_dtype = dtype;
     h->alpha = alpha;
     h->built = h->solved = false;
@@ -3572,10 +3677,10 @@ int mgc_set_markers(mgc_handle h, const uint8_t* fg, const uint8_t* bg)
     h->built = h->solved = false;
     int rc = MGC_OK;
     if (fg) rc = mgc_upload(h, (void**)&h->d_fg, fg, (size_t)h->nvox);
-    else if (h->d_fg) { (void)hipFree(h->d_fg); h->d_fg = nullptr; }
+    else if (h->d_fg) { (void)mgc_dfree(h->d_fg); h->d_fg = nullptr; }
     if (rc) return rc;
     if (bg) rc = mgc_upload(h, (void**)&h->d_bg, bg, (size_t)h->nvox);
-    else if (h->d_bg) { (void)hipFree(h->d_bg); h->d_bg = nullptr; }
+    else if (h->d_bg) { (void)mgc_dfree(h->d_bg); h->d_bg = nullptr; }
     return rc;
 }
 
@@ -3597,7 +3702,7 @@ int mgc_validate(mgc_handle h, mgc_validation* out)
     MgcLattice& L = h->L;
     memset(out, 0, sizeof(*out));
     if (!h->labels_valid) return mgc_fail(h, MGC_ERR_STATE, "mgc_validate before a solve: the distance labels of this build were never computed");
-    if (!h->d_vout) MGC_HIP(h, hipMalloc((void**)&h->d_vout, sizeof(MgcValidateOut)));
+    if (!h->d_vout) MGC_HIP(h, mgc_dmalloc((void**)&h->d_vout, sizeof(MgcValidateOut)));
     MgcValidateOut* const d_out = (MgcValidateOut*)h->d_vout;
     MGC_HIP(h, hipMemsetAsync(d_out, 0, sizeof(MgcValidateOut), h->stream));
     const int grid = L.ntiles < h->grid_cap * 4 ? L.ntiles : h->grid_cap * 4;
@@ -3963,12 +4068,12 @@ int mgc_get_nweights(mgc_handle h, int axis, double* out)
     const int64_t n = osh[0] * osh[1] * osh[2];
     if (n <= 0) return MGC_OK;
     double* d = nullptr;
-    MGC_HIP(h, hipMalloc((void**)&d, (size_t)n * sizeof(double)));
+    MGC_HIP(h, mgc_dmalloc((void**)&d, (size_t)n * sizeof(double)));
     hipLaunchKernelGGL(k_get_nweights, dim3(1024), dim3(256), 0, h->stream, h->L, h->build_args, a3, d);
     hipError_t e = hipGetLastError();
     if (e == hipSuccess) e = hipMemcpyAsync(out, d, (size_t)n * sizeof(double), hipMemcpyDeviceToHost, h->stream);
     if (e == hipSuccess) e = hipStreamSynchronize(h->stream);
-    (void)hipFree(d);
+    (void)mgc_dfree(d);
     MGC_HIP(h, e);
     return MGC_OK;
 }
@@ -3985,12 +4090,12 @@ int mgc_get_nweights_offset(mgc_handle h, const int* offset, double* out)
     if (nz == 0 || (h->L.ndir == 6 && nz != 1)) return mgc_fail(h, MGC_ERR_INVALID, "offset is not a neighbour of this lattice");
     MGC_HIP(h, hipSetDevice(h->device));
     double* d = nullptr;
-    MGC_HIP(h, hipMalloc((void**)&d, (size_t)h->nvox * sizeof(double)));
+    MGC_HIP(h, mgc_dmalloc((void**)&d, (size_t)h->nvox * sizeof(double)));
     hipLaunchKernelGGL(k_get_nweights_offset, dim3(1024), dim3(256), 0, h->stream, h->L, h->build_args, o[0], o[1], o[2], d);
     hipError_t e = hipGetLastError();
     if (e == hipSuccess) e = hipMemcpyAsync(out, d, (size_t)h->nvox * sizeof(double), hipMemcpyDeviceToHost, h->stream);
     if (e == hipSuccess) e = hipStreamSynchronize(h->stream);
-    (void)hipFree(d);
+    (void)mgc_dfree(d);
     MGC_HIP(h, e);
     return MGC_OK;
 }
@@ -4001,12 +4106,12 @@ int mgc_get_tweights(mgc_handle h, double* out)
     if (!h->built) return mgc_fail(h, MGC_ERR_STATE, "mgc_get_tweights before mgc_build");
     MGC_HIP(h, hipSetDevice(h->device));
     double* d = nullptr;
-    MGC_HIP(h, hipMalloc((void**)&d, (size_t)h->nvox * sizeof(double)));
+    MGC_HIP(h, mgc_dmalloc((void**)&d, (size_t)h->nvox * sizeof(double)));
     hipLaunchKernelGGL(k_untile_f64, dim3(1024), dim3(256), 0, h->stream, h->L, (const double*)h->d_tr0, (const uint8_t*)h->d_tflags, d);
     hipError_t e = hipGetLastError();
     if (e == hipSuccess) e = hipMemcpyAsync(out, d, (size_t)h->nvox * sizeof(double), hipMemcpyDeviceToHost, h->stream);
     if (e == hipSuccess) e = hipStreamSynchronize(h->stream);
-    (void)hipFree(d);
+    (void)mgc_dfree(d);
     MGC_HIP(h, e);
     return MGC_OK;
 }
@@ -4091,10 +4196,10 @@ int mgc_set_param(mgc_handle h, const char* name, int64_t value)
     else if (!strcmp(name, "timing_stride") && value > 0) h->timing_stride = (int)value;
     else if (!strcmp(name, "profile_sections")) {
         if (value && !h->L.prof) {
-            MGC_HIP(h, hipMalloc((void**)&h->L.prof, 16 * sizeof(unsigned long long)));
+            MGC_HIP(h, mgc_dmalloc((void**)&h->L.prof, 16 * sizeof(unsigned long long)));
         }
         if (h->L.prof) MGC_HIP(h, hipMemset(h->L.prof, 0, 16 * sizeof(unsigned long long)));
-        if (!value && h->L.prof) { (void)hipFree(h->L.prof); h->L.prof = nullptr; }
+        if (!value && h->L.prof) { (void)mgc_dfree(h->L.prof); h->L.prof = nullptr; }
     }
     else return mgc_fail(h, MGC_ERR_INVALID, "unknown or invalid parameter %s=%lld", name, (long long)value);
     return MGC_OK;

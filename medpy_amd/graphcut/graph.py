@@ -317,7 +317,7 @@ class SparseGraph(object):
         self._first_arc = {}   # (i, j) -> capacity of the arc get_arc(i, j) meets first (raw add_edge / sum_edge calls only)
         self._raw_pairs = set()
         self._host_arcs = {}   # GraphFloat / GraphInt: (i, j) -> [capacity of the front arc, sum of the parallel arcs behind it]
-        self._host_sent = False
+        self._host_sent = {}   # ... (i, j) with i < j -> (capacity, reverse capacity) the device holds for the pair so far
 
     def reset(self):
         """Graph::reset, reference graph.cpp:46-60 (wrapper.cpp:68): back to the state just after construction -- no nodes
@@ -500,17 +500,26 @@ class SparseGraph(object):
         return self._out(flow.value)
 
     def _send_host_arcs(self):
-        """GraphFloat / GraphInt: the arcs accumulated on the host go to the device once, parallel arcs summed (exactly: float32
-        values and integers add without rounding in float64)"""
-        if not self._host_arcs or self._host_sent:
+        """GraphFloat / GraphInt: the arcs accumulated on the host go to the device, parallel arcs summed (exactly: float32
+        values and integers add without rounding in float64).  The reference's Graph<int> / Graph<float> take ``add_edge`` /
+        ``sum_edge`` at any time (graph.h:428-480), also between two ``maxflow()`` calls: what goes down here is, per node pair,
+        the DIFFERENCE between the pair's capacities now and what the device was last told -- exact in float64 for the same
+        reason the sums are -- so edges added after a first solve are part of the next one."""
+        if not self._host_arcs:
             return
-        keys = [k for k in self._host_arcs if k[0] < k[1]]
-        i = numpy.array([k[0] for k in keys], dtype=numpy.int64)
-        j = numpy.array([k[1] for k in keys], dtype=numpy.int64)
-        cap = numpy.array([float(self._host_arcs[k][0]) + float(self._host_arcs[k][1]) for k in keys], dtype=numpy.float64)
-        rev = numpy.array([float(self._host_arcs[(k[1], k[0])][0]) + float(self._host_arcs[(k[1], k[0])][1]) for k in keys], dtype=numpy.float64)
-        self._add_edges(i, j, cap, rev)
-        self._host_sent = True
+        ii, jj, cc, rr = [], [], [], []
+        for k, a in self._host_arcs.items():
+            if k[0] >= k[1]:
+                continue
+            b = self._host_arcs[(k[1], k[0])]
+            now = (float(a[0]) + float(a[1]), float(b[0]) + float(b[1]))
+            was = self._host_sent.get(k, (0.0, 0.0))
+            if now != was:
+                ii.append(k[0]); jj.append(k[1]); cc.append(now[0] - was[0]); rr.append(now[1] - was[1])
+                self._host_sent[k] = now
+        if ii:
+            self._add_edges(numpy.array(ii, dtype=numpy.int64), numpy.array(jj, dtype=numpy.int64),
+                            numpy.array(cc, dtype=numpy.float64), numpy.array(rr, dtype=numpy.float64))
 
     def labels(self):
         """every node at once: bool array, False where what_segment == SINK"""

@@ -51,6 +51,18 @@ def ties(shape, seed=0):
     return {"image": img, "fg": fg, "bg": bg, "sigma": 1.0, "term": "difference_exponential"}
 
 
+def ct(shape, seed=0):
+    """Integer-valued volume in the manner of CT / MR data (uint16): soft tissue at 1040 +- 20 around a denser organ (1100 +- 20,
+    r < 0.3 n), whole numbers throughout -- so the exponential term goes by table (graph.py:boundary_table), weights repeat
+    everywhere and exact ties between cuts are the rule; sigma 25; fg = r < 0.1 n, bg = the six faces."""
+    shape = tuple(int(s) for s in shape)
+    n = min(shape)
+    r = _radius(shape)
+    img = 1040.0 + 60.0 * (r < 0.3 * n) + np.random.default_rng(seed).normal(0.0, 20.0, shape)
+    img = np.clip(np.rint(img), 0, 65535).astype(np.uint16)
+    return {"image": img, "fg": r < 0.1 * n, "bg": _faces(shape), "sigma": 25.0, "term": "difference_exponential"}
+
+
 def regional(shape, seed=1):
     """float32 probability map for regional_probability_map (alpha 0.5)."""
     shape = tuple(int(s) for s in shape)

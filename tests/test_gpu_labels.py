@@ -321,3 +321,45 @@ def test_graph_float_and_int_compute_in_their_type():
     assert flow == 2 and isinstance(flow, int)
     with pytest.raises(TypeError):
         g.add_edge(0, 2, 1.5, 0)
+
+
+@pytest.mark.parametrize("kind", ["float", "int"])
+def test_edges_added_after_a_solve_are_part_of_the_next(kind):
+    """Graph<int> / Graph<float> take add_edge / sum_edge at any time (graph.h:428-480), also between two maxflow() calls: the
+    second solve sees the new arcs (the capacities went to the device once only until round 6).  Against GraphDouble driven
+    through the same calls and against the compiled reference."""
+    from medpy_amd.graphcut import GraphDouble, GraphFloat, GraphInt
+    from oracle import bk
+    rng = np.random.default_rng(5)
+    n = 40
+    G = GraphFloat if kind == "float" else GraphInt
+    g, d = G(n, 4), GraphDouble(n, 4)
+    g.add_node(n); d.add_node(n)
+    # (float: eighths, so that the float32 running sums of sum_edge are exact and GraphDouble / the reference see the same capacities)
+    val = (lambda: float(rng.integers(1, 33)) / 8.0) if kind == "float" else (lambda: int(rng.integers(1, 9)))
+    calls = []
+
+    def both(name, *a):
+        calls.append((name, a))
+        getattr(g, name)(*a); getattr(d, name)(*a)
+
+    for u in range(n):
+        both("add_tweights", u, val(), val())
+    for _ in range(3):  # three solves, edges added in between with both calls
+        for _e in range(60):
+            i, j = (int(v) for v in rng.integers(0, n, 2))
+            if i != j:
+                both("add_edge" if rng.random() < 0.5 else "sum_edge", i, j, val(), val())
+        fg, fd = g.maxflow(), d.maxflow()
+        assert abs(fg - fd) <= 1e-9 * max(1.0, abs(fd)), (fg, fd)
+        assert np.array_equal(g.labels(), d.labels())
+        # ... and the reference, told everything so far
+        o = bk.BKGraph(n, 4 * len(calls))
+        for name, a in calls:
+            if name == "add_tweights":
+                o.add_tweights(np.array([a[0]]), np.array([float(a[1])]), np.array([float(a[2])]))
+            else:
+                o.sum_edges(np.array([a[0]]), np.array([a[1]]), np.array([float(a[2])]), np.array([float(a[3])]))
+        fo = o.maxflow()
+        assert abs(fg - fo) <= 1e-9 * max(1.0, abs(fo)), (fg, fo)
+        assert np.array_equal(g.labels().astype(np.uint8), o.labels())
