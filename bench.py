@@ -397,7 +397,7 @@ def main():
             n, conn, " + regional_probability_map (float32, alpha 0.5)" if regional else "")
     else:
         from medpy_amd.rendezvous import FileStore
-        from medpy_amd.slab import HipSlab, LoopbackExchange, RcclExchange, StoreExchange, solve_slabs, validate_slabs
+        from medpy_amd.slab import HipSlab, LoopbackExchange, RcclExchange, StoreExchange, solve_slabs, sync_boundary_table, validate_slabs
         # The launcher of the contract only provides RANK / LOCAL_RANK / WORLD_SIZE / MASTER_*; nothing here imports an ML framework.  Out-of-band channel (the RCCL id, barriers, a few host scalars): a private directory of files
         # (medpy_amd/rendezvous.py).  MEDPY_DIST_BACKEND=host: development aid -- the borders travel through host buffers and that
         # directory, the ranks may share a GPU (exercises this code path on a 1-GPU box).  Default: RCCL over xGMI, driven by the
@@ -434,8 +434,8 @@ def main():
                 try:
                     e = RcclExchange(slab, store)
                     slab.build()
-                    e.exchange(0, 1, 4)
-                    e.global_counts()
+                    slab.exchange(0, 1, 4)   # (one border message each way and one counter reduction: the channel works before the clock starts)
+                    slab.allreduce_counts()
                     box["ex"] = e
                 except Exception as err:  # noqa: BLE001 -- reported below
                     box["err"] = repr(err)
@@ -453,6 +453,8 @@ def main():
         else:
             ex, transport = StoreExchange(slab, store), "host-staged borders through files (MEDPY_DIST_BACKEND=host: development run, not an RCCL number)"
 
+        # integer-valued images: the term by table is ONE decision for the whole volume; a float image leaves the device's exp
+        sync_boundary_table([slab], ex if world > 1 else LoopbackExchange([slab]))
         wall = {"build": 0.0, "solve": 0.0}
 
         def step():

@@ -268,6 +268,26 @@ typedef struct mgc_slab_stats {
     int64_t reserved[7];
 } mgc_slab_stats;
 int mgc_solve_slab(mgc_handle h, mgc_slab_stats* out);
+
+/* ONE entry point for every way a volume's slabs can be laid out (round 6; the schedule is the single handle's own, mgc_solve in
+ * medpy_amd/csrc/mgc_driver.inl, with the borders exchanged at its hook points -- first relabel by distance transform carried
+ * across the slab borders, flood phase on radial labels, incremental relabels):
+ *   n == the number of slabs of the volume: ALL slabs are handles of this process on one device (time-multiplexed on one GPU: how
+ *       the multi-GPU schedule is exercised and measured where there is one GPU); `t` is ignored;
+ *   n == 1, mgc_comm_init was called: this rank's slab, borders and reductions over RCCL / xGMI (what bench.py --gpus N runs);
+ *   n == 1, `t` given: borders and reductions through the caller's callbacks on HOST buffers (development transports: gloo,
+ *       a directory of files).
+ * Replaces the serial loop of Graph::maxflow (maxflow.cpp:472-604) for a volume cut into Z-slabs. */
+typedef struct mgc_transport {
+    void* ctx;
+    /* both borders at once: send_lo / recv_lo with rank - 1, send_hi / recv_hi with rank + 1 (a pair is NULL where the volume ends), nbytes each */
+    int (*exchange)(void* ctx, const void* send_lo, void* recv_lo, const void* send_hi, void* recv_hi, int64_t nbytes);
+    int (*allreduce)(void* ctx, int64_t* v, int n, int op); /* in place over all ranks; op 0 = sum, 1 = min */
+    /* point to point with the neighbour on `side` (0: rank - 1, 1: rank + 1): the carry planes of the distance transforms, a pipeline over the ranks */
+    int (*send)(void* ctx, int side, const void* buf, int64_t nbytes);
+    int (*recv)(void* ctx, int side, void* buf, int64_t nbytes);
+} mgc_transport;
+int mgc_solve_slabs(mgc_handle* slabs, int n, const mgc_transport* t, mgc_slab_stats* out);
 int mgc_allreduce_counts(mgc_handle h, int64_t* out32);
 
 

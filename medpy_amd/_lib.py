@@ -85,6 +85,17 @@ class SlabStats(C.Structure):
         return {k: int(getattr(self, k)) for k, _ in self._fields_ if k != "reserved"}
 
 
+# mgc_transport (include/medpy_hip.h): the callbacks of a host transport for mgc_solve_slabs
+XCHG_FN = C.CFUNCTYPE(C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int64)
+ALLREDUCE_FN = C.CFUNCTYPE(C.c_int, C.c_void_p, C.POINTER(C.c_int64), C.c_int, C.c_int)
+SEND_FN = C.CFUNCTYPE(C.c_int, C.c_void_p, C.c_int, C.c_void_p, C.c_int64)
+RECV_FN = C.CFUNCTYPE(C.c_int, C.c_void_p, C.c_int, C.c_void_p, C.c_int64)
+
+
+class Transport(C.Structure):
+    _fields_ = [("ctx", C.c_void_p), ("exchange", XCHG_FN), ("allreduce", ALLREDUCE_FN), ("send", SEND_FN), ("recv", RECV_FN)]
+
+
 class SparseStats(C.Structure):
     _fields_ = [("build_ms", C.c_double), ("solve_ms", C.c_double), ("rounds", C.c_int64), ("global_relabels", C.c_int64),
                 ("relabel_passes", C.c_int64), ("nodes", C.c_int64), ("arcs", C.c_int64), ("edges_added", C.c_int64),
@@ -141,6 +152,7 @@ SIGNATURES = {
     "mgc_halo_exchange": (_INT, [_VP, _INT, C.c_uint32, _INT]),
     "mgc_allreduce_counts": (_INT, [_VP, _VP]),
     "mgc_solve_slab": (_INT, [_VP, C.POINTER(SlabStats)]),
+    "mgc_solve_slabs": (_INT, [C.POINTER(C.c_void_p), _INT, C.POINTER(Transport), C.POINTER(SlabStats)]),
     # sparse graphs (region graph cut, n-D voxel graphs, edge-by-edge plug-ins)
     "msg_create": (_INT, [_I64, _INT, C.POINTER(_VP)]),
     "msg_destroy": (_INT, [_VP]),

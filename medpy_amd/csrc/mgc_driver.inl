@@ -24,11 +24,18 @@
  *   radial labels (mgc_dt_ops.inl; only after first_relabel_dt() returned true):
  *   radial_begin(c_min) -> bool  (distance from the source, C into MGC_CNT_RADIAL_C, exact labels kept aside, labels lowered)
  *   radial_restore_exact()  radial_save_exact()  radial_lower(c_min)  source_open() (counts into MGC_CNT_SOURCE_OPEN)  set_radial(bool)
+ *   Z-slabs (a Dev that stands for the slabs of one volume, MgcSlabGroup below): multi() -> bool  exchange(kind, epoch, list)  (border
+ *   messages of kind 0 labels / 1 labels + outbox flow / 2 suspect flags to the neighbour slabs; a single device: multi() is false and
+ *   exchange() is never called).  read_counts() of such a Dev returns the counters SUMMED OVER ALL SLABS, so every rank takes every
+ *   decision of the schedule alike.
  */
 #ifndef MGC_DRIVER_INL
 #define MGC_DRIVER_INL
 
 #include "mgc_common.h"
+#include "../../include/medpy_hip.h" /* mgc_transport */
+
+#include <vector>
 
 struct MgcSolveParams {
     int rounds_per_relabel; /* colour-phase rounds between two global relabels            */
@@ -48,6 +55,9 @@ struct MgcSolveParams {
     int radial_min_c;       /* ... only when the shortest source -> sink path has at least this many hops               */
     int radial_rounds0;     /* colour rounds of the first radial cycle; 0: one cycle of the whole budget                 */
     int radial_budget_x16;  /* most colour rounds on radial labels, in sixteenths of (tiles on the shortest source -> sink path) */
+    int exchange_passes;    /* Z-slabs: relabel passes between two exchanges of the border labels */
+    int exchange_rounds;    /* Z-slabs: colour rounds between two exchanges of the border labels + outbox flow (6-neighbourhood; the full
+                               neighbourhood pushes into the ghost tiles in place and exchanges after every phase) */
 };
 
 struct MgcSolveStats {
@@ -60,6 +70,7 @@ struct MgcSolveStats {
     int64_t last_active;      /* active tiles found by the last activation pass            */
     int64_t readbacks;        /* counter read-backs (host syncs)                           */
     int64_t radial_cycles;    /* cycles of colour phases that ran on radial labels         */
+    int64_t deferred_drains;  /* Z-slabs: extra exchanges that carried what a full border message had left behind */
 };
 
 /* where a solver variant keeps its lists and counters (6-neighbourhood: 2 colours, lists 0..3 + 4,5;
@@ -97,6 +108,8 @@ static inline MgcSolveParams mgc_default_params(int ndir = 6)
     p.radial = ndir == 6 ? 2 : 0; /* 2: decided per graph by whoever calls mgc_solve (mgc_maxflow: wall tiles counted by k_build); the host simulator treats 2 as 1 */
     p.radial_min_c = 8;
     p.radial_budget_x16 = 8;
+    p.exchange_passes = 4; /* (2048 x 1024 x 1024 in eight slabs: 2 072 passes per solve at 4, 6 280 when every slab ran to its local fixpoint first, round 4) */
+    p.exchange_rounds = 1;
     p.radial_rounds0 = 0; /* 0: ONE radial cycle as long as the flood may take (radial_budget below).  Measured on MI355X, headline volume 512^3:
                              35.9 ms on exact labels; first radial cycle of 4 rounds (then 8, then 4, a relabel in between) 26.1 ms, 6: 23.4,
                              8: 24.4, 16 (= the budget, one cycle): 22.0 ms; 256^3: 9.5 / 5.3 (4) / 4.8 (8 = the budget).  A short first cycle
@@ -121,6 +134,16 @@ int mgc_solve(Dev& dev, const MgcLattice& L, const MgcSolveParams& P, MgcSolveSt
     for (int outer = 0; outer < P.max_outer; ++outer) {
         /* ---- global relabel ---- */
         dev.range_push("global relabel");
+        if (dev.multi() && outer > 0) { /* flow a full border message left behind during the colour phases must have crossed before the masks are read */
+            for (;;) {
+                dev.read_counts(cnt);
+                st.readbacks++;
+                if (cnt[MGC_CNT_DEFERRED] == 0) break;
+                dev.zero_count(MGC_CNT_DEFERRED);
+                dev.exchange(1, phase - 1, 0);
+                st.deferred_drains++;
+            }
+        }
         dev.absorb_all();
         dev.zero_count(lay.rl_base);
         dev.zero_count(lay.rl_base + 1);
@@ -138,6 +161,7 @@ int mgc_solve(Dev& dev, const MgcLattice& L, const MgcSolveParams& P, MgcSolveSt
             for (;;) {
                 dev.zero_count(MGC_CNT_CHANGED);
                 for (int b = 0; b < dev.suspect_batch(); ++b) dev.suspect_pass();
+                if (dev.multi()) dev.exchange(2, 0, 0); /* the DIRTY / SUSPECT flags of the border tiles: the closure crosses the slab borders */
                 dev.read_counts(cnt);
                 st.readbacks++;
                 if (cnt[MGC_CNT_CHANGED] == 0) break;
@@ -161,33 +185,48 @@ int mgc_solve(Dev& dev, const MgcLattice& L, const MgcSolveParams& P, MgcSolveSt
              * a look at the counters a stream drain) */
             int batch = outer > 0 && last_passes > P.relabel_batch ? (int)last_passes : P.relabel_batch;
             int64_t passes_now = 0;
+            /* Z-slabs: the label wave of a global relabel has to cross every slab border on its way through the volume, so the border
+             * labels travel every `xk` passes whatever the slabs' state (labels only go down during a relabel: a ghost label is an upper
+             * bound whenever it is read, and a wave that reaches a border is on the other side at most xk passes later); what an
+             * exchange wakes goes to the list the next pass consumes.  Every rank runs the same passes (one over an empty list is a
+             * no-op of microseconds) and the ranks compare notes at the end of a stretch, behind one more exchange. */
+            const bool multi = dev.multi();
+            const int xk = P.exchange_passes > 0 ? P.exchange_passes : 4;
             for (;;) {
+                if (multi) dev.zero_count(MGC_CNT_DEFERRED); /* (counts what the exchanges of this stretch leave behind) */
+                int since = 0;
                 for (int b = 0; b < batch; ++b, ++k) {
                     rep++;
                     dev.relabel_list(lists[k % 3], rep + 1, lists[(k + 1) % 3], lists[(k + 2) % 3]);
                     st.relabel_passes++;
                     passes_now++;
+                    if (multi && (++since == xk || b + 1 == batch)) { dev.exchange(0, rep + 1, lists[(k + 1) % 3]); since = 0; }
                 }
                 dev.read_counts(cnt);
                 st.readbacks++;
-                if (cnt[lists[k % 3]] == 0) { /* the last pass woke nobody: fixpoint */
+                if (cnt[lists[k % 3]] == 0 && !(multi && cnt[MGC_CNT_DEFERRED])) { /* the last pass (and the exchange behind it) woke nobody, nothing was left behind: fixpoint */
                     last_passes = passes_now - batch + 1; /* (the wave died somewhere inside the last stretch: what is known to have been needed) */
                     break;
                 }
                 batch = P.relabel_batch > 4 ? P.relabel_batch / 2 : P.relabel_batch;
             }
         } else {
+            const bool multi = dev.multi();
+            const int xk = P.exchange_passes > 0 ? P.exchange_passes : 4;
             for (;;) {
+                if (multi) dev.zero_count(MGC_CNT_DEFERRED);
+                int since = 0;
                 for (int b = 0; b < P.relabel_batch; ++b) {
                     rep++;
                     const int cur = lay.rl_base + (int)(rep & 1u), nxt = lay.rl_base + (int)((rep + 1) & 1u);
                     dev.zero_count(nxt);
                     dev.relabel_list(cur, rep + 1, nxt, -1);
                     st.relabel_passes++;
+                    if (multi && (++since == xk || b + 1 == P.relabel_batch)) { dev.exchange(0, rep + 1, nxt); since = 0; }
                 }
                 dev.read_counts(cnt);
                 st.readbacks++;
-                if (cnt[lay.rl_base + (int)((rep + 1) & 1u)] == 0) break; /* the last pass woke nobody: fixpoint */
+                if (cnt[lay.rl_base + (int)((rep + 1) & 1u)] == 0 && !(multi && cnt[MGC_CNT_DEFERRED])) break; /* the last pass woke nobody: fixpoint */
             }
         }
         st.outer++;
@@ -255,18 +294,26 @@ int mgc_solve(Dev& dev, const MgcLattice& L, const MgcSolveParams& P, MgcSolveSt
         dev.range_push("colour phases");
         const int rounds_now = radial ? radial_next : rounds;
         if (radial) { st.radial_cycles++; radial_done += rounds_now; }
+        /* Z-slabs: border labels + outbox flow cross once per ROUND of the two colours (6-neighbourhood; every `exchange_rounds` rounds):
+         * what a tile pushed over the slab border waits in its outbox until then -- region discharge only ever assumes a neighbour's
+         * labels and outbox as of SOME earlier moment -- and mgc_halo_unpack_tile queues the receiving tile for the next phase of ITS
+         * colour.  The full neighbourhood pushes into the ghost tiles in place and exchanges after every phase. */
+        const bool multi = dev.multi();
+        const int xr = P.exchange_rounds > 0 ? P.exchange_rounds : 1;
+        if (multi) dev.zero_count(MGC_CNT_DEFERRED);
         for (int r = 0; r < rounds_now; ++r) {
             for (int c = 0; c < lay.ncolours; ++c) {
                 const int lst = (int)(phase & (uint32_t)lay.list_mask);
                 dev.discharge(lst, phase, P.max_cycles, P.max_sweeps);
                 dev.zero_count(lst);
+                if (multi && (lay.ncolours != 2 || (c == 1 && ((r + 1) % xr == 0 || r + 1 == rounds_now)))) dev.exchange(1, phase, 0);
                 st.phases++;
                 phase++;
             }
             if ((r + 1) % P.check_rounds == 0 && r + 1 < rounds_now) {
                 dev.read_counts(cnt);
                 st.readbacks++;
-                int pending = 0;
+                int pending = multi ? cnt[MGC_CNT_DEFERRED] : 0;
                 for (int i = 0; i <= lay.list_mask; ++i) pending += cnt[i];
                 if (pending <= P.stop_below) break; /* (a few stragglers: their tiles keep their excess flag and come back after the relabel) */
             }
@@ -280,5 +327,198 @@ int mgc_solve(Dev& dev, const MgcLattice& L, const MgcSolveParams& P, MgcSolveSt
     }
     return 1;
 }
+
+/* ---------------------------------------------------------------------------------------------------------------------
+ * Z-SLABS (no reference counterpart: the reference is single-process and its only splitter, wrapper.py:72-204, is
+ * approximate).  The slabs of one volume as ONE Dev of mgc_solve: every operation of the schedule goes to each LOCAL slab (the one
+ * slab of this rank on its GPU; or all slabs of the volume when they are time-multiplexed on one GPU or run on the host simulator),
+ * the counters come back summed over all slabs of the volume, and the border messages / the carry planes of the distance transforms
+ * move through a transport X:
+ *     x.local_only()                      every slab of the volume is local (nothing crosses a process border)
+ *     x.exchange(kind, epoch, list)       border messages of all local slabs to / from their neighbours (mgc_halo_pack_tile / unpack)
+ *     x.allreduce(int64_t* v, n, op)      over all ranks, op 0 = sum, 1 = min (local_only: nothing to do)
+ *     x.carry_in(slab, dir) -> const uint16_t*   the carry plane slab's z-scan in direction dir (0 up, 1 down) starts from, ready on
+ *                                         the slab's stream; nullptr at the end of the volume
+ *     x.carry_out(slab, dir)              the slab's scan has written its carry plane (Slab::carry_buf(dir)): hand it on
+ * Slab (HipDevT / the simulator's HostDev) adds to the Dev concept:
+ *     dt_applicable() -> bool   dt_scans_xy(seed)   dt_scan_z(bwd, final, c_min, carry_in, want_carry_out)   dt_finish()   shadow_sync()
+ *     radial_prepare() -> bool  radial_cmin()  count_get(i) -> int  count_set(i, v)  radial_swap()
+ * With one exchange per round of the two colours and the transforms carried across the borders the slabs run the schedule of the
+ * single handle -- first relabel by distance transform, flood on radial labels, incremental relabels -- on their share of the tiles.
+ * ------------------------------------------------------------------------------------------------------------------- */
+template <class Slab, class X>
+struct MgcSlabGroup {
+    std::vector<Slab*>& d; /* the local slabs in ascending rank order */
+    X& x;
+    int64_t exchanges = 0, reductions = 0;
+    MgcSlabGroup(std::vector<Slab*>& slabs, X& xchg) : d(slabs), x(xchg) {}
+    bool multi() const { return true; }
+    bool labels_inexact() const { return false; }
+    int suspect_batch() const { return d[0]->suspect_batch(); }
+    void range_push(const char* name) { d[0]->range_push(name); }
+    void range_pop() { d[0]->range_pop(); }
+    void fill_heights_inf() { for (Slab* p : d) p->fill_heights_inf(); }
+    void zero_count(int i) { for (Slab* p : d) p->zero_count(i); }
+    void absorb_all() { for (Slab* p : d) p->absorb_all(); }
+    void suspect_pass() { for (Slab* p : d) p->suspect_pass(); }
+    void relabel_all(uint32_t epoch, int next) { for (Slab* p : d) p->relabel_all(epoch, next); }
+    void relabel_list(int lst, uint32_t epoch, int next, int zero_list = -1) { for (Slab* p : d) p->relabel_list(lst, epoch, next, zero_list); }
+    void reset_suspect(uint32_t epoch, int list) { for (Slab* p : d) p->reset_suspect(epoch, list); }
+    void activate_all(uint32_t phase) { for (Slab* p : d) p->activate_all(phase); }
+    void discharge(int lst, uint32_t phase, int cycles, int sweeps) { for (Slab* p : d) p->discharge(lst, phase, cycles, sweeps); }
+    void set_radial(bool on) { for (Slab* p : d) p->set_radial(on); }
+    void radial_save_exact() { for (Slab* p : d) p->radial_save_exact(); }
+    void radial_restore_exact() { for (Slab* p : d) p->radial_restore_exact(); }
+    void radial_lower(int c_min) { for (Slab* p : d) p->radial_lower(c_min); }
+    void source_open() { for (Slab* p : d) p->source_open(); }
+    void exchange(int kind, uint32_t epoch, int list) { x.exchange(kind, epoch, list); exchanges++; }
+    /* the counter block summed over every slab of the volume (MGC_CNT_RADIAL_C is the same word on every slab, see radial_begin) */
+    void read_counts(int* out)
+    {
+        int64_t g[MGC_NCOUNT];
+        int c[MGC_NCOUNT];
+        for (int i = 0; i < MGC_NCOUNT; ++i) g[i] = 0;
+        int radial_c = MGC_HINF;
+        for (Slab* p : d) {
+            p->read_counts(c);
+            for (int i = 0; i < MGC_NCOUNT; ++i) g[i] += c[i];
+            radial_c = c[MGC_CNT_RADIAL_C];
+        }
+        g[MGC_CNT_RADIAL_C] = 0;
+        if (!x.local_only()) x.allreduce(g, MGC_NCOUNT, 0);
+        reductions++;
+        for (int i = 0; i < MGC_NCOUNT; ++i) out[i] = g[i] > 0x7fffffff ? 0x7fffffff : (int)g[i];
+        out[MGC_CNT_RADIAL_C] = radial_c;
+    }
+    /* the six scans of a transform over all slabs: x and y stay inside a plane; the z-scans run slab after slab, each starting
+     * from the carry plane of the slab before (a pipeline: ranks wait for their neighbour's plane on the stream, not on the host) */
+    void transform(int seed, int final_kind, int c_min)
+    {
+        for (Slab* p : d) p->dt_scans_xy(seed);
+        for (size_t i = 0; i < d.size(); ++i) { /* upwards */
+            const uint16_t* cin = x.carry_in(*d[i], 0);
+            const bool more = d[i]->sends_carry(0);
+            d[i]->dt_scan_z(false, 0, 0, cin, more);
+            if (more) x.carry_out(*d[i], 0);
+        }
+        for (size_t i = d.size(); i-- > 0;) { /* downwards: the scan that writes the labels */
+            const uint16_t* cin = x.carry_in(*d[i], 1);
+            const bool more = d[i]->sends_carry(1);
+            d[i]->dt_scan_z(true, final_kind, c_min, cin, more);
+            if (more) x.carry_out(*d[i], 1);
+        }
+    }
+    bool first_relabel_dt()
+    {
+        int64_t ok = 1;
+        for (Slab* p : d) ok = ok && p->dt_applicable() ? 1 : 0;
+        if (!x.local_only()) x.allreduce(&ok, 1, 1);
+        if (!ok) return false;
+        transform(1, 1, 0);
+        for (Slab* p : d) { p->dt_finish(); p->shadow_sync(); }
+        return true;
+    }
+    bool radial_begin(int c_min)
+    {
+        int64_t ok = 1;
+        for (Slab* p : d) ok = ok && p->radial_prepare() ? 1 : 0;
+        if (!x.local_only()) x.allreduce(&ok, 1, 1);
+        if (!ok) return false;
+        /* C = hops of the shortest source -> sink path of the WHOLE volume: the smallest exact label a source voxel carries anywhere */
+        int64_t c = MGC_HINF;
+        for (Slab* p : d) { p->radial_cmin(); const int v = p->count_get(MGC_CNT_RADIAL_C); c = v < c ? v : c; }
+        if (!x.local_only()) x.allreduce(&c, 1, 1);
+        for (Slab* p : d) p->count_set(MGC_CNT_RADIAL_C, (int)c);
+        transform(2, 2, c_min);
+        for (Slab* p : d) { p->radial_swap(); p->shadow_sync(); } /* (both sides of a border lowered their copies alike) */
+        return true;
+    }
+};
+
+/* The transport of a slab group.  Either every slab of the volume is local -- messages move between the slabs' own buffers, nothing to
+ * reduce -- or this rank holds ONE slab and its neighbours live in other processes: over the slab's native channel when it has one
+ * (Slab::has_comm(): RCCL send / receive / all-reduce over xGMI inside the library, stream-ordered), else through the caller's
+ * callbacks (mgc_transport, include/medpy_hip.h: host buffers; the CPU test tier over gloo / a directory of files, a development
+ * mode of bench.py).  Slab adds to what MgcSlabGroup asks for:
+ *     halo_msg_bytes(kind)  halo_pack(side, kind) -> void* (the slab's send buffer)  halo_unpack(side, kind, buf, epoch, list)
+ *     recv_buf(side) -> void*  to_host(host, buf, n)  from_host(buf, host, n)  carry_buf(dir)  carry_recv_buf(dir)  carry_bytes()
+ *     has_lower() has_upper() needs_carry(dir)  has_comm()  native_exchange(kind, epoch, list)  native_allreduce(v, n, op)
+ *     native_send(side, buf, n)  native_recv(side, buf, n) */
+template <class Slab>
+struct MgcXchg {
+    std::vector<Slab*>& d;
+    const mgc_transport* cb;
+    bool local;
+    int error = 0; /* first failure of a native call or a callback (the schedule runs on; the caller reports it) */
+    std::vector<char> hs[2], hr[2];
+    MgcXchg(std::vector<Slab*>& slabs, const mgc_transport* callbacks, bool all_local) : d(slabs), cb(callbacks), local(all_local) {}
+    bool local_only() const { return local; }
+    void fail(int rc) { if (rc && !error) error = rc; }
+    void exchange(int kind, uint32_t epoch, int list)
+    {
+        if (local) { /* every border of the volume: pack both sides of all of them, then unpack */
+            std::vector<void*> up(d.size(), nullptr), dn(d.size(), nullptr);
+            for (size_t i = 0; i + 1 < d.size(); ++i) {
+                up[i] = d[i]->halo_pack(1, kind);
+                dn[i] = d[i + 1]->halo_pack(0, kind);
+            }
+            for (size_t i = 0; i + 1 < d.size(); ++i) {
+                d[i + 1]->halo_unpack(0, kind, up[i], epoch, list);
+                d[i]->halo_unpack(1, kind, dn[i], epoch, list);
+            }
+            return;
+        }
+        Slab& s = *d[0];
+        if (s.has_comm()) { fail(s.native_exchange(kind, epoch, list)); return; }
+        const int64_t nb = s.halo_msg_bytes(kind);
+        const bool has[2] = {s.has_lower(), s.has_upper()};
+        for (int side = 0; side < 2; ++side)
+            if (has[side]) {
+                hs[side].resize((size_t)nb); hr[side].resize((size_t)nb);
+                s.to_host(hs[side].data(), s.halo_pack(side, kind), nb);
+            }
+        fail(cb->exchange(cb->ctx, has[0] ? hs[0].data() : nullptr, has[0] ? hr[0].data() : nullptr, has[1] ? hs[1].data() : nullptr, has[1] ? hr[1].data() : nullptr, nb));
+        for (int side = 0; side < 2; ++side)
+            if (has[side]) {
+                s.from_host(s.recv_buf(side), hr[side].data(), nb);
+                s.halo_unpack(side, kind, s.recv_buf(side), epoch, list);
+            }
+    }
+    void allreduce(int64_t* v, int n, int op)
+    {
+        if (local) return;
+        if (d[0]->has_comm()) fail(d[0]->native_allreduce(v, n, op));
+        else fail(cb->allreduce(cb->ctx, v, n, op));
+    }
+    /* dir 0: the scan runs upwards, the plane comes from the slab below; dir 1: downwards, from the slab above */
+    const uint16_t* carry_in(Slab& s, int dir)
+    {
+        if (!s.needs_carry(dir)) return nullptr;
+        if (local) {
+            for (size_t i = 0; i < d.size(); ++i)
+                if (d[i] == &s) return dir == 0 ? d[i - 1]->carry_buf(0) : d[i + 1]->carry_buf(1);
+            return nullptr;
+        }
+        const int side = dir == 0 ? 0 : 1;
+        if (s.has_comm()) fail(s.native_recv(side, s.carry_recv_buf(dir), s.carry_bytes()));
+        else {
+            hr[0].resize((size_t)s.carry_bytes());
+            fail(cb->recv(cb->ctx, side, hr[0].data(), s.carry_bytes()));
+            s.from_host(s.carry_recv_buf(dir), hr[0].data(), s.carry_bytes());
+        }
+        return s.carry_recv_buf(dir);
+    }
+    void carry_out(Slab& s, int dir)
+    {
+        if (local) return; /* (the next slab reads the buffer where it lies) */
+        const int side = dir == 0 ? 1 : 0;
+        if (s.has_comm()) fail(s.native_send(side, s.carry_buf(dir), s.carry_bytes()));
+        else {
+            hs[0].resize((size_t)s.carry_bytes());
+            s.to_host(hs[0].data(), s.carry_buf(dir), s.carry_bytes());
+            fail(cb->send(cb->ctx, side, hs[0].data(), s.carry_bytes()));
+        }
+    }
+};
 
 #endif /* MGC_DRIVER_INL */

@@ -49,9 +49,14 @@ MGC_HD int mgc_dt_lines(const MgcLattice& L) { return AXIS == 0 ? L.gz * L.gy : 
  * int32 label array (MGC_HINF for "no seed anywhere" and for the padding voxels of a partial tile), otherwise uint16. */
 template <int AXIS, bool BWD, int SEED, int FINAL, class W> /* FINAL 2: the last scan of the distance FROM THE SOURCE -- uint16 out as for 0, and the labels
                                                                in L.height lowered to max(1, C - (distance - 1)) on the way (mgc_dt_lower_tile without a pass of its own) */
-MGC_HD void mgc_dt_scan_line(W& w, const MgcLattice& L, int line, const void* in, void* out, int c_min = 0, int32_t* hout = nullptr)
+MGC_HD void mgc_dt_scan_line(W& w, const MgcLattice& L, int line, const void* in, void* out, int c_min = 0, int32_t* hout = nullptr,
+                             const uint16_t* carry_in = nullptr, uint16_t* carry_out = nullptr, int carry_plane = -1)
 {   /* hout (FINAL 2): where the lowered labels go -- EVERY label, lowered or not, so that the caller can swap the two arrays instead of copying
-     * the exact labels aside first (HipDevT::radial_begin); nullptr: in place, only what changed */
+     * the exact labels aside first (HipDevT::radial_begin); nullptr: in place, only what changed.
+     * Z-SLABS (AXIS 2 only; MgcSlabGroup::first_relabel_dt): the lattice is one slab of a taller volume and the scan continues the
+     * neighbour slab's -- carry_in[y * dx + x] = the scan value of the plane in front of this slab's first plane (the scan's own
+     * direction), or nullptr at the end of the volume; carry_out (if not nullptr) receives the value of local plane `carry_plane`:
+     * what the NEXT slab's scan starts from.  A pipeline over the slabs, one uint16 plane per border and direction. */
     int C = MGC_HINF;
     if (FINAL == 2) { C = L.count[MGC_CNT_RADIAL_C]; if (C < c_min) C = MGC_HINF; }
     const int na = AXIS == 0 ? L.gx : (AXIS == 1 ? L.gy : L.gz);
@@ -64,6 +69,7 @@ MGC_HD void mgc_dt_scan_line(W& w, const MgcLattice& L, int line, const void* in
         else { cu = (int64_t)(line / L.gx) * 8 + (l >> 3); cv = (int64_t)(line % L.gx) * 8 + (l & 7); du = L.dy; dv = L.dx; }
         const bool live = cu < du && cv < dv;
         int carry = MGC_DT_INF;
+        if (AXIS == 2 && carry_in && live) carry = carry_in[cu * dv + cv];
         /* tiles in groups of four: all loads of a group are issued before the first value is needed (a wave has 4 KiB in
          * flight; the scan itself is a register chain) */
         for (int s0 = 0; s0 < na; s0 += 4) {
@@ -103,6 +109,7 @@ MGC_HD void mgc_dt_scan_line(W& w, const MgcLattice& L, int line, const void* in
                     if (!inside) val = MGC_DT_INF; /* padding: never a seed, never a relay (the scan has left the volume) */
                     else carry = val;
                     v[g][i] = val;
+                    if (AXIS == 2 && carry_out && inside && a * 8 + i == carry_plane) carry_out[cu * dv + cv] = (uint16_t)val;
                 }
 #pragma unroll
                 for (int i = 0; i < 8; ++i) {
@@ -156,6 +163,18 @@ MGC_HD void mgc_dt_finish_tile(W& w, const MgcLattice& L, int tile)
     w.lanes([&](int l) MGCW_INL {
         if (l == 0) L.status[tile] = (L.status[tile] & ~((63u << MGC_ST_DEP_SHIFT) | MGC_ST_ALLINF)) | (dep << MGC_ST_DEP_SHIFT) | (finite ? 0u : MGC_ST_ALLINF);
     });
+}
+
+/* Z-slabs: after a transform that every slab ran over its ghost layers too, both sides of a border hold the same labels without
+ * any having travelled -- the shadow of "what the neighbour holds" (mgc_halo_pack_tile) is brought in line.  i = tile index inside
+ * the layer; one wave per border tile and side. */
+template <class W>
+MGC_HD void mgc_shadow_sync_tile(W& w, const MgcLattice& L, int side, int i, const int32_t* height)
+{
+    if (!L.hshadow[side] || (side == 0 ? L.tz_own_lo == 0 : L.tz_own_hi == L.gz)) return;
+    const int layer = side ? L.tz_own_hi - 1 : L.tz_own_lo, f = side ? 5 : 4;
+    const int64_t tile = (int64_t)layer * L.gy * L.gx + i;
+    w.lanes([&](int l) MGCW_INL { L.hshadow[side][(int64_t)i * MGC_TF + l] = height[tile * MGC_TV + mgc_face_voxel(f, l)]; });
 }
 
 /* ---------------------------------------------------------------------------------------------------------------------
@@ -230,7 +249,7 @@ MGC_HD void mgc_dt_lower_tile(W& w, const MgcLattice& L, int tile, const uint16_
 template <class W>
 MGC_HD void mgc_source_open_tile(W& w, const MgcLattice& L, int tile)
 {
-    if (!(L.status[tile] & MGC_ST_SOURCE) || (L.status[tile] & MGC_ST_ALLINF)) return;
+    if (!(L.status[tile] & MGC_ST_SOURCE) || (L.status[tile] & MGC_ST_ALLINF) || !mgc_owned(L, tile)) return; /* (a ghost tile's excess is as built for ever: its owner answers) */
     const bool open = w.any([&](int l) MGCW_INL -> bool {
         bool o = false;
         for (int k = 0; k < 8; ++k) {

@@ -958,14 +958,26 @@ __global__ __launch_bounds__(MGC_TV) void k_activate_list(MgcLattice L, int list
 
 /* first global relabel as a distance transform (mgc_dt_ops.inl): one scan of every tile line along AXIS, one wave per line */
 template <int AXIS, bool BWD, int SEED, int FINAL> /* SEED 1: from the sink links (rmask), 2: from the voxels that hold excess (the radial labels), 0: a later pass */
-__global__ __launch_bounds__(256) void k_dt_scan(MgcLattice L, const void* in, void* out, int c_min, int32_t* hout)
+__global__ __launch_bounds__(256) void k_dt_scan(MgcLattice L, const void* in, void* out, int c_min, int32_t* hout, const uint16_t* carry_in, uint16_t* carry_out, int carry_plane)
 {
     __shared__ MgcWaveShared S; /* (not touched: the executor wants one) */
     GpuWave w(S);
     const int n = mgc_dt_lines<AXIS>(L);
     for (int line = (int)blockIdx.x * 4 + (int)(threadIdx.x >> 6); line < n; line += (int)gridDim.x * 4) {
         w.new_tile();
-        mgc_dt_scan_line<AXIS, BWD, SEED, FINAL>(w, L, __builtin_amdgcn_readfirstlane(line), in, out, c_min, hout);
+        mgc_dt_scan_line<AXIS, BWD, SEED, FINAL>(w, L, __builtin_amdgcn_readfirstlane(line), in, out, c_min, hout, carry_in, carry_out, carry_plane);
+    }
+}
+
+/* Z-slabs: the shadows of the border labels after a transform that ran on both sides of every border (mgc_shadow_sync_tile) */
+__global__ __launch_bounds__(256) void k_shadow_sync(MgcLattice L)
+{
+    __shared__ MgcWaveShared S;
+    GpuWave w(S);
+    const int T = L.gy * L.gx;
+    for (int i = (int)blockIdx.x * 4 + (int)(threadIdx.x >> 6); i < 2 * T; i += (int)gridDim.x * 4) {
+        w.new_tile();
+        mgc_shadow_sync_tile(w, L, i / T, __builtin_amdgcn_readfirstlane(i % T), L.height);
     }
 }
 
@@ -2243,6 +2255,10 @@ struct mgc_graph {
     int use_dt = 1;            /* first global relabel as a distance transform when all_residual (parameter first_relabel_dt) */
     int rank = 0, nranks = 1;
     int64_t plane0 = 0, plane1 = 0, own0 = 0, own1 = 0; /* global plane ranges of a slab */
+    int64_t gd0 = 0;                  /* planes of the WHOLE volume (a slab: of the volume it was cut from) */
+    uint16_t* d_carry[2] = {nullptr, nullptr};    /* slabs: the plane this slab's upward / downward z-scan of a distance transform hands to the next slab */
+    uint16_t* d_carry_in[2] = {nullptr, nullptr}; /* ... and where the plane of the slab before arrives when it lives in another process */
+    uint16_t* dt_cur = nullptr;       /* scratch array of the transform in progress (d_dt16 / d_ds16) */
     void* d_halo = nullptr; int64_t halo_cap = 0;
     ncclComm_t comm = nullptr; void* d_xchg[4] = {nullptr, nullptr, nullptr, nullptr}; int64_t xchg_cap = 0; /* send lo, recv lo, send hi, recv hi */
     int64_t* d_cnt64 = nullptr;
@@ -2258,7 +2274,6 @@ struct mgc_graph {
     int est_phase_tiles = 1 << 30; /* length of the discharge lists at the last counter read-back */
     int sweeps_sparse26 = 5;       /* 26-neighbourhood: sweep budget of a discharge while fewer than 20 % of a colour's tiles are active (8 until incremental relabels got cheap; 512^3 markers only 285 ms at 8, 265 at 5 and 4, 287 at 3: profiles/r4_sched26_sparse_sweeps.jsonl) */
     int wave_grid26 = 0;           /* persistent grid of k26_discharge_w: one wave per SIMD (it needs the whole register file) */
-    int relabel_exchange_every = 4; /* slabs: relabel passes between two exchanges of the border labels (0: iterate to the local fixpoint first, round 3's schedule) */
     bool rounds_set = false, sparse26_set = false, wave_set = false;
     bool w26_auto = false; /* (during a solve) k26_discharge_w chosen by mgc_maxflow for a pre-pushed graph */ /* the caller chose rounds_per_relabel / sweeps_sparse26 (mgc_set_param): no automatic choice */
     int prepush = 1;               /* k_build (26-neighbourhood): settle source -> u -> v -> sink paths inside a tile while its weights are in registers (parameter prepush) */
@@ -2520,7 +2535,7 @@ struct HipDevT {
     {
         /* only on a graph as built: a solve that runs again on its own residual graph (after MGC_ERR_NOT_CONVERGED, without a rebuild) has
          * saturated arcs, and all_residual is what k_build counted (labels_valid: some solve of this build filled the labels already) */
-        if (FULL || !h->use_dt || !h->all_residual || h->labels_valid) return false;
+        if (FULL || !h->use_dt || !h->all_residual || h->labels_valid || h->nranks > 1) return false; /* (slabs: MgcSlabGroup::first_relabel_dt carries the scans across the borders) */
         if (!h->d_dt16) {
             if (mgc_dmalloc((void**)&h->d_dt16, (size_t)h->L.ntiles * MGC_TV * sizeof(uint16_t)) != hipSuccess) { (void)hipGetLastError(); return false; }
             h->device_bytes += (int64_t)h->L.ntiles * MGC_TV * (int64_t)sizeof(uint16_t);
@@ -2532,12 +2547,12 @@ struct HipDevT {
         void* const T = h->d_dt16;
         const dim3 blk(256);
         auto g = [&](int lines) { return dim3(grid((lines + 3) / 4)); };
-        hipLaunchKernelGGL((k_dt_scan<0, false, 1, 0>), g(L.gz * L.gy), blk, 0, h->stream, L, (const void*)L.rmask, T, 0, (int32_t*)nullptr);
-        hipLaunchKernelGGL((k_dt_scan<0, true, 0, 0>), g(L.gz * L.gy), blk, 0, h->stream, L, (const void*)T, T, 0, (int32_t*)nullptr);
-        hipLaunchKernelGGL((k_dt_scan<1, false, 0, 0>), g(L.gz * L.gx), blk, 0, h->stream, L, (const void*)T, T, 0, (int32_t*)nullptr);
-        hipLaunchKernelGGL((k_dt_scan<1, true, 0, 0>), g(L.gz * L.gx), blk, 0, h->stream, L, (const void*)T, T, 0, (int32_t*)nullptr);
-        hipLaunchKernelGGL((k_dt_scan<2, false, 0, 0>), g(L.gy * L.gx), blk, 0, h->stream, L, (const void*)T, T, 0, (int32_t*)nullptr);
-        hipLaunchKernelGGL((k_dt_scan<2, true, 0, 1>), g(L.gy * L.gx), blk, 0, h->stream, L, (const void*)T, (void*)L.height, 0, (int32_t*)nullptr);
+        hipLaunchKernelGGL((k_dt_scan<0, false, 1, 0>), g(L.gz * L.gy), blk, 0, h->stream, L, (const void*)L.rmask, T, 0, (int32_t*)nullptr, (const uint16_t*)nullptr, (uint16_t*)nullptr, -1);
+        hipLaunchKernelGGL((k_dt_scan<0, true, 0, 0>), g(L.gz * L.gy), blk, 0, h->stream, L, (const void*)T, T, 0, (int32_t*)nullptr, (const uint16_t*)nullptr, (uint16_t*)nullptr, -1);
+        hipLaunchKernelGGL((k_dt_scan<1, false, 0, 0>), g(L.gz * L.gx), blk, 0, h->stream, L, (const void*)T, T, 0, (int32_t*)nullptr, (const uint16_t*)nullptr, (uint16_t*)nullptr, -1);
+        hipLaunchKernelGGL((k_dt_scan<1, true, 0, 0>), g(L.gz * L.gx), blk, 0, h->stream, L, (const void*)T, T, 0, (int32_t*)nullptr, (const uint16_t*)nullptr, (uint16_t*)nullptr, -1);
+        hipLaunchKernelGGL((k_dt_scan<2, false, 0, 0>), g(L.gy * L.gx), blk, 0, h->stream, L, (const void*)T, T, 0, (int32_t*)nullptr, (const uint16_t*)nullptr, (uint16_t*)nullptr, -1);
+        hipLaunchKernelGGL((k_dt_scan<2, true, 0, 1>), g(L.gy * L.gx), blk, 0, h->stream, L, (const void*)T, (void*)L.height, 0, (int32_t*)nullptr, (const uint16_t*)nullptr, (uint16_t*)nullptr, -1);
         hipLaunchKernelGGL(k_dt_finish, g(L.ntiles), blk, 0, h->stream, L);
         check(hipGetLastError());
         time_end(id);
@@ -2566,15 +2581,15 @@ struct HipDevT {
         auto g = [&](int lines) { return dim3(grid((lines + 3) / 4)); };
         check(hipMemsetAsync(L.count + MGC_CNT_RADIAL_C, 0x3f, sizeof(int32_t), h->stream)); /* MGC_HINF */
         hipLaunchKernelGGL(k_dt_cmin, g(L.ntiles), blk, 0, h->stream, L); /* C from the exact labels of the source voxels */
-        hipLaunchKernelGGL((k_dt_scan<0, false, 2, 0>), g(L.gz * L.gy), blk, 0, h->stream, L, (const void*)L.excess, T, 0, (int32_t*)nullptr);
-        hipLaunchKernelGGL((k_dt_scan<0, true, 0, 0>), g(L.gz * L.gy), blk, 0, h->stream, L, (const void*)T, T, 0, (int32_t*)nullptr);
-        hipLaunchKernelGGL((k_dt_scan<1, false, 0, 0>), g(L.gz * L.gx), blk, 0, h->stream, L, (const void*)T, T, 0, (int32_t*)nullptr);
-        hipLaunchKernelGGL((k_dt_scan<1, true, 0, 0>), g(L.gz * L.gx), blk, 0, h->stream, L, (const void*)T, T, 0, (int32_t*)nullptr);
-        hipLaunchKernelGGL((k_dt_scan<2, false, 0, 0>), g(L.gy * L.gx), blk, 0, h->stream, L, (const void*)T, T, 0, (int32_t*)nullptr);
+        hipLaunchKernelGGL((k_dt_scan<0, false, 2, 0>), g(L.gz * L.gy), blk, 0, h->stream, L, (const void*)L.excess, T, 0, (int32_t*)nullptr, (const uint16_t*)nullptr, (uint16_t*)nullptr, -1);
+        hipLaunchKernelGGL((k_dt_scan<0, true, 0, 0>), g(L.gz * L.gy), blk, 0, h->stream, L, (const void*)T, T, 0, (int32_t*)nullptr, (const uint16_t*)nullptr, (uint16_t*)nullptr, -1);
+        hipLaunchKernelGGL((k_dt_scan<1, false, 0, 0>), g(L.gz * L.gx), blk, 0, h->stream, L, (const void*)T, T, 0, (int32_t*)nullptr, (const uint16_t*)nullptr, (uint16_t*)nullptr, -1);
+        hipLaunchKernelGGL((k_dt_scan<1, true, 0, 0>), g(L.gz * L.gx), blk, 0, h->stream, L, (const void*)T, T, 0, (int32_t*)nullptr, (const uint16_t*)nullptr, (uint16_t*)nullptr, -1);
+        hipLaunchKernelGGL((k_dt_scan<2, false, 0, 0>), g(L.gy * L.gx), blk, 0, h->stream, L, (const void*)T, T, 0, (int32_t*)nullptr, (const uint16_t*)nullptr, (uint16_t*)nullptr, -1);
         /* ... and the labels lowered on the way, INTO THE OTHER ARRAY: the last scan reads the exact labels anyway, so it writes every label
          * (lowered or not) to the array that keeps the exact ones aside and the two trade places -- no copy of 4 bytes per voxel to keep them
          * aside here (0.2 ms at 512^3), none to bring them back (radial_restore_exact) */
-        hipLaunchKernelGGL((k_dt_scan<2, true, 0, 2>), g(L.gy * L.gx), blk, 0, h->stream, L, (const void*)T, T, c_min, h->d_hexact);
+        hipLaunchKernelGGL((k_dt_scan<2, true, 0, 2>), g(L.gy * L.gx), blk, 0, h->stream, L, (const void*)T, T, c_min, h->d_hexact, (const uint16_t*)nullptr, (uint16_t*)nullptr, -1);
         std::swap(h->L.height, h->d_hexact); /* (kernels take the lattice by value at launch: everything from here on sees the lowered labels) */
         check(hipGetLastError());
         time_end(id);
@@ -2697,6 +2712,155 @@ struct HipDevT {
         discharge_launches++;
         last_discharged = lst;
     }
+    /* ---- one slab of a volume, as MgcSlabGroup / MgcXchg (mgc_driver.inl) drive it ---- */
+    bool multi() const { return false; }
+    void exchange(int, uint32_t, int) {}
+    bool has_lower() const { return h->L.tz_own_lo > 0; }
+    bool has_upper() const { return h->L.tz_own_hi < h->L.gz; }
+    bool needs_carry(int dir) const { return dir == 0 ? h->plane0 > 0 : h->plane1 < h->gd0; }
+    bool sends_carry(int dir) const { return dir == 0 ? (has_upper() && h->own1 - 9 >= h->plane0) : (has_lower() && h->own0 + 8 < h->gd0); }
+    int carry_plane(int dir) const { return (int)(dir == 0 ? h->own1 - 9 - h->plane0 : h->own0 + 8 - h->plane0); }
+    int64_t carry_bytes() const { return (int64_t)h->L.dy * h->L.dx * (int64_t)sizeof(uint16_t); }
+    uint16_t* carry_buf(int dir) { return h->d_carry[dir]; }
+    uint16_t* carry_recv_buf(int dir) { return h->d_carry_in[dir]; }
+    bool ensure(void** p, size_t bytes)
+    {
+        if (*p) return true;
+        if (mgc_dmalloc(p, bytes) != hipSuccess) { (void)hipGetLastError(); *p = nullptr; return false; }
+        h->device_bytes += (int64_t)bytes;
+        return true;
+    }
+    bool dt_applicable()
+    {
+        if (FULL || !h->use_dt || !h->all_residual || h->labels_valid) return false;
+        bool ok = ensure((void**)&h->d_dt16, (size_t)h->L.ntiles * MGC_TV * sizeof(uint16_t));
+        for (int k = 0; k < 2 && ok; ++k) ok = ensure((void**)&h->d_carry[k], (size_t)carry_bytes()) && ensure((void**)&h->d_carry_in[k], (size_t)carry_bytes());
+        return ok;
+    }
+    dim3 dt_grid(int lines) const { return dim3(grid((lines + 3) / 4)); }
+    int dt_span = -1;
+    void dt_scans_xy(int seed)
+    {
+        flush_zero();
+        h->labels_valid = true;
+        dt_span = time_begin(2);
+        const MgcLattice& L = h->L;
+        void* const T = h->dt_cur = seed == 1 ? h->d_dt16 : h->d_ds16;
+        const dim3 blk(256);
+        if (seed == 1) hipLaunchKernelGGL((k_dt_scan<0, false, 1, 0>), dt_grid(L.gz * L.gy), blk, 0, h->stream, L, (const void*)L.rmask, T, 0, (int32_t*)nullptr, (const uint16_t*)nullptr, (uint16_t*)nullptr, -1);
+        else hipLaunchKernelGGL((k_dt_scan<0, false, 2, 0>), dt_grid(L.gz * L.gy), blk, 0, h->stream, L, (const void*)L.excess, T, 0, (int32_t*)nullptr, (const uint16_t*)nullptr, (uint16_t*)nullptr, -1);
+        hipLaunchKernelGGL((k_dt_scan<0, true, 0, 0>), dt_grid(L.gz * L.gy), blk, 0, h->stream, L, (const void*)T, T, 0, (int32_t*)nullptr, (const uint16_t*)nullptr, (uint16_t*)nullptr, -1);
+        hipLaunchKernelGGL((k_dt_scan<1, false, 0, 0>), dt_grid(L.gz * L.gx), blk, 0, h->stream, L, (const void*)T, T, 0, (int32_t*)nullptr, (const uint16_t*)nullptr, (uint16_t*)nullptr, -1);
+        hipLaunchKernelGGL((k_dt_scan<1, true, 0, 0>), dt_grid(L.gz * L.gx), blk, 0, h->stream, L, (const void*)T, T, 0, (int32_t*)nullptr, (const uint16_t*)nullptr, (uint16_t*)nullptr, -1);
+        check(hipGetLastError());
+        relabel_launches += 4;
+    }
+    /* final_kind 0: an intermediate scan; 1: the scan that writes the labels (transform towards the sink); 2: the scan that lowers the
+     * labels into the other array (transform away from the source) */
+    void dt_scan_z(bool bwd, int final_kind, int c_min, const uint16_t* cin, bool want_out)
+    {
+        const MgcLattice& L = h->L;
+        void* const T = h->dt_cur;
+        const dim3 blk(256), g = dt_grid(L.gy * L.gx);
+        uint16_t* const cout = want_out ? h->d_carry[bwd ? 1 : 0] : nullptr;
+        const int plane = want_out ? carry_plane(bwd ? 1 : 0) : -1;
+        if (!bwd) hipLaunchKernelGGL((k_dt_scan<2, false, 0, 0>), g, blk, 0, h->stream, L, (const void*)T, T, 0, (int32_t*)nullptr, cin, cout, plane);
+        else if (final_kind == 1) hipLaunchKernelGGL((k_dt_scan<2, true, 0, 1>), g, blk, 0, h->stream, L, (const void*)T, (void*)L.height, 0, (int32_t*)nullptr, cin, cout, plane);
+        else if (final_kind == 2) hipLaunchKernelGGL((k_dt_scan<2, true, 0, 2>), g, blk, 0, h->stream, L, (const void*)T, T, c_min, h->d_hexact, cin, cout, plane);
+        else hipLaunchKernelGGL((k_dt_scan<2, true, 0, 0>), g, blk, 0, h->stream, L, (const void*)T, T, 0, (int32_t*)nullptr, cin, cout, plane);
+        check(hipGetLastError());
+        relabel_launches++;
+        if (bwd) { time_end(dt_span); dt_span = -1; }
+    }
+    void dt_finish()
+    {
+        hipLaunchKernelGGL(k_dt_finish, dt_grid(h->L.ntiles), dim3(256), 0, h->stream, h->L);
+        check(hipGetLastError());
+        relabel_launches++;
+    }
+    void shadow_sync()
+    {
+        if (FULL || (!has_lower() && !has_upper())) return;
+        hipLaunchKernelGGL(k_shadow_sync, dt_grid(2 * h->L.gy * h->L.gx), dim3(256), 0, h->stream, h->L);
+        check(hipGetLastError());
+    }
+    bool radial_prepare()
+    {
+        if (FULL) return false;
+        const size_t nv = (size_t)h->L.ntiles * MGC_TV;
+        return ensure((void**)&h->d_ds16, nv * sizeof(uint16_t)) && ensure((void**)&h->d_hexact, nv * sizeof(int32_t));
+    }
+    void radial_cmin()
+    {
+        flush_zero();
+        check(hipMemsetAsync(h->L.count + MGC_CNT_RADIAL_C, 0x3f, sizeof(int32_t), h->stream)); /* MGC_HINF */
+        hipLaunchKernelGGL(k_dt_cmin, dt_grid(h->L.ntiles), dim3(256), 0, h->stream, h->L);
+        check(hipGetLastError());
+    }
+    int count_get(int i)
+    {
+        int v = 0;
+        check(hipMemcpyAsync(&v, h->L.count + i, sizeof(int32_t), hipMemcpyDeviceToHost, h->stream));
+        check(hipStreamSynchronize(h->stream));
+        readbacks++;
+        return v;
+    }
+    void count_set(int i, int v) { check(hipMemsetD32Async((hipDeviceptr_t)(h->L.count + i), v, 1, h->stream)); }
+    void radial_swap() { std::swap(h->L.height, h->d_hexact); }
+    /* border messages: a fixed size per kind that both sides know without asking the device (mgc_halo_exchange) */
+    int64_t halo_msg_bytes(int kind) const
+    {
+        return mgc_halo_compact_nd(h->L, kind) ? mgc_halo_off_rec_nd(h->L) + (int64_t)h->L.halo_max_rec * mgc_halo_rec_bytes_nd(h->L, kind) : mgc_halo_bytes_nd(h->L, kind);
+    }
+    bool xchg_ready()
+    {
+        int64_t bytes = mgc_halo_bytes_nd(h->L, 1);
+        if (mgc_halo_bytes_nd(h->L, 0) > bytes) bytes = mgc_halo_bytes_nd(h->L, 0);
+        if (h->xchg_cap >= bytes) return true;
+        for (int i = 0; i < 4; ++i) {
+            if (h->d_xchg[i]) (void)mgc_dfree(h->d_xchg[i]);
+            h->d_xchg[i] = nullptr;
+            if (mgc_dmalloc(&h->d_xchg[i], (size_t)bytes) != hipSuccess) { check(hipErrorOutOfMemory); return false; }
+        }
+        h->xchg_cap = bytes;
+        return true;
+    }
+    void* recv_buf(int side) { return xchg_ready() ? h->d_xchg[2 * side + 1] : nullptr; }
+    void* halo_pack(int side, int kind)
+    {
+        flush_zero();
+        if (!xchg_ready()) return nullptr;
+        void* const dst = h->d_xchg[2 * side];
+        const int T = h->L.gy * h->L.gx;
+        if (mgc_halo_compact_nd(h->L, kind)) check(hipMemsetAsync((char*)dst + mgc_halo_off_count_nd(h->L), 0, 4, h->stream));
+        hipLaunchKernelGGL(k_halo_pack, dim3(T < 2048 ? T : 2048), dim3(MGC_TV), 0, h->stream, h->L, side, kind, dst);
+        check(hipGetLastError());
+        return dst;
+    }
+    void halo_unpack(int side, int kind, const void* buf, uint32_t epoch, int list)
+    {
+        if (!buf) return;
+        flush_zero();
+        const int T = h->L.gy * h->L.gx;
+        hipLaunchKernelGGL(k_halo_unpack, dim3(T < 2048 ? T : 2048), dim3(MGC_TV), 0, h->stream, h->L, side, kind, buf, epoch, list);
+        check(hipGetLastError());
+    }
+    void to_host(void* host, const void* buf, int64_t n)
+    {
+        check(hipMemcpyAsync(host, buf, (size_t)n, hipMemcpyDeviceToHost, h->stream));
+        check(hipStreamSynchronize(h->stream));
+    }
+    void from_host(void* buf, const void* host, int64_t n)
+    {
+        check(hipMemcpyAsync(buf, host, (size_t)n, hipMemcpyHostToDevice, h->stream));
+        check(hipStreamSynchronize(h->stream)); /* (the host buffer is the caller's again on return) */
+    }
+    bool has_comm() const { return h->comm != nullptr; }
+    int native_exchange(int kind, uint32_t epoch, int list);
+    int native_allreduce(int64_t* v, int n, int op);
+    int native_send(int side, const void* buf, int64_t n);
+    int native_recv(int side, void* buf, int64_t n);
+
     int64_t timed[4] = {0, 0, 0, 0}, seen[4] = {0, 0, 0, 0}; /* launches with an event pair / launches, per kind: 0 = k_discharge_w (26-neighbourhood:
                                                                  k26_discharge), 1 = relabel passes, 2 = one-off stretches, 3 = k_discharge (short lists) */
     float block_ms = 0.f;
@@ -2887,7 +3051,7 @@ int mgc_pool_info(int device, int64_t* idle_bytes, int64_t* hits, int64_t* misse
     return MGC_OK;
 }
 
-static int mgc_create_impl(int ndim, const int64_t* shape, int connectivity, int device, const MgcSlabSpec* slab, mgc_handle* out)
+static int mgc_create_impl(int ndim, const int64_t* shape, int connectivity, int device, const MgcSlabSpec* slab, mgc_handle* out, int64_t gd0 = 0)
 {
     if (!out) return mgc_fail(nullptr, MGC_ERR_INVALID, "mgc_create: out is NULL");
     *out = nullptr;
@@ -2931,6 +3095,7 @@ static int mgc_create_impl(int ndim, const int64_t* shape, int connectivity, int
     } else {
         h->plane0 = h->own0 = 0; h->plane1 = h->own1 = L.dz;
     }
+    h->gd0 = gd0 > 0 ? gd0 : L.dz;
     *out = h; /* from here on errors are reported through the handle; caller destroys it */
     MGC_HIP(h, hipSetDevice(device));
     MGC_HIP(h, hipStreamCreateWithFlags(&h->stream, hipStreamNonBlocking));
@@ -3009,7 +3174,7 @@ int mgc_create_slab(int ndim, const int64_t* gshape, int connectivity, int devic
     MgcSlabSpec sp;
     if (mgc_slab_spec(gshape[0], rank, nranks, &sp)) return mgc_fail(nullptr, MGC_ERR_INVALID, "cannot cut %lld planes into %d slabs", (long long)gshape[0], nranks);
     const int64_t lshape[3] = {sp.plane1 - sp.plane0, gshape[1], gshape[2]};
-    return mgc_create_impl(3, lshape, connectivity, device, &sp, out);
+    return mgc_create_impl(3, lshape, connectivity, device, &sp, out, gshape[0]);
 }
 
 int mgc_slab_info(mgc_handle h, int64_t* info)
@@ -3273,166 +3438,41 @@ int mgc_halo_exchange(mgc_handle h, int kind, uint32_t epoch, int list)
 
 } /* extern "C" */
 
-/* the schedule of medpy_amd/slab.py:solve_slabs on the device policy Dev (6- or 26-neighbourhood kernels) */
-template <class Dev>
-static int mgc_solve_slab_on(mgc_handle h, const MgcLayout lay, mgc_slab_stats* out)
+/* ---- the native channel of a slab whose neighbours live in other processes: RCCL over xGMI, stream-ordered ---- */
+template <bool FULL>
+int HipDevT<FULL>::native_exchange(int kind, uint32_t epoch, int list) { return mgc_halo_exchange(h, kind, epoch, list); }
+
+template <bool FULL>
+int HipDevT<FULL>::native_allreduce(int64_t* v, int n, int op)
 {
-    Dev dev;
-    dev.h = h;
-    const MgcSolveParams P = h->params;
-    const bool multi = h->nranks > 1;
-    mgc_slab_stats st{};
-    int64_t g[MGC_NCOUNT];
+    if (n > MGC_NCOUNT) return mgc_fail(h, MGC_ERR_INVALID, "native_allreduce: %d values", n);
+    flush_zero();
+    MGC_HIP(h, hipMemcpyAsync(h->d_cnt64, v, (size_t)n * sizeof(int64_t), hipMemcpyHostToDevice, h->stream));
+    MGC_NCCL(h, g_rccl.AllReduce(h->d_cnt64, h->d_cnt64 + MGC_NCOUNT, (size_t)n, ncclInt64, op == 1 ? ncclMin : ncclSum, h->comm, h->stream));
+    MGC_HIP(h, hipMemcpyAsync(v, h->d_cnt64 + MGC_NCOUNT, (size_t)n * sizeof(int64_t), hipMemcpyDeviceToHost, h->stream));
+    MGC_HIP(h, hipStreamSynchronize(h->stream));
+    return MGC_OK;
+}
+
+template <bool FULL>
+int HipDevT<FULL>::native_send(int side, const void* buf, int64_t n)
+{
+    MGC_NCCL(h, g_rccl.Send(buf, (size_t)n, ncclUint8, h->rank + (side ? 1 : -1), h->comm, h->stream));
+    return MGC_OK;
+}
+
+template <bool FULL>
+int HipDevT<FULL>::native_recv(int side, void* buf, int64_t n)
+{
+    MGC_NCCL(h, g_rccl.Recv(buf, (size_t)n, ncclUint8, h->rank + (side ? 1 : -1), h->comm, h->stream));
+    return MGC_OK;
+}
+
+/* what mgc_get_stats reports for one slab after a group solve (its own launches and tiles; the global totals are in mgc_slab_stats) */
+template <class Dev>
+static void mgc_slab_handle_stats(mgc_handle h, Dev& dev, const MgcLayout lay, const MgcSolveStats& st)
+{
     int cnt[MGC_NCOUNT];
-    int rc = MGC_OK;
-    auto exchange = [&](int kind, uint32_t epoch, int list) -> int {
-        if (!multi) return MGC_OK;
-        st.exchanges++;
-        return mgc_halo_exchange(h, kind, epoch, list);
-    };
-    auto reduce = [&]() -> int { /* the counter block summed over all slabs: every rank decides alike */
-        st.reductions++;
-        if (multi) return mgc_allreduce_counts(h, g);
-        dev.read_counts(cnt);
-        for (int i = 0; i < MGC_NCOUNT; ++i) g[i] = cnt[i];
-        return MGC_OK;
-    };
-#define MGC_SLAB_TRY(call) do { if ((rc = (call)) != MGC_OK) return rc; } while (0)
-    const int lmask = lay.list_mask, rl = lay.rl_base;
-    int batch = P.relabel_batch < 2 ? 2 : P.relabel_batch + (P.relabel_batch & 1); /* even: every rank keeps the same list parity */
-    uint32_t phase = 2 * (uint32_t)(lmask + 1), rep = 2;
-    dev.zero_count(lay.cnt_dis);
-    dev.zero_count(lay.cnt_rel);
-    int rounds = P.rounds_per_relabel;
-    int64_t prev_dis = 0, prev_rel = 0;
-    dev.zero_count(MGC_CNT_DEFERRED);
-    for (int outer = 0; outer < P.max_outer; ++outer) {
-        mgc_range_push("global relabel");
-        /* flow a full border message left behind during the colour phases must have crossed before the masks are read */
-        if (multi && outer > 0) {
-            for (;;) {
-                MGC_SLAB_TRY(reduce());
-                if (g[MGC_CNT_DEFERRED] == 0) break;
-                dev.zero_count(MGC_CNT_DEFERRED);
-                MGC_SLAB_TRY(exchange(1, phase - 1, 0));
-                st.deferred_drains++;
-            }
-        }
-        dev.absorb_all();
-        dev.zero_count(rl);
-        dev.zero_count(rl + 1);
-        int nxt = rl + (int)((rep + 1) & 1u);
-        if (outer == 0 || !lay.incremental || !P.incremental_relabel) {
-            dev.fill_heights_inf();
-            dev.relabel_all(rep + 1, nxt);
-        } else {
-            for (;;) { /* which tiles may have lost the support of their labels (closure across the slab borders) */
-                dev.zero_count(MGC_CNT_CHANGED);
-                for (int b = 0; b < 8; ++b) dev.suspect_pass();
-                MGC_SLAB_TRY(exchange(2, 0, 0));
-                MGC_SLAB_TRY(reduce());
-                if (g[MGC_CNT_CHANGED] == 0) break;
-            }
-            dev.reset_suspect(rep + 1, nxt);
-        }
-        st.relabel_passes++;
-        if (h->relabel_exchange_every > 0) {
-            /* The label wave of a global relabel has to cross every slab border on its way through the volume.  Border labels
-             * therefore travel every `xk` passes, whether or not this slab has reached its local fixpoint: labels only go down
-             * during a relabel, so a ghost label is an upper bound whenever it is read, and a wave that reaches a border is on the
-             * other side at most xk passes later.  (Round 3 iterated every slab to its LOCAL fixpoint between two exchanges:
-             * eight slabs of a 2048 x 1024 x 1024 volume needed 6 280 passes where one handle needs 1 483,
-             * profiles/r4_slab_scaling_one_gpu.jsonl.)  Every rank runs the same number of passes (a pass over an empty list is a
-             * ~4 us no-op) and the ranks compare notes every second exchange. */
-            const int xk = h->relabel_exchange_every + (h->relabel_exchange_every & 1); /* even: every rank keeps the same list parity */
-            for (int round = 0;; ++round) {
-                for (int b = 0; b < xk; ++b) {
-                    rep++;
-                    const int cur = rl + (int)(rep & 1u);
-                    nxt = rl + (int)((rep + 1) & 1u);
-                    dev.zero_count(nxt);
-                    dev.relabel_list(cur, rep + 1, nxt, -1);
-                    st.relabel_passes++;
-                }
-                if (round % 2 == 0) dev.zero_count(MGC_CNT_DEFERRED); /* (counts what the exchanges since the last look left behind) */
-                MGC_SLAB_TRY(exchange(0, rep + 1, nxt));
-                if (round % 2 == 0) continue;
-                MGC_SLAB_TRY(reduce());
-                if (g[nxt] == 0 && g[MGC_CNT_DEFERRED] == 0) break; /* nobody is queued anywhere, nothing was left behind: global fixpoint */
-            }
-        } else
-        for (;;) {
-            for (;;) { /* passes to the LOCAL fixpoint: no collective (labels only go down, stale ghost labels are upper bounds) */
-                dev.read_counts(cnt);
-                if (cnt[nxt] == 0) break;
-                for (int b = 0; b < batch; ++b) {
-                    rep++;
-                    const int cur = rl + (int)(rep & 1u);
-                    nxt = rl + (int)((rep + 1) & 1u);
-                    dev.zero_count(nxt);
-                    dev.relabel_list(cur, rep + 1, nxt, -1);
-                    st.relabel_passes++;
-                }
-            }
-            dev.zero_count(MGC_CNT_DEFERRED);
-            MGC_SLAB_TRY(exchange(0, rep + 1, nxt));
-            MGC_SLAB_TRY(reduce());
-            if (g[nxt] == 0 && g[MGC_CNT_DEFERRED] == 0) break; /* the exchange woke nobody anywhere and left nothing behind: global fixpoint */
-        }
-        st.outer++;
-        mgc_range_pop();
-
-        /* ---- who can still push towards the sink? */
-        phase += 2 * (uint32_t)(lmask + 1); /* fresh stamps: anything queued before the relabel is void */
-        for (int i = 0; i <= lmask; ++i) dev.zero_count(i);
-        dev.zero_count(lay.cnt_active);
-        dev.activate_all(phase);
-        MGC_SLAB_TRY(reduce());
-        if (g[lay.cnt_active] == 0) {
-            st.converged = 1;
-            break;
-        }
-        /* the rule of mgc_solve (mgc_driver.inl): a relabel that visits several times the tiles the discharges before it did is paid
-         * too often -- the rounds between two relabels double, up to four times the setting.  Decided on the GLOBAL counters (the
-         * reduce above), so every rank runs the same number of rounds. */
-        {
-            const int64_t d_dis = g[lay.cnt_dis] - prev_dis, d_rel = g[lay.cnt_rel] - prev_rel;
-            if (P.adaptive_rounds > 0 && st.outer > 1 && d_rel > (int64_t)P.adaptive_rounds * d_dis && rounds < 4 * P.rounds_per_relabel) rounds *= 2;
-            prev_dis = g[lay.cnt_dis];
-            prev_rel = g[lay.cnt_rel];
-        }
-
-        /* ---- colour phases.  Border labels + outbox flow are exchanged once per ROUND of the two colours (6-neighbourhood): what a
-         * tile of the first colour pushed over the slab border waits in its outbox one phase longer -- region discharge only
-         * ever assumes a neighbour's labels and outbox as of SOME earlier moment -- and a solve needs half the exchanges.  The
-         * 26-neighbourhood pushes into the ghost tiles in place and exchanges after every phase. */
-        mgc_range_push("colour phases");
-        dev.zero_count(MGC_CNT_DEFERRED);
-        for (int r = 0; r < rounds; ++r) {
-            for (int c = 0; c < lay.ncolours; ++c) {
-                const int lst = (int)(phase & (uint32_t)lmask);
-                dev.discharge(lst, phase, P.max_cycles, P.max_sweeps);
-                dev.zero_count(lst);
-                if (lay.ncolours != 2 || c == 1) MGC_SLAB_TRY(exchange(1, phase, 0));
-                st.phases++;
-                phase++;
-            }
-            if ((r + 1) % P.check_rounds == 0 && r + 1 < rounds) {
-                MGC_SLAB_TRY(reduce());
-                int64_t pending = g[MGC_CNT_DEFERRED];
-                for (int i = 0; i <= lmask; ++i) pending += g[i];
-                if (pending == 0) break;
-            }
-        }
-        mgc_range_pop();
-    }
-    MGC_SLAB_TRY(reduce());
-#undef MGC_SLAB_TRY
-    st.discharge_tiles = g[lay.cnt_dis];
-    st.relabel_tiles = g[lay.cnt_rel];
-    mgc_flush_zero(h);
-    if (dev.first_error != hipSuccess) return mgc_fail(h, MGC_ERR_HIP, "slab solver: HIP error %s", hipGetErrorString(dev.first_error));
-    if (hipStreamSynchronize(h->stream) != hipSuccess) return mgc_fail(h, MGC_ERR_HIP, "slab solver: stream synchronisation failed");
     dev.resolve_timing();
     h->stats.discharge_ms = dev.discharge_ms + dev.block_ms;
     h->stats.discharge_wave_ms = dev.discharge_ms;
@@ -3442,38 +3482,102 @@ static int mgc_solve_slab_on(mgc_handle h, const MgcLayout lay, mgc_slab_stats* 
     h->stats.discharge_launches = dev.discharge_launches;
     h->stats.relabel_launches = dev.relabel_launches;
     h->stats.reserved[0] = dev.readbacks;
-    dev.read_counts(cnt); /* this slab's own share (mgc_get_stats is per handle; the global totals are in mgc_slab_stats) */
+    h->stats.reserved[1] = st.radial_cycles;
+    dev.read_counts(cnt);
     h->stats.discharge_tiles = cnt[lay.cnt_dis];
     h->stats.relabel_tiles = cnt[lay.cnt_rel];
     h->stats.discharge_wave_tiles = h->L.ndir == 6 ? cnt[MGC_CNT_WAVE_TILES] : cnt[lay.cnt_dis];
     h->stats.global_relabels = st.outer;
     h->stats.phases = st.phases;
-    if (out) *out = st;
-    if (!st.converged) return mgc_fail(h, MGC_ERR_NOT_CONVERGED, "slab solver did not converge within %d global relabels", P.max_outer);
+}
+
+/* mgc_solve (mgc_driver.inl) over the slabs of one volume: the single handle's schedule with the borders exchanged at its hook points */
+template <class Dev>
+static int mgc_solve_slabs_on(mgc_handle* hs, int n, const mgc_transport* cb, const MgcLayout lay, mgc_slab_stats* out)
+{
+    mgc_handle h0 = hs[0];
+    const bool all_local = n == h0->nranks;
+    std::vector<Dev> devs((size_t)n);
+    std::vector<Dev*> ptr((size_t)n);
+    std::vector<hipStream_t> own_stream((size_t)n);
+    for (int i = 0; i < n; ++i) {
+        devs[(size_t)i].h = hs[i];
+        ptr[(size_t)i] = &devs[(size_t)i];
+        /* the slabs of one device share ONE stream for the length of the solve: their launches are in order without an event between them,
+         * and a slab's kernels run alone on the device (what is measured per slab is what a device of its own would take) */
+        own_stream[(size_t)i] = hs[i]->stream;
+        hs[i]->stream = h0->stream;
+        hs[i]->timing_offset++;
+        hs[i]->solved = false;
+    }
+    MgcXchg<Dev> x(ptr, cb, all_local);
+    MgcSlabGroup<Dev, MgcXchg<Dev>> group(ptr, x);
+    MgcSolveParams P = h0->params;
+    if (h0->L.ndir == 6 && P.radial == 2) { /* wall tiles of the WHOLE volume decide (mgc_maxflow's rule) */
+        int64_t walls = 0;
+        for (int i = 0; i < n; ++i) walls += hs[i]->wall_tiles;
+        x.allreduce(&walls, 1, 0);
+        P.radial = walls >= h0->radial_min_walls ? 1 : 0;
+    }
+    MgcSolveStats st;
+    const int rc = mgc_solve(group, h0->L, P, st, lay);
+    hipError_t first = hipSuccess;
+    for (int i = 0; i < n; ++i) {
+        mgc_flush_zero(hs[i]);
+        if (devs[(size_t)i].first_error != hipSuccess && first == hipSuccess) first = devs[(size_t)i].first_error;
+    }
+    if (first == hipSuccess) first = hipStreamSynchronize(h0->stream);
+    for (int i = 0; i < n; ++i) {
+        if (first == hipSuccess) mgc_slab_handle_stats(hs[i], devs[(size_t)i], lay, st);
+        hs[i]->stream = own_stream[(size_t)i];
+    }
+    if (first != hipSuccess) return mgc_fail(h0, MGC_ERR_HIP, "slab solver: HIP error %s", hipGetErrorString(first));
+    if (x.error) return mgc_fail(h0, x.error, "slab solver: the transport failed (%s)", h0->err.c_str());
+    if (out) {
+        mgc_slab_stats so{};
+        so.outer = st.outer; so.relabel_passes = st.relabel_passes; so.phases = st.phases; so.exchanges = group.exchanges; so.reductions = group.reductions;
+        so.converged = st.converged; so.discharge_tiles = st.discharge_tiles; so.relabel_tiles = st.relabel_tiles; so.deferred_drains = st.deferred_drains;
+        so.reserved[0] = st.radial_cycles;
+        *out = so;
+    }
+    if (rc) return mgc_fail(h0, MGC_ERR_NOT_CONVERGED, "slab solver did not converge within %d global relabels", P.max_outer);
     return MGC_OK;
 }
 
 extern "C" {
 
-int mgc_solve_slab(mgc_handle h, mgc_slab_stats* out)
+int mgc_solve_slabs(mgc_handle* hs, int n, const mgc_transport* t, mgc_slab_stats* out)
 {
-    if (!h) return MGC_ERR_INVALID;
-    if (!h->built) return mgc_fail(h, MGC_ERR_STATE, "mgc_solve_slab before mgc_build");
-    if (h->nranks > 1 && !h->comm) return mgc_fail(h, MGC_ERR_STATE, "mgc_solve_slab: this slab has neighbours, call mgc_comm_init first");
-    MGC_HIP(h, hipSetDevice(h->device));
-    MgcRange range_("mgc_solve_slab");
-    h->solved = false;
+    if (!hs || n < 1 || !hs[0]) return MGC_ERR_INVALID;
+    mgc_handle h0 = hs[0];
+    for (int i = 0; i < n; ++i) {
+        if (!hs[i]) return MGC_ERR_INVALID;
+        if (!hs[i]->built) return mgc_fail(h0, MGC_ERR_STATE, "mgc_solve_slabs before mgc_build (slab %d)", i);
+        if (hs[i]->device != h0->device || hs[i]->L.ndir != h0->L.ndir || hs[i]->nranks != h0->nranks || hs[i]->gd0 != h0->gd0 || hs[i]->L.dy != h0->L.dy || hs[i]->L.dx != h0->L.dx)
+            return mgc_fail(h0, MGC_ERR_INVALID, "mgc_solve_slabs: the local slabs are cut from one volume and live on one device");
+        if (n > 1 && hs[i]->rank != i) return mgc_fail(h0, MGC_ERR_INVALID, "mgc_solve_slabs: all slabs of the volume, in rank order");
+    }
+    if (n > 1 && n != h0->nranks) return mgc_fail(h0, MGC_ERR_INVALID, "mgc_solve_slabs: %d local slabs of a volume cut into %d (either all of them or this rank's one)", n, h0->nranks);
+    if (n == 1 && h0->nranks > 1) {
+        if (!h0->comm && !(t && t->exchange && t->allreduce && t->send && t->recv))
+            return mgc_fail(h0, MGC_ERR_STATE, "mgc_solve_slabs: this slab has neighbours in other processes: call mgc_comm_init first (RCCL), or pass the four callbacks of a host transport");
+    }
+    MGC_HIP(h0, hipSetDevice(h0->device));
+    MgcRange range_("mgc_solve_slabs");
     float ms = 0.f;
-    MGC_HIP(h, hipEventRecord(h->ev[0], h->stream));
-    const int rc = h->L.ndir == MGC26_NDIR ? mgc_solve_slab_on<HipDev26>(h, mgc_layout26(), out) : mgc_solve_slab_on<HipDev>(h, mgc_layout6(), out);
+    MGC_HIP(h0, hipEventRecord(h0->ev[0], h0->stream));
+    const int rc = h0->L.ndir == MGC26_NDIR ? mgc_solve_slabs_on<HipDev26>(hs, n, t, mgc_layout26(), out) : mgc_solve_slabs_on<HipDev>(hs, n, t, mgc_layout6(), out);
     if (rc == MGC_OK) {
-        MGC_HIP(h, hipEventRecord(h->ev[1], h->stream));
-        MGC_HIP(h, hipStreamSynchronize(h->stream));
-        MGC_HIP(h, hipEventElapsedTime(&ms, h->ev[0], h->ev[1]));
-        h->stats.solve_ms = ms;
+        MGC_HIP(h0, hipEventRecord(h0->ev[1], h0->stream));
+        MGC_HIP(h0, hipStreamSynchronize(h0->stream));
+        MGC_HIP(h0, hipEventElapsedTime(&ms, h0->ev[0], h0->ev[1]));
+        for (int i = 0; i < n; ++i) hs[i]->stats.solve_ms = ms;
     }
     return rc;
 }
+
+/* this rank's slab (the entry point of rounds 3 - 5; the same schedule since round 6) */
+int mgc_solve_slab(mgc_handle h, mgc_slab_stats* out) { return mgc_solve_slabs(&h, 1, nullptr, out); }
 
 int mgc_destroy(mgc_handle h)
 {
@@ -3485,7 +3589,7 @@ int mgc_destroy(mgc_handle h)
     void* ptrs[] = {L.rcap, L.cap0, L.excess, L.sink, L.height, L.rmask, L.rmask32, L.obox, L.oflags, L.list[0], L.list[1], L.list[2],
                     L.list[3], L.list[4], L.list[5], L.list[6], L.list[7], L.list[8], L.list[9], L.list[10], L.list[11], L.list[12],
                     L.list[13], L.list[14], L.list[15], L.list[16], L.list[17], L.count, L.stamp, L.rstamp, L.status, h->d_tr0, h->d_part, h->d_part2, h->d_scalar,
-                    h->d_labels, h->d_tflags, h->d_tsum, h->d_image, h->d_lut, h->d_prob, h->d_fg, h->d_bg, h->d_tr_in, h->d_eslot, h->d_eval, h->d_erun, L.hshadow[0], L.hshadow[1], h->d_vout, h->d_dt16, h->d_ds16, h->d_hexact, h->d_halo, h->d_xchg[0], h->d_xchg[1], h->d_xchg[2], h->d_xchg[3], h->d_cnt64};
+                    h->d_labels, h->d_tflags, h->d_tsum, h->d_image, h->d_lut, h->d_prob, h->d_fg, h->d_bg, h->d_tr_in, h->d_eslot, h->d_eval, h->d_erun, L.hshadow[0], L.hshadow[1], h->d_vout, h->d_dt16, h->d_ds16, h->d_hexact, h->d_halo, h->d_xchg[0], h->d_xchg[1], h->d_xchg[2], h->d_xchg[3], h->d_cnt64, h->d_carry[0], h->d_carry[1], h->d_carry_in[0], h->d_carry_in[1]};
     for (void* p : ptrs)
         if (p) (void)mgc_dfree(p);
     if (h->h_count) (void)hipHostFree(h->h_count);
@@ -3884,8 +3988,8 @@ int mgc_build(mgc_handle h)
     /* the two build counters are read: their slots (MGC_CNT_NOT_FULL is MGC_CNT_DEFERRED during a solve) are cleared with the next
      * batch of counter clears, whichever schedule drives the solve */
     h->zero_mask |= (1u << MGC_CNT_NOT_FULL) | (1u << MGC_CNT_SINK_TILES) | (1u << MGC_CNT_WALL_TILES);
-    h->all_residual = L.ndir == 6 && A.term != MGC_TERM_NONE && h->h_count[MGC_CNT_NOT_FULL] == 0 && !h->n_edges && h->nranks == 1 &&
-                      L.dz + L.dy + L.dx < MGC_DT_INF - 8;
+    h->all_residual = L.ndir == 6 && A.term != MGC_TERM_NONE && h->h_count[MGC_CNT_NOT_FULL] == 0 && !h->n_edges &&
+                      h->gd0 + L.dy + L.dx < MGC_DT_INF - 8; /* (a slab: of ITS planes; the slab group asks every slab, MgcSlabGroup::first_relabel_dt) */
     float ms = 0.f;
     MGC_HIP(h, hipEventElapsedTime(&ms, h->ev[0], h->ev[1]));
     h->stats.build_ms = ms;
@@ -4170,7 +4274,8 @@ int mgc_set_param(mgc_handle h, const char* name, int64_t value)
     else if (!strcmp(name, "wave_grid_dis") && value > 0) h->wave_grid_dis = (int)value;
     else if (!strcmp(name, "wave_grid26") && value > 0) h->wave_grid26 = (int)value;
     else if (!strcmp(name, "prepush")) h->prepush = value != 0;
-    else if (!strcmp(name, "relabel_exchange_every") && value >= 0) h->relabel_exchange_every = (int)value;
+    else if ((!strcmp(name, "exchange_passes") || !strcmp(name, "relabel_exchange_every")) && value > 0) h->params.exchange_passes = (int)value; /* slabs: relabel passes between two exchanges of the border labels */
+    else if (!strcmp(name, "exchange_rounds") && value > 0) h->params.exchange_rounds = (int)value; /* slabs (6-neighbourhood): colour rounds between two exchanges of labels + outbox flow */
     else if (!strcmp(name, "w26_passes") && value > 0) h->w26_passes = (int)value;
     else if (!strcmp(name, "w26_raises") && value > 0) h->w26_raises = (int)value;
     else if (!strcmp(name, "w26_flags") && value >= 0) h->w26_flags = (int)value;

@@ -12,49 +12,23 @@ Because region discharge only ever reads a neighbour tile's labels and outbox as
 tile's last discharge, the distributed run performs exactly the single-GPU computation:
 labels are bit-identical to the single-GPU (and hence the reference's) labels.
 
-This module holds the schedule (a mirror of ``medpy_amd/csrc/mgc_driver.inl`` with exchanges
-and all-reduces added) and the two transports.  It is backend-agnostic: the CPU test tier runs
-the same code over the host simulator, two processes over gloo or over a directory of files (tests/test_slab_*.py).
+The schedule itself is the single handle's (``mgc_solve``, ``medpy_amd/csrc/mgc_driver.inl``) with the borders exchanged at its
+hook points; it lives in the library (``mgc_solve_slabs``) and, as the same source, in the host simulator of the CPU test tier.
+This module holds the slab handle, the layouts (all slabs in one process / one per process over RCCL / one per process over a host
+transport: two processes over gloo or over a directory of files in tests/test_slab_*.py) and the helpers around a solve.
 """
 import numpy as np
 
 (OP_ABSORB_ALL, OP_FILL_INF, OP_ZERO_COUNT, OP_RELABEL_ALL, OP_RELABEL_LIST, OP_ACTIVATE, OP_DISCHARGE, OP_SUSPECT_PASS,
- OP_RESET_SUSPECT) = range(9)
-CNT_CHANGED = 21  # MGC_CNT_CHANGED (mgc_common.h)
-CNT_DEFERRED = 28  # MGC_CNT_DEFERRED: border tiles a full message left for the next exchange
+ OP_RESET_SUSPECT) = range(9)  # mgc_solver_op: single launches for profiling tools (tools/gpu_slab_ops_profile.py); no schedule uses them
 
 
 class LoopbackExchange(object):
-    """All slabs live in this process (one GPU time-multiplexed, or the host simulator)."""
+    """All slabs of the volume live in this process (one GPU time-multiplexed, or the host simulator): their borders move inside the
+    library / the simulator (``solve_slabs``); what is left here are the sums over the local slabs that the helpers below ask for."""
 
     def __init__(self, slabs):
         self.slabs = list(slabs)
-        self._bufs = {}
-        self.on_device = False
-
-    def _buf(self, key, nbytes):
-        b = self._bufs.get(key)
-        if b is None or b.size != nbytes:
-            b = np.zeros(nbytes, dtype=np.uint8)
-            self._bufs[key] = b
-        return b
-
-    def _raw(self, b):
-        return b
-
-    def exchange(self, kind, epoch, lst):
-        packed = []
-        for i in range(len(self.slabs) - 1):
-            lo, hi = self.slabs[i], self.slabs[i + 1]
-            nb = lo.halo_bytes(kind)
-            up = self._buf((i, "up", kind), nb)
-            dn = self._buf((i, "dn", kind), nb)
-            lo.halo_pack(1, kind, self._raw(up), on_device=self.on_device)
-            hi.halo_pack(0, kind, self._raw(dn), on_device=self.on_device)
-            packed.append((up, dn))
-        for i, (up, dn) in enumerate(packed):
-            self.slabs[i + 1].halo_unpack(0, kind, self._raw(up), epoch, lst, on_device=self.on_device)
-            self.slabs[i].halo_unpack(1, kind, self._raw(dn), epoch, lst, on_device=self.on_device)
 
     def allreduce_sum(self, values):
         """values: one number (or vector) per local slab -> global sum"""
@@ -63,10 +37,6 @@ class LoopbackExchange(object):
     def allreduce_max(self, values):
         """values: one vector per local slab -> element-wise global maximum"""
         return np.max(np.asarray(values, dtype=np.float64), axis=0)
-
-    def global_counts(self):
-        """the 16 solver counters summed over every slab of the volume"""
-        return np.sum([s.read_counts().astype(np.int64) for s in self.slabs], axis=0)
 
 
 class StoreExchange(object):
@@ -79,17 +49,24 @@ class StoreExchange(object):
         self.store, self.slabs = store, [slab]
         self.rank, self.world = store.rank, store.world
 
-    def exchange(self, kind, epoch, lst):
-        slab = self.slabs[0]
-        nb = slab.halo_bytes(kind)
-        peers = [(side, peer) for side, peer in ((0, self.rank - 1), (1, self.rank + 1)) if 0 <= peer < self.world]
-        for side, peer in peers:
-            buf = np.zeros(nb, dtype=np.uint8)
-            slab.halo_pack(side, kind, buf, on_device=False)
-            self.store.send(peer, buf.tobytes())
-        for side, peer in peers:
-            buf = np.frombuffer(self.store.recv(peer, nb), dtype=np.uint8).copy()
-            slab.halo_unpack(side, kind, buf, epoch, lst, on_device=False)
+    # -- what HostTransport hands to the library as the callbacks of an mgc_transport
+    def xchg(self, lo, hi):
+        for peer, data in ((self.rank - 1, lo), (self.rank + 1, hi)):
+            if data is not None:
+                self.store.send(peer, data)
+        return (self.store.recv(self.rank - 1, len(lo)) if lo is not None else None,
+                self.store.recv(self.rank + 1, len(hi)) if hi is not None else None)
+
+    def allreduce_i64(self, a, op):
+        a = np.asarray(a, dtype=np.float64)  # (counters and distances: far below 2^53)
+        out = self.store.allreduce(a, "sum") if op == 0 else -np.asarray(self.store.allreduce(-a, "max"))
+        return np.asarray(out).reshape(-1).astype(np.int64)
+
+    def send(self, side, data):
+        self.store.send(self.rank + (1 if side else -1), data)
+
+    def recv(self, side, nbytes):
+        return self.store.recv(self.rank + (1 if side else -1), nbytes)
 
     def allreduce_sum(self, values):
         out = self.store.allreduce(np.sum(np.asarray(values, dtype=np.float64), axis=0), "sum")
@@ -98,14 +75,11 @@ class StoreExchange(object):
     def allreduce_max(self, values):
         return self.store.allreduce(np.max(np.asarray(values, dtype=np.float64), axis=0), "max")
 
-    def global_counts(self):
-        return np.asarray(self.allreduce_sum([self.slabs[0].read_counts().astype(np.float64)])).astype(np.int64)
-
 
 class RcclExchange(object):
     """One slab per process, borders moved by the library itself: pack -> grouped ncclSend/ncclRecv with
-    rank-1 / rank+1 -> unpack, stream-ordered in HBM (``mgc_halo_exchange``); counters summed with
-    ncclAllReduce (``mgc_allreduce_counts``).  ``store`` (medpy_amd.rendezvous.FileStore, or anything with ``rank``, ``world``,
+    rank-1 / rank+1 -> unpack, stream-ordered in HBM (``mgc_halo_exchange``); counters reduced with ncclAllReduce, the carry planes
+    of the distance transforms by ncclSend / ncclRecv.  ``store`` (medpy_amd.rendezvous.FileStore, or anything with ``rank``, ``world``,
     ``broadcast(bytes, src, nbytes)`` and ``allreduce(array, op)``) is only the out-of-band channel that hands rank 0's
     128-byte RCCL id to the other ranks and sums a few host scalars at the end -- no PyTorch anywhere."""
 
@@ -116,13 +90,7 @@ class RcclExchange(object):
         uid = slab.comm_unique_id() if self.rank == 0 else b""
         slab.comm_init(store.broadcast(uid, src=0, nbytes=128))
 
-    native = True  # solve_slabs hands the whole schedule to the library (mgc_solve_slab)
-
-    def exchange(self, kind, epoch, lst):
-        self.slabs[0].exchange(kind, epoch, lst)
-
-    def global_counts(self):
-        return self.slabs[0].allreduce_counts()
+    native = True  # the slab has its own channel (mgc_comm_init): no callbacks
 
     def allreduce_sum(self, values):
         out = self.store.allreduce(np.sum(np.asarray(values, dtype=np.float64), axis=0), "sum")
@@ -165,154 +133,71 @@ def sync_boundary_table(slabs, ex):
         s.set_boundary_table(-g[1], g[2])
 
 
-def solve_slabs(slabs, ex, rounds_per_relabel=None, max_cycles=None, max_sweeps=None, max_outer=100000, check_rounds=4, relabel_batch=8,
-                incremental_relabel=True, exchange_every=4):
+def solve_slabs(slabs, ex=None, rounds_per_relabel=None, max_cycles=None, max_sweeps=None, max_outer=None, check_rounds=None, relabel_batch=None,
+                incremental_relabel=True, exchange_every=None, exchange_rounds=None, radial=None):
     """Drives the local slabs to a maximum preflow.  Returns a stats dict (global numbers).
 
-    Every loop decision that involves the other ranks is taken on globally summed counters, so all ranks run the same
-    outer control flow.  Between two border exchanges of a global relabel every rank iterates its own slabs to a LOCAL
-    fixpoint (labels only go down during a relabel, so stale ghost labels are upper bounds and the chaotic iteration
-    still converges to the exact distances); the borders are exchanged after every round of the two colours (after every
-    colour phase in the 26-neighbourhood, whose pushes land in the ghost tiles in place).  Later global
-    relabels are incremental like the single-GPU driver's (mgc_driver.inl): the DIRTY / SUSPECT flags of the border
-    tiles travel as halo kind 2 until the suspect closure is stable everywhere."""
-    if getattr(ex, "native", False) and len(slabs) == 1 and hasattr(slabs[0], "solve_native"):
-        # the library's own transport: the schedule below runs inside libmedpyhip (mgc_solve_slab), no call per kernel from here
-        # None = the library's default for the slab's neighbourhood (rounds_per_relabel: 8 / 6)
-        for name, value in (("rounds_per_relabel", rounds_per_relabel), ("max_cycles", max_cycles), ("max_sweeps", max_sweeps),
-                            ("max_outer", max_outer), ("check_rounds", check_rounds), ("relabel_batch", relabel_batch),
-                            ("incremental_relabel", int(bool(incremental_relabel))), ("relabel_exchange_every", exchange_every)):
-            if value is not None:
-                slabs[0].set_param(name, value)
-        return slabs[0].solve_native()  # (converged == 0 in the stats when max_outer ran out, as the Python schedule reports it)
-    if rounds_per_relabel is None:
-        rounds_per_relabel = 6 if getattr(slabs[0], "ndir", 6) == 26 else 8
-    relabel_batch = max(2, relabel_batch + (relabel_batch & 1))  # even: every rank keeps the same list parity
-    # where the solver variant keeps its lists / counters (MgcLayout, mgc_driver.inl:51-62)
-    if getattr(slabs[0], "ndir", 6) == 26:
-        ncol, lmask, rl, c_act, c_dis, c_rel = 8, 15, 16, 18, 19, 20
-        max_sweeps = max_sweeps or 3  # mgc_default_params(26)
-        max_cycles = max_cycles or -1  # stored labels, mgc_default_params(26)
-    else:
-        ncol, lmask, rl, c_act, c_dis, c_rel = 2, 3, 4, 6, 8, 9
-        max_sweeps = max_sweeps or 12  # mgc_default_params(6)
-        max_cycles = max_cycles or 1
-    phase, rep = 2 * (lmask + 1), 2
-    for s in slabs:
-        s.op(OP_ZERO_COUNT, c_dis)
-        s.op(OP_ZERO_COUNT, c_rel)
-    st = {"outer": 0, "relabel_passes": 0, "phases": 0, "exchanges": 0, "reductions": 0, "converged": 0}
+    There is ONE schedule, and it is not here: ``mgc_solve`` (medpy_amd/csrc/mgc_driver.inl) -- the single handle's own, with the
+    borders exchanged at its hook points: first relabel by distance transform carried across the slab borders, flood phase on radial
+    labels, incremental relabels whose suspect closure crosses the borders.  The library runs it for HipSlab handles
+    (``mgc_solve_slabs``), the host simulator of the CPU test tier for its slabs (the same source, ``hostsim_solve_slabs``).  What
+    this function chooses is the layout:
 
-    def exchange(kind, epoch, lst):
-        ex.exchange(kind, epoch, lst)
-        st["exchanges"] += 1
+    * ``slabs`` = every slab of the volume (time-multiplexed on one GPU, or simulator slabs): borders move between the slabs' own
+      buffers; ``ex`` is ignored (a ``LoopbackExchange`` by tradition);
+    * one slab and ``ex`` = ``RcclExchange``: borders and reductions over RCCL / xGMI inside the library;
+    * one slab and a host transport (``StoreExchange``; the gloo transport of the tests): borders through the transport's
+      ``xchg`` / ``allreduce_i64`` / ``send`` / ``recv``, handed to the library as the callbacks of an ``mgc_transport``.
 
-    def global_counts():
-        st["reductions"] += 1
-        return ex.global_counts()
+    ``None`` leaves a parameter at the library's default for the slab's neighbourhood."""
+    params = {"rounds_per_relabel": rounds_per_relabel, "max_cycles": max_cycles, "max_sweeps": max_sweeps, "max_outer": max_outer,
+              "check_rounds": check_rounds, "relabel_batch": relabel_batch, "incremental_relabel": int(bool(incremental_relabel)),
+              "exchange_passes": exchange_every, "exchange_rounds": exchange_rounds, "radial": radial}
+    transport = None
+    if len(slabs) == 1 and ex is not None and not getattr(ex, "native", False) and not isinstance(ex, LoopbackExchange):
+        transport = ex
+    return slabs[0].solve_group(slabs, transport, {k: v for k, v in params.items() if v is not None})
 
-    for s in slabs:
-        s.op(OP_ZERO_COUNT, CNT_DEFERRED)
-    for outer in range(max_outer):
-        # ---- flow that a full border message left behind during the colour phases has to cross before the masks are read
-        while outer > 0 and int(global_counts()[CNT_DEFERRED]) != 0:
-            for s in slabs:
-                s.op(OP_ZERO_COUNT, CNT_DEFERRED)
-            exchange(1, phase - 1, 0)
-            st["deferred_drains"] = st.get("deferred_drains", 0) + 1
-        # ---- global relabel: tile BFS passes to a local fixpoint, border label exchange, until nothing moves anywhere
-        for s in slabs:
-            s.op(OP_ABSORB_ALL)
-            s.op(OP_ZERO_COUNT, rl)
-            s.op(OP_ZERO_COUNT, rl + 1)
-        nxt = rl + ((rep + 1) & 1)
-        if outer == 0 or not incremental_relabel:
-            for s in slabs:
-                s.op(OP_FILL_INF)
-                s.op(OP_RELABEL_ALL, rep + 1, nxt)
-        else:
-            while True:  # which tiles may have lost the support of their labels (closure across the slab borders)
-                for s in slabs:
-                    s.op(OP_ZERO_COUNT, CNT_CHANGED)
-                    for _b in range(8):
-                        s.op(OP_SUSPECT_PASS)
-                exchange(2, 0, 0)
-                if global_counts()[CNT_CHANGED] == 0:
-                    break
-            for s in slabs:
-                s.op(OP_RESET_SUSPECT, rep + 1, nxt)
-        st["relabel_passes"] += 1
-        rounds_done = 0
-        while exchange_every > 0:
-            # Border labels travel every `xk` passes, whether or not a slab has reached its local fixpoint: the label wave of the
-            # relabel crosses a slab border at most xk passes after it reaches it (labels only go down during a relabel, so a ghost
-            # label is an upper bound whenever it is read).  Every rank runs the same number of passes; counters are compared
-            # every second exchange.  (mgc_solve_slab runs the same loop.)
-            xk = exchange_every + (exchange_every & 1)
-            for _b in range(xk):
-                rep += 1
-                cur, nxt = rl + (rep & 1), rl + ((rep + 1) & 1)
-                for s in slabs:
-                    s.op(OP_ZERO_COUNT, nxt)
-                    s.op(OP_RELABEL_LIST, cur, rep + 1, nxt)
-                st["relabel_passes"] += 1
-            if rounds_done % 2 == 0:
-                for s in slabs:
-                    s.op(OP_ZERO_COUNT, CNT_DEFERRED)
-            exchange(0, rep + 1, nxt)
-            rounds_done += 1
-            if rounds_done % 2 == 1:
-                continue
-            g = global_counts()
-            if g[nxt] == 0 and g[CNT_DEFERRED] == 0:
-                break
-        while exchange_every <= 0:  # round 3's schedule: every slab to its local fixpoint between two exchanges
-            while any(int(s.read_counts()[nxt]) != 0 for s in slabs):  # local read-back, no collective
-                for _b in range(relabel_batch):
-                    rep += 1
-                    cur, nxt = rl + (rep & 1), rl + ((rep + 1) & 1)
-                    for s in slabs:
-                        s.op(OP_ZERO_COUNT, nxt)
-                        s.op(OP_RELABEL_LIST, cur, rep + 1, nxt)
-                    st["relabel_passes"] += 1
-            for s in slabs:
-                s.op(OP_ZERO_COUNT, CNT_DEFERRED)
-            exchange(0, rep + 1, nxt)
-            g = global_counts()
-            if g[nxt] == 0 and g[CNT_DEFERRED] == 0:  # the exchange woke nobody anywhere and left nothing behind: global fixpoint
-                break
-        st["outer"] += 1
 
-        # ---- who can still push towards the sink?
-        phase += 2 * (lmask + 1)  # fresh stamps: anything queued before the relabel is void
-        for s in slabs:
-            for i in list(range(lmask + 1)) + [c_act]:
-                s.op(OP_ZERO_COUNT, i)
-            s.op(OP_ACTIVATE, phase)
-        if global_counts()[c_act] == 0:
-            st["converged"] = 1
-            break
+class HostTransport(object):
+    """the four callbacks of an ``mgc_transport`` (include/medpy_hip.h) over a Python transport ``ex`` with
+    ``xchg(lo, hi) -> (lo', hi')`` (bytes or None per side), ``allreduce_i64(array, op)`` (op 0 sum / 1 min, returns the array),
+    ``send(side, bytes)`` and ``recv(side, nbytes) -> bytes``.  Keeps the ctypes thunks alive for as long as it lives."""
 
-        # ---- colour phases, border (labels + outbox flow) exchanged after each
-        for s in slabs:
-            s.op(OP_ZERO_COUNT, CNT_DEFERRED)
-        for r in range(rounds_per_relabel):
-            for _c in range(ncol):
-                lst = phase & lmask
-                for s in slabs:
-                    s.op(OP_DISCHARGE, lst, phase, max_cycles, max_sweeps)
-                    s.op(OP_ZERO_COUNT, lst)
-                if ncol != 2 or _c == 1:  # 6-neighbourhood: once per round of the two colours (mgc_halo_unpack_tile queues by colour)
-                    exchange(1, phase, 0)
-                st["phases"] += 1
-                phase += 1
-            if (r + 1) % check_rounds == 0 and r + 1 < rounds_per_relabel:
-                c = global_counts()
-                if int(np.sum(c[:lmask + 1])) + int(c[CNT_DEFERRED]) == 0:
-                    break
-    c = ex.global_counts()
-    st["discharge_tiles"], st["relabel_tiles"] = int(c[c_dis]), int(c[c_rel])
-    return st
+    def __init__(self, ex):
+        import ctypes as C
+        from . import _lib
+        self.error = None
+
+        def guard(fn):
+            def wrapped(*a):
+                try:
+                    fn(*a)
+                    return 0
+                except Exception as e:  # noqa: BLE001  (an exception must not unwind through the C frames: report and fail the call)
+                    self.error = e
+                    return _lib.ERR_INVALID
+            return wrapped
+
+        def exchange(_ctx, send_lo, recv_lo, send_hi, recv_hi, n):
+            lo, hi = ex.xchg(C.string_at(send_lo, n) if send_lo else None, C.string_at(send_hi, n) if send_hi else None)
+            if recv_lo:
+                C.memmove(recv_lo, lo, n)
+            if recv_hi:
+                C.memmove(recv_hi, hi, n)
+
+        def allreduce(_ctx, v, n, op):
+            a = np.ctypeslib.as_array(v, shape=(n,))
+            a[:] = np.asarray(ex.allreduce_i64(a.copy(), int(op)), dtype=np.int64)
+
+        def send(_ctx, side, buf, n):
+            ex.send(int(side), C.string_at(buf, n))
+
+        def recv(_ctx, side, buf, n):
+            C.memmove(buf, ex.recv(int(side), int(n)), n)
+
+        self._thunks = (_lib.XCHG_FN(guard(exchange)), _lib.ALLREDUCE_FN(guard(allreduce)), _lib.SEND_FN(guard(send)), _lib.RECV_FN(guard(recv)))
+        self.struct = _lib.Transport(None, *self._thunks)
 
 
 class HipSlab(object):
@@ -423,15 +308,25 @@ class HipSlab(object):
     def set_param(self, name, value):
         self._call("mgc_set_param", name.encode(), int(value))
 
-    def solve_native(self):
-        """the distributed schedule inside the library (mgc_solve_slab): needs comm_init() when the volume has several slabs"""
-        st = self._lib.SlabStats()
-        try:
-            self._call("mgc_solve_slab", self._C.byref(st))
-        except self._lib.MedpyHipError as err:
-            if err.code != self._lib.ERR_NOT_CONVERGED:
-                raise  # (the stats are filled before the library reports max_outer exhausted: converged stays 0)
-        return st.as_dict()
+    @staticmethod
+    def solve_group(slabs, transport, params):
+        """mgc_solve_slabs over ``slabs`` (all slabs of the volume, or this rank's one); ``transport``: None, or a Python host transport"""
+        import ctypes as C
+        from . import _lib
+        lib = _lib.load()
+        for name, value in params.items():
+            slabs[0].set_param(name, value)  # (the group runs on the parameters of its first slab)
+        hs = (C.c_void_p * len(slabs))(*[s._h for s in slabs])
+        st = _lib.SlabStats()
+        cb = HostTransport(transport) if transport is not None else None
+        rc = lib.mgc_solve_slabs(hs, len(slabs), C.byref(cb.struct) if cb else None, C.byref(st))
+        if cb is not None and cb.error is not None:
+            raise cb.error
+        if rc not in (_lib.OK, _lib.ERR_NOT_CONVERGED):  # (max_outer exhausted: the stats say converged = 0, as they always did)
+            _lib.check(slabs[0]._h, rc)
+        out = st.as_dict()
+        out["radial_cycles"] = int(st.reserved[0])
+        return out
 
     def halo_bytes(self, kind):
         n = self._C.c_int64(0)

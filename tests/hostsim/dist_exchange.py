@@ -32,25 +32,34 @@ class DistExchange(object):
     def _raw(self, t):
         return t.data_ptr() if self.on_device else t.numpy()
 
-    def exchange(self, kind, epoch, lst):
-        slab, dist = self.slabs[0], self.dist
-        nb = slab.halo_bytes(kind)
-        ops, recvs = [], []
-        for side, peer in ((0, self.rank - 1), (1, self.rank + 1)):
-            if peer < 0 or peer >= self.world:
+    # -- what medpy_amd.slab.HostTransport hands to the schedule (mgc_solve over the slab group) as the callbacks of an mgc_transport
+    def xchg(self, lo, hi):
+        torch, dist = self.torch, self.dist
+        ops, out = [], [None, None]
+        for k, (peer, data) in enumerate(((self.rank - 1, lo), (self.rank + 1, hi))):
+            if data is None:
                 continue
-            snd, rcv = self._buf((side, "s", kind), nb), self._buf((side, "r", kind), nb)
-            slab.halo_pack(side, kind, self._raw(snd), on_device=self.on_device)
+            snd = torch.frombuffer(bytearray(data), dtype=torch.uint8)
+            out[k] = torch.zeros(len(data), dtype=torch.uint8)
             ops.append(dist.P2POp(dist.isend, snd, peer, self.group))
-            ops.append(dist.P2POp(dist.irecv, rcv, peer, self.group))
-            recvs.append((side, rcv))
+            ops.append(dist.P2POp(dist.irecv, out[k], peer, self.group))
         if ops:
             for w in dist.batch_isend_irecv(ops):
                 w.wait()
-            if self.on_device:
-                self.torch.cuda.synchronize()
-        for side, rcv in recvs:
-            slab.halo_unpack(side, kind, self._raw(rcv), epoch, lst, on_device=self.on_device)
+        return tuple(None if t is None else t.numpy().tobytes() for t in out)
+
+    def allreduce_i64(self, a, op):
+        t = self.torch.as_tensor(np.asarray(a, dtype=np.int64))
+        self.dist.all_reduce(t, op=self.dist.ReduceOp.MIN if op == 1 else self.dist.ReduceOp.SUM, group=self.group)
+        return t.numpy()
+
+    def send(self, side, data):
+        self.dist.send(self.torch.frombuffer(bytearray(data), dtype=self.torch.uint8), self.rank + (1 if side else -1), group=self.group)
+
+    def recv(self, side, nbytes):
+        t = self.torch.zeros(int(nbytes), dtype=self.torch.uint8)
+        self.dist.recv(t, self.rank + (1 if side else -1), group=self.group)
+        return t.numpy().tobytes()
 
     def allreduce_sum(self, values):
         t = self.torch.as_tensor(np.sum(np.asarray(values, dtype=np.float64), axis=0), dtype=self.torch.float64).reshape(-1).to(self.dev)
@@ -62,6 +71,3 @@ class DistExchange(object):
         t = self.torch.as_tensor(np.max(np.asarray(values, dtype=np.float64), axis=0), dtype=self.torch.float64).reshape(-1).to(self.dev)
         self.dist.all_reduce(t, op=self.dist.ReduceOp.MAX, group=self.group)
         return t.cpu().numpy()
-
-    def global_counts(self):
-        return self.allreduce_sum([self.slabs[0].read_counts().astype(np.float64)]).astype(np.int64)

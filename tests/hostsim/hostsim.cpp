@@ -235,7 +235,67 @@ typedef HostBlockT<MgcTileShared> HostBlock;
 typedef HostBlockT<MgcTileShared26> HostBlock26;
 typedef HostBlockT<MgcTileShared26D> HostBlock26D;
 
-struct HostDev {
+
+/* ---- what MgcSlabGroup / MgcXchg (mgc_driver.inl) ask of a slab, on host memory: the same schedule and the same transport logic as the
+ * library's run in the CPU test tier ---- */
+template <class D, class BlockT>
+struct HostSlabOps {
+    D& self() { return *static_cast<D*>(this); }
+    const D& self() const { return *static_cast<const D*>(this); }
+    int64_t gd0 = 0; /* planes of the whole volume */
+    std::vector<char> xbuf[4]; /* send lo, recv lo, send hi, recv hi */
+    std::vector<uint16_t> carry[2], carry_recv[2];
+    bool multi() const { return false; }
+    void exchange(int, uint32_t, int) {}
+    bool has_lower() const { return self().L.tz_own_lo > 0; }
+    bool has_upper() const { return self().L.tz_own_hi < self().L.gz; }
+    bool needs_carry(int dir) const { return dir == 0 ? self().spec.plane0 > 0 : self().spec.plane1 < gd0; }
+    bool sends_carry(int dir) const { return dir == 0 ? (has_upper() && self().spec.own1 - 9 >= self().spec.plane0) : (has_lower() && self().spec.own0 + 8 < gd0); }
+    int carry_plane(int dir) const { return (int)(dir == 0 ? self().spec.own1 - 9 - self().spec.plane0 : self().spec.own0 + 8 - self().spec.plane0); }
+    int64_t carry_bytes() const { return (int64_t)self().L.dy * self().L.dx * (int64_t)sizeof(uint16_t); }
+    uint16_t* carry_buf(int dir) { carry[dir].resize((size_t)(self().L.dy * self().L.dx)); return carry[dir].data(); }
+    uint16_t* carry_recv_buf(int dir) { carry_recv[dir].resize((size_t)(self().L.dy * self().L.dx)); return carry_recv[dir].data(); }
+    int64_t halo_msg_bytes(int kind) const
+    {
+        const MgcLattice& L = self().L;
+        return mgc_halo_compact_nd(L, kind) ? mgc_halo_off_rec_nd(L) + (int64_t)L.halo_max_rec * mgc_halo_rec_bytes_nd(L, kind) : mgc_halo_bytes_nd(L, kind);
+    }
+    void* buf(int i)
+    {
+        const MgcLattice& L = self().L;
+        int64_t n = mgc_halo_bytes_nd(L, 0);
+        for (int k = 1; k < 3; ++k) n = mgc_halo_bytes_nd(L, k) > n ? mgc_halo_bytes_nd(L, k) : n;
+        if ((int64_t)xbuf[i].size() < n) xbuf[i].assign((size_t)n, 0);
+        return xbuf[i].data();
+    }
+    void* recv_buf(int side) { return buf(2 * side + 1); }
+    void* halo_pack(int side, int kind)
+    {
+        MgcLattice& L = self().L;
+        BlockT x(self().S);
+        void* const dst = buf(2 * side);
+        if (mgc_halo_compact_nd(L, kind)) memset((char*)dst + mgc_halo_off_count_nd(L), 0, 4);
+        for (int i = 0; i < L.gy * L.gx; ++i) mgc_halo_pack_nd(x, L, side, kind, i, dst);
+        return dst;
+    }
+    void halo_unpack(int side, int kind, const void* b, uint32_t epoch, int list)
+    {
+        MgcLattice& L = self().L;
+        BlockT x(self().S);
+        for (int i = 0; i < L.gy * L.gx; ++i) mgc_halo_unpack_nd(x, L, side, kind, i, b, epoch, list);
+    }
+    void to_host(void* host, const void* b, int64_t n) { memcpy(host, b, (size_t)n); }
+    void from_host(void* b, const void* host, int64_t n) { memcpy(b, host, (size_t)n); }
+    bool has_comm() const { return false; }
+    int native_exchange(int, uint32_t, int) { return 1; }
+    int native_allreduce(int64_t*, int, int) { return 1; }
+    int native_send(int, const void*, int64_t) { return 1; }
+    int native_recv(int, void*, int64_t) { return 1; }
+    int count_get(int i) { return self().L.count[i]; }
+    void count_set(int i, int v) { self().L.count[i] = v; }
+};
+
+struct HostDev : HostSlabOps<HostDev, HostBlockT<MgcTileShared>> {
     MgcLattice L;
     MgcTileShared S;
     MgcWaveShared WS;
@@ -281,7 +341,7 @@ struct HostDev {
      * the volume residual, one handle (no slabs) */
     bool first_relabel_dt()
     {
-        if (!g_use_dt || spec.nranks > 1 || L.dz + L.dy + L.dx >= MGC_DT_INF - 8) return false;
+        if (!g_use_dt || spec.nranks > 1 || labels_valid || L.dz + L.dy + L.dx >= MGC_DT_INF - 8) return false;
         for (int64_t z = 0; z < L.dz; ++z)
             for (int64_t y = 0; y < L.dy; ++y)
                 for (int64_t x = 0; x < L.dx; ++x) {
@@ -304,6 +364,72 @@ struct HostDev {
         g_prof[28]++;
         return true;
     }
+    /* ---- the transforms of a slab, scan by scan (MgcSlabGroup::transform) ---- */
+    bool all_residual_local() const
+    {
+        for (int64_t z = 0; z < L.dz; ++z)
+            for (int64_t y = 0; y < L.dy; ++y)
+                for (int64_t x = 0; x < L.dx; ++x) {
+                    int tile, loc;
+                    mgc_node_to_tile(L, (z * L.dy + y) * L.dx + x, tile, loc);
+                    const uint32_t need = (x > 0 ? 1u : 0u) | (x + 1 < L.dx ? 2u : 0u) | (y > 0 ? 4u : 0u) | (y + 1 < L.dy ? 8u : 0u) |
+                                          (z > 0 ? 16u : 0u) | (z + 1 < L.dz ? 32u : 0u);
+                    if ((rmask[(int64_t)tile * MGC_TV + loc] & need) != need) return false;
+                }
+        return true;
+    }
+    std::vector<uint16_t> dt16;
+    uint16_t* dt_cur = nullptr;
+    bool labels_valid = false;
+    bool dt_applicable() { return g_use_dt && !labels_valid && gd0 + L.dy + L.dx < MGC_DT_INF - 8 && all_residual_local(); }
+    void dt_scans_xy(int seed)
+    {
+        HostWave w(WS);
+        labels_valid = true;
+        std::vector<uint16_t>& A = seed == 1 ? dt16 : ds16;
+        A.assign((size_t)L.ntiles * MGC_TV, 0);
+        uint16_t* const T = dt_cur = A.data();
+        if (seed == 1) for (int i = 0; i < L.gz * L.gy; ++i) mgc_dt_scan_line<0, false, 1, 0>(w, L, i, L.rmask, T);
+        else for (int i = 0; i < L.gz * L.gy; ++i) mgc_dt_scan_line<0, false, 2, 0>(w, L, i, L.excess, T);
+        for (int i = 0; i < L.gz * L.gy; ++i) mgc_dt_scan_line<0, true, 0, 0>(w, L, i, T, T);
+        for (int i = 0; i < L.gz * L.gx; ++i) mgc_dt_scan_line<1, false, 0, 0>(w, L, i, T, T);
+        for (int i = 0; i < L.gz * L.gx; ++i) mgc_dt_scan_line<1, true, 0, 0>(w, L, i, T, T);
+    }
+    void dt_scan_z(bool bwd, int final_kind, int c_min, const uint16_t* cin, bool want_out)
+    {
+        HostWave w(WS);
+        uint16_t* const T = dt_cur;
+        uint16_t* const cout = want_out ? carry_buf(bwd ? 1 : 0) : nullptr;
+        const int plane = want_out ? carry_plane(bwd ? 1 : 0) : -1;
+        for (int i = 0; i < L.gy * L.gx; ++i) {
+            if (!bwd) mgc_dt_scan_line<2, false, 0, 0>(w, L, i, T, T, 0, nullptr, cin, cout, plane);
+            else if (final_kind == 1) mgc_dt_scan_line<2, true, 0, 1>(w, L, i, T, L.height, 0, nullptr, cin, cout, plane);
+            else if (final_kind == 2) mgc_dt_scan_line<2, true, 0, 2>(w, L, i, T, T, c_min, hexact.data(), cin, cout, plane);
+            else mgc_dt_scan_line<2, true, 0, 0>(w, L, i, T, T, 0, nullptr, cin, cout, plane);
+        }
+        if (bwd && final_kind == 2) lowered = L.count[MGC_CNT_RADIAL_C] < MGC_HINF && L.count[MGC_CNT_RADIAL_C] >= c_min;
+    }
+    void dt_finish()
+    {
+        HostWave w(WS);
+        for (int t = 0; t < L.ntiles; ++t) mgc_dt_finish_tile(w, L, t);
+        L.count[9] += L.ntiles;
+        g_prof[28]++;
+    }
+    void shadow_sync()
+    {
+        HostWave w(WS);
+        for (int side = 0; side < 2; ++side)
+            for (int i = 0; i < L.gy * L.gx; ++i) mgc_shadow_sync_tile(w, L, side, i, L.height);
+    }
+    bool radial_prepare() { hexact.assign((size_t)L.ntiles * MGC_TV, 0); return true; }
+    void radial_cmin()
+    {
+        HostWave w(WS);
+        L.count[MGC_CNT_RADIAL_C] = MGC_HINF;
+        for (int t = 0; t < L.ntiles; ++t) mgc_dt_cmin_tile(w, L, t);
+    }
+    void radial_swap() { std::swap(height, hexact); L.height = height.data(); }
     /* ---- radial labels of the flood phase (mgc_dt_ops.inl), the library's HipDevT ops on host arrays ---- */
     std::vector<uint16_t> ds16;      /* 1 + L1 distance from the nearest voxel that held excess when the solve began */
     std::vector<int32_t> hexact;     /* the exact labels of the last global relabel */
@@ -609,6 +735,7 @@ void hostsim_prof(int64_t* out, int32_t* tiles, int ntiles)
 void* hostsim_create(const int64_t* gshape, int rank, int nranks)
 {
     HostDev* d = new HostDev();
+    d->gd0 = gshape[0];
     if (nranks <= 1) {
         d->init(gshape[0], gshape[1], gshape[2], NULL);
     } else {
@@ -741,9 +868,18 @@ int hostsim_first_relabel(const int64_t* shape, const double* w0, const double* 
 /* ------------------------------------------------------------------------------------------
  * 26-neighbourhood (mgc_tile_ops26.inl): one-call solve for the CPU tests
  * ---------------------------------------------------------------------------------------- */
-struct HostDev26 {
+struct HostDev26 : HostSlabOps<HostDev26, HostBlockT<MgcTileShared26D>> {
     MgcLattice L;
     MgcTileShared26D S;
+    /* (no transforms in the full neighbourhood: an L-infinity distance is not separable) */
+    bool dt_applicable() { return false; }
+    void dt_scans_xy(int) {}
+    void dt_scan_z(bool, int, int, const uint16_t*, bool) {}
+    void dt_finish() {}
+    void shadow_sync() {}
+    bool radial_prepare() { return false; }
+    void radial_cmin() {}
+    void radial_swap() {}
     std::vector<double> rcap, excess, sink;
     std::vector<int32_t> height, lists, count;
     std::vector<uint32_t> rmask32, stamp, rstamp, status;
@@ -941,6 +1077,7 @@ int hostsim_solve26(const int64_t* shape, const double* w, const double* trcap, 
 void* hostsim26_create(const int64_t* gshape, int rank, int nranks)
 {
     HostDev26* d = new HostDev26();
+    d->gd0 = gshape[0];
     if (nranks <= 1) {
         d->init(gshape[0], gshape[1], gshape[2], NULL);
     } else {
@@ -1008,6 +1145,45 @@ int hostsim26_halo_unpack(void* h, int side, int kind, const void* buf, int on_d
 int hostsim26_labels(void* h, uint8_t* out) { ((HostDev26*)h)->labels(out); return 0; }
 
 } /* extern "C" */
+
+/* The slabs of one volume through mgc_solve (mgc_driver.inl) -- the schedule the library runs for them (mgc_solve_slabs), with the same
+ * group and transport code: n = all slabs of the volume (handles of this process), or n = 1 with the callbacks of a host transport.
+ * params[0..7]: rounds_per_relabel, max_cycles, max_sweeps, max_outer, incremental_relabel, exchange_passes, radial (-1: the default), exchange_rounds
+ * (0 / as noted: the default).  stats_out[0..15]: MgcSolveStats, then exchanges, reductions. */
+template <class Dev>
+static int hostsim_solve_slabs_on(void** handles, int n, const mgc_transport* cb, const int64_t* params, const MgcLayout lay, int ndir, int64_t* stats_out)
+{
+    std::vector<Dev*> ptr((size_t)n);
+    for (int i = 0; i < n; ++i) ptr[(size_t)i] = (Dev*)handles[i];
+    const bool all_local = n == (ptr[0]->spec.nranks > 0 ? ptr[0]->spec.nranks : 1);
+    MgcXchg<Dev> x(ptr, cb, all_local);
+    MgcSlabGroup<Dev, MgcXchg<Dev>> group(ptr, x);
+    MgcSolveParams P = mgc_default_params(ndir);
+    if (params[0] > 0) P.rounds_per_relabel = (int)params[0];
+    if (params[1] != 0) P.max_cycles = (int)params[1];
+    if (params[2] > 0) P.max_sweeps = (int)params[2];
+    if (params[3] > 0) P.max_outer = (int)params[3];
+    P.incremental_relabel = params[4] != 0;
+    if (params[5] > 0) P.exchange_passes = (int)params[5];
+    if (params[6] >= 0) P.radial = (int)params[6];
+    if (params[7] > 0) P.exchange_rounds = (int)params[7];
+    if (getenv("HOSTSIM_TRACE")) P.trace = atoi(getenv("HOSTSIM_TRACE"));
+    if (getenv("HOSTSIM_RADIAL_MIN_C")) P.radial_min_c = atoi(getenv("HOSTSIM_RADIAL_MIN_C"));
+    MgcSolveStats st;
+    const int rc = mgc_solve(group, ptr[0]->L, P, st, lay);
+    memset(stats_out, 0, 16 * sizeof(int64_t));
+    memcpy(stats_out, &st, sizeof(st) < 12 * sizeof(int64_t) ? sizeof(st) : 12 * sizeof(int64_t));
+    stats_out[12] = group.exchanges;
+    stats_out[13] = group.reductions;
+    stats_out[14] = x.error;
+    return x.error ? 100 + x.error : rc;
+}
+
+extern "C" int hostsim_solve_slabs(void** handles, int n, int ndir, const mgc_transport* cb, const int64_t* params, int64_t* stats_out)
+{
+    if (ndir == 26) return hostsim_solve_slabs_on<HostDev26>(handles, n, cb, params, mgc_layout26(), 26, stats_out);
+    return hostsim_solve_slabs_on<HostDev>(handles, n, cb, params, mgc_layout6(), 6, stats_out);
+}
 
 extern "C" void hostsim_set_halo_max(void* h, int which, int n)
 {

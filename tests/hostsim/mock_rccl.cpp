@@ -175,7 +175,7 @@ ncclResult_t ncclRecv(void* buf, size_t count, ncclDataType_t dt, int peer, nccl
 ncclResult_t ncclAllReduce(const void* sendbuf, void* recvbuf, size_t count, ncclDataType_t dt, ncclRedOp_t op, ncclComm_t comm, hipStream_t stream)
 {
     Comm* c = (Comm*)comm;
-    if (!c || dt != ncclInt64 || op != ncclSum) return ncclInvalidArgument;
+    if (!c || dt != ncclInt64 || (op != ncclSum && op != ncclMin)) return ncclInvalidArgument;
     if (hipStreamSynchronize(stream) != hipSuccess) return ncclUnhandledCudaError;
     std::vector<int64_t> mine(count);
     if (hipMemcpy(mine.data(), sendbuf, count * 8, hipMemcpyDeviceToHost) != hipSuccess) return ncclUnhandledCudaError;
@@ -183,9 +183,11 @@ ncclResult_t ncclAllReduce(const void* sendbuf, void* recvbuf, size_t count, ncc
     std::vector<int64_t> res;
     {
         std::unique_lock<std::mutex> lk(w->mu);
-        if (w->arrived == 0) w->acc.assign(count, 0);
-        if (w->acc.size() != count) return ncclInvalidArgument;
-        for (size_t i = 0; i < count; ++i) w->acc[i] += mine[i];
+        if (w->arrived == 0) w->acc = mine;
+        else {
+            if (w->acc.size() != count) return ncclInvalidArgument;
+            for (size_t i = 0; i < count; ++i) w->acc[i] = op == ncclMin ? (mine[i] < w->acc[i] ? mine[i] : w->acc[i]) : w->acc[i] + mine[i];
+        }
         const int gen = w->generation;
         if (++w->arrived == w->nranks) {
             w->result = w->acc;

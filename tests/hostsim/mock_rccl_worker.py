@@ -1,5 +1,6 @@
 """TEST ONLY (run as a subprocess by tests/test_gpu_slabs.py): N threads = N ranks on ONE GPU, each driving its own slab
-handle through the library's native transport (mgc_comm_init / mgc_halo_exchange / mgc_allreduce_counts) with the
+handle through the library's own schedule and native transport (mgc_solve_slabs over mgc_comm_init / mgc_halo_exchange / ncclAllReduce / the
+carry planes of the distance transforms by ncclSend / ncclRecv) with the
 in-process mock of librccl (tests/hostsim/mock_rccl.cpp, selected by MEDPY_HIP_RCCL).  Prints one JSON line."""
 import json
 import os
@@ -11,40 +12,35 @@ import numpy as np
 
 root, nranks, conn, gen = sys.argv[1], int(sys.argv[2]), int(sys.argv[3]), sys.argv[4]
 shape = tuple(int(v) for v in sys.argv[5].split("x"))
-NATIVE = len(sys.argv) > 7 and sys.argv[7] == "native"  # the schedule inside the library (mgc_solve_slab) instead of slab.py's
 ROUNDS = int(sys.argv[8]) if len(sys.argv) > 8 else 2  # colour rounds between two global relabels (the tests: 2, many relabels on small volumes)
 sys.path.insert(0, root)
 from medpy_amd import synthetic  # noqa: E402
-from medpy_amd.slab import HipSlab, solve_slabs  # noqa: E402
+from medpy_amd.slab import HipSlab, LoopbackExchange, solve_slabs, sync_boundary_table  # noqa: E402
 
 
 class ThreadRcclExchange(object):
-    """RcclExchange without torch.distributed: the unique id is handed over in-process"""
+    """RcclExchange without a store: the unique id is handed over in-process"""
 
-    native = NATIVE
+    native = True
 
     def __init__(self, slab, id_bytes):
         self.slabs = [slab]
         slab.comm_init(id_bytes)
-
-    def exchange(self, kind, epoch, lst):
-        self.slabs[0].exchange(kind, epoch, lst)
-
-    def global_counts(self):
-        return self.slabs[0].allreduce_counts()
 
 
 s = getattr(synthetic, gen)(shape)
 slabs = [HipSlab(shape, r, nranks, connectivity=conn) for r in range(nranks)]
 uid = slabs[0].comm_unique_id()
 out, errs = [None] * nranks, []
+for sl in slabs:  # the term-by-table decision is one for the whole volume (integer-valued images): before any slab builds
+    sl.set_boundary(s["term"], s["image"][sl.plane0:sl.plane1], s["sigma"], False)
+sync_boundary_table(slabs, LoopbackExchange(slabs))
 
 
 def run(r):
     try:
         sl = slabs[r]
         z = slice(sl.plane0, sl.plane1)
-        sl.set_boundary(s["term"], s["image"][z], s["sigma"], False)
         sl.set_markers(s["fg"][z], s["bg"][z])
         sl.build()
         t0 = time.perf_counter()

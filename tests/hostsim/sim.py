@@ -109,8 +109,42 @@ def first_relabel(shape, weights, trcap, use_dt):
 # Slab handle over the host simulator: same surface as medpy_amd.slab.HipSlab, so the
 # distributed schedule (medpy_amd/slab.py:solve_slabs) and the transports are tested on CPU.
 # ------------------------------------------------------------------------------------------
+def _solve_group(slabs, transport, params, ndir):
+    """hostsim_solve_slabs: mgc_solve (mgc_driver.inl) over simulator slabs -- all slabs of the volume, or this process' one with a Python
+    host transport handed over as the callbacks of an mgc_transport (medpy_amd.slab.HostTransport)"""
+    from medpy_amd.slab import HostTransport
+    from medpy_amd import _lib as hip
+    L = lib()
+    L.hostsim_solve_slabs.restype = C.c_int
+    L.hostsim_solve_slabs.argtypes = [C.POINTER(C.c_void_p), C.c_int, C.c_int, C.POINTER(hip.Transport), np.ctypeslib.ndpointer(np.int64),
+                                      np.ctypeslib.ndpointer(np.int64)]
+    p = np.zeros(8, np.int64)
+    p[0] = params.get("rounds_per_relabel", 0)
+    p[1] = params.get("max_cycles", 0)
+    p[2] = params.get("max_sweeps", 0)
+    p[3] = params.get("max_outer", 0)
+    p[4] = params.get("incremental_relabel", 1)
+    p[5] = params.get("exchange_passes", 0)
+    p[6] = params.get("radial", -1)
+    p[7] = params.get("exchange_rounds", 0)
+    hs = (C.c_void_p * len(slabs))(*[s._h for s in slabs])
+    st = np.zeros(16, np.int64)
+    cb = HostTransport(transport) if transport is not None else None
+    rc = L.hostsim_solve_slabs(hs, len(slabs), ndir, C.byref(cb.struct) if cb else None, p, st)
+    if cb is not None and cb.error is not None:
+        raise cb.error
+    assert rc in (0, 1), "hostsim_solve_slabs failed (%d)" % rc
+    out = dict(zip(STAT_NAMES, st.tolist()))
+    out.update(exchanges=int(st[12]), reductions=int(st[13]), deferred_drains=int(st[9]))
+    return out
+
+
 class SimSlab(object):
     ndir = 6
+
+    @staticmethod
+    def solve_group(slabs, transport, params):
+        return _solve_group(slabs, transport, params, 6)
 
     def __init__(self, global_shape, rank, nranks):
         L = lib()
@@ -231,6 +265,10 @@ def solve26(shape, weights_by_offset, trcap, rounds=0, cycles=0, sweeps=0, max_o
 class SimSlab26(object):
     """26-neighbourhood slab over the host simulator (same surface as SimSlab / medpy_amd.slab.HipSlab)."""
     ndir = 26
+
+    @staticmethod
+    def solve_group(slabs, transport, params):
+        return _solve_group(slabs, transport, params, 26)
 
     def __init__(self, global_shape, rank, nranks):
         L = lib()

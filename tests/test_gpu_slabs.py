@@ -190,14 +190,14 @@ def test_full_neighbourhood_slabs_equal_single_and_oracle(gen, shape, nslabs, re
     assert flow == pytest.approx(sflow, rel=1e-9)
 
 
-@pytest.mark.parametrize("driver,halo_max", [("slab.py", 0), ("native", 0), ("native", 2)])
+@pytest.mark.parametrize("halo_max", [0, 2])
 @pytest.mark.parametrize("nranks,conn,gen,shape", [(2, 6, "sphere", (64, 40, 48)), (3, 6, "hard", (48, 48, 40)), (2, 26, "sphere", (64, 40, 48)),
                                                    (4, 26, "sphere", (64, 32, 32)),
                                                    (8, 6, "sphere", (128, 40, 48)), (8, 26, "sphere", (128, 32, 32))])  # (the rank count of configs 4 / 5's node)
-def test_native_transport_protocol_with_mock_rccl(nranks, conn, gen, shape, driver, halo_max, tmp_path, monkeypatch):
-    """The multi-rank protocol of mgc_halo_exchange / mgc_allreduce_counts (one grouped send / receive per neighbour and
-    exchange, bounded compacted messages with deferral, every rank taking the same decisions) -- driven by slab.py and by the
-    library's own mgc_solve_slab -- with N ranks as N
+def test_native_transport_protocol_with_mock_rccl(nranks, conn, gen, shape, halo_max, tmp_path, monkeypatch):
+    """The multi-rank protocol of mgc_solve_slabs over the native channel (one grouped send / receive per neighbour and
+    exchange, bounded compacted messages with deferral, the carry planes of the distance transforms as a pipeline of sends and
+    receives, minimum and sum reductions, every rank taking the same decisions) -- with N ranks as N
     threads on ONE GPU over an in-process stand-in for librccl (tests/hostsim/mock_rccl.cpp: FIFO channels, a Send and
     its Recv must agree on the size).  Real RCCL refuses two ranks on one device; with it this path runs at
     bench.py --gpus N."""
@@ -213,9 +213,8 @@ def test_native_transport_protocol_with_mock_rccl(nranks, conn, gen, shape, driv
     env = dict(os.environ, MEDPY_HIP_RCCL=sim.build_mock_rccl())
     if halo_max:  # two record slots per border message: nearly every exchange overflows, tiles are deferred and drained
         env["MEDPY_HIP_PARAMS"] = ",".join(filter(None, [env.get("MEDPY_HIP_PARAMS", ""), "halo_max_records=%d" % halo_max]))
-    # driver "native": the whole schedule inside the library (mgc_solve_slab), "slab.py": the same schedule from Python
     res = subprocess.run([sys.executable, os.path.join(root, "tests", "hostsim", "mock_rccl_worker.py"), root, str(nranks), str(conn), gen,
-                          "x".join(str(v) for v in shape), out, driver], env=env, capture_output=True, text=True, timeout=600)
+                          "x".join(str(v) for v in shape), out, "native"], env=env, capture_output=True, text=True, timeout=600)
     assert res.returncode == 0, (res.stdout[-2000:], res.stderr[-2000:])
     info = json.loads(res.stdout.strip().splitlines()[-1])
     assert all(st["converged"] == 1 for st in info["stats"])

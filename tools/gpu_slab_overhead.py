@@ -44,5 +44,5 @@ else:
         st = solve_slabs(slabs, ex)
         fl = sum(s.finish_device() for s in slabs)
         dt = time.perf_counter() - t0
-        print(json.dumps({"shape": list(img.shape), "path": "%d slab(s), Python schedule, loopback" % nslabs, "ms": round(dt * 1e3, 1), "mvox_s": round(img.size / dt / 1e6, 1), "flow": fl, **st}), flush=True)
+        print(json.dumps({"shape": list(img.shape), "path": "%d slab(s), mgc_solve_slabs, all slabs on this GPU" % nslabs, "ms": round(dt * 1e3, 1), "mvox_s": round(img.size / dt / 1e6, 1), "flow": fl, **st}), flush=True)
     for s in slabs: s.close()
