@@ -153,16 +153,17 @@ def golden_large():
 
 
 def parity_relaxation_summary():
-    """how many comparisons of the last GPU test tier needed the equivalence checker instead of strict label equality (exact ties
-    between minimum cuts; profiles/r5_parity_relaxations.jsonl, written by tests/conftest.py on the GPU box and committed)"""
-    for name in ("r5_parity_relaxations.jsonl", "r4_parity_relaxations.jsonl"):
-        p = os.path.join(ROOT, "profiles", name)
-        if os.path.exists(p):
-            rows = [json.loads(ln) for ln in open(p) if ln.strip().startswith("{")]
-            return {"file": "profiles/" + name, "relaxed_comparisons": len(rows), "most_voxels_differing": max([r.get("differing", 0) for r in rows] or [0]),
-                    "all_equivalent": all(r.get("verdict") == "equivalent" for r in rows),
-                    "note": "labels are bit-exact with the reference except inside its own ambiguity set on exact ties between minimum cuts (b0: 7 of 1 048 576 voxels)"}
-    return None
+    """the committed record of the last full GPU test tier (tests/conftest.py writes it on the GPU box): how many comparisons needed the
+    equivalence checker (oracle/cutcheck.py: exact ties between minimum cuts) instead of strict label equality.  Historical -- values
+    read from the file, nothing asserted about this run."""
+    import glob
+    recs = sorted(glob.glob(os.path.join(ROOT, "profiles", "r*_parity_relaxations.jsonl")))
+    if not recs:
+        return None
+    rows = [json.loads(ln) for ln in open(recs[-1]) if ln.strip().startswith("{")]
+    return {"file": "profiles/" + os.path.basename(recs[-1]), "relaxed_comparisons": len(rows), "most_voxels_differing": max([r.get("differing", 0) for r in rows] or [0]),
+            "verdicts": sorted({str(r.get("verdict")) for r in rows}), "adjudicated_exactly": sum(1 for r in rows if r.get("exact_adjudication")),
+            "note": "record of the last full GPU tier, not of this run"}
 
 
 def also_case(name, n, conn, regional, steps=3, warmup=1, golden_key=None, workload="sphere"):

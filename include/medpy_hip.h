@@ -209,10 +209,11 @@ int mgc_get_profile(mgc_handle h, uint64_t* out16);
  * single-process; its only splitter, wrapper.py:72-204, is approximate and label-based).
  * One handle per slab.  The slab owns whole tile layers (8 voxel planes) of axis 0 and mirrors
  * one ghost tile layer per neighbour; mgc_set_* take the LOCAL sub-arrays (planes
- * info[0]..info[1] of the global arrays, ghost planes included).  The solve is driven from the
- * host layer (medpy_amd/slab.py) through mgc_solver_op + mgc_halo_pack/unpack, exchanging the
- * packed border (labels, outbox flow) with the neighbour rank after every pass / phase; the
- * transport (RCCL over xGMI via torch.distributed, or an in-process loopback) is the caller's.
+ * info[0]..info[1] of the global arrays, ghost planes included).  The solve is mgc_solve_slabs (below): the single handle's
+ * schedule with the packed borders (labels, outbox flow, suspect flags) exchanged at its hook points -- between the slabs' own
+ * buffers when all slabs are handles of one process, over RCCL / xGMI inside the library (mgc_comm_init) when every rank holds
+ * one, or through the caller's callbacks on host buffers (development transports).  mgc_solver_op / mgc_halo_pack / mgc_halo_unpack
+ * issue single launches and single messages (profiling tools, the transport tests); no schedule is driven through them any more.
  * ---------------------------------------------------------------------------------------- */
 enum {
     MGC_OP_ABSORB_ALL = 0,   /* -                                          */
@@ -240,8 +241,8 @@ int mgc_halo_unpack(mgc_handle h, int side, int kind, const void* buf, int buf_o
 int mgc_finish(mgc_handle h, double* flow_partial);
 
 /* Native transport: RCCL over xGMI (librccl is dlopen()ed on first use, single-GPU users never need it).
- * Rank 0 obtains a 128-byte id (mgc_comm_unique_id) that the launcher broadcasts out of band (bench.py uses the
- * gloo store of torch.distributed); every rank then calls mgc_comm_init on its slab handle.  mgc_halo_exchange =
+ * Rank 0 obtains a 128-byte id (mgc_comm_unique_id) that the launcher broadcasts out of band (bench.py: a private directory of
+ * files, medpy_amd/rendezvous.py -- no PyTorch anywhere in the package); every rank then calls mgc_comm_init on its slab handle.  mgc_halo_exchange =
  * pack both borders -> grouped ncclSend/ncclRecv with rank-1 / rank+1 -> unpack, all ordered on the handle's
  * stream (no host synchronisation).  mgc_allreduce_counts sums the 32 solver counters over all ranks
  * (ncclAllReduce) and returns them: the termination / fixpoint tests of the distributed schedule. */
@@ -249,12 +250,8 @@ int mgc_comm_unique_id(uint8_t* id128);
 int mgc_comm_init(mgc_handle h, const uint8_t* id128);
 int mgc_halo_exchange(mgc_handle h, int kind, uint32_t epoch, int list);
 
-/* The whole distributed solve of one slab inside the library: the schedule of medpy_amd/slab.py:solve_slabs (itself the
- * single-GPU schedule of mgc_driver.inl with border exchanges and counter all-reduces added) driven from C++ over the
- * native transport -- no host-language call per kernel, one grouped transfer per border exchange, the host looks at the
- * device only where every rank has to take the same decision (all-reduced counters).  Call it on every rank after
- * mgc_build (and mgc_comm_init when the volume has more than one slab); then mgc_finish.  Per-kernel times and counts of
- * the run are in mgc_get_stats afterwards, as after mgc_maxflow. */
+/* What a distributed solve did (global numbers; per-kernel times and this slab's own counts are in mgc_get_stats afterwards, as after
+ * mgc_maxflow).  The host looks at the device only where every rank has to take the same decision (reduced counters). */
 typedef struct mgc_slab_stats {
     int64_t outer;            /* global relabels                                            */
     int64_t relabel_passes;
@@ -265,7 +262,7 @@ typedef struct mgc_slab_stats {
     int64_t discharge_tiles;  /* global                                                     */
     int64_t relabel_tiles;    /* global                                                     */
     int64_t deferred_drains;  /* extra exchanges because a border message was full          */
-    int64_t reserved[7];
+    int64_t reserved[7];      /* [0]: cycles of colour phases that ran on radial labels */
 } mgc_slab_stats;
 int mgc_solve_slab(mgc_handle h, mgc_slab_stats* out);
 

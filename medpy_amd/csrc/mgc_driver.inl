@@ -108,8 +108,11 @@ static inline MgcSolveParams mgc_default_params(int ndir = 6)
     p.radial = ndir == 6 ? 2 : 0; /* 2: decided per graph by whoever calls mgc_solve (mgc_maxflow: wall tiles counted by k_build); the host simulator treats 2 as 1 */
     p.radial_min_c = 8;
     p.radial_budget_x16 = 8;
-    p.exchange_passes = 4; /* (2048 x 1024 x 1024 in eight slabs: 2 072 passes per solve at 4, 6 280 when every slab ran to its local fixpoint first, round 4) */
-    p.exchange_rounds = 1;
+    /* measured with eight slabs of 2048 x 1024 x 1024 time-multiplexed on one MI355X (profiles/r6_slab_exchange_cadence.jsonl; the label
+     * SHA-256 is the single handle's in every row): labels every 4 passes + flow every round 372 exchanges, 124 ms of kernels on the
+     * busiest slab; every 8 passes 297 / 126 ms; every 8 passes and every 2nd round 226 / 123 ms */
+    p.exchange_passes = 8;
+    p.exchange_rounds = 2;
     p.radial_rounds0 = 0; /* 0: ONE radial cycle as long as the flood may take (radial_budget below).  Measured on MI355X, headline volume 512^3:
                              35.9 ms on exact labels; first radial cycle of 4 rounds (then 8, then 4, a relabel in between) 26.1 ms, 6: 23.4,
                              8: 24.4, 16 (= the budget, one cycle): 22.0 ms; 256^3: 9.5 / 5.3 (4) / 4.8 (8 = the budget).  A short first cycle

@@ -60,6 +60,9 @@
 #include "mgc_tile_ops.inl"
 
 #define MGCW_LANES 64
+#ifndef MGCW_VOTE4
+#define MGCW_VOTE4 0 /* 1: one batch of votes per slot for its four in-plane directions (see the sweeps of mgcw_discharge_impl) */
+#endif
 /* every lambda of this file must be inlined into the kernel: a call would force the register arrays it captures into memory */
 #define MGCW_INL __attribute__((always_inline))
 #define MGCW_BFS 1            /* discharge flag: exact in-tile labels (from scratch) before the sweeps */
@@ -451,9 +454,23 @@ MGC_HD void mgcw_discharge_impl(W& w, const MgcLattice& L, int tile, uint32_t ph
                     sat(l, 0) |= (can && delta == sk) ? (1 << K) : 0;
                 });
             }
+#if MGCW_VOTE4
+            /* the four in-plane votes of a slot in one go: four independent ballots issue back to back and the scalar side waits once, not
+             * four times.  A direction that only becomes pushable through what an earlier direction of this slot handed over runs in the
+             * next sweep (push() decides per lane anyway: a vote only says whether a step is worth running) */
+            uint32_t dvote = 0;
             mgcw_static_for<4>([&](auto DD) MGCW_INL {
                 constexpr int D = decltype(DD)::value;
+                if (w.any([&](int l) MGCW_INL -> bool { return can_push(l, KK, DD, hn(l, 4 * J + D)); })) dvote |= 1u << D;
+            });
+#endif
+            mgcw_static_for<4>([&](auto DD) MGCW_INL {
+                constexpr int D = decltype(DD)::value;
+#if MGCW_VOTE4
+                if (!(dvote & (1u << D))) return;
+#else
                 if (!w.any([&](int l) MGCW_INL -> bool { return can_push(l, KK, DD, hn(l, 4 * J + D)); })) return;
+#endif
                 dirty |= 3u << (D & ~1);
                 w.lanes([&](int l) MGCW_INL {
                     const int y = l >> 3, x = l & 7;

@@ -29,9 +29,10 @@ class FileStore(object):
         self.rank, self.world, self.timeout = int(rank), int(world), float(timeout)
         self.dir = directory or default_directory()
         os.makedirs(self.dir, mode=0o700, exist_ok=True)
-        st = os.stat(self.dir)
-        if st.st_uid != os.getuid() or (st.st_mode & 0o077):
-            raise RuntimeError("rendezvous directory %s is not private to this user" % self.dir)
+        st = os.lstat(self.dir)  # (lstat: a symbolic link planted under the predictable name is refused, not followed -- ADVICE r5)
+        import stat as _stat
+        if not _stat.S_ISDIR(st.st_mode) or st.st_uid != os.getuid() or (st.st_mode & 0o077):
+            raise RuntimeError("rendezvous directory %s is not a directory private to this user" % self.dir)
         self._seq = 0
         self._p2p = {}
 
@@ -146,8 +147,10 @@ class FileStore(object):
                 self._get("bye", r, 1)
         except TimeoutError:
             return
-        for f in os.listdir(self.dir):
-            self._unlink(os.path.join(self.dir, f))
+        for f in os.listdir(self.dir):  # (plain files only: what this store writes)
+            q = os.path.join(self.dir, f)
+            if os.path.isfile(q) and not os.path.islink(q):
+                self._unlink(q)
         try:
             os.rmdir(self.dir)
         except OSError:

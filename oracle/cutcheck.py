@@ -145,6 +145,16 @@ def assert_labels_equivalent(labels, ref_cut, max_differing=None, exact=None, to
         entry["cut_capacity_rational_equal"] = bool(d == 0)
         entry["cut_capacity_rational_difference"] = "0" if d == 0 else "%s (= %.6e)" % (str(d) if len(str(d)) <= 80 else "p/q with %d-digit q" % len(str(d.denominator)), float(d))
         entry["cut_capacity_relative_difference"] = 0.0 if d == 0 or b == 0 else abs(float(d / b))
+        # ... and which of the two label sets is the one exact arithmetic defines (oracle/exact_maxflow.py): the reference reports the
+        # complement of its sink tree, which in exact arithmetic is the source side of the LARGEST minimum cut.  Solved outright
+        # (integer-scaled Dinic, no rounding anywhere) for graphs of a few thousand nodes; for larger ones the relation of the two
+        # cuts is still exact: which is smaller as a rational, and on an exact tie which source side contains the other
+        try:
+            from . import exact_maxflow
+            n_nodes = int(np.asarray(exact[4]).size)
+            entry["exact_adjudication"] = exact_maxflow.adjudicate(labels.ravel(), ref.ravel(), n_nodes, *exact, a, b)
+        except Exception as e:  # noqa: BLE001  (bookkeeping must not fail a parity test)
+            entry["exact_adjudication"] = {"error": repr(e)}
         if float(a) != float(b):
             _record(dict(entry, verdict="FAIL: cut capacities differ"))
         assert float(a) == float(b), "cut capacities differ: %r vs %r (by %r)" % (float(a), float(b), float(a - b))

@@ -83,3 +83,36 @@ def test_sub_ulp_capacities_are_below_the_rounding_granularity():
     g.maxflow()
     fs, ts, amb = cutcheck.ambiguity(g)
     assert ts[1] and ts[0]  # residual 9e-4 of 1e-3: a real way to the sink
+
+
+def test_exact_adjudication_names_the_canonical_label_set():
+    """oracle/exact_maxflow.py: on an exact tie between two minimum cuts the reference's definition (complement of the sink tree,
+    graph.h:561-571) picks the LARGEST source side; an integer-scaled Dinic finds it without a rounding, and `adjudicate` says which of
+    two label sets is that one.  A chain s -> 0 -> 1 -> 2 -> t with two arcs of the same capacity: cutting either is minimum."""
+    from fractions import Fraction
+    from oracle import exact_maxflow as em
+    i, j = np.array([0, 1]), np.array([1, 2])
+    cap, rev = np.array([0.1, 0.1]), np.array([0.1, 0.1])
+    tr = np.array([5.0, 0.0, -5.0])
+    t = em.canonical_sink_side(3, i, j, cap, rev, tr)
+    assert t.tolist() == [False, False, True]  # node 1 cannot reach the sink once 1 -> 2 is saturated: the larger source side
+    small, large = np.array([True, False, False]), np.array([True, True, False])
+    v = Fraction(0.1)
+    verdict = em.adjudicate(small, large, 3, i, j, cap, rev, tr, v, v)
+    assert verdict["canonical"] == "reference" and verdict["hip_vs_reference"] == {"capacity": "equal", "source_sides": "second_contains_first"}
+    assert em.adjudicate(large, large, 3, i, j, cap, rev, tr, v, v)["canonical"] == "both"
+    # against the compiled reference on random graphs with dyadic capacities (every sum exact: BK itself is canonical there)
+    from oracle import bk
+    rng = np.random.default_rng(3)
+    for _ in range(10):
+        n = 30
+        a, b = rng.integers(0, n, 150), rng.integers(0, n, 150)
+        keep = a != b
+        a, b = a[keep], b[keep]
+        c, r = rng.integers(0, 16, a.size) / 4.0, rng.integers(0, 16, a.size) / 4.0
+        trc = rng.integers(-8, 9, n) / 2.0
+        o = bk.BKGraph(n, a.size)
+        o.sum_edges(a, b, c, r)
+        o.add_tweights(None, np.maximum(trc, 0), np.maximum(-trc, 0))
+        o.maxflow()
+        assert ((~em.canonical_sink_side(n, a, b, c, r, trc)).astype(np.uint8) == o.labels()).all()
