@@ -39,6 +39,7 @@ class Stats(C.Structure):
         d = {k: getattr(self, k) for k, _ in self._fields_ if k != "reserved"}
         d["readbacks"] = self.reserved[0]
         d["radial_cycles"] = self.reserved[1]  # cycles of colour phases that ran on radial labels (mgc_driver.inl)
+        d["wall_tiles"] = self.reserved[2]  # tiles a surface of weak arcs passes through, as built (MGC_WALL_*, mgc_common.h)
         return d
 
 

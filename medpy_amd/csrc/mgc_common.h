@@ -42,12 +42,17 @@
                                   relabel pass lowers one of its labels (a clear bit promises nothing) */
 #define MGC_ST_SOURCE 64u      /* (6-neighbourhood) the tile held a source link (tr_cap > 0) when the graph was built: where the schedule looks for
                                   "can excess of the source still reach the sink?" (mgc_source_open_tile) */
-/* A "wall": a tile in which at least MGC_WALL_VOXELS voxels hold an n-link below MGC_WALL_WEIGHT -- the patch of a closed surface of
- * weak arcs (an intensity edge under an exponential / power term: exp(-44) ~ 1e-19 on the headline volume) that crosses the tile.
- * Isolated weak arcs of a noisy image do not qualify (weak-contrast volume: ~2 per tile).  mgc_build counts the wall tiles; the
- * flood phase of the solve runs on radial labels (mgc_dt_ops.inl) only when there are walls to flood against. */
+/* A "wall": a tile in which at least MGC_WALL_VOXELS voxels hold a WEAK forward n-link -- the patch of a closed surface of weak arcs (an
+ * intensity edge under an exponential / power term: exp(-44) ~ 1e-19 on the headline volume) that crosses the tile.  Weak = g(.) below
+ * MGC_WALL_WEIGHT, judged BEFORE the division by the voxel spacing: every boundary term of the reference takes values in (0, 1]
+ * (energy_voxel.py:99-114, 174-189, 226-236, 290-300, 337-345, 399-407, 444-452, 506-514), so the threshold is relative to the largest
+ * weight the term can produce and does not move with the units of the spacing.  A surface of arcs that weak SEALS: what crosses it is
+ * nothing next to the excess behind it, and the flood phase on radial labels (mgc_dt_ops.inl) is what saturates it fastest.  An edge
+ * under a linear or division term is never weaker than ~1 / (1 + range / sigma): it leaks, the cut lies elsewhere or carries a
+ * flow of the order of the weights, and exact labels are the better guide (measured: profiles/r6_radial_on_off.jsonl).  Isolated weak
+ * arcs of a noisy image do not qualify (~1 per tile).  mgc_build counts the wall tiles. */
 #define MGC_WALL_WEIGHT 9.313225746154785e-10 /* 2^-30 */
-#define MGC_WALL_VOXELS 24
+#define MGC_WALL_VOXELS 12                    /* (every pair is counted once, by its lower voxel; until round 6 by both ends: 24) */
 #define MGC_ST_DEP_SHIFT 8
 /* counter slots no layout uses as a work list (6-neighbourhood: lists 0..7, totals 8 / 9; 26-neighbourhood: lists 0..17,
  * totals 18..20; tickets of the wave kernels 24..27) */
@@ -55,6 +60,9 @@
 #define MGC_CNT_WALL_TILES 12  /* (6-neighbourhood) k_build: tiles a surface of weak arcs passes through (MGC_WALL_*), read by mgc_build */
 #define MGC_CNT_RADIAL_C 14    /* (6-neighbourhood) hop length of the shortest source -> sink path (mgc_dt_cmin_tile) or MGC_HINF */
 #define MGC_CNT_SOURCE_OPEN 15 /* (6-neighbourhood) source tiles whose excess still stands under a finite label (mgc_source_open_tile) */
+/* (the full neighbourhood's lists take slots 0 .. 17: its two radial-label counters live in the ticket slots of the wave relabel kernel, which it has not) */
+#define MGC26_CNT_RADIAL_C 26
+#define MGC26_CNT_SOURCE_OPEN 27
 #define MGC_CNT_CHANGED 21     /* suspect-closure pass changed something */
 #define MGC_CNT_FILTER 22      /* length of the scratch list the tile filters fill (absorb / relabel seeding / suspect reset) */
 #define MGC_CNT_FILTER_ACT 23  /* ... of the activation filter */
@@ -121,6 +129,8 @@ struct MgcLattice {
     int32_t*  hshadow[2];     /* slabs, 6-neighbourhood: [gy*gx][64] labels of the owned border layer (lower / upper) as the neighbour
                                  slab last received them -- a border tile only travels when it differs from this (or holds flow) */
     unsigned long long* prof; /* optional [16] cycle accumulators of the discharge sections (development aid) or NULL */
+    const uint8_t* tsrc;      /* full neighbourhood: [ntiles] bit 0 = the tile held a source link when the graph was built (what status bit MGC_ST_SOURCE says in
+                                 the 6-neighbourhood, whose status words have room for it), or NULL */
 };
 
 /* Measured on MI355X (round 3): 16 regions per list do NOT pay -- 512^3 sphere 38.6 ms with 16, 37.6 ms with 1; 26-neighbourhood
@@ -130,6 +140,9 @@ struct MgcLattice {
 #ifndef MGC_NSHARD
 #define MGC_NSHARD 1
 #endif
+
+MGC_HD int mgc_cnt_radial_c(const MgcLattice& L) { return L.ndir == 26 ? MGC26_CNT_RADIAL_C : MGC_CNT_RADIAL_C; }
+MGC_HD int mgc_cnt_source_open(const MgcLattice& L) { return L.ndir == 26 ? MGC26_CNT_SOURCE_OPEN : MGC_CNT_SOURCE_OPEN; }
 
 MGC_HD int32_t* mgc_counter(const MgcLattice& L, int c, int shard) { return L.scount + c * L.nshard + shard; }
 
@@ -164,6 +177,9 @@ MGC_HD int mgc_list_at(const MgcLattice& L, int l, const MgcListView& v, int i)
         if (i >= v.pre[k] && v.pre[k + 1] > v.pre[k]) { s = k; base = v.pre[k]; }
     return L.list[l][(int64_t)s * L.shard_cap + (i - base)];
 }
+
+/* did the tile hold a source link (tr_cap > 0) when the graph was built? */
+MGC_HD bool mgc_source_tile(const MgcLattice& L, int tile) { return L.tsrc ? (L.tsrc[tile] & 1u) != 0 : (L.status[tile] & MGC_ST_SOURCE) != 0u; }
 
 MGC_HD int mgc_tile_id(const MgcLattice& L, int tz, int ty, int tx) { return (tz * L.gy + ty) * L.gx + tx; }
 

@@ -81,12 +81,13 @@ struct MgcLayout {
     int rl_base;    /* relabel lists rl_base, rl_base + 1        */
     int cnt_active, cnt_dis, cnt_rel;
     int incremental; /* global relabels after the first recompute only suspect tiles (Dev: suspect_pass, reset_suspect) */
+    int cnt_radial_c, cnt_source_open; /* counter slots of the radial labels (mgc_cnt_radial_c / mgc_cnt_source_open, mgc_common.h) */
     int rl_third;    /* third relabel list (rotation: a pass clears the counter of the list consumed one pass earlier, so
                         no memset sits between two passes) or -1 */
 };
 
-static inline MgcLayout mgc_layout6() { MgcLayout l = {2, 3, 4, 6, 8, 9, 1, 7}; return l; }
-static inline MgcLayout mgc_layout26() { MgcLayout l = {8, 15, 16, 18, 19, 20, 1, -1}; return l; }
+static inline MgcLayout mgc_layout6() { MgcLayout l = {2, 3, 4, 6, 8, 9, 1, MGC_CNT_RADIAL_C, MGC_CNT_SOURCE_OPEN, 7}; return l; }
+static inline MgcLayout mgc_layout26() { MgcLayout l = {8, 15, 16, 18, 19, 20, 1, MGC26_CNT_RADIAL_C, MGC26_CNT_SOURCE_OPEN, -1}; return l; }
 
 static inline MgcSolveParams mgc_default_params(int ndir = 6)
 {
@@ -232,13 +233,17 @@ int mgc_solve(Dev& dev, const MgcLattice& L, const MgcSolveParams& P, MgcSolveSt
                 if (cnt[lay.rl_base + (int)((rep + 1) & 1u)] == 0 && !(multi && cnt[MGC_CNT_DEFERRED])) break; /* the last pass woke nobody: fixpoint */
             }
         }
+        /* the full neighbourhood has no transform towards the sink (a Chebyshev distance is not separable): its first relabel ran as
+         * passes, and the radial labels -- which only need the L1 transform AWAY from the source, mgc_radial_steps -- are put on top of
+         * the exact ones here */
+        if (outer == 0 && !by_transform && P.radial && lay.incremental && P.incremental_relabel && dev.radial_after_passes()) radial = dev.radial_begin(P.radial_min_c);
         st.outer++;
         dev.range_pop();
         const bool after_flood = radial && outer > 0; /* (this relabel followed a cycle on radial labels: its size says nothing about the relabels to come) */
         if (radial && outer > 0 && radial_done >= radial_budget) radial = false; /* the flood has had its rounds: the exact labels of this relabel stay (nothing to keep aside, nobody to ask) */
         if (radial && outer > 0) { /* the labels are exact now: keep them, and ask whether excess of the source still reaches the sink */
             dev.radial_save_exact();
-            dev.zero_count(MGC_CNT_SOURCE_OPEN);
+            dev.zero_count(lay.cnt_source_open);
             dev.source_open();
         }
 
@@ -271,17 +276,17 @@ int mgc_solve(Dev& dev, const MgcLattice& L, const MgcSolveParams& P, MgcSolveSt
         }
         if (radial) {
             if (outer == 0) {
-                if (cnt[MGC_CNT_RADIAL_C] >= MGC_HINF || cnt[MGC_CNT_RADIAL_C] < P.radial_min_c) radial = false; /* (the device left the labels alone for the same reason) */
+                if (cnt[lay.cnt_radial_c] >= MGC_HINF || cnt[lay.cnt_radial_c] < P.radial_min_c) radial = false; /* (the device left the labels alone for the same reason) */
                 /* a flood front moves a tile per colour phase, and nothing a shortest path's length away from the source is still
                  * "behind the cut": half that many ROUNDS (two phases each) reach the far side of a cut that surrounds the source.
                  * Measured on MI355X, headline volume (C = 206 hops = 26 tiles): budget 13 rounds 19.7 ms, 16: 22.5, 20: 22.2, 23: 24.3,
                  * 26: 25.2; 256^3 (C = 103): 7 rounds 4.44 ms, 8: 4.79, 10: 5.31, 13: 6.0 -- what the flood has not closed by then
                  * are holes the exact labels find faster */
                 else {
-                    radial_budget = (P.radial_budget_x16 * cnt[MGC_CNT_RADIAL_C] / 16 + 7) / 8;
+                    radial_budget = (P.radial_budget_x16 * cnt[lay.cnt_radial_c] / 16 + 7) / 8;
                     if (radial_next > radial_budget) radial_next = radial_budget;
                 }
-            } else if (cnt[MGC_CNT_SOURCE_OPEN] == 0 || radial_done >= radial_budget) {
+            } else if (cnt[lay.cnt_source_open] == 0 || radial_done >= radial_budget) {
                 /* the source is sealed in -- or the flood has had its time, and what is still open are holes that only exact
                  * labels find (radial labels lead past them: measured, a solve that re-lowers for ever) */
                 radial = false;
@@ -289,7 +294,7 @@ int mgc_solve(Dev& dev, const MgcLattice& L, const MgcSolveParams& P, MgcSolveSt
                 dev.radial_lower(P.radial_min_c);
                 radial_next = 2 * radial_next < radial_budget - radial_done ? 2 * radial_next : radial_budget - radial_done;
             }
-            if (P.trace) fprintf(stderr, "[mgc] relabel %d: radial labels %s (shortest source -> sink path %d hops, %d source tiles open)\n", outer, radial ? "on" : "off", cnt[MGC_CNT_RADIAL_C], outer ? cnt[MGC_CNT_SOURCE_OPEN] : -1);
+            if (P.trace) fprintf(stderr, "[mgc] relabel %d: radial labels %s (shortest source -> sink path %d hops, %d source tiles open)\n", outer, radial ? "on" : "off", cnt[lay.cnt_radial_c], outer ? cnt[lay.cnt_source_open] : -1);
         }
         dev.set_radial(radial);
 
@@ -374,6 +379,7 @@ struct MgcSlabGroup {
     void radial_restore_exact() { for (Slab* p : d) p->radial_restore_exact(); }
     void radial_lower(int c_min) { for (Slab* p : d) p->radial_lower(c_min); }
     void source_open() { for (Slab* p : d) p->source_open(); }
+    bool radial_after_passes() const { return d[0]->radial_after_passes(); }
     void exchange(int kind, uint32_t epoch, int list) { x.exchange(kind, epoch, list); exchanges++; }
     /* the counter block summed over every slab of the volume (MGC_CNT_RADIAL_C is the same word on every slab, see radial_begin) */
     void read_counts(int* out)
@@ -382,16 +388,17 @@ struct MgcSlabGroup {
         int c[MGC_NCOUNT];
         for (int i = 0; i < MGC_NCOUNT; ++i) g[i] = 0;
         int radial_c = MGC_HINF;
+        const int slot_c = mgc_cnt_radial_c(d[0]->lattice());
         for (Slab* p : d) {
             p->read_counts(c);
             for (int i = 0; i < MGC_NCOUNT; ++i) g[i] += c[i];
-            radial_c = c[MGC_CNT_RADIAL_C];
+            radial_c = c[slot_c];
         }
-        g[MGC_CNT_RADIAL_C] = 0;
+        g[slot_c] = 0;
         if (!x.local_only()) x.allreduce(g, MGC_NCOUNT, 0);
         reductions++;
         for (int i = 0; i < MGC_NCOUNT; ++i) out[i] = g[i] > 0x7fffffff ? 0x7fffffff : (int)g[i];
-        out[MGC_CNT_RADIAL_C] = radial_c;
+        out[slot_c] = radial_c;
     }
     /* the six scans of a transform over all slabs: x and y stay inside a plane; the z-scans run slab after slab, each starting
      * from the carry plane of the slab before (a pipeline: ranks wait for their neighbour's plane on the stream, not on the host) */
@@ -429,9 +436,9 @@ struct MgcSlabGroup {
         if (!ok) return false;
         /* C = hops of the shortest source -> sink path of the WHOLE volume: the smallest exact label a source voxel carries anywhere */
         int64_t c = MGC_HINF;
-        for (Slab* p : d) { p->radial_cmin(); const int v = p->count_get(MGC_CNT_RADIAL_C); c = v < c ? v : c; }
+        for (Slab* p : d) { p->radial_cmin(); const int v = p->count_get(mgc_cnt_radial_c(p->lattice())); c = v < c ? v : c; }
         if (!x.local_only()) x.allreduce(&c, 1, 1);
-        for (Slab* p : d) p->count_set(MGC_CNT_RADIAL_C, (int)c);
+        for (Slab* p : d) p->count_set(mgc_cnt_radial_c(p->lattice()), (int)c);
         transform(2, 2, c_min);
         for (Slab* p : d) { p->radial_swap(); p->shadow_sync(); } /* (both sides of a border lowered their copies alike) */
         return true;

@@ -43,6 +43,12 @@ MGC_HD int mgc_dt_tile(const MgcLattice& L, int line, int a)
 template <int AXIS>
 MGC_HD int mgc_dt_lines(const MgcLattice& L) { return AXIS == 0 ? L.gz * L.gy : (AXIS == 1 ? L.gz * L.gx : L.gy * L.gx); }
 
+/* label steps that an L1 distance of `dist` from the source is worth.  6-neighbourhood: one per hop.  Full neighbourhood: an arc changes the L1
+ * distance by up to three (a corner neighbour), so floor(dist / 3) is what stays 1-Lipschitz along EVERY one of the 26 arcs -- the labelling
+ * min(exact, max(1, C - floor(ds / 3))) is valid for the same reason C - ds is in the 6-neighbourhood, and the L1 transform is the separable
+ * one (a Chebyshev distance is not).  Away from the source there is always a corner neighbour three L1 steps further out: one label down. */
+MGC_HD int mgc_radial_steps(const MgcLattice& L, int dist) { return L.ndir == 26 ? dist / 3 : dist; }
+
 /* One scan of one tile line.  SEED 1: `in` is the residual mask (bit 6 = sink link) and the scan starts the transform
  * towards the SINK; SEED 2: `in` is the excess plane (f64) and the scan starts the transform away from the SOURCE (voxels
  * that hold excess, mgc_dt_lower_tile); SEED 0: `in` holds uint16 distances.  BWD: back to front.  FINAL: `out` is the
@@ -58,7 +64,7 @@ MGC_HD void mgc_dt_scan_line(W& w, const MgcLattice& L, int line, const void* in
      * direction), or nullptr at the end of the volume; carry_out (if not nullptr) receives the value of local plane `carry_plane`:
      * what the NEXT slab's scan starts from.  A pipeline over the slabs, one uint16 plane per border and direction. */
     int C = MGC_HINF;
-    if (FINAL == 2) { C = L.count[MGC_CNT_RADIAL_C]; if (C < c_min) C = MGC_HINF; }
+    if (FINAL == 2) { C = L.count[mgc_cnt_radial_c(L)]; if (C < c_min) C = MGC_HINF; }
     const int na = AXIS == 0 ? L.gx : (AXIS == 1 ? L.gy : L.gz);
     const int64_t len = AXIS == 0 ? L.dx : (AXIS == 1 ? L.dy : L.dz);
     w.lanes([&](int l) MGCW_INL {
@@ -79,7 +85,7 @@ MGC_HD void mgc_dt_scan_line(W& w, const MgcLattice& L, int line, const void* in
 #pragma unroll
                 for (int g = 0; g < 4; ++g) {
                     const int s = s0 + g < na ? s0 + g : na - 1;
-                    src[g] = (L.status[mgc_dt_tile<AXIS>(L, line, BWD ? na - 1 - s : s)] & MGC_ST_SOURCE) != 0u; /* (uniform over the wave) */
+                    src[g] = mgc_source_tile(L, mgc_dt_tile<AXIS>(L, line, BWD ? na - 1 - s : s)); /* (uniform over the wave) */
                 }
             }
 #pragma unroll
@@ -120,7 +126,7 @@ MGC_HD void mgc_dt_scan_line(W& w, const MgcLattice& L, int line, const void* in
                         const int hv = L.height[base + loc];
                         int nv = hv;
                         if (C < MGC_HINF && v[g][i] < MGC_DT_INF) {
-                            int gl = C - (v[g][i] - 1);
+                            int gl = C - mgc_radial_steps(L, v[g][i] - 1);
                             gl = gl < 1 ? 1 : gl;
                             if (hv < MGC_HINF && gl < hv) nv = gl;
                         }
@@ -207,7 +213,7 @@ MGC_HD void mgc_shadow_sync_tile(W& w, const MgcLattice& L, int side, int i, con
 template <class W>
 MGC_HD void mgc_dt_cmin_tile(W& w, const MgcLattice& L, int tile)
 {
-    if (!(L.status[tile] & MGC_ST_SOURCE)) return;
+    if (!mgc_source_tile(L, tile)) return;
     typename W::template Reg<int, 1> best;
     w.lanes([&](int l) MGCW_INL {
         int b = MGC_HINF;
@@ -219,7 +225,7 @@ MGC_HD void mgc_dt_cmin_tile(W& w, const MgcLattice& L, int tile)
         best(l, 0) = b;
     });
     w.lanes([&](int l) MGCW_INL {
-        if (best(l, 0) < MGC_HINF) w.atomic_min(&L.count[MGC_CNT_RADIAL_C], best(l, 0));
+        if (best(l, 0) < MGC_HINF) w.atomic_min(&L.count[mgc_cnt_radial_c(L)], best(l, 0));
     });
 }
 
@@ -229,7 +235,7 @@ MGC_HD void mgc_dt_cmin_tile(W& w, const MgcLattice& L, int tile)
 template <class W>
 MGC_HD void mgc_dt_lower_tile(W& w, const MgcLattice& L, int tile, const uint16_t* ds, int c_min)
 {
-    const int C = L.count[MGC_CNT_RADIAL_C];
+    const int C = L.count[mgc_cnt_radial_c(L)];
     if (C >= MGC_HINF || C < c_min) return;
     w.lanes([&](int l) MGCW_INL {
         for (int k = 0; k < 8; ++k) {
@@ -237,7 +243,7 @@ MGC_HD void mgc_dt_lower_tile(W& w, const MgcLattice& L, int tile, const uint16_
             const int hv = L.height[i];
             const int d = (int)ds[i];
             if (hv >= MGC_HINF || d >= MGC_DT_INF) continue;
-            int g = C - (d - 1);
+            int g = C - mgc_radial_steps(L, d - 1);
             g = g < 1 ? 1 : g;
             if (g < hv) L.height[i] = g;
         }
@@ -249,7 +255,7 @@ MGC_HD void mgc_dt_lower_tile(W& w, const MgcLattice& L, int tile, const uint16_
 template <class W>
 MGC_HD void mgc_source_open_tile(W& w, const MgcLattice& L, int tile)
 {
-    if (!(L.status[tile] & MGC_ST_SOURCE) || (L.status[tile] & MGC_ST_ALLINF) || !mgc_owned(L, tile)) return; /* (a ghost tile's excess is as built for ever: its owner answers) */
+    if (!mgc_source_tile(L, tile) || (L.status[tile] & MGC_ST_ALLINF) || !mgc_owned(L, tile)) return; /* (a ghost tile's excess is as built for ever: its owner answers) */
     const bool open = w.any([&](int l) MGCW_INL -> bool {
         bool o = false;
         for (int k = 0; k < 8; ++k) {
@@ -259,7 +265,7 @@ MGC_HD void mgc_source_open_tile(W& w, const MgcLattice& L, int tile)
         return o;
     });
     w.lanes([&](int l) MGCW_INL {
-        if (l == 0 && open) w.atomic_add(&L.count[MGC_CNT_SOURCE_OPEN], 1);
+        if (l == 0 && open) w.atomic_add(&L.count[mgc_cnt_source_open(L)], 1);
     });
 }
 

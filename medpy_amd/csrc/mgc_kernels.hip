@@ -1276,7 +1276,7 @@ __device__ __forceinline__ void k_build_tiles(const MgcLattice& L, const MgcBuil
          * t-links), the 6-neighbourhood path behind them (its weight hand-over barrier separates the reset of the vote word from the votes). */
         double tr = 0.0, fc = 0.0;
         int tbits = 0, weak_voxels = 0;
-        bool weak_voxel = false; /* one of this voxel's n-links is below MGC_WALL_WEIGHT (6-neighbourhood, markers only: set before the vote) */
+        bool weak_voxel = false; /* one of this voxel's three FORWARD n-links is weak (MGC_WALL_WEIGHT; 6-neighbourhood, markers only: set before the vote) */
         /* Two halves.  tlinks(): everything that WAITS for memory (the marker bytes asked for at the top of the tile, the explicit t-links,
          * the probability map) and the merge; vote(): ballots and the barrier.  The 6-neighbourhood path runs tlinks() in FRONT of its
          * plane stores: a wave's vector memory operations retire in issue order, so a wait for a marker byte placed behind the six plane
@@ -1332,9 +1332,14 @@ __device__ __forceinline__ void k_build_tiles(const MgcLattice& L, const MgcBuil
              * weight of the pair (c - 1, c) along `axis`.  512 lanes evaluate their three forward pairs, 192 of them also the
              * pair that enters the tile through a lower face: 1728 evaluations of g per tile instead of 3072. */
             if (TERM != MGC_TERM_NONE) {
-                auto pair_weight = [&](int axis, int lo, bool ok) -> double { /* lo = img[] index of the lower voxel; ok = both voxels exist */
+                auto pair_weight = [&](int axis, int lo, bool ok, bool own = true) -> double { /* lo = img[] index of the lower voxel; ok = both voxels exist */
                     if (!ok) return 0.0;
                     double w = mgc_boundary_g(TERM, img[lo], img[lo + (axis == 0 ? 1 : (axis == 1 ? 10 : 100))], A.p0, TABLE ? A.lut : nullptr, TABLE ? A.lut_n : 0);
+                    /* a WEAK pair (MGC_WALL_*): judged on g(.) itself, before the division by the spacing -- all eight terms take values in
+                     * (0, 1], so "below 2^-30" is relative to the largest weight the term can produce whatever the voxel spacing (round 5
+                     * compared the divided weight: a volume with a spacing of 1e-3 or 1e3 moved the rule by that factor).  Every pair is looked at
+                     * once, by its lower voxel -- the lanes that evaluate the pair entering through a lower face leave it to the tile next door */
+                    if (own) weak_voxel = weak_voxel || (w > 0.0 && w < MGC_WALL_WEIGHT);
                     if (A.has_spacing) w = w / A.inv_axis[axis]; /* energy_voxel.py:657-658 */
                     return w;
                 };
@@ -1353,7 +1358,7 @@ __device__ __forceinline__ void k_build_tiles(const MgcLattice& L, const MgcBuil
                     const int lo = axis == 0 ? mgc_hs_index(u, v, -1) : (axis == 1 ? mgc_hs_index(u, -1, v) : mgc_hs_index(-1, u, v));
                     const bool ok = axis == 0 ? (x0 > 0 && z0 + u < L.dz && y0 + v < L.dy)
                                               : (axis == 1 ? (y0 > 0 && z0 + u < L.dz && x0 + v < L.dx) : (z0 > 0 && y0 + u < L.dy && x0 + v < L.dx));
-                    wf[axis * 576 + u * 8 + v] = pair_weight(axis, lo, ok);
+                    wf[axis * 576 + u * 8 + v] = pair_weight(axis, lo, ok, false);
                 }
             }
             __syncthreads();
@@ -1431,7 +1436,6 @@ __device__ __forceinline__ void k_build_tiles(const MgcLattice& L, const MgcBuil
                 __builtin_nontemporal_store(w, &L.rcap[o]); /* 6.4 GB at 512^3 that nothing reads before the caches have turned over many times (2.78 -> 2.70 ms) */
                 if (L.cap0) L.cap0[o] = w;
                 if (w > 0.0) m |= 1u << d; /* NaN (0/0 of the linear terms on a constant image) is not residual */
-                weak_voxel = weak_voxel || (w > 0.0 && w < MGC_WALL_WEIGHT);
             }
             }
         } else {
@@ -2579,7 +2583,7 @@ struct HipDevT {
         void* const T = h->d_ds16;
         const dim3 blk(256);
         auto g = [&](int lines) { return dim3(grid((lines + 3) / 4)); };
-        check(hipMemsetAsync(L.count + MGC_CNT_RADIAL_C, 0x3f, sizeof(int32_t), h->stream)); /* MGC_HINF */
+        check(hipMemsetAsync(L.count + mgc_cnt_radial_c(L), 0x3f, sizeof(int32_t), h->stream)); /* MGC_HINF */
         hipLaunchKernelGGL(k_dt_cmin, g(L.ntiles), blk, 0, h->stream, L); /* C from the exact labels of the source voxels */
         hipLaunchKernelGGL((k_dt_scan<0, false, 2, 0>), g(L.gz * L.gy), blk, 0, h->stream, L, (const void*)L.excess, T, 0, (int32_t*)nullptr, (const uint16_t*)nullptr, (uint16_t*)nullptr, -1);
         hipLaunchKernelGGL((k_dt_scan<0, true, 0, 0>), g(L.gz * L.gy), blk, 0, h->stream, L, (const void*)T, T, 0, (int32_t*)nullptr, (const uint16_t*)nullptr, (uint16_t*)nullptr, -1);
@@ -2715,6 +2719,8 @@ struct HipDevT {
     /* ---- one slab of a volume, as MgcSlabGroup / MgcXchg (mgc_driver.inl) drive it ---- */
     bool multi() const { return false; }
     void exchange(int, uint32_t, int) {}
+    const MgcLattice& lattice() const { return h->L; }
+    bool radial_after_passes() const { return FULL && h->nranks == 1; } /* the full neighbourhood: radial labels on top of a first relabel by passes (single handles) */
     bool has_lower() const { return h->L.tz_own_lo > 0; }
     bool has_upper() const { return h->L.tz_own_hi < h->L.gz; }
     bool needs_carry(int dir) const { return dir == 0 ? h->plane0 > 0 : h->plane1 < h->gd0; }
@@ -2793,7 +2799,7 @@ struct HipDevT {
     void radial_cmin()
     {
         flush_zero();
-        check(hipMemsetAsync(h->L.count + MGC_CNT_RADIAL_C, 0x3f, sizeof(int32_t), h->stream)); /* MGC_HINF */
+        check(hipMemsetAsync(h->L.count + mgc_cnt_radial_c(h->L), 0x3f, sizeof(int32_t), h->stream)); /* MGC_HINF */
         hipLaunchKernelGGL(k_dt_cmin, dt_grid(h->L.ntiles), dim3(256), 0, h->stream, h->L);
         check(hipGetLastError());
     }
@@ -3483,6 +3489,7 @@ static void mgc_slab_handle_stats(mgc_handle h, Dev& dev, const MgcLayout lay, c
     h->stats.relabel_launches = dev.relabel_launches;
     h->stats.reserved[0] = dev.readbacks;
     h->stats.reserved[1] = st.radial_cycles;
+    h->stats.reserved[2] = h->wall_tiles;
     dev.read_counts(cnt);
     h->stats.discharge_tiles = cnt[lay.cnt_dis];
     h->stats.relabel_tiles = cnt[lay.cnt_rel];
@@ -4083,6 +4090,7 @@ int mgc_maxflow(mgc_handle h, double* flow)
         h->stats.relabel_launches = dev.relabel_launches;
         h->stats.reserved[0] = dev.readbacks;
         h->stats.reserved[1] = st.radial_cycles;
+        h->stats.reserved[2] = h->wall_tiles;
         h->stats.discharge_tiles = st.discharge_tiles;
         h->stats.discharge_wave_tiles = L.ndir == 6 ? h->h_count[MGC_CNT_WAVE_TILES] : st.discharge_tiles; /* (as of the solve's last counter read-back) */
         h->stats.relabel_tiles = st.relabel_tiles;

@@ -290,6 +290,11 @@ MGC_HD void mgc26_discharge_tile(X& x, const MgcLattice& L, int tile, uint32_t p
     int sweep_id = 0;
     /* max_cycles < 0: no exact in-tile labelling at all -- the stored labels are valid lower bounds (distances only grow),
      * and the local relabel at the end of every sweep raises the voxels that are stuck; -max_cycles sweep blocks */
+    /* max_cycles <= -1024: the visit runs on RADIAL labels (mgc_dt_ops.inl) -- stored labels, -(max_cycles + 1024) sweep blocks, and ANY
+     * saturated arc marks the tile DIRTY (whether a voxel keeps "a residual arc one label down" says nothing about its distance when the
+     * labels are not distances) */
+    const bool sat_dirty = max_cycles <= -1024;
+    if (sat_dirty) max_cycles += 1024;
     const bool stored_labels = max_cycles < 0;
     if (stored_labels) max_cycles = -max_cycles;
     for (int cyc = 0; cyc < max_cycles; ++cyc) {
@@ -472,9 +477,12 @@ MGC_HD void mgc26_discharge_tile(X& x, const MgcLattice& L, int tile, uint32_t p
         x.par([&](int t) {
             if ((pushed[t] >> 31) && hme[t] < MGC_HINF) {
                 const int me = mgc_hs_index(t >> 6, (t >> 3) & 7, t & 7);
-                bool kept = snk[t] > 0.0; /* (a label of 1 stands on the sink link) */
+                bool kept = false;
+                if (!sat_dirty) {
+                    kept = snk[t] > 0.0; /* (a label of 1 stands on the sink link) */
 #pragma unroll
-                for (int d = 0; d < MGC26_NDIR; ++d) kept = kept || (R(d, t) > 0.0 && x.S.hs[me + mgc26_hs_step(d)] == hme[t] - 1);
+                    for (int d = 0; d < MGC26_NDIR; ++d) kept = kept || (R(d, t) > 0.0 && x.S.hs[me + mgc26_hs_step(d)] == hme[t] - 1);
+                }
                 if (!kept) x.S.satflag = 1;
             }
         });

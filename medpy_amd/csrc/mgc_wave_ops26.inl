@@ -43,6 +43,7 @@
 #include "mgc_wave_ops.inl"
 
 #define MGCW26_ALL_SLOTS 1 /* discharge flag, see pass A */
+#define MGCW26_SAT_DIRTY 2 /* discharge flag: the visit runs on radial labels (mgc_dt_ops.inl) -- any saturated arc marks the tile DIRTY */
 #ifndef MGCW26_NLDS
 #define MGCW26_NLDS 3
 #endif
@@ -487,6 +488,7 @@ MGC_HD void mgcw26_discharge_tile(W& w, const MgcLattice& L, int tile, uint32_t 
      * iff a label rose, or a voxel that saturated an arc has no residual arc one label down left.  A voxel that keeps one of its
      * supports keeps its distance: with 26 neighbours most do, and the tiles a small flow merely passes through stay clean. */
     bool saturated = relabelled;
+    if (!saturated && (flags & MGCW26_SAT_DIRTY)) saturated = w.any([&](int l) MGCW_INL -> bool { return satl(l, 0) != 0; });
     if (!saturated && w.any([&](int l) MGCW_INL -> bool { return satl(l, 0) != 0; })) {
 #if defined(__HIP_DEVICE_COMPILE__)
 #pragma unroll 1

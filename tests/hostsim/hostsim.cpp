@@ -247,6 +247,7 @@ struct HostSlabOps {
     std::vector<uint16_t> carry[2], carry_recv[2];
     bool multi() const { return false; }
     void exchange(int, uint32_t, int) {}
+    const MgcLattice& lattice() const { return self().L; }
     bool has_lower() const { return self().L.tz_own_lo > 0; }
     bool has_upper() const { return self().L.tz_own_hi < self().L.gz; }
     bool needs_carry(int dir) const { return dir == 0 ? self().spec.plane0 > 0 : self().spec.plane1 < gd0; }
@@ -364,6 +365,7 @@ struct HostDev : HostSlabOps<HostDev, HostBlockT<MgcTileShared>> {
         g_prof[28]++;
         return true;
     }
+    bool radial_after_passes() const { return false; } /* (radial labels only on top of a first relabel by transform, as in the library) */
     /* ---- the transforms of a slab, scan by scan (MgcSlabGroup::transform) ---- */
     bool all_residual_local() const
     {
@@ -407,7 +409,7 @@ struct HostDev : HostSlabOps<HostDev, HostBlockT<MgcTileShared>> {
             else if (final_kind == 2) mgc_dt_scan_line<2, true, 0, 2>(w, L, i, T, T, c_min, hexact.data(), cin, cout, plane);
             else mgc_dt_scan_line<2, true, 0, 0>(w, L, i, T, T, 0, nullptr, cin, cout, plane);
         }
-        if (bwd && final_kind == 2) lowered = L.count[MGC_CNT_RADIAL_C] < MGC_HINF && L.count[MGC_CNT_RADIAL_C] >= c_min;
+        if (bwd && final_kind == 2) lowered = L.count[mgc_cnt_radial_c(L)] < MGC_HINF && L.count[mgc_cnt_radial_c(L)] >= c_min;
     }
     void dt_finish()
     {
@@ -426,7 +428,7 @@ struct HostDev : HostSlabOps<HostDev, HostBlockT<MgcTileShared>> {
     void radial_cmin()
     {
         HostWave w(WS);
-        L.count[MGC_CNT_RADIAL_C] = MGC_HINF;
+        L.count[mgc_cnt_radial_c(L)] = MGC_HINF;
         for (int t = 0; t < L.ntiles; ++t) mgc_dt_cmin_tile(w, L, t);
     }
     void radial_swap() { std::swap(height, hexact); L.height = height.data(); }
@@ -440,7 +442,7 @@ struct HostDev : HostSlabOps<HostDev, HostBlockT<MgcTileShared>> {
         HostWave w(WS);
         ds16.assign((size_t)L.ntiles * MGC_TV, 0);
         uint16_t* const T = ds16.data();
-        L.count[MGC_CNT_RADIAL_C] = MGC_HINF;
+        L.count[mgc_cnt_radial_c(L)] = MGC_HINF;
         for (int t = 0; t < L.ntiles; ++t) mgc_dt_cmin_tile(w, L, t); /* C from the exact labels of the source voxels */
         hexact.assign((size_t)L.ntiles * MGC_TV, 0); /* (filled by the last scan: the library's HipDevT::radial_begin, array for array) */
         for (int i = 0; i < L.gz * L.gy; ++i) mgc_dt_scan_line<0, false, 2, 0>(w, L, i, L.excess, T);
@@ -448,7 +450,7 @@ struct HostDev : HostSlabOps<HostDev, HostBlockT<MgcTileShared>> {
         for (int i = 0; i < L.gz * L.gx; ++i) mgc_dt_scan_line<1, false, 0, 0>(w, L, i, T, T);
         for (int i = 0; i < L.gz * L.gx; ++i) mgc_dt_scan_line<1, true, 0, 0>(w, L, i, T, T);
         for (int i = 0; i < L.gy * L.gx; ++i) mgc_dt_scan_line<2, false, 0, 0>(w, L, i, T, T);
-        lowered = L.count[MGC_CNT_RADIAL_C] < MGC_HINF && L.count[MGC_CNT_RADIAL_C] >= c_min;
+        lowered = L.count[mgc_cnt_radial_c(L)] < MGC_HINF && L.count[mgc_cnt_radial_c(L)] >= c_min;
         /* ... and the labels lowered on the way, into the OTHER array -- every label, lowered or not -- and the two trade places: the exact labels
          * are never copied aside */
         for (int i = 0; i < L.gy * L.gx; ++i) mgc_dt_scan_line<2, true, 0, 2>(w, L, i, T, T, c_min, hexact.data());
@@ -461,7 +463,7 @@ struct HostDev : HostSlabOps<HostDev, HostBlockT<MgcTileShared>> {
     void radial_lower(int c_min)
     {
         HostWave w(WS);
-        lowered = L.count[MGC_CNT_RADIAL_C] < MGC_HINF && L.count[MGC_CNT_RADIAL_C] >= c_min; /* (what mgc_dt_lower_tile decides by) */
+        lowered = L.count[mgc_cnt_radial_c(L)] < MGC_HINF && L.count[mgc_cnt_radial_c(L)] >= c_min; /* (what mgc_dt_lower_tile decides by) */
         for (int t = 0; t < L.ntiles; ++t) mgc_dt_lower_tile(w, L, t, ds16.data(), c_min);
     }
     void source_open()
@@ -648,7 +650,7 @@ struct HostDev : HostSlabOps<HostDev, HostBlockT<MgcTileShared>> {
         L.nvox = d0 * d1 * d2;
         L.gz = (int)((d0 + 7) / 8); L.gy = (int)((d1 + 7) / 8); L.gx = (int)((d2 + 7) / 8);
         L.ntiles = L.gz * L.gy * L.gx;
-        L.tz_own_lo = 0; L.tz_own_hi = L.gz; L.tz_global0 = 0;
+        L.tz_own_lo = 0; L.tz_own_hi = L.gz; L.tz_global0 = 0; L.ndir = 6;
         if (sp) { spec = *sp; L.tz_own_lo = sp->own_lo; L.tz_own_hi = sp->own_hi; L.tz_global0 = sp->tz_global0; }
         else { memset(&spec, 0, sizeof(spec)); spec.nranks = 1; spec.own_hi = L.gz; spec.plane1 = spec.own1 = d0; }
         const int64_t nt = L.ntiles;
@@ -871,25 +873,80 @@ int hostsim_first_relabel(const int64_t* shape, const double* w0, const double* 
 struct HostDev26 : HostSlabOps<HostDev26, HostBlockT<MgcTileShared26D>> {
     MgcLattice L;
     MgcTileShared26D S;
-    /* (no transforms in the full neighbourhood: an L-infinity distance is not separable) */
+    /* No transform TOWARDS the sink in the full neighbourhood (a Chebyshev distance is not separable): the first relabel runs as passes.
+     * The radial labels of the flood phase only need the L1 transform AWAY from the source (mgc_radial_steps, mgc_dt_ops.inl): the scans
+     * of the 6-neighbourhood on this lattice's excess plane, the library's HipDevT<true> ops on host arrays. */
     bool dt_applicable() { return false; }
-    void dt_scans_xy(int) {}
-    void dt_scan_z(bool, int, int, const uint16_t*, bool) {}
+    bool radial_after_passes() const { return true; }
+    MgcWaveShared WSr;
+    std::vector<uint16_t> ds16;
+    std::vector<int32_t> hexact;
+    std::vector<uint8_t> tsrc;
+    uint16_t* dt_cur = nullptr;
+    bool radial_on = false, lowered = false;
+    void set_radial(bool on) { radial_on = on; }
+    void dt_scans_xy(int)
+    {
+        HostWave w(WSr);
+        ds16.assign((size_t)L.ntiles * MGC_TV, 0);
+        uint16_t* const T = dt_cur = ds16.data();
+        for (int i = 0; i < L.gz * L.gy; ++i) mgc_dt_scan_line<0, false, 2, 0>(w, L, i, L.excess, T);
+        for (int i = 0; i < L.gz * L.gy; ++i) mgc_dt_scan_line<0, true, 0, 0>(w, L, i, T, T);
+        for (int i = 0; i < L.gz * L.gx; ++i) mgc_dt_scan_line<1, false, 0, 0>(w, L, i, T, T);
+        for (int i = 0; i < L.gz * L.gx; ++i) mgc_dt_scan_line<1, true, 0, 0>(w, L, i, T, T);
+    }
+    void dt_scan_z(bool bwd, int final_kind, int c_min, const uint16_t* cin, bool want_out)
+    {
+        HostWave w(WSr);
+        uint16_t* const T = dt_cur;
+        uint16_t* const cout = want_out ? carry_buf(bwd ? 1 : 0) : nullptr;
+        const int plane = want_out ? carry_plane(bwd ? 1 : 0) : -1;
+        for (int i = 0; i < L.gy * L.gx; ++i) {
+            if (!bwd) mgc_dt_scan_line<2, false, 0, 0>(w, L, i, T, T, 0, nullptr, cin, cout, plane);
+            else if (final_kind == 2) mgc_dt_scan_line<2, true, 0, 2>(w, L, i, T, T, c_min, hexact.data(), cin, cout, plane);
+            else mgc_dt_scan_line<2, true, 0, 0>(w, L, i, T, T, 0, nullptr, cin, cout, plane);
+        }
+        if (bwd && final_kind == 2) lowered = L.count[mgc_cnt_radial_c(L)] < MGC_HINF && L.count[mgc_cnt_radial_c(L)] >= c_min;
+    }
     void dt_finish() {}
     void shadow_sync() {}
-    bool radial_prepare() { return false; }
-    void radial_cmin() {}
-    void radial_swap() {}
+    bool radial_prepare() { if (spec.nranks > 1) return false; hexact.assign((size_t)L.ntiles * MGC_TV, 0); return true; }
+    void radial_cmin()
+    {
+        HostWave w(WSr);
+        L.count[mgc_cnt_radial_c(L)] = MGC_HINF;
+        for (int t = 0; t < L.ntiles; ++t) mgc_dt_cmin_tile(w, L, t);
+    }
+    void radial_swap() { std::swap(height, hexact); L.height = height.data(); }
     std::vector<double> rcap, excess, sink;
     std::vector<int32_t> height, lists, count;
     std::vector<uint32_t> rmask32, stamp, rstamp, status;
-    bool first_relabel_dt() { return false; } /* (an L-infinity distance is not separable) */
-    bool radial_begin(int) { return false; }
-    void radial_save_exact() {}
-    void radial_restore_exact() {}
-    void radial_lower(int) {}
-    void source_open() {}
-    void set_radial(bool) {}
+    bool first_relabel_dt() { return false; }
+    bool radial_begin(int c_min)
+    {
+        if (getenv("HOSTSIM_RADIAL26") && !atoi(getenv("HOSTSIM_RADIAL26"))) return false;
+        if (spec.nranks > 1) return false; /* (a slab's ghost tiles hold no excess to seed the transform from: single handles only) */
+        radial_prepare();
+        radial_cmin();
+        dt_scans_xy(2);
+        dt_scan_z(false, 0, 0, nullptr, false);
+        dt_scan_z(true, 2, c_min, nullptr, false);
+        radial_swap();
+        return true;
+    }
+    void radial_save_exact() { hexact.assign(L.height, L.height + (size_t)L.ntiles * MGC_TV); }
+    void radial_restore_exact() { std::swap(height, hexact); L.height = height.data(); lowered = false; }
+    void radial_lower(int c_min)
+    {
+        HostWave w(WSr);
+        lowered = L.count[mgc_cnt_radial_c(L)] < MGC_HINF && L.count[mgc_cnt_radial_c(L)] >= c_min;
+        for (int t = 0; t < L.ntiles; ++t) mgc_dt_lower_tile(w, L, t, ds16.data(), c_min);
+    }
+    void source_open()
+    {
+        HostWave w(WSr);
+        for (int t = 0; t < L.ntiles; ++t) mgc_source_open_tile(w, L, t);
+    }
     void fill_heights_inf()
     {
         for (int64_t i = 0; i < (int64_t)L.ntiles * MGC_TV; ++i) L.height[i] = MGC_HINF;
@@ -987,8 +1044,8 @@ struct HostDev26 : HostSlabOps<HostDev26, HostBlockT<MgcTileShared26D>> {
         L.count[MGC26_CNT_DIS] += n;
         if (getenv("HOSTSIM_TRACE26")) fprintf(stderr, "%d ", n);
         for (int i = 0; i < n; ++i) {
-            if ((g_wave_mode & 16) && cycles < 0) mgcw26_discharge_tile(w, L, L.list[lst][i], phase, sweeps, g_w26_passes, g_w26_raises, g_w26_flags); /* one wave per tile, stored labels */
-            else mgc26_discharge_tile(x, L, L.list[lst][i], phase, cycles, sweeps);
+            if ((g_wave_mode & 16) && cycles < 0) mgcw26_discharge_tile(w, L, L.list[lst][i], phase, sweeps, g_w26_passes, g_w26_raises, g_w26_flags | (radial_on ? MGCW26_SAT_DIRTY : 0)); /* one wave per tile, stored labels */
+            else mgc26_discharge_tile(x, L, L.list[lst][i], phase, radial_on && cycles < 0 ? cycles - 1024 : cycles, sweeps);
         }
     }
     std::vector<uint32_t> oflags;
@@ -1008,8 +1065,9 @@ struct HostDev26 : HostSlabOps<HostDev26, HostBlockT<MgcTileShared26D>> {
         rcap.assign(nt * 26 * MGC_TV, 0.0); excess.assign(nt * MGC_TV, 0.0); sink.assign(nt * MGC_TV, 0.0);
         height.assign(nt * MGC_TV, MGC_HINF); lists.assign(18 * nt, 0); count.assign(MGC_NCOUNT, 0);
         rmask32.assign(nt * MGC_TV, 0); stamp.assign(nt, 0); rstamp.assign(nt, 0); status.assign(nt, 0); oflags.assign(nt, 0);
+        tsrc.assign(nt, 0);
         L.rcap = rcap.data(); L.excess = excess.data(); L.sink = sink.data(); L.height = height.data();
-        L.rmask32 = rmask32.data(); L.oflags = oflags.data();
+        L.rmask32 = rmask32.data(); L.oflags = oflags.data(); L.tsrc = tsrc.data();
         for (int i = 0; i < 18; ++i) L.list[i] = lists.data() + i * nt;
         L.count = count.data(); L.stamp = stamp.data(); L.rstamp = rstamp.data(); L.status = status.data();
         L.scount = L.count; L.nshard = 1; L.shard_cap = (int)nt;
@@ -1033,6 +1091,7 @@ struct HostDev26 : HostSlabOps<HostDev26, HostBlockT<MgcTileShared26D>> {
             }
             const double tr = trcap[id];
             excess[(int64_t)tile * MGC_TV + loc] = tr > 0 ? tr : 0.0;
+            if (tr > 0) tsrc[tile] |= 1u;
             sink[(int64_t)tile * MGC_TV + loc] = tr < 0 ? -tr : 0.0;
             if (tr < 0) { m |= MGC26_MASK_SINK; status[tile] |= 2u; }
             rmask32[(int64_t)tile * MGC_TV + loc] = m;
@@ -1062,6 +1121,9 @@ int hostsim_solve26(const int64_t* shape, const double* w, const double* trcap, 
     if (cycles != 0) P.max_cycles = cycles; /* < 0: stored labels instead of the exact in-tile labelling */
     if (sweeps > 0) P.max_sweeps = sweeps;
     if (max_outer > 0) P.max_outer = max_outer;
+    if (getenv("HOSTSIM_RADIAL")) P.radial = atoi(getenv("HOSTSIM_RADIAL"));
+    if (getenv("HOSTSIM_RADIAL_BUDGET")) P.radial_budget_x16 = atoi(getenv("HOSTSIM_RADIAL_BUDGET"));
+    if (getenv("HOSTSIM_TRACE")) P.trace = atoi(getenv("HOSTSIM_TRACE"));
     MgcSolveStats st;
     const int rc = mgc_solve(*d, d->L, P, st, mgc_layout26());
     memcpy(stats_out, &st, sizeof(st));

@@ -455,3 +455,24 @@ def test_table_facts_of_images_that_take_no_table():
     assert image_table_facts("difference_linear", whole) is None  # IEEE-basic term: no table, no question
     assert image_table_facts("difference_exponential", np.zeros((0, 3), np.float32)) is None
     assert image_table_facts("maximum_exponential", np.arange(12, dtype=np.int16).reshape(3, 4)) == (True, 0.0, 11.0)
+
+
+@pytest.mark.parametrize("wave", [0, 16], ids=["workgroup_form", "wave_form"])
+def test_hostsim_full_neighbourhood_on_radial_labels_reaches_the_same_cut(wave, monkeypatch):
+    """Radial labels for the 26-neighbourhood: min(exact, max(1, C - floor(L1 distance from the source / 3))) is 1-Lipschitz along all 26
+    arcs (mgc_radial_steps, mgc_dt_ops.inl), put on top of a first relabel by passes.  Measured and left off by default
+    (profiles/r6_rejected_radial26_hostsim.jsonl); forced on here, the cut is the reference's."""
+    import sim
+    from medpy_amd import synthetic
+    from oracle import energy_numpy, pipeline
+    shape = (40, 40, 40)
+    s = synthetic.sphere(shape)
+    offs = energy_numpy.forward_offsets(3, 26)
+    w = energy_numpy.boundary_weights_offsets(s["term"], s["image"], offs, s["sigma"])
+    g = pipeline.build_graph(s["fg"], s["bg"], weights=w, connectivity=26)
+    tr = np.array([g.get_trcap(i) for i in range(s["fg"].size)])
+    g.maxflow()
+    monkeypatch.setenv("HOSTSIM_RADIAL", "1")
+    labels, st = sim.solve26(shape, w, tr, wave_mode=wave)
+    assert st["converged"] == 1 and st["radial_cycles"] >= 1
+    np.testing.assert_array_equal(labels.astype(bool), g.labels().reshape(shape).astype(bool))
