@@ -52,7 +52,8 @@
  * flow of the order of the weights, and exact labels are the better guide (measured: profiles/r6_radial_on_off.jsonl).  Isolated weak
  * arcs of a noisy image do not qualify (~1 per tile).  mgc_build counts the wall tiles. */
 #define MGC_WALL_WEIGHT 9.313225746154785e-10 /* 2^-30 */
-#define MGC_WALL_VOXELS 12                    /* (every pair is counted once, by its lower voxel; until round 6 by both ends: 24) */
+#define MGC_WALL_VOXELS 24                    /* of the 64+ pairs a surface cuts in a tile it crosses (a sealing wall: nearly all of them weak; the edge of the
+                                                 weak-contrast volume: 3 %, a dozen tiles of 262 144 reached 12 and flipped the rule) */
 #define MGC_ST_DEP_SHIFT 8
 /* counter slots no layout uses as a work list (6-neighbourhood: lists 0..7, totals 8 / 9; 26-neighbourhood: lists 0..17,
  * totals 18..20; tickets of the wave kernels 24..27) */

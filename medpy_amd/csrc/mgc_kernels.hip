@@ -438,6 +438,7 @@ __device__ __forceinline__ void mgc_clear_counter(const MgcLattice& L, int c)
                                   of discharge kernels per step, 3 (168 VGPRs, 150 of them spilled around the load / store phases) -> 31.8 ms,
                                   4 -> 57 ms */
 #endif
+template <int REP> /* in-plane push steps per (slot, direction) and sweep: 1, or MGCW_REPEAT_MAX (mgc_wave_ops.inl) */
 __global__ __launch_bounds__(MGCW_LANES) __attribute__((amdgpu_waves_per_eu(MGCW_DISCHARGE_WAVES, MGCW_DISCHARGE_WAVES)))
 void k_discharge_w(MgcLattice L, int lst, uint32_t phase, int sweeps, int flags, int tk, int zero_idx, int stagger)
 {
@@ -464,8 +465,8 @@ void k_discharge_w(MgcLattice L, int lst, uint32_t phase, int sweeps, int flags,
         w.new_tile();
         w.mark(1); /* between two tiles */
         /* the tile id is wave-uniform: keep it (and every base address derived from it) in SGPRs */
-        if (__builtin_amdgcn_readfirstlane(st) & (int)MGC_ST_SINK) mgcw_discharge_impl<true>(w, L, tile, phase, sweeps, flags | ((flags & MGCW_BFS_SINK) ? MGCW_BFS : 0));
-        else mgcw_discharge_impl<false>(w, L, tile, phase, sweeps, flags);
+        if (__builtin_amdgcn_readfirstlane(st) & (int)MGC_ST_SINK) mgcw_discharge_impl<true, REP>(w, L, tile, phase, sweeps, flags | ((flags & MGCW_BFS_SINK) ? MGCW_BFS : 0));
+        else mgcw_discharge_impl<false, REP>(w, L, tile, phase, sweeps, flags);
 #if MGCW_RUNAHEAD
         tile = w.next_tile; /* resolved inside the visit (hint_begin / hint_end in mgcw_discharge_impl) */
         st = w.nst;
@@ -2284,6 +2285,14 @@ struct mgc_graph {
     int w26_passes = 2, w26_raises = 1, w26_flags = 0; /* k26_discharge_w: passes over the steps / relabel rounds per sweep, MGCW26_* flags */
     int activate_exact_max = 4096; /* activation looks at the voxels of its candidate tiles only when there are at most this many (mgcw_activate_tile) */
     int wave_stagger = 0;          /* development knob of k_discharge_w (see there) */
+    /* k_discharge_w<MGCW_REPEAT_MAX> (in-plane push steps repeated within a sweep, mgc_wave_ops.inl) -- parameter repeat_steps: bit 0 = for
+     * graphs solved on exact labels throughout (no walls: weak contrast, integer-valued images, markers everywhere), bit 1 = also for graphs
+     * whose flood runs on radial labels.  Measured on MI355X (profiles/r6_ab_repeat_policy.jsonl): 512^3 ct 73.4 -> 52.1 ms, hard 63.4 -> 59.7,
+     * ties 706 -> 666; the headline volume 18.2 -> 18.0 at 512^3 but 4.40 -> 4.83 ms at 256^3 (every pushing direction pays a second vote,
+     * and there the launches are a visit or two deep): on for the first kind, off for the second */
+    int repeat_steps = 1;
+    int repeat_min_tiles = 0;      /* ... only for launches of at least this many tiles (parameter repeat_min_tiles) */
+    bool repeat_now = false;       /* (during a solve) */
     int wave_min_tiles = 512;      /* shorter lists are discharged by the workgroup-per-tile kernel (measured: 128^3 4.8 -> 3.4 ms, 256^3 10.8 -> 10.5 ms,
                                       512^3 unchanged; 1024 costs 512^3 8 % more discharges) */
     uint32_t zero_mask = 0; /* counters to clear before the next launch (HipDevT::flush_zero) */
@@ -2706,7 +2715,11 @@ struct HipDevT {
             const bool exact_sink = h->exact_sink_tiles == 2 || (h->exact_sink_tiles == 1 && 2 * (int64_t)h->sink_tiles > h->L.ntiles);
             /* a visit that starts from exact in-tile labels needs fewer sweeps to move what it can (tie-heavy 512^3: 796 ms at 12, 731 at 8, 788 at 6) */
             if (exact_sink && h->exact_sink_tiles == 1 && sweeps > h->sink_sweeps) sweeps = h->sink_sweeps;
-            hipLaunchKernelGGL(k_discharge_w, dim3(h->wave_grid_dis), dim3(MGCW_LANES), 0, h->stream, h->L, lst, phase, sweeps, ((h->wave_kernels & 4) ? MGCW_BFS : 0) | (exact_sink ? MGCW_BFS_SINK : 0) | (h->radial_on ? MGCW_SAT_DIRTY : 0), h->tk_dis, zero_idx, h->wave_stagger);
+            const int dflags = ((h->wave_kernels & 4) ? MGCW_BFS : 0) | (exact_sink ? MGCW_BFS_SINK : 0) | (h->radial_on ? MGCW_SAT_DIRTY : 0);
+            /* repeated in-plane steps (mgcw_discharge_impl<.., MGCW_REPEAT_MAX>): decided per SOLVE (repeat_now, mgc_maxflow / mgc_solve_slabs) */
+            const bool rep = h->repeat_now && h->est_phase_tiles >= h->repeat_min_tiles;
+            if (rep) hipLaunchKernelGGL(k_discharge_w<MGCW_REPEAT_MAX>, dim3(h->wave_grid_dis), dim3(MGCW_LANES), 0, h->stream, h->L, lst, phase, sweeps, dflags, h->tk_dis, zero_idx, h->wave_stagger);
+            else hipLaunchKernelGGL(k_discharge_w<1>, dim3(h->wave_grid_dis), dim3(MGCW_LANES), 0, h->stream, h->L, lst, phase, sweeps, dflags, h->tk_dis, zero_idx, h->wave_stagger);
             h->tk_dis ^= 1;
         }
         else hipLaunchKernelGGL(k_discharge, dim3(grid(h->L.ntiles)), dim3(MGC_TV), 0, h->stream, h->L, lst, phase,
@@ -3155,7 +3168,7 @@ static int mgc_create_impl(int ndim, const int64_t* shape, int connectivity, int
         hipDeviceProp_t prop;
         MGC_HIP(h, hipGetDeviceProperties(&prop, device));
         int per_cu_dis = 0, per_cu_rel = 0;
-        MGC_HIP(h, hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu_dis, k_discharge_w, MGCW_LANES, 0));
+        MGC_HIP(h, hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu_dis, k_discharge_w<1>, MGCW_LANES, 0));
         MGC_HIP(h, hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu_rel, k_relabel_w, MGCW_LANES, 0));
         h->wave_grid_dis = prop.multiProcessorCount * (per_cu_dis > 0 ? per_cu_dis : 8);
         h->wave_grid_rel = prop.multiProcessorCount * (per_cu_rel > 0 ? per_cu_rel : 16);
@@ -3526,6 +3539,7 @@ static int mgc_solve_slabs_on(mgc_handle* hs, int n, const mgc_transport* cb, co
         x.allreduce(&walls, 1, 0);
         P.radial = walls >= h0->radial_min_walls ? 1 : 0;
     }
+    for (int i = 0; i < n; ++i) hs[i]->repeat_now = (h0->repeat_steps & (P.radial ? 2 : 1)) != 0;
     MgcSolveStats st;
     const int rc = mgc_solve(group, h0->L, P, st, lay);
     hipError_t first = hipSuccess;
@@ -4034,6 +4048,7 @@ int mgc_maxflow(mgc_handle h, double* flow)
              * takes many cycles of exact labels to saturate: 35.9 -> 23.7 ms on the headline volume); on a weak-contrast volume, where
              * what leaves the source mostly reaches the sink, exact labels are the better guide (66 vs 104 ms at 512^3) */
             if (P.radial == 2) P.radial = h->wall_tiles >= h->radial_min_walls ? 1 : 0;
+            h->repeat_now = (h->repeat_steps & (P.radial ? 2 : 1)) != 0;
             if (h->prepush && h->d_prob && !h->rounds_set) P.rounds_per_relabel = 2; /* (a pre-pushed graph, see the 26-neighbourhood branch; 512^3 + regional map: 19.0 ms at 3, 17.8 at 2, 20.1 at 4; without the pre-push 21.4) */
             rc = mgc_solve(dev, L, P, st);
         } else {
@@ -4297,6 +4312,8 @@ int mgc_set_param(mgc_handle h, const char* name, int64_t value)
         h->L.halo_max_rec = (int)(value < T ? value : T);
     }
     else if (!strcmp(name, "wave_stagger") && value >= 0) h->wave_stagger = (int)value;
+    else if (!strcmp(name, "repeat_steps") && value >= 0 && value <= 3) h->repeat_steps = (int)value;
+    else if (!strcmp(name, "repeat_min_tiles") && value >= 0) h->repeat_min_tiles = (int)value;
     else if (!strcmp(name, "list_shards") && (value == 1 || value == MGC_NSHARD)) { /* regions per work list (MgcLattice::scount); between solves only */
         mgc_flush_zero(h);
         MGC_HIP(h, hipMemsetAsync(h->L.count, 0, MGC_NCOUNT * (1 + MGC_NSHARD) * sizeof(int32_t), h->stream));

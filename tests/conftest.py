@@ -72,7 +72,8 @@ def _build_oracle():
 # discharge (wave_kernels bit 4).
 _FORMS_MODULES = ("test_gpu_parity", "test_gpu_edge_cases", "test_gpu_slabs", "test_gpu_full_neighbourhood")
 LARGE_VOLUME_FORMS = "wave_min_tiles=0,activate_exact_max=0,wave_kernels=25,exact_sink_tiles=2"
-STORED_LABEL_FORMS = "wave_min_tiles=0,exact_sink_tiles=0"  # the wave discharge without the exact labelling of tiles that hold a sink link
+STORED_LABEL_FORMS = "wave_min_tiles=0,exact_sink_tiles=0,repeat_steps=2"  # the wave discharge without the exact labelling of tiles that hold a sink link;
+# repeat_steps = 2: the instance with repeated in-plane steps exactly where the default uses the other one (graphs with walls) and vice versa
 WAVE26_FORMS = "wave_kernels=41,prepush=0"  # 26-neighbourhood: the one-wave-per-tile discharge (k26_discharge_w), graph as built (no pre-push)
 
 

@@ -229,6 +229,7 @@ static int g_w26_passes = 2, g_w26_raises = 1, g_w26_flags = 0; /* hostsim_set_w
 static int g_act_exact_max = 4096; /* hostsim_set_act_exact: see mgcw_activate_tile */
 static FILE* g_trace = NULL; /* one line per wave-form discharge: phase, tile, sweeps (hostsim_trace; tools/sim_launch_model.py) */
 static int g_check_exact = 0; /* hostsim_set_check_exact: labels after a global relabel vs exact distances (g_prof[40], [41]) */
+static int g_repeat_steps = 1; /* hostsim_set_repeat: which launches run the repeated in-plane steps (bit 0 exact labels, bit 1 radial labels), as the library's repeat_steps */
 static int g_use_dt = 1; /* the first global relabel may be a distance transform (hostsim_set_dt) */
 
 typedef HostBlockT<MgcTileShared> HostBlock;
@@ -634,7 +635,9 @@ struct HostDev : HostSlabOps<HostDev, HostBlockT<MgcTileShared>> {
             if ((int)g_tile_discharges.size() == L.ntiles) g_tile_discharges[L.list[lst][i]]++;
             if (g_wave_mode & 1) {
                 const int64_t sweeps_before = g_prof[2];
-                mgcw_discharge_tile(w, L, L.list[lst][i], phase, sweeps, ((g_wave_mode & 4) ? MGCW_BFS : 0) | ((g_wave_mode & 8) ? MGCW_BFS_SINK : 0) | (radial_on ? MGCW_SAT_DIRTY : 0));
+                const int dflags = ((g_wave_mode & 4) ? MGCW_BFS : 0) | ((g_wave_mode & 8) ? MGCW_BFS_SINK : 0) | (radial_on ? MGCW_SAT_DIRTY : 0);
+                if (g_repeat_steps & (radial_on ? 2 : 1)) mgcw_discharge_tile<MGCW_REPEAT_MAX>(w, L, L.list[lst][i], phase, sweeps, dflags);
+                else mgcw_discharge_tile<1>(w, L, L.list[lst][i], phase, sweeps, dflags);
                 if (g_trace) fprintf(g_trace, "%u %d %d\n", phase, L.list[lst][i], (int)(g_prof[2] - sweeps_before));
                 g_prof[3]++;
             } else {
@@ -717,6 +720,7 @@ extern "C" {
 void hostsim_set_wave_mode(int mode) { g_wave_mode = mode; }
 void hostsim_set_w26(int passes, int raises, int flags) { g_w26_passes = passes; g_w26_raises = raises; g_w26_flags = flags; }
 void hostsim_set_dt(int on) { g_use_dt = on; }
+void hostsim_set_repeat(int bits) { g_repeat_steps = bits; }
 void hostsim_set_check_exact(int on) { g_check_exact = on; }
 void hostsim_trace(const char* path) { if (g_trace) fclose(g_trace); g_trace = path && *path ? fopen(path, "w") : NULL; }
 void hostsim_set_bricks(int on) { g_bricks = on; }

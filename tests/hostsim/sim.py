@@ -50,6 +50,12 @@ def set_wave_mode(mode):
     lib().hostsim_set_wave_mode(int(mode))
 
 
+def set_repeat(bits):
+    """which launches of the wave discharge repeat their in-plane push steps (mgcw_discharge_impl<.., MGCW_REPEAT_MAX>): bit 0 on exact
+    labels (the library's default), bit 1 during the flood on radial labels; 0 = never"""
+    lib().hostsim_set_repeat(int(bits))
+
+
 def set_check_exact(on):
     """after every global relabel, compare the labels with the exact distances to the sink in the residual graph (a plain
     relaxation over the volume); read the result with prof(): [40] relabels checked, [41] voxels whose label differs"""

@@ -112,6 +112,21 @@ def test_hostsim_wave_forms_match_bk(gen, shape, mode):
         np.testing.assert_array_equal(lab, ref)
 
 
+@pytest.mark.parametrize("repeat", [0, 3])
+@pytest.mark.parametrize("gen,shape", [("sphere", (32, 32, 32)), ("hard", (24, 32, 40))])
+def test_hostsim_wave_discharge_with_and_without_repeated_steps(gen, shape, repeat):
+    """the two instances of the wave discharge (one in-plane push step per direction and sweep / repeated while somebody can push): never,
+    and in every launch including the flood on radial labels -- the cut is the reference's either way"""
+    import sim
+    sim.set_repeat(repeat)
+    try:
+        lab, ref, st = _sim_case(gen, shape, wave_mode=3)
+    finally:
+        sim.set_repeat(1)
+    assert st["converged"] == 1
+    np.testing.assert_array_equal(lab, ref)
+
+
 def test_hostsim_wave_schedule_independence():
     for kw in (dict(rounds=1, sweeps=1), dict(rounds=3, sweeps=4), dict(rounds=50, sweeps=64)):
         for mode in (3, 7):
