@@ -1,7 +1,16 @@
 # one GPU call of round 6 (development aid; edited per call)
 cd $GRAFT_REPO_ROOT; mkdir -p gpurun_out
-rm -f gpurun_out/parity_relaxations.jsonl
-timeout 2400 python -m pytest tests -m gpu -q 2>&1 | grep -E "passed|failed|error" | tail -8 > gpurun_out/r6_pytest.txt; cat gpurun_out/r6_pytest.txt
-[ -f gpurun_out/parity_relaxations.jsonl ] && cp gpurun_out/parity_relaxations.jsonl gpurun_out/r6_parity_relaxations.jsonl
-( timeout 300 python tools/gpu_ab.py --n 256 --reps 5 --tag policy base; timeout 300 python tools/gpu_ab.py --n 512 --reps 5 --tag policy base; timeout 300 python tools/gpu_ab.py --n 512 --wl hard --reps 3 --tag policy base ) 2>&1 | cut -c1-260
-SLAB_TOTAL_PLANES=2048 timeout 900 python tools/gpu_slab_scaling.py 256 1024 6 8 2>&1 | cut -c1-600
+( for L in build/lib_before_z.so ""; do
+    timeout 300 python tools/gpu_ab.py ${L:+--lib $L} --n 512 --tag "${L:-tree_one_z_vote}" --reps 7 base
+    timeout 300 python tools/gpu_ab.py ${L:+--lib $L} --n 512 --wl hard --tag "${L:-tree_one_z_vote}" --reps 3 base
+    timeout 300 python tools/gpu_ab.py ${L:+--lib $L} --n 256 --tag "${L:-tree_one_z_vote}" --reps 7 base
+    timeout 300 python tools/gpu_ab.py ${L:+--lib $L} --n 512 --wl ct --tag "${L:-tree_one_z_vote}" --reps 3 base
+    timeout 300 python tools/gpu_ab.py ${L:+--lib $L} --n 512 --wl ties --tag "${L:-tree_one_z_vote}" --reps 1 base
+  done ) > gpurun_out/r6_ab_z_votes.jsonl 2>&1
+python - <<'PY'
+import json
+for l in open("gpurun_out/r6_ab_z_votes.jsonl"):
+    if not l.startswith("{"): print(l[:200]); continue
+    d = json.loads(l)
+    print(d["tag"], d["wl"], d["n"], d["ms"], "dis", d["discharge_ms"], "rel", d["relabel_ms"], "tiles", d["dis_tiles"], "phases", d["phases"], "relabels", d["relabels"], d["flow"])
+PY
