@@ -65,7 +65,7 @@ def pmc_traffic_per_launch(name="pmc_discharge.json"):
     d = json.load(open(path))
     info = {"fetch_kib_per_launch": d.get("fetch_kib_per_launch"), "write_kib_per_launch": d.get("write_kib_per_launch"),
             "kernel_sources": d.get("kernel_sources"), "matches_this_tree": d.get("kernel_sources") == kernel_source_hash()}
-    if not info["matches_this_tree"]:
+    if not info["matches_this_tree"] or d.get("fetch_kib_per_launch") is None or d.get("write_kib_per_launch") is None:
         return None, info
     return int((2.0 * d["fetch_kib_per_launch"] + d["write_kib_per_launch"]) * 1024), info
 

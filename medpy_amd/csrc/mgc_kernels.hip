@@ -320,10 +320,17 @@ struct GpuWaveT {
         return v;
     }
     int tk = 0; /* ticket word of this launch */
+    int nvis = 0;
     __device__ __forceinline__ void ticket_issue(const MgcLattice& L)
     {
+#if defined(MGCW_DEV_STATIC_STRIDE) /* development aid: no ticket word at all -- wave b takes entries b, b + G, b + 2 G ... (what does the hot word cost?) */
+        tkv = nvis * (int)gridDim.x + (int)blockIdx.x;
+        nvis++;
+        (void)L;
+#else
         tkv = 0;
         if (threadIdx.x == 0) tkv = atomicAdd(&L.count[tk], 1);
+#endif
     }
     __device__ __forceinline__ void hint_begin()
     {
@@ -381,26 +388,33 @@ struct GpuWaveT {
     /* the loads issued so far are not moved below this point, nor later ones above it */
     __device__ __forceinline__ void load_batch_end() { __builtin_amdgcn_sched_barrier(0); }
     __device__ __forceinline__ void gor(uint32_t* p, uint32_t v) { (void)__hip_atomic_fetch_or(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
-#if defined(MGCW_PROFILE) /* development build (tools/gpu_sections.py): cycles per section of a tile discharge, per wave */
-    unsigned long long last = 0, acc[8] = {0, 0, 0, 0, 0, 0, 0, 0};
-    unsigned int cnt[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+#if defined(MGCW_PROFILE) /* development build (tools/gpu_sections.py): cycles per section of a tile discharge, per wave.  The accumulators
+                           * live in LDS (prof_lds: [0] the previous mark, [1..8] cycles, [9..16] counts), not in registers: the build
+                           * must keep the register budget of the kernel it measures */
+    unsigned long long* prof_lds = nullptr;
     __device__ __forceinline__ void mark(int id)
     {
-        const unsigned long long now = __builtin_readcyclecounter();
-        if (last) { acc[id & 7] += now - last; cnt[id & 7]++; }
-        last = now;
+        if (threadIdx.x == 0) {
+            const unsigned long long now = __builtin_readcyclecounter();
+            const unsigned long long last = prof_lds[0];
+            if (last) { prof_lds[1 + (id & 7)] += now - last; prof_lds[9 + (id & 7)] += 1; }
+            prof_lds[0] = now;
+        }
     }
     __device__ __forceinline__ void flush_marks(const MgcLattice& L)
     {
         if (L.prof && threadIdx.x == 0)
             for (int i = 0; i < 8; ++i)
-                if (cnt[i]) { atomicAdd(&L.prof[i], acc[i]); atomicAdd(&L.prof[i + 8], (unsigned long long)cnt[i]); }
+                if (prof_lds[9 + i]) { atomicAdd(&L.prof[i], prof_lds[1 + i]); atomicAdd(&L.prof[i + 8], prof_lds[9 + i]); }
     }
 #else
     __device__ __forceinline__ void mark(int) {}
     __device__ __forceinline__ void flush_marks(const MgcLattice&) {}
 #endif
     __device__ __forceinline__ void fresh() { asm volatile("" : "+v"(lane)); lane &= 63; }
+    /* min(a, b) of two doubles the caller knows to be numbers where the result is used: ONE v_min_f64 (fmin() costs two canonicalising
+     * v_max_f64 in front of it under IEEE mode, three instructions in the innermost step of the discharge) */
+    __device__ __forceinline__ double fmin_pos(double a, double b) { double r; asm("v_min_f64 %0, %1, %2" : "=v"(r) : "v"(a), "v"(b)); return r; }
     /* v unchanged, but nothing computed from it may move above this point, nor may memory operations cross it: pins the
      * FIRST USE of a value still on its way back from memory (and with it the wait for it) to where the code says */
     __device__ __forceinline__ int use_here(int v) { asm volatile("" : "+v"(v) : : "memory"); return v; }
@@ -457,6 +471,11 @@ void k_discharge_w(MgcLattice L, int lst, uint32_t phase, int sweeps, int flags,
         for (int k = 0; k < stagger; ++k) __builtin_amdgcn_s_sleep(127);
     __shared__ int32_t pf[256];
     w.pf = pf;
+#if defined(MGCW_PROFILE)
+    __shared__ unsigned long long prof_lds[17];
+    if (threadIdx.x < 17) prof_lds[threadIdx.x] = 0;
+    w.prof_lds = prof_lds;
+#endif
     w.list_begin(L, lst);
     w.tk = tk;
     int tile = __builtin_amdgcn_readfirstlane(w.entry_load((int)blockIdx.x)), st = 0; /* first visit: no ticket */
@@ -465,8 +484,7 @@ void k_discharge_w(MgcLattice L, int lst, uint32_t phase, int sweeps, int flags,
         w.new_tile();
         w.mark(1); /* between two tiles */
         /* the tile id is wave-uniform: keep it (and every base address derived from it) in SGPRs */
-        if (__builtin_amdgcn_readfirstlane(st) & (int)MGC_ST_SINK) mgcw_discharge_impl<true, REP>(w, L, tile, phase, sweeps, flags | ((flags & MGCW_BFS_SINK) ? MGCW_BFS : 0));
-        else mgcw_discharge_impl<false, REP>(w, L, tile, phase, sweeps, flags);
+        mgcw_discharge_pick<REP>(w, L, tile, (__builtin_amdgcn_readfirstlane(st) & (int)MGC_ST_SINK) != 0, phase, sweeps, flags);
 #if MGCW_RUNAHEAD
         tile = w.next_tile; /* resolved inside the visit (hint_begin / hint_end in mgcw_discharge_impl) */
         st = w.nst;
@@ -518,6 +536,11 @@ void k26_discharge_w(MgcLattice L, int lst, uint32_t phase, int sweeps, int pass
         if (threadIdx.x == 0 && n) atomicAdd(&L.count[MGC26_CNT_DIS], n);
     }
     if (blockIdx.x == 0 && threadIdx.x == 0) L.count[tk ^ 1] = 0; /* the next launch's ticket word */
+#if defined(MGCW_PROFILE)
+    __shared__ unsigned long long prof_lds[17];
+    if (threadIdx.x < 17) prof_lds[threadIdx.x] = 0;
+    w.prof_lds = prof_lds;
+#endif
     w.list_begin(L, lst);
     w.tk = tk;
     int tile = __builtin_amdgcn_readfirstlane(w.entry_load((int)blockIdx.x)); /* first visit: no ticket */

@@ -190,6 +190,7 @@ struct HostWaveT {
     template <class T> T ld(const T* p, int l) { return p[l]; }
     template <class T> void st(T* p, int l, T v) { p[l] = v; }
     void fresh() {}
+    double fmin_pos(double a, double b) { return a < b ? a : b; }
     int use_here(int v) { return v; }
 };
 typedef HostWaveT<MgcWaveShared> HostWave;
@@ -629,7 +630,32 @@ struct HostDev : HostSlabOps<HostDev, HostBlockT<MgcTileShared>> {
         if (getenv("HOSTSIM_WEAK") && atoi(getenv("HOSTSIM_WEAK")) > 1 && !weak0.empty()) {
             int64_t sat = 0;
             for (size_t i = 0; i < rcap.size(); ++i) sat += weak0[i] && rcap[i] == 0.0;
-            fprintf(stderr, "[sim]   phase %u: %d tiles, weak arcs saturated so far %lld\n", phase, n, (long long)sat);
+            /* voxels that hold excess under a finite label AND a residual arc one label down (could push now), split by whether their tile is queued */
+            int64_t can_q = 0, can_nq = 0, obox_pending = 0;
+            std::vector<char> queued(L.ntiles, 0);
+            for (int i = 0; i < n; ++i) queued[L.list[lst][i]] = 1;
+            for (int i = 0; i < L.count[(lst + 1) & 3]; ++i) queued[L.list[(lst + 1) & 3][i]] = 1;
+            for (int t = 0; t < L.ntiles; ++t) {
+                int tz, ty, tx;
+                mgc_tile_coords(L, t, tz, ty, tx);
+                for (int f = 0; f < 6; ++f) for (int k = 0; k < MGC_TF; ++k) obox_pending += L.obox[((int64_t)t * 6 + f) * MGC_TF + k] != 0.0;
+                for (int v = 0; v < MGC_TV; ++v) {
+                    const int64_t g = (int64_t)t * MGC_TV + v;
+                    if (!(L.excess[g] > 0.0) || L.height[g] >= MGC_HINF) continue;
+                    const int z = v >> 6, y = (v >> 3) & 7, xx = v & 7;
+                    bool can = false;
+                    for (int d = 0; d < 6 && !can; ++d) {
+                        if (!(L.rcap[((int64_t)t * 6 + d) * MGC_TV + v] > 0.0)) continue;
+                        int nz = z + (d == 4 ? -1 : d == 5 ? 1 : 0), ny = y + (d == 2 ? -1 : d == 3 ? 1 : 0), nx = xx + (d == 0 ? -1 : d == 1 ? 1 : 0);
+                        int nt = t;
+                        if (nz < 0 || nz > 7 || ny < 0 || ny > 7 || nx < 0 || nx > 7) { nt = mgc_tile_nbr(L, tz, ty, tx, d); nz &= 7; ny &= 7; nx &= 7; }
+                        if (nt < 0) continue;
+                        can = L.height[(int64_t)nt * MGC_TV + nz * 64 + ny * 8 + nx] == L.height[g] - 1;
+                    }
+                    if (can) (queued[t] ? can_q : can_nq)++;
+                }
+            }
+            fprintf(stderr, "[sim]   phase %u: %d tiles, weak arcs saturated so far %lld; voxels that could push: %lld in queued tiles, %lld elsewhere; outbox cells pending %lld\n", phase, n, (long long)sat, (long long)can_q, (long long)can_nq, (long long)obox_pending);
         }
         for (int i = 0; i < n; ++i) {
             if ((int)g_tile_discharges.size() == L.ntiles) g_tile_discharges[L.list[lst][i]]++;
@@ -834,6 +860,7 @@ int hostsim_solve(const int64_t* shape, const double* w0, const double* w1, cons
     if (getenv("HOSTSIM_RADIAL")) P.radial = atoi(getenv("HOSTSIM_RADIAL"));
     if (getenv("HOSTSIM_RADIAL_ROUNDS0")) P.radial_rounds0 = atoi(getenv("HOSTSIM_RADIAL_ROUNDS0"));
     if (getenv("HOSTSIM_RADIAL_MIN_C")) P.radial_min_c = atoi(getenv("HOSTSIM_RADIAL_MIN_C"));
+    if (getenv("HOSTSIM_RADIAL_BUDGET")) P.radial_budget_x16 = atoi(getenv("HOSTSIM_RADIAL_BUDGET"));
     MgcSolveStats st;
     const int rc = mgc_solve(*d, d->L, P, st);
     memcpy(stats_out, &st, sizeof(st));

@@ -60,7 +60,7 @@ PY
     [ -n "$T" ] && python tools/rocpd_summary.py stats $T > $G/${TAG}_config3_trace.csv
     [ -n "$F" ] && python tools/rocpd_summary.py pmc $F > $G/${TAG}_config3_fetch.csv
     [ -n "$W" ] && python tools/rocpd_summary.py pmc $W > $G/${TAG}_config3_write.csv
-    [ -n "$F" ] && [ -n "$W" ] && python tools/rocpd_summary.py json $F $W k26_discharge > $G/pmc_discharge26.json && cp $G/pmc_discharge26.json profiles/
+    [ -n "$F" ] && [ -n "$W" ] && python tools/rocpd_summary.py json $F $W k26_discharge_w > $G/pmc_discharge26.json && cp $G/pmc_discharge26.json profiles/
     rm -rf $OUT
     python bench.py --config 3 --no-cpu --no-extras 2>> $G/${TAG}_bench.err | tail -1 > $G/${TAG}_bench_config3.json; cut -c1-400 $G/${TAG}_bench_config3.json ;;
   workloads)

@@ -50,7 +50,9 @@ def main():
         out = {"kernel": kern}
         for key, db in (("fetch_kib_per_launch", sys.argv[2]), ("write_kib_per_launch", sys.argv[3])):
             c = sqlite3.connect(db).cursor()
-            n, v = c.execute("select count(*), avg(value) from counters_collection where kernel_name like ?", (kern + "(%",)).fetchone()
+            # (the discharge kernels are templates: "void k_discharge_w<1>(MgcLattice, ...)"; every instance counts)
+            n, v = c.execute("select count(*), avg(value) from counters_collection where kernel_name like ? or kernel_name like ? or kernel_name like ?",
+                             (kern + "(%", "void " + kern + "<%", "void " + kern + "(%")).fetchone()
             out[key] = v
             out[key.replace("kib_per_launch", "launches")] = n
         import hashlib, os
