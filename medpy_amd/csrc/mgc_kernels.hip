@@ -320,17 +320,10 @@ struct GpuWaveT {
         return v;
     }
     int tk = 0; /* ticket word of this launch */
-    int nvis = 0;
     __device__ __forceinline__ void ticket_issue(const MgcLattice& L)
     {
-#if defined(MGCW_DEV_STATIC_STRIDE) /* development aid: no ticket word at all -- wave b takes entries b, b + G, b + 2 G ... (what does the hot word cost?) */
-        tkv = nvis * (int)gridDim.x + (int)blockIdx.x;
-        nvis++;
-        (void)L;
-#else
         tkv = 0;
         if (threadIdx.x == 0) tkv = atomicAdd(&L.count[tk], 1);
-#endif
     }
     __device__ __forceinline__ void hint_begin()
     {
@@ -412,8 +405,8 @@ struct GpuWaveT {
     __device__ __forceinline__ void flush_marks(const MgcLattice&) {}
 #endif
     __device__ __forceinline__ void fresh() { asm volatile("" : "+v"(lane)); lane &= 63; }
-    /* min(a, b) of two doubles the caller knows to be numbers where the result is used: ONE v_min_f64 (fmin() costs two canonicalising
-     * v_max_f64 in front of it under IEEE mode, three instructions in the innermost step of the discharge) */
+    /* min(a, b) of two doubles that are never NaNs: ONE v_min_f64 (fmin() costs two canonicalising v_max_f64 in front of it under IEEE mode, three
+     * instructions in the innermost step of the discharge).  Call it in front of a select, not inside its arm: the compiler branches around the asm there */
     __device__ __forceinline__ double fmin_pos(double a, double b) { double r; asm("v_min_f64 %0, %1, %2" : "=v"(r) : "v"(a), "v"(b)); return r; }
     /* v unchanged, but nothing computed from it may move above this point, nor may memory operations cross it: pins the
      * FIRST USE of a value still on its way back from memory (and with it the wait for it) to where the code says */
@@ -448,9 +441,14 @@ __device__ __forceinline__ void mgc_clear_counter(const MgcLattice& L, int c)
 }
 
 #ifndef MGCW_DISCHARGE_WAVES
-#define MGCW_DISCHARGE_WAVES 2 /* waves per SIMD the register allocator leaves room for: 256 VGPRs each.  Measured on MI355X at 512^3: 2 -> 24.0 ms
-                                  of discharge kernels per step, 3 (168 VGPRs, 150 of them spilled around the load / store phases) -> 31.8 ms,
-                                  4 -> 57 ms */
+#define MGCW_DISCHARGE_WAVES 2 /* waves per SIMD the register allocator leaves room for: 256 VGPRs each.  Rounds 2 - 5 (150 - 360 registers spilled at three):
+                                  24.0 ms of discharge kernels per step at 2, 31.8 at 3, 57 at 4.  Round 6 built the kernel WITHOUT a byte of scratch at 168
+                                  registers (tools/experiments/r6_three_waves_lazy_planes.patch: outflow collected in LDS, the exact in-tile labelling as an
+                                  instance of its own, the inbox absorbed slot by slot, nothing kept for all eight slots) and measured it: 11.3 - 11.6 ms at three
+                                  waves against 11.4 - 12.1 at two -- the memory system is saturated at ~48 visits per microsecond whatever the number of waves
+                                  in flight (profiles/r6_resident_waves_curve.jsonl, r6_discharge_sections_{2,3}_waves.txt: a sweep takes 7.1 k cycles at two
+                                  and 7.2 k at three, the memory phases of a visit 42 k against 96 k) -- while the leaner code is 12 % slower per visit where
+                                  nothing queues (16.6 -> 18.6 us with one wave per CU): 256^3 4.4 -> 4.7 ms, 128^3 2.4 -> 2.6.  Two waves stay. */
 #endif
 template <int REP> /* in-plane push steps per (slot, direction) and sweep: 1, or MGCW_REPEAT_MAX (mgc_wave_ops.inl) */
 __global__ __launch_bounds__(MGCW_LANES) __attribute__((amdgpu_waves_per_eu(MGCW_DISCHARGE_WAVES, MGCW_DISCHARGE_WAVES)))
@@ -484,7 +482,8 @@ void k_discharge_w(MgcLattice L, int lst, uint32_t phase, int sweeps, int flags,
         w.new_tile();
         w.mark(1); /* between two tiles */
         /* the tile id is wave-uniform: keep it (and every base address derived from it) in SGPRs */
-        mgcw_discharge_pick<REP>(w, L, tile, (__builtin_amdgcn_readfirstlane(st) & (int)MGC_ST_SINK) != 0, phase, sweeps, flags);
+        if (__builtin_amdgcn_readfirstlane(st) & (int)MGC_ST_SINK) mgcw_discharge_impl<true, REP>(w, L, tile, phase, sweeps, flags | ((flags & MGCW_BFS_SINK) ? MGCW_BFS : 0));
+        else mgcw_discharge_impl<false, REP>(w, L, tile, phase, sweeps, flags);
 #if MGCW_RUNAHEAD
         tile = w.next_tile; /* resolved inside the visit (hint_begin / hint_end in mgcw_discharge_impl) */
         st = w.nst;

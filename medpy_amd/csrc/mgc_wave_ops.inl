@@ -264,7 +264,7 @@ MGC_HD void mgcw_prefetch_tile(W& w, const MgcLattice& L, int tile)
  * predicate, the wave votes, and the update runs branch-free (selects) only if somebody can -- no EXEC-mask
  * juggling, and a (slot, direction) pair in which nobody pushes costs three compares and a scalar branch.
  * ------------------------------------------------------------------------------------- */
-template <bool SINK, int REP = 1, bool BFS = false, class W>
+template <bool SINK, int REP = 1, class W>
 MGC_HD void mgcw_discharge_impl(W& w, const MgcLattice& L, int tile, uint32_t phase, int max_sweeps, int flags)
 {
     typename W::template Reg<double, 8> e;
@@ -302,9 +302,6 @@ MGC_HD void mgcw_discharge_impl(W& w, const MgcLattice& L, int tile, uint32_t ph
         /* the ticket for the tile AFTER this one goes out behind the loads: a wave's memory operations retire in issue order, and
          * the ticket word is the one address every wave of the launch hits (ahead of the loads it would hold them all up) */
         if constexpr (W::kPrefetch >= 0) w.ticket_issue(L);
-#if defined(MGCW_DEV_EXTRA_TRAFFIC) /* development aid: is a visit bound by bytes?  24 KB more per visit that nobody uses (the planes of some other tile) */
-        w.prefetch(L.rcap + (int64_t)((tile * 7919 + 13) % L.ntiles) * 6 * MGC_TV, 6 * MGC_TV * (int)sizeof(double));
-#endif
         mgcw_halo_commit(w, L, tile, l, hv, dnb);
         if (l < 6) { /* retire the outbox flags of the slots just emptied */
             const int nt = mgc_tile_nbr(L, tz, ty, tx, l);
@@ -312,30 +309,23 @@ MGC_HD void mgcw_discharge_impl(W& w, const MgcLattice& L, int tile, uint32_t ph
         }
     });
     w.mark(4); /* loads issued, halo + inbox back and staged */
-    w.fresh();
-    /* ---- absorb the staged inbox: e += delta, reverse residual += delta, fixed face order.  Slot by slot, a fence between two slots:
-     * asked for all at once the 34 reads are 68 registers on top of the state (the peak of the whole visit), and every lane reads its
-     * row's / column's cell and keeps it or not -- a read only on the face lanes is a branch around it ---- */
-    mgcw_static_for<8>([&](auto KK) MGCW_INL {
-        constexpr int K = decltype(KK)::value;
-        w.lanes([&](int l) MGCW_INL {
-            const int y = l >> 3, x = l & 7;
+    /* ---- absorb the staged inbox: e += delta, reverse residual += delta, fixed face order ---- */
+    w.lanes([&](int l) MGCW_INL {
+        const int y = l >> 3, x = l & 7;
+        mgcw_static_for<8>([&](auto KK) MGCW_INL {
+            constexpr int K = decltype(KK)::value;
             /* selects on the VALUES, never on which register is updated: a branch per face makes the optimiser merge
              * the updates into one store through a pointer phi, which pins the residual arrays to scratch memory */
-            const double v0 = w.S.inbox[0][K * 8 + y], v1 = w.S.inbox[1][K * 8 + y], v2 = w.S.inbox[2][K * 8 + x], v3 = w.S.inbox[3][K * 8 + x];
-            const double d0 = x == 0 ? v0 : 0.0;
-            const double d1 = x == 7 ? v1 : 0.0;
-            const double d2 = y == 0 ? v2 : 0.0;
-            const double d3 = y == 7 ? v3 : 0.0;
+            const double d0 = x == 0 ? w.S.inbox[0][K * 8 + y] : 0.0;
+            const double d1 = x == 7 ? w.S.inbox[1][K * 8 + y] : 0.0;
+            const double d2 = y == 0 ? w.S.inbox[2][K * 8 + x] : 0.0;
+            const double d3 = y == 7 ? w.S.inbox[3][K * 8 + x] : 0.0;
             e(l, K) += d0; r[0](l, K) += d0;
             e(l, K) += d1; r[1](l, K) += d1;
             e(l, K) += d2; r[2](l, K) += d2;
             e(l, K) += d3; r[3](l, K) += d3;
             if constexpr (K == 0) { const double d = w.S.inbox[4][l]; e(l, K) += d; r[4](l, K) += d; }
             if constexpr (K == 7) { const double d = w.S.inbox[5][l]; e(l, K) += d; r[5](l, K) += d; }
-            w.pin(r[0](l, K)); w.pin(r[1](l, K)); w.pin(r[2](l, K)); w.pin(r[3](l, K));
-            w.pin(e(l, K)); /* the sums exist HERE: left to itself the optimiser sinks these additions to the first use of the values, below
-                               the relaxation of the BFS instances, and keeps all 34 summands alive until then */
         });
     });
     w.mark(5); /* own state back, inbox absorbed */
@@ -345,16 +335,10 @@ MGC_HD void mgcw_discharge_impl(W& w, const MgcLattice& L, int tile, uint32_t ph
 #pragma unroll
     for (int f = 0; f < 6; ++f)
         if (w.any([&](int l) MGCW_INL -> bool { return w.S.inbox[f][l] != 0.0; })) dirty |= 1u << f;
-    /* the staged inbox is spent; from here on the same cells collect what this visit pushes OUT across the six faces -- they are
-     * in outbox order already, and 36 registers per lane are free for a third wave on the SIMD */
-    w.lanes([&](int l) MGCW_INL {
-#pragma unroll
-        for (int f = 0; f < 6; ++f) w.S.inbox[f][l] = 0.0;
-    });
-    bool relabelled = BFS; /* some label of the tile changed */
+    bool relabelled = (flags & MGCW_BFS) != 0; /* some label of the tile changed */
 
     /* ---- labels: exact in-tile distances given the frozen halo, or the stored (valid lower-bound) labels ---- */
-    if constexpr (BFS) { /* (an instance of its own: as a run-time branch the relaxation sat in every visit's register budget) */
+    if (flags & MGCW_BFS) {
         w.lanes([&](int l) MGCW_INL {
             mgcw_static_for<8>([&](auto KK) MGCW_INL {
                 constexpr int K = decltype(KK)::value;
@@ -362,25 +346,15 @@ MGC_HD void mgcw_discharge_impl(W& w, const MgcLattice& L, int tile, uint32_t ph
                 w.S.hs[mgcw_hs(l, K)] = MGC_HINF;
             });
         });
-        /* which arcs are residual, as seven bits per voxel taken once: asked of the planes in every round of the relaxation the 56 answers
-         * per lane stay alive as lane masks, and the instance needs 239 registers instead of 160 */
-        typename W::template Reg<int, 8> mk;
-        w.lanes([&](int l) MGCW_INL {
-            mgcw_static_for<8>([&](auto KK) MGCW_INL {
-                constexpr int K = decltype(KK)::value;
-                int m = 0;
-                if constexpr (SINK) m = w.S.snk[K * 64 + l] > 0.0 ? 64 : 0;
-                mgcw_static_for<6>([&](auto DD) MGCW_INL {
-                    constexpr int D = decltype(DD)::value;
-                    m |= r[D](l, K) > 0.0 ? (1 << D) : 0;
-                });
-                mk(l, K) = m;
-            });
-        });
         mgcw_relax(w, h, [&](int l, auto KK, auto DD) MGCW_INL -> bool {
             constexpr int K = decltype(KK)::value;
             constexpr int D = decltype(DD)::value;
-            return ((mk(l, K) >> D) & 1) != 0;
+            if constexpr (D == 6) {
+                if constexpr (SINK) return w.S.snk[K * 64 + l] > 0.0;
+                else return false;
+            } else {
+                return r[D](l, K) > 0.0;
+            }
         });
     } else {
         w.lanes([&](int l) MGCW_INL {
@@ -396,10 +370,18 @@ MGC_HD void mgcw_discharge_impl(W& w, const MgcLattice& L, int tile, uint32_t ph
      * MI355X (512^3, ms of discharge kernels per step): a vote before the push AND around saturation / outflow / hand-off
      * 24.0; no vote at all inside a sweep (every active slot always pushes and shifts in all directions, twice the VALU
      * work, fewer stalls) 28.7 -- but 20 % faster on small volumes, where a launch is one tile deep. */
+    typename W::template Reg<double, 8> obx, oby; /* flow pushed out across the x / y faces (meaningful on the face lanes) */
+    typename W::template Reg<double, 2> obz;      /* ... across the -z / +z faces */
     typename W::template Reg<int, 16> hn;         /* in-plane neighbour labels of the four slots being swept */
     typename W::template Reg<int, 2> hz;          /* halo labels below slot 0 / above slot 7 (frozen) */
-    typename W::template Reg<int, 1> sat;         /* bit K: this lane's voxel of slot K saturated an arc (or its sink link); negative: a label of the lane rose */
+    typename W::template Reg<int, 1> sat;         /* bit K: this lane's voxel of slot K saturated an arc (or its sink link); bit 8: a label of the lane rose */
     w.lanes([&](int l) MGCW_INL {
+        mgcw_static_for<8>([&](auto KK) MGCW_INL {
+            constexpr int K = decltype(KK)::value;
+            obx(l, K) = 0.0;
+            oby(l, K) = 0.0;
+        });
+        obz(l, 0) = obz(l, 1) = 0.0;
         sat(l, 0) = 0;
         hz(l, 0) = w.S.hs[mgcw_hs(l, 0) - 100];
         hz(l, 1) = w.S.hs[mgcw_hs(l, 7) + 100];
@@ -410,8 +392,8 @@ MGC_HD void mgcw_discharge_impl(W& w, const MgcLattice& L, int tile, uint32_t ph
         constexpr int K = decltype(KK)::value;
         constexpr int D = decltype(DD)::value;
         const double rd = r[D](l, K);
-        const bool can = e(l, K) > 0.0 && rd > 0.0 && hnb - h(l, K) == -1; /* (not hnb == h - 1: the compiler keeps h - 1 of all eight slots in registers) */
-        const double m = w.fmin_pos(e(l, K), rd); /* (neither is ever a NaN: a bare v_min_f64 on the GPU, no canonicalisation around it; taken in front of the select -- inside its arm the compiler branches around it) */
+        const bool can = e(l, K) > 0.0 && rd > 0.0 && hnb == h(l, K) - 1;
+        const double m = w.fmin_pos(e(l, K), rd);
         const double delta = can ? m : 0.0;
         e(l, K) -= delta;
         r[D](l, K) = rd - delta; /* saturating push: rd - rd == 0.0 exactly */
@@ -430,11 +412,10 @@ MGC_HD void mgcw_discharge_impl(W& w, const MgcLattice& L, int tile, uint32_t ph
     auto can_push = [&](int l, auto KK, auto DD, int hnb) MGCW_INL -> bool {
         constexpr int K = decltype(KK)::value;
         constexpr int D = decltype(DD)::value;
-        return e(l, K) > 0.0 && r[D](l, K) > 0.0 && hnb - h(l, K) == -1;
+        return e(l, K) > 0.0 && r[D](l, K) > 0.0 && hnb == h(l, K) - 1;
     };
 
     w.mark(0); /* load + absorb + label set-up */
-    w.fresh();
     /* the ticket is looked at after the first sweep, the list entry it names after the second (or right after the loop): by
      * then both have long arrived, however many waves queued up on the ticket word */
     int hint_stage = 0;
@@ -492,8 +473,10 @@ MGC_HD void mgcw_discharge_impl(W& w, const MgcLattice& L, int tile, uint32_t ph
                     const int y = l >> 3, x = l & 7;
                     const double delta = push(l, KK, DD, hn(l, 4 * J + D));
                     const bool inside = D == 0 ? x > 0 : (D == 1 ? x < 7 : (D == 2 ? y > 0 : y < 7));
-                    dl(l, 0) = inside ? delta : 0.0;
-                    if (!inside) w.S.inbox[D][K * 8 + (D < 2 ? y : x)] += delta; /* what leaves the tile across face D (the face lanes: one cell each) */
+                    const double stay = inside ? delta : 0.0;
+                    dl(l, 0) = stay;
+                    if constexpr (D < 2) obx(l, K) += delta - stay; /* what leaves the tile across face D: delta or 0.0, exactly */
+                    else oby(l, K) += delta - stay;
                 });
                 /* -x: from the lane at x + 1, ...; dl is 0.0 on the lanes whose push left the tile, which are exactly the lanes
                  * at the end of an x-row: the x shifts never carry anything from one row of eight into the next */
@@ -522,7 +505,7 @@ MGC_HD void mgcw_discharge_impl(W& w, const MgcLattice& L, int tile, uint32_t ph
             w.lanes([&](int l) MGCW_INL {
                 const double delta = push(l, KC, DC, below(l));
                 if constexpr (K > 0) { e(l, K - 1) += delta; r[5](l, K - 1) += delta; }
-                else w.S.inbox[4][l] += delta;
+                else obz(l, 0) += delta;
             });
         });
         mgcw_static_for<8>([&](auto KK) MGCW_INL {
@@ -538,7 +521,7 @@ MGC_HD void mgcw_discharge_impl(W& w, const MgcLattice& L, int tile, uint32_t ph
             w.lanes([&](int l) MGCW_INL {
                 const double delta = push(l, KK, DC, above(l));
                 if constexpr (K < 7) { e(l, K + 1) += delta; r[4](l, K + 1) += delta; }
-                else w.S.inbox[5][l] += delta;
+                else obz(l, 1) += delta;
             });
         });
         /* ---- local relabel (classic push-relabel step): a voxel that still holds excess rises to 1 + the lowest label
@@ -571,7 +554,7 @@ MGC_HD void mgcw_discharge_impl(W& w, const MgcLattice& L, int tile, uint32_t ph
                     c = cd < c ? cd : c;
                 });
                 const bool rises = e(l, K) > 0.0 && h(l, K) < c;
-                sat(l, 0) |= rises ? -1 : 0; /* (every bit: a label that rose makes the tile DIRTY whatever else happened; -1 and 1 << K, K < 7, are inline constants) */
+                sat(l, 0) |= rises ? 256 : 0;
                 h(l, K) = rises ? c : h(l, K);
                 w.S.hs[mgcw_hs(l, K)] = h(l, K);
             });
@@ -592,9 +575,23 @@ MGC_HD void mgcw_discharge_impl(W& w, const MgcLattice& L, int tile, uint32_t ph
      * (which need the positions) go out last.  (Round 2 issued the claims after the stores: every visit ended by waiting
      * for its whole write-back to retire, twice.) ---- */
     uint32_t face = 0; /* bit f: flow left the tile across face f */
-#pragma unroll
-    for (int f = 0; f < 6; ++f)
-        if (w.any([&](int l) MGCW_INL -> bool { return w.S.inbox[f][l] != 0.0; })) face |= 1u << f;
+    {
+        typename W::template Reg<int, 1> nz; /* bit 0 / 1 / 2: this lane pushed something across an x / y / z face */
+        w.lanes([&](int l) MGCW_INL {
+            int m = 0;
+            mgcw_static_for<8>([&](auto KK) MGCW_INL {
+                constexpr int K = decltype(KK)::value;
+                m |= (obx(l, K) != 0.0 ? 1 : 0) | (oby(l, K) != 0.0 ? 2 : 0);
+            });
+            nz(l, 0) = m | (obz(l, 0) != 0.0 ? 4 : 0) | (obz(l, 1) != 0.0 ? 8 : 0);
+        });
+        if (w.any([&](int l) MGCW_INL -> bool { return (nz(l, 0) & 1) && (l & 7) == 0; })) face |= 1u;
+        if (w.any([&](int l) MGCW_INL -> bool { return (nz(l, 0) & 1) && (l & 7) == 7; })) face |= 2u;
+        if (w.any([&](int l) MGCW_INL -> bool { return (nz(l, 0) & 2) && (l >> 3) == 0; })) face |= 4u;
+        if (w.any([&](int l) MGCW_INL -> bool { return (nz(l, 0) & 2) && (l >> 3) == 7; })) face |= 8u;
+        if (w.any([&](int l) MGCW_INL -> bool { return (nz(l, 0) & 4) != 0; })) face |= 16u;
+        if (w.any([&](int l) MGCW_INL -> bool { return (nz(l, 0) & 8) != 0; })) face |= 32u;
+    }
     /* lane l < 6 wakes the neighbour across face l, lane 6 this tile itself (budget exhausted with work left) */
     typename W::template Reg<int, 4> wk; /* tile to wake (-1: none), its list, claimed?, position */
     int32_t* const list_nbr = L.list[(phase + 1) & 3u];
@@ -627,8 +624,8 @@ MGC_HD void mgcw_discharge_impl(W& w, const MgcLattice& L, int tile, uint32_t ph
     /* DIRTY (the tile's labels may no longer be exact distances: the next global relabel recomputes it and whoever depends on it)
      * iff a label rose or was recomputed, or a voxel that saturated an arc has no residual arc one label down left.  A voxel that
      * keeps one of its supports keeps its distance, and the tiles a small flow merely passes through stay clean. */
-    bool saturated = (BFS || (flags & MGCW_SAT_DIRTY)) ? w.any([&](int l) MGCW_INL -> bool { return sat(l, 0) != 0; })
-                                        : w.any([&](int l) MGCW_INL -> bool { return sat(l, 0) < 0; });
+    bool saturated = (flags & (MGCW_BFS | MGCW_SAT_DIRTY)) ? w.any([&](int l) MGCW_INL -> bool { return sat(l, 0) != 0; })
+                                        : w.any([&](int l) MGCW_INL -> bool { return (sat(l, 0) & 256) != 0; });
     if (!saturated && w.any([&](int l) MGCW_INL -> bool { return sat(l, 0) != 0; })) {
         mgcw_static_for<8>([&](auto KK) MGCW_INL {
             constexpr int K = decltype(KK)::value;
@@ -649,6 +646,18 @@ MGC_HD void mgcw_discharge_impl(W& w, const MgcLattice& L, int tile, uint32_t ph
             });
         });
     }
+    w.lanes([&](int l) MGCW_INL { /* outbox staged through LDS (face order: the neighbours read 64 consecutive doubles per face) */
+        const int y = l >> 3, x = l & 7;
+        mgcw_static_for<8>([&](auto KK) MGCW_INL {
+            constexpr int K = decltype(KK)::value;
+            if (x == 0) w.S.inbox[0][K * 8 + y] = obx(l, K);
+            if (x == 7) w.S.inbox[1][K * 8 + y] = obx(l, K);
+            if (y == 0) w.S.inbox[2][K * 8 + x] = oby(l, K);
+            if (y == 7) w.S.inbox[3][K * 8 + x] = oby(l, K);
+        });
+        w.S.inbox[4][l] = obz(l, 0);
+        w.S.inbox[5][l] = obz(l, 1);
+    });
     w.mark(6); /* face votes, claims issued, tail votes, outbox staged */
     w.lanes([&](int l) MGCW_INL { /* positions in the lists (region of this workgroup, MgcLattice::scount) */
         const uint32_t ep = l == 6 ? phase + 2 : phase + 1;
@@ -710,28 +719,11 @@ MGC_HD void mgcw_discharge_impl(W& w, const MgcLattice& L, int tile, uint32_t ph
     w.mark(3); /* tail votes + stores */
 }
 
-/* the instance a visit needs: SINK = the tile holds a sink link, BFS = exact in-tile labels first (MGCW_BFS, or MGCW_BFS_SINK on a tile that holds one) */
-template <int REP = 1, class W>
-MGC_HD void mgcw_discharge_pick(W& w, const MgcLattice& L, int tile, bool sink, uint32_t phase, int max_sweeps, int flags)
-{
-    const bool bfs = (flags & MGCW_BFS) != 0 || (sink && (flags & MGCW_BFS_SINK) != 0);
-#if defined(MGCW_DEV_ONLY) /* development aid: the resource figures of ONE instance (hipcc -S of the kernel alone): bit 0 SINK, bit 1 BFS */
-    mgcw_discharge_impl<(MGCW_DEV_ONLY & 1) != 0, REP, (MGCW_DEV_ONLY & 2) != 0>(w, L, tile, phase, max_sweeps, flags);
-    return;
-#endif
-    if (sink) {
-        if (bfs) mgcw_discharge_impl<true, REP, true>(w, L, tile, phase, max_sweeps, flags);
-        else mgcw_discharge_impl<true, REP, false>(w, L, tile, phase, max_sweeps, flags);
-    } else {
-        if (bfs) mgcw_discharge_impl<false, REP, true>(w, L, tile, phase, max_sweeps, flags);
-        else mgcw_discharge_impl<false, REP, false>(w, L, tile, phase, max_sweeps, flags);
-    }
-}
-
 template <int REP = 1, class W>
 MGC_HD void mgcw_discharge_tile(W& w, const MgcLattice& L, int tile, uint32_t phase, int max_sweeps, int flags)
 {
-    mgcw_discharge_pick<REP>(w, L, tile, (L.status[tile] & MGC_ST_SINK) != 0, phase, max_sweeps, flags);
+    if (L.status[tile] & MGC_ST_SINK) mgcw_discharge_impl<true, REP>(w, L, tile, phase, max_sweeps, flags | ((flags & MGCW_BFS_SINK) ? MGCW_BFS : 0));
+    else mgcw_discharge_impl<false, REP>(w, L, tile, phase, max_sweeps, flags);
 }
 
 /* ---------------------------------------------------------------------------------------

@@ -1,12 +1,16 @@
 # one GPU call of round 6 (development aid; edited per call)
 cd $GRAFT_REPO_ROOT; mkdir -p gpurun_out
-O=gpurun_out/r6_resident_waves_curve.jsonl; : > $O
-timeout 300 python tools/gpu_ab.py --n 512 --tag w2 --reps 3 wave_grid_dis=256 wave_grid_dis=512 wave_grid_dis=768 wave_grid_dis=1024 wave_grid_dis=1536 wave_grid_dis=2048 >> $O 2>&1
-timeout 300 python tools/gpu_ab.py --lib build/lib_w3.so --n 512 --tag w3 --reps 3 wave_grid_dis=2048 wave_grid_dis=2560 wave_grid_dis=3072 >> $O 2>&1
+O=gpurun_out/r6_ab_single_vmin.jsonl; : > $O
+for R in 1 2; do for L in build/lib_head.so ""; do
+  T=${L:-tree_vmin}
+  timeout 300 python tools/gpu_ab.py ${L:+--lib $L} --n 512 --tag "$T" --reps 7 base >> $O 2>&1
+  timeout 300 python tools/gpu_ab.py ${L:+--lib $L} --n 256 --tag "$T" --reps 9 base >> $O 2>&1
+  timeout 300 python tools/gpu_ab.py ${L:+--lib $L} --n 512 --wl hard --tag "$T" --reps 3 base >> $O 2>&1
+done; done
 python - <<'PY'
 import json
-for l in open("gpurun_out/r6_resident_waves_curve.jsonl"):
+for l in open("gpurun_out/r6_ab_single_vmin.jsonl"):
     if not l.startswith("{"): print(l[:200]); continue
     d = json.loads(l)
-    print(d["tag"], d["variant"], d["ms"], "dis", d["discharge_ms"], "tiles", d["dis_tiles"], "visits/us", round(d["dis_tiles"]/d["discharge_ms"]/1e3,1))
+    print(d["tag"], d["variant"], d["wl"], d["n"], d["ms"], "dis", d["discharge_ms"], "rel", d["relabel_ms"], "tiles", d["dis_tiles"], "phases", d["phases"], "relabels", d["relabels"], d["same_labels"])
 PY

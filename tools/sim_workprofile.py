@@ -57,6 +57,7 @@ def main():
     print("stats", st)
     print("wave steps: lanes %d any %d shift %d (per discharge %.0f / %.0f / %.0f)" % (
         prof[20], prof[21], prof[22], prof[20] / max(1, prof[3]), prof[21] / max(1, prof[3]), prof[22] / max(1, prof[3])))
+    print("wave forms through w.ld / w.st: %.1f KB read, %.1f KB written per discharge" % (prof[50] / 1024.0 / max(1, prof[3]), prof[51] / 1024.0 / max(1, prof[3])))
     print("discharges %d  label sections %d  sweeps %d (%.2f/discharge)  waves active %.3f" % (
         prof[3], prof[1], prof[2], prof[2] / max(1, prof[3]), prof[16] / max(1, prof[17])))
     for name, m in (("inside", inside), ("shell", shell), ("outside", outside)):
