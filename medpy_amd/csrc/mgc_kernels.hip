@@ -1197,6 +1197,21 @@ __device__ __forceinline__ double mgc_block_sum(double v, double* scratch)
     return scratch[0];
 }
 
+/* A kernel's own arguments, read AGAIN where they are used.  The twenty-odd pointers of k_build's two argument structs are loop invariants: the
+ * optimiser loads them once in front of the tile loop and keeps them -- more scalar registers than the wave has, so they went to and fro between
+ * SGPRs and lanes of a VGPR around every use (65 - 70 spilled registers, ~150 v_readlane / v_writelane per tile).  A pointer to the kernarg segment
+ * that went through an empty asm statement is opaque: what is loaded through it is loaded HERE (s_load from the scalar cache, a few per tile) and
+ * lives only as long as it is used.  OFF = byte offset of the argument in the segment. */
+#define MGC_KARG __attribute__((address_space(4)))
+template <class T>
+__device__ __forceinline__ const MGC_KARG T* mgc_kernarg_again(int off)
+{
+    const MGC_KARG char* p = (const MGC_KARG char*)__builtin_amdgcn_kernarg_segment_ptr();
+    asm volatile("" : "+s"(p));
+    return (const MGC_KARG T*)(p + off);
+}
+#define MGC_BUILD_ARGS_OFFSET ((int)((sizeof(MgcLattice) + 7) & ~(size_t)7)) /* k_build(MgcLattice, MgcBuildArgs) */
+
 /* TERM: the boundary term as a compile-time constant (the kernel dispatches once), so g(.) is straight-line code */
 /* TABLE false: an instance without the term-by-table of integer-valued images (mgc_set_boundary_lut).  Not a micro-saving: a table load's wait sits
  * where the table path and the arithmetic path of g(.) merge, so every tile runs into it, table or not -- and on this hardware it is a wait for
@@ -1224,7 +1239,7 @@ __device__ __forceinline__ void k_build_tiles(const MgcLattice& L, const MgcBuil
         int nz, ny, nxx;
         mgc_tile_coords(L, tile_n, nz, ny, nxx);
         const int64_t bz = (int64_t)nz * 8, by = (int64_t)ny * 8, bx = (int64_t)nxx * 8;
-        const float* const im = (const float*)A.image;
+        const float* const im = (const float*)mgc_kernarg_again<MgcBuildArgs>(MGC_BUILD_ARGS_OFFSET)->image;
         raw_a = raw_b = 0.f;
         {
             const int k = tl;
@@ -1268,8 +1283,9 @@ __device__ __forceinline__ void k_build_tiles(const MgcLattice& L, const MgcBuil
             const int64_t pz = z0 + plz, py = y0 + ply, px = x0 + plx;
             if (pz < L.dz && py < L.dy && px < L.dx) {
                 const int64_t pid = (pz * L.dy + py) * L.dx + px;
-                if (A.fg) pre_fg = A.fg[pid];
-                if (A.bg) pre_bg = A.bg[pid];
+                const MGC_KARG MgcBuildArgs* const Am = mgc_kernarg_again<MgcBuildArgs>(MGC_BUILD_ARGS_OFFSET);
+                if (Am->fg) pre_fg = Am->fg[pid];
+                if (Am->bg) pre_bg = Am->bg[pid];
             }
         }
         if (TERM != MGC_TERM_NONE && !ahead) {
@@ -1310,18 +1326,19 @@ __device__ __forceinline__ void k_build_tiles(const MgcLattice& L, const MgcBuil
             /* the bytes are looked at HERE and not where they were loaded: left alone the compiler turns "byte != 0" into a lane mask right
              * behind the load, and the wait that goes with it -- at the top of the tile -- is a wait for the stores of the tile before */
             asm volatile("" : "+v"(pre_fg), "+v"(pre_bg));
+            const MGC_KARG MgcBuildArgs* const At = mgc_kernarg_again<MgcBuildArgs>(MGC_BUILD_ARGS_OFFSET);
             if (valid) {
-                if (A.tr_in) tr = A.tr_in[id];
-                if (A.prob) {
+                if (At->tr_in) tr = At->tr_in[id];
+                if (At->prob) {
                     double cs, ck;
-                    if (A.prob_dtype == MGC_F32) {
-                        const float p = ((const float*)A.prob)[id], al = (float)A.alpha;
+                    if (At->prob_dtype == MGC_F32) {
+                        const float p = ((const float*)At->prob)[id], al = (float)At->alpha;
                         cs = (double)(p * al);
                         ck = (double)((1.0f - p) * al);
                     } else {
-                        const double p = ((const double*)A.prob)[id];
-                        cs = p * A.alpha;
-                        ck = (1.0 - p) * A.alpha;
+                        const double p = ((const double*)At->prob)[id];
+                        cs = p * At->alpha;
+                        ck = (1.0 - p) * At->alpha;
                     }
                     mgc_add_tweights(tr, fc, cs, ck);
                 }
@@ -1445,6 +1462,7 @@ __device__ __forceinline__ void k_build_tiles(const MgcLattice& L, const MgcBuil
                 }
             } else {
             tlinks(); /* (in front of the stores: see above) */
+            const MGC_KARG MgcLattice* const Lw = mgc_kernarg_again<MgcLattice>(0);
 #pragma unroll
             for (int d = 0; d < 6; ++d) {
                 double w = 0.0;
@@ -1456,8 +1474,8 @@ __device__ __forceinline__ void k_build_tiles(const MgcLattice& L, const MgcBuil
                 /* (16-byte stores -- two x-neighbours per lane, fetched from wf -- were measured on MI355X: 4.9 ms instead of
                  * 4.4 ms for this kernel at 512^3; the kernel is bound by instruction issue, not by the store width) */
                 const int64_t o = ((int64_t)tile * 6 + d) * MGC_TV + t;
-                __builtin_nontemporal_store(w, &L.rcap[o]); /* 6.4 GB at 512^3 that nothing reads before the caches have turned over many times (2.78 -> 2.70 ms) */
-                if (L.cap0) L.cap0[o] = w;
+                __builtin_nontemporal_store(w, &Lw->rcap[o]); /* 6.4 GB at 512^3 that nothing reads before the caches have turned over many times (2.78 -> 2.70 ms) */
+                if (Lw->cap0) Lw->cap0[o] = w;
                 if (w > 0.0) m |= 1u << d; /* NaN (0/0 of the linear terms on a constant image) is not residual */
             }
             }
@@ -1556,37 +1574,39 @@ __device__ __forceinline__ void k_build_tiles(const MgcLattice& L, const MgcBuil
         const int64_t v = (int64_t)tile * MGC_TV + t;
         const int any_sink = tbits & 2, any_exc = tbits & 1;
         if constexpr (!FULL && !PRE6) { exc_out = tr > 0.0 ? tr : 0.0; snk_out = tr < 0.0 ? -tr : 0.0; }
-        __builtin_nontemporal_store(exc_out, &L.excess[v]);
+        const MGC_KARG MgcLattice* const Ls = mgc_kernarg_again<MgcLattice>(0);
+        const MGC_KARG MgcBuildArgs* const As = mgc_kernarg_again<MgcBuildArgs>(MGC_BUILD_ARGS_OFFSET);
+        __builtin_nontemporal_store(exc_out, &Ls->excess[v]);
         if constexpr (!FULL) {
             /* 6-neighbourhood: the merged t-links and the residual sink links of a tile are only READ where the tile holds a t-link
              * of the sign in question (A.tflags, status bit MGC_ST_SINK: k_discharge_w, k_cut_value6, k_validate ...), so they are only
              * written there: 16 of the 79 bytes per voxel this kernel writes, for 98 % of the tiles of a marker-seeded volume */
-            if (tbits & 3) A.tr0[v] = tr;
-            if (any_sink) L.sink[v] = snk_out; /* (what a pre-push left of it) */
+            if (tbits & 3) As->tr0[v] = tr;
+            if (any_sink) Ls->sink[v] = snk_out; /* (what a pre-push left of it) */
         } else {
-            A.tr0[v] = tr;       /* (as built: the cut value and the invariant check start from the merged t-link) */
-            L.sink[v] = snk_out; /* (what the pre-push left of it) */
+            As->tr0[v] = tr;       /* (as built: the cut value and the invariant check start from the merged t-link) */
+            Ls->sink[v] = snk_out; /* (what the pre-push left of it) */
         }
         if constexpr (!FULL) {
             /* is every n-link of the volume residual?  (then the first global relabel is a distance transform, mgc_dt_ops.inl) */
             const uint32_t need = (gx > 0 ? 1u : 0u) | (gx + 1 < L.dx ? 2u : 0u) | (gy > 0 ? 4u : 0u) | (gy + 1 < L.dy ? 8u : 0u) |
                                   (gz > 0 ? 16u : 0u) | (gz + 1 < L.dz ? 32u : 0u);
-            if (__ballot(valid && (m & need) != need) != 0ull && (t & 63) == 0) atomicAdd(&L.count[MGC_CNT_NOT_FULL], 1);
+            if (__ballot(valid && (m & need) != need) != 0ull && (t & 63) == 0) atomicAdd(&Ls->count[MGC_CNT_NOT_FULL], 1);
             if (snk_out > 0.0) m |= MGC_MASK_SINK;
-            L.rmask[v] = (uint8_t)m;
+            Ls->rmask[v] = (uint8_t)m;
         } else {
             if (snk_out > 0.0) m |= MGC26_MASK_SINK;
-            L.rmask32[v] = m;
+            Ls->rmask32[v] = m;
         }
         /* (labels are not initialised here: every solve starts by filling them, mgc_driver.inl) */
         if (!FULL && t < 6 * MGC_TF / 2) /* 192 lanes x 16 bytes clear the 6x64 outbox */
-            *(double2*)(L.obox + (int64_t)tile * 6 * MGC_TF + t * 2) = make_double2(0.0, 0.0);
+            *(double2*)(Ls->obox + (int64_t)tile * 6 * MGC_TF + t * 2) = make_double2(0.0, 0.0);
         if (t == 0) {
-            L.oflags[tile] = 0;
-            L.stamp[tile] = 0;
-            L.rstamp[tile] = 0;
-            L.status[tile] = (any_sink ? MGC_ST_SINK : 0u) | (any_exc ? MGC_ST_EXCESS : 0u) | ((!FULL && (tbits & 1)) ? MGC_ST_SOURCE : 0u);
-            A.tflags[tile] = (uint8_t)((any_exc ? 1 : 0) | (any_sink ? 2 : 0));
+            Ls->oflags[tile] = 0;
+            Ls->stamp[tile] = 0;
+            Ls->rstamp[tile] = 0;
+            Ls->status[tile] = (any_sink ? MGC_ST_SINK : 0u) | (any_exc ? MGC_ST_EXCESS : 0u) | ((!FULL && (tbits & 1)) ? MGC_ST_SOURCE : 0u);
+            As->tflags[tile] = (uint8_t)((any_exc ? 1 : 0) | (any_sink ? 2 : 0));
             sink_tiles += any_sink ? 1 : 0;
             wall_tiles += weak_voxels >= MGC_WALL_VOXELS ? 1 : 0;
         }
@@ -1594,10 +1614,10 @@ __device__ __forceinline__ void k_build_tiles(const MgcLattice& L, const MgcBuil
          * marker on one voxel): most tiles skip the ten barriers of the tree sum */
         if (tbits & 4) { /* uniform */
             const double s = mgc_block_sum(fc, scratch);
-            if (t == 0) A.fpart[tile] = mgc_owned(L, tile) ? s : 0.0;
+            if (t == 0) As->fpart[tile] = mgc_owned(L, tile) ? s : 0.0;
             __syncthreads();
         } else if (t == 0) {
-            A.fpart[tile] = 0.0;
+            As->fpart[tile] = 0.0;
         }
         if constexpr (FULL) __syncthreads(); /* the weights above read the image tile in LDS, the next tile's load overwrites it (the
                                                 6-neighbourhood path has its vote barrier behind the weights) */

@@ -1,3 +1,3 @@
 # one GPU call of round 6 (development aid; edited per call)
 cd $GRAFT_REPO_ROOT; mkdir -p gpurun_out
-bash tools/gpu_evidence.sh r6 tests bench profile timeline config3 workloads slabs 2>&1 | tail -60
+bash tools/gpu_evidence.sh r6 tests profile config3 bench timeline workloads 2>&1 | tail -40
