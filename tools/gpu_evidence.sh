@@ -73,7 +73,7 @@ PY
     MEDPY_HIP_LIB=$ROOT/build/lib_prof.so timeout 200 python tools/gpu_sections26.py 512 0 2>&1 | grep -v Warn | tail -6 > $G/${TAG}_discharge26_sections_noreg.txt
     cat $G/${TAG}_discharge_sections.txt ;;
   slabs)
-    for N in 1 2 4 8; do timeout 1500 python tools/gpu_slab_scaling.py 256 1024 6 $N; done > $G/${TAG}_slab_scaling_one_gpu.jsonl 2>&1
+    timeout 3000 python tools/gpu_slab_scaling.py 256 1024 6 1 2 4 8 > $G/${TAG}_slab_scaling_one_gpu.jsonl 2>&1
     cut -c1-400 $G/${TAG}_slab_scaling_one_gpu.jsonl ;;
   ab:*)
     N=$(ls $G/${TAG}_ab_*.jsonl 2>/dev/null | wc -l)
