@@ -76,6 +76,15 @@
 #define MGC_CNT_WAVE_TILES 29  /* running total of the tiles k_discharge_w visited (count[8] pools both discharge kernels) */
 #define MGC_CNT_NOT_FULL 28    /* k_build: tiles holding an n-link inside the volume that is not residual (0: the first global relabel is a distance transform) */
 
+/* *p = v as a STREAMING store on the GPU: the write-back of a tile's own state by a discharge (excess, residual planes, masks) is not read again before the
+ * caches have turned over many times; written through them it only pushes out what the visits in flight are about to read (measured in round 6:
+ * profiles/r6_ab_nontemporal.jsonl).  Labels and outboxes, which neighbours read in the very next phase, stay ordinary stores. */
+#if defined(__HIP_DEVICE_COMPILE__)
+#define MGC_STORE_STREAM(p, v) __builtin_nontemporal_store((v), (p))
+#else
+#define MGC_STORE_STREAM(p, v) (*(p) = (v))
+#endif
+
 struct MgcLattice {
     /* logical volume */
     int64_t dz, dy, dx;       /* D0, D1, D2                                         */

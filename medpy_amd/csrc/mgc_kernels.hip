@@ -416,6 +416,12 @@ struct GpuWaveT {
     __device__ __forceinline__ T ld(const T* p, int l) { return *(const T*)((const char*)p + (unsigned)(l * (int)sizeof(T))); }
     template <class T>
     __device__ __forceinline__ void st(T* p, int l, T v) { *(T*)((char*)p + (unsigned)(l * (int)sizeof(T))) = v; }
+    /* the same as a STREAMING store: what a visit writes back of a tile's own state (excess, residual planes, masks) is not read again before the caches
+     * have turned over many times -- the next visit of the tile is two colour phases away at the earliest -- and written through them it only pushes
+     * out what the visits in flight are about to read (512^3 headline 18.5 -> 18.1 ms, weak contrast 60.2 -> 59.3; labels and outboxes, which the
+     * neighbours read in the very next phase, stay ordinary stores; streaming LOADS of the state on top: no gain) */
+    template <class T>
+    __device__ __forceinline__ void st_stream(T* p, int l, T v) { __builtin_nontemporal_store(v, (T*)((char*)p + (unsigned)(l * (int)sizeof(T)))); }
 };
 typedef GpuWaveT<MgcWaveShared> GpuWave;
 struct alignas(16) MgcWaveSharedR { int32_t hs[1000]; }; /* what a relabel visit touches of MgcWaveShared: 4 KB, 32 waves per CU */

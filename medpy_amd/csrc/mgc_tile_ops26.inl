@@ -514,15 +514,15 @@ MGC_HD void mgc26_discharge_tile(X& x, const MgcLattice& L, int tile, uint32_t p
     });
     const uint32_t PM = x.uniform(x.S.pushmask);
     x.par([&](int t) {
-        L.excess[base + t] = e[t];
-        L.sink[base + t] = snk[t];
+        MGC_STORE_STREAM(&L.excess[base + t], e[t]);
+        MGC_STORE_STREAM(&L.sink[base + t], snk[t]);
         uint32_t m = snk[t] > 0.0 ? MGC26_MASK_SINK : 0u;
 #pragma unroll
         for (int d = 0; d < MGC26_NDIR; ++d) {
-            if (((PM >> d) | (PM >> (25 - d))) & 1u) L.rcap[((int64_t)tile * MGC26_NDIR + d) * MGC_TV + t] = R(d, t);
+            if (((PM >> d) | (PM >> (25 - d))) & 1u) MGC_STORE_STREAM(&L.rcap[((int64_t)tile * MGC26_NDIR + d) * MGC_TV + t], R(d, t));
             m |= (R(d, t) > 0.0) ? (1u << d) : 0u;
         }
-        L.rmask32[base + t] = m;
+        MGC_STORE_STREAM(&L.rmask32[base + t], m);
         L.height[base + t] = x.S.hs[mgc_hs_index(t >> 6, (t >> 3) & 7, t & 7)];
     });
     x.mark(L, 3); /* store */

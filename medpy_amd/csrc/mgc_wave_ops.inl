@@ -35,6 +35,7 @@
  *   w.shift(dst, src, k)  dst(l,0) = src(l + k, 0) inside the wave, 0.0 beyond its ends
  *   w.S                   MgcWaveShared& (LDS)
  *   w.atomic_*            device-scope atomics on global words
+ *   w.st_stream(p, l, v)  w.st as a streaming (non-temporal) store on the GPU: the write-back of a tile's own state
  *   w.ld(p, l) / w.st(p, l, v)   p[l] for a wave-uniform pointer p: SGPR base + 32-bit lane offset on the GPU, so the
  *                         64 + 70 state accesses of a discharge need ONE address register instead of a 64-bit pair each
  *   w.fresh()             the lane id becomes opaque to the optimiser again (GPU): addresses derived from it before this
@@ -669,18 +670,18 @@ MGC_HD void mgcw_discharge_impl(W& w, const MgcLattice& L, int tile, uint32_t ph
     w.lanes([&](int l) MGCW_INL {
         mgcw_static_for<8>([&](auto KK) MGCW_INL {
             constexpr int K = decltype(KK)::value;
-            w.st(t_excess, K * 64 + l, e(l, K));
+            w.st_stream(t_excess, K * 64 + l, e(l, K));
             int m = 0;
             if constexpr (SINK) {
                 const double sk = w.S.snk[K * 64 + l];
-                w.st(t_sink, K * 64 + l, sk);
+                w.st_stream(t_sink, K * 64 + l, sk);
                 m = sk > 0.0 ? MGC_MASK_SINK : 0;
             }
             mgcw_static_for<6>([&](auto DD) MGCW_INL {
                 constexpr int D = decltype(DD)::value;
                 m |= (r[D](l, K) > 0.0) ? (1 << D) : 0;
             });
-            w.st(t_rmask, K * 64 + l, (uint8_t)m);
+            w.st_stream(t_rmask, K * 64 + l, (uint8_t)m);
         });
     });
     mgcw_static_for<6>([&](auto DD) MGCW_INL { /* only the residual planes that changed */
@@ -689,7 +690,7 @@ MGC_HD void mgcw_discharge_impl(W& w, const MgcLattice& L, int tile, uint32_t ph
         w.lanes([&](int l) MGCW_INL {
             mgcw_static_for<8>([&](auto KK) MGCW_INL {
                 constexpr int K = decltype(KK)::value;
-                w.st(t_rcap + D * MGC_TV, K * 64 + l, r[D](l, K));
+                w.st_stream(t_rcap + D * MGC_TV, K * 64 + l, r[D](l, K));
             });
         });
     });

@@ -536,9 +536,9 @@ MGC_HD void mgcw26_discharge_tile(W& w, const MgcLattice& L, int tile, uint32_t 
     w.lanes([&](int l) MGCW_INL {
         mgcw_static_for<8>([&](auto KK) MGCW_INL {
             constexpr int K = decltype(KK)::value;
-            w.st(t_excess, K * 64 + l, e(l, K));
-            w.st(t_rmask, K * 64 + l, (uint32_t)m8(l, K));
-            if (SINK) w.st(t_sink, K * 64 + l, w.S.snk[K * 64 + l]);
+            w.st_stream(t_excess, K * 64 + l, e(l, K)); /* (streaming stores for the tile's own state, as in mgc_wave_ops.inl) */
+            w.st_stream(t_rmask, K * 64 + l, (uint32_t)m8(l, K));
+            if (SINK) w.st_stream(t_sink, K * 64 + l, w.S.snk[K * 64 + l]);
             if (relabelled) w.st(t_height, K * 64 + l, w.S.hs[mgcw_hs(l, K)]);
         });
     });
@@ -548,7 +548,7 @@ MGC_HD void mgcw26_discharge_tile(W& w, const MgcLattice& L, int tile, uint32_t 
         w.lanes([&](int l) MGCW_INL {
             mgcw_static_for<8>([&](auto KK) MGCW_INL {
                 constexpr int K = decltype(KK)::value;
-                w.st(t_rcap + D * MGC_TV, K * 64 + l, RGET(DD, KK, l));
+                w.st_stream(t_rcap + D * MGC_TV, K * 64 + l, RGET(DD, KK, l));
             });
         });
     });

@@ -189,6 +189,7 @@ struct HostWaveT {
     void mark(int id) { g_prof[id & 15]++; }
     template <class T> T ld(const T* p, int l) { g_prof[50] += (int64_t)sizeof(T); return p[l]; } /* bytes the wave forms move through w.ld / w.st: g_prof[50] read, [51] written */
     template <class T> void st(T* p, int l, T v) { g_prof[51] += (int64_t)sizeof(T); p[l] = v; }
+    template <class T> void st_stream(T* p, int l, T v) { st(p, l, v); }
     void fresh() {}
     double fmin_pos(double a, double b) { return a < b ? a : b; }
     int use_here(int v) { return v; }
