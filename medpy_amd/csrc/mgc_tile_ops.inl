@@ -398,6 +398,9 @@ MGC_HD void mgc_discharge_tile(X& x, const MgcLattice& L, int tile, uint32_t pha
             if (delta != 0.0) {
                 e[t] += delta;
                 x.S.r[d][t] += delta;
+                /* on RADIAL labels flow that comes in marks the tile DIRTY: the push that sent it was admissible under the radial labels only,
+                 * and the residual arc it opened back towards the sender may undercut the exact label kept aside for this voxel (see mgcw_discharge_impl) */
+                if (max_cycles == -2) x.S.satflag = 1;
             }
         }
         mgc_clear_inbox_flags(x, L, t);

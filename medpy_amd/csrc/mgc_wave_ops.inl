@@ -336,6 +336,7 @@ MGC_HD void mgcw_discharge_impl(W& w, const MgcLattice& L, int tile, uint32_t ph
 #pragma unroll
     for (int f = 0; f < 6; ++f)
         if (w.any([&](int l) MGCW_INL -> bool { return w.S.inbox[f][l] != 0.0; })) dirty |= 1u << f;
+    const bool inflow = dirty != 0; /* a neighbour left flow for this tile */
     bool relabelled = (flags & MGCW_BFS) != 0; /* some label of the tile changed */
 
     /* ---- labels: exact in-tile distances given the frozen halo, or the stored (valid lower-bound) labels ---- */
@@ -627,6 +628,12 @@ MGC_HD void mgcw_discharge_impl(W& w, const MgcLattice& L, int tile, uint32_t ph
      * keeps one of its supports keeps its distance, and the tiles a small flow merely passes through stay clean. */
     bool saturated = (flags & (MGCW_BFS | MGCW_SAT_DIRTY)) ? w.any([&](int l) MGCW_INL -> bool { return sat(l, 0) != 0; })
                                         : w.any([&](int l) MGCW_INL -> bool { return (sat(l, 0) & 256) != 0; });
+    /* On RADIAL labels flow that came in marks the tile DIRTY as well.  The push that sent it was admissible under the radial labels only; the
+     * residual arc it opened back towards the sender can undercut the EXACT label kept aside for the receiving voxel (exact(v) > exact(u) + 1 for
+     * the new arc v -> u), and a tile that merely passed the flow on would keep that label through the incremental relabel that ends the flood.
+     * (In the default schedule it cannot happen -- the one radial cycle starts from the distance transform's labels, all arcs residual,
+     * neighbours at most one apart -- but floods cut into several cycles, radial_rounds0 > 0, start from graphs with saturated arcs.) */
+    if ((flags & MGCW_SAT_DIRTY) && inflow) saturated = true;
     if (!saturated && w.any([&](int l) MGCW_INL -> bool { return sat(l, 0) != 0; })) {
         mgcw_static_for<8>([&](auto KK) MGCW_INL {
             constexpr int K = decltype(KK)::value;

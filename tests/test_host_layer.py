@@ -237,6 +237,33 @@ def test_hostsim_incremental_relabels_leave_exact_distances(conn, gen, shape, kw
     assert p[40] == st["outer"] and p[41] == 0
 
 
+@pytest.mark.parametrize("wave_mode,n", [(3, 112)])
+def test_hostsim_floods_in_several_radial_cycles_leave_exact_distances(wave_mode, n, monkeypatch):
+    """a flood cut into several cycles on radial labels (radial_rounds0 = 1, a relabel in between, labels lowered again) starts
+    its later cycles from graphs with saturated arcs; a push that is admissible under the radial labels only can then open a residual arc that
+    undercuts the exact label kept aside for the receiving voxel.  Tiles that take flow in on radial labels are DIRTY for that reason
+    (mgcw_discharge_impl, mgc_discharge_tile): after EVERY global relabel of such a solve the labels are the exact distances.  The volume is large
+    enough for the shortest source -> sink path to have some 45 hops."""
+    import sim
+    from medpy_amd import synthetic
+    from oracle import energy_numpy
+    shape = (n, n, n)
+    s = synthetic.sphere(shape)
+    tr = (np.where(s["fg"], 65535.0, 0.0) - np.where(s["bg"], 65535.0, 0.0)).ravel()
+    monkeypatch.setenv("HOSTSIM_RADIAL", "1")
+    monkeypatch.setenv("HOSTSIM_RADIAL_ROUNDS0", "1")
+    monkeypatch.setenv("HOSTSIM_RADIAL_BUDGET", "16")
+    sim.set_check_exact(1)
+    sim.prof()
+    try:
+        _, st = sim.solve(shape, energy_numpy.boundary_weights(s["term"], s["image"], s["sigma"]), tr, wave_mode=wave_mode)
+        p = sim.prof()
+    finally:
+        sim.set_check_exact(0)
+    assert st["converged"] == 1 and st["radial_cycles"] >= 3
+    assert p[40] == st["outer"] and p[41] == 0
+
+
 def test_dimacs_writer_text_equals_the_reference_layout():
     """reference medpy/graphcut/write.py:29-76 on the dict Graph (graph.py:31-264); expected text written out by hand from
     the reference's format strings"""
