@@ -2291,6 +2291,7 @@ struct mgc_graph {
     uint16_t* d_ds16 = nullptr; /* radial labels: 1 + L1 distance from the nearest voxel that held excess when the solve began (allocated on first use) */
     int32_t* d_hexact = nullptr; /* radial labels: the exact labels of the last global relabel, kept aside while the labels in L.height are the radial ones */
     bool radial_on = false;      /* the discharges run on radial labels (every saturation marks the tile DIRTY) */
+    int radial_cycle_no = 0;     /* radial cycles of the current solve so far: from the second on, flow taken in marks a tile DIRTY too (MGCW_INFLOW_DIRTY) */
     bool all_residual = false; /* k_build found every n-link inside the volume residual */
     int exact_sink_tiles = 1;  /* k_discharge_w: exact in-tile labels per visit for the tiles that hold a sink link (MGCW_BFS_SINK; parameter
                                   exact_sink_tiles): 0 never, 2 always, 1 when most tiles of the volume hold one (markers scattered over the
@@ -2621,7 +2622,7 @@ struct HipDevT {
         return true;
     }
     /* ---- radial labels of the flood phase (mgc_dt_ops.inl; the schedule: mgc_driver.inl) ---- */
-    void set_radial(bool on) { h->radial_on = on; }
+    void set_radial(bool on) { h->radial_on = on; if (on) h->radial_cycle_no++; } /* (radial_cycle_no: reset by whoever starts a solve) */
     bool radial_begin(int c_min)
     {
         if (FULL) return false;
@@ -2763,7 +2764,7 @@ struct HipDevT {
             const bool exact_sink = h->exact_sink_tiles == 2 || (h->exact_sink_tiles == 1 && 2 * (int64_t)h->sink_tiles > h->L.ntiles);
             /* a visit that starts from exact in-tile labels needs fewer sweeps to move what it can (tie-heavy 512^3: 796 ms at 12, 731 at 8, 788 at 6) */
             if (exact_sink && h->exact_sink_tiles == 1 && sweeps > h->sink_sweeps) sweeps = h->sink_sweeps;
-            const int dflags = ((h->wave_kernels & 4) ? MGCW_BFS : 0) | (exact_sink ? MGCW_BFS_SINK : 0) | (h->radial_on ? MGCW_SAT_DIRTY : 0);
+            const int dflags = ((h->wave_kernels & 4) ? MGCW_BFS : 0) | (exact_sink ? MGCW_BFS_SINK : 0) | (h->radial_on ? MGCW_SAT_DIRTY : 0) | ((h->radial_on && h->radial_cycle_no > 1) ? MGCW_INFLOW_DIRTY : 0);
             /* repeated in-plane steps (mgcw_discharge_impl<.., MGCW_REPEAT_MAX>): decided per SOLVE (repeat_now, mgc_maxflow / mgc_solve_slabs) */
             const bool rep = h->repeat_now && h->est_phase_tiles >= h->repeat_min_tiles;
             if (rep) hipLaunchKernelGGL(k_discharge_w<MGCW_REPEAT_MAX>, dim3(h->wave_grid_dis), dim3(MGCW_LANES), 0, h->stream, h->L, lst, phase, sweeps, dflags, h->tk_dis, zero_idx, h->wave_stagger);
@@ -2771,7 +2772,7 @@ struct HipDevT {
             h->tk_dis ^= 1;
         }
         else hipLaunchKernelGGL(k_discharge, dim3(grid(h->L.ntiles)), dim3(MGC_TV), 0, h->stream, h->L, lst, phase,
-                                (h->wave_kernels & 1) && !(h->wave_kernels & 4) ? (h->radial_on ? -2 : -1) : cycles, sweeps, zero_idx); /* same labelling policy as the wave form (-2: radial labels, any saturation marks the tile) */
+                                (h->wave_kernels & 1) && !(h->wave_kernels & 4) ? (h->radial_on ? (h->radial_cycle_no > 1 ? -3 : -2) : -1) : cycles, sweeps, zero_idx); /* same labelling policy as the wave form (-2: radial labels, any saturation marks the tile) */
         check(hipGetLastError());
         time_end(id);
         discharge_launches++;
@@ -3587,7 +3588,7 @@ static int mgc_solve_slabs_on(mgc_handle* hs, int n, const mgc_transport* cb, co
         x.allreduce(&walls, 1, 0);
         P.radial = walls >= h0->radial_min_walls ? 1 : 0;
     }
-    for (int i = 0; i < n; ++i) hs[i]->repeat_now = (h0->repeat_steps & (P.radial ? 2 : 1)) != 0;
+    for (int i = 0; i < n; ++i) { hs[i]->repeat_now = (h0->repeat_steps & (P.radial ? 2 : 1)) != 0; hs[i]->radial_cycle_no = 0; }
     MgcSolveStats st;
     const int rc = mgc_solve(group, h0->L, P, st, lay);
     hipError_t first = hipSuccess;
@@ -4097,6 +4098,7 @@ int mgc_maxflow(mgc_handle h, double* flow)
              * what leaves the source mostly reaches the sink, exact labels are the better guide (66 vs 104 ms at 512^3) */
             if (P.radial == 2) P.radial = h->wall_tiles >= h->radial_min_walls ? 1 : 0;
             h->repeat_now = (h->repeat_steps & (P.radial ? 2 : 1)) != 0;
+            h->radial_cycle_no = 0;
             if (h->prepush && h->d_prob && !h->rounds_set) P.rounds_per_relabel = 2; /* (a pre-pushed graph, see the 26-neighbourhood branch; 512^3 + regional map: 19.0 ms at 3, 17.8 at 2, 20.1 at 4; without the pre-push 21.4) */
             rc = mgc_solve(dev, L, P, st);
         } else {

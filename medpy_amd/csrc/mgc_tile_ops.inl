@@ -400,7 +400,7 @@ MGC_HD void mgc_discharge_tile(X& x, const MgcLattice& L, int tile, uint32_t pha
                 x.S.r[d][t] += delta;
                 /* on RADIAL labels flow that comes in marks the tile DIRTY: the push that sent it was admissible under the radial labels only,
                  * and the residual arc it opened back towards the sender may undercut the exact label kept aside for this voxel (see mgcw_discharge_impl) */
-                if (max_cycles == -2) x.S.satflag = 1;
+                if (max_cycles == -3) x.S.satflag = 1; /* (-3: a radial cycle that is not the first of its solve) */
             }
         }
         mgc_clear_inbox_flags(x, L, t);
@@ -412,7 +412,7 @@ MGC_HD void mgc_discharge_tile(X& x, const MgcLattice& L, int tile, uint32_t pha
     /* max_cycles < 0: no exact in-tile labelling -- the stored labels are valid lower bounds (distances only grow) and the
      * local relabel at the end of every sweep raises the voxels that are stuck (what the one-wave-per-tile form does) */
     const bool stored_labels = max_cycles < 0;
-    const bool any_saturation = max_cycles == -2; /* the stored labels are RADIAL labels (mgc_dt_ops.inl), not distances: every saturated arc marks the tile DIRTY */
+    const bool any_saturation = max_cycles <= -2; /* the stored labels are RADIAL labels (mgc_dt_ops.inl), not distances: every saturated arc marks the tile DIRTY */
     if (stored_labels) max_cycles = 1;
     for (int cyc = 0; cyc < max_cycles; ++cyc) {
         if (stored_labels) {

@@ -69,6 +69,7 @@
                                  labelling per visit saves visits (tie-heavy volume, markers everywhere, 512^3 on MI355X: 1077 -> 710 ms);
                                  elsewhere labels come from far away and the stored ones are as good (weak contrast: 69 -> 80 ms with
                                  MGCW_BFS on every tile) */
+#define MGCW_INFLOW_DIRTY 8    /* ... (with MGCW_SAT_DIRTY) a radial cycle that is NOT the first of its solve: flow that comes in marks the tile DIRTY too (see the tail) */
 #define MGCW_SAT_DIRTY 4      /* ... the visit runs on RADIAL labels (mgc_dt_ops.inl): any saturated arc marks the tile DIRTY -- whether a voxel
                                  keeps "a residual arc one label down" says nothing about its distance when the labels are not distances */
 
@@ -631,9 +632,10 @@ MGC_HD void mgcw_discharge_impl(W& w, const MgcLattice& L, int tile, uint32_t ph
     /* On RADIAL labels flow that came in marks the tile DIRTY as well.  The push that sent it was admissible under the radial labels only; the
      * residual arc it opened back towards the sender can undercut the EXACT label kept aside for the receiving voxel (exact(v) > exact(u) + 1 for
      * the new arc v -> u), and a tile that merely passed the flow on would keep that label through the incremental relabel that ends the flood.
-     * (In the default schedule it cannot happen -- the one radial cycle starts from the distance transform's labels, all arcs residual,
-     * neighbours at most one apart -- but floods cut into several cycles, radial_rounds0 > 0, start from graphs with saturated arcs.) */
-    if ((flags & MGCW_SAT_DIRTY) && inflow) saturated = true;
+     * In the FIRST radial cycle of a solve it cannot happen -- it starts from the distance transform's labels, all arcs residual, neighbours at
+     * most one apart -- and marking there would only add 40 k tiles to the relabel behind the flood of the headline volume (+0.4 ms); floods cut
+     * into several cycles (radial_rounds0 > 0) start their later ones from graphs with saturated arcs: MGCW_INFLOW_DIRTY. */
+    if ((flags & MGCW_INFLOW_DIRTY) && inflow) saturated = true;
     if (!saturated && w.any([&](int l) MGCW_INL -> bool { return sat(l, 0) != 0; })) {
         mgcw_static_for<8>([&](auto KK) MGCW_INL {
             constexpr int K = decltype(KK)::value;

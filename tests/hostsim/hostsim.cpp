@@ -439,7 +439,8 @@ struct HostDev : HostSlabOps<HostDev, HostBlockT<MgcTileShared>> {
     std::vector<uint16_t> ds16;      /* 1 + L1 distance from the nearest voxel that held excess when the solve began */
     std::vector<int32_t> hexact;     /* the exact labels of the last global relabel */
     bool radial_on = false, lowered = false;
-    void set_radial(bool on) { radial_on = on; }
+    int radial_cycle_no = 0;
+    void set_radial(bool on) { radial_on = on; if (on) radial_cycle_no++; }
     bool radial_begin(int c_min)
     {
         HostWave w(WS);
@@ -662,13 +663,13 @@ struct HostDev : HostSlabOps<HostDev, HostBlockT<MgcTileShared>> {
             if ((int)g_tile_discharges.size() == L.ntiles) g_tile_discharges[L.list[lst][i]]++;
             if (g_wave_mode & 1) {
                 const int64_t sweeps_before = g_prof[2];
-                const int dflags = ((g_wave_mode & 4) ? MGCW_BFS : 0) | ((g_wave_mode & 8) ? MGCW_BFS_SINK : 0) | (radial_on ? MGCW_SAT_DIRTY : 0);
+                const int dflags = ((g_wave_mode & 4) ? MGCW_BFS : 0) | ((g_wave_mode & 8) ? MGCW_BFS_SINK : 0) | (radial_on ? MGCW_SAT_DIRTY : 0) | ((radial_on && radial_cycle_no > 1) ? MGCW_INFLOW_DIRTY : 0);
                 if (g_repeat_steps & (radial_on ? 2 : 1)) mgcw_discharge_tile<MGCW_REPEAT_MAX>(w, L, L.list[lst][i], phase, sweeps, dflags);
                 else mgcw_discharge_tile<1>(w, L, L.list[lst][i], phase, sweeps, dflags);
                 if (g_trace) fprintf(g_trace, "%u %d %d\n", phase, L.list[lst][i], (int)(g_prof[2] - sweeps_before));
                 g_prof[3]++;
             } else {
-                mgc_discharge_tile(x, L, L.list[lst][i], phase, radial_on && cycles < 0 ? -2 : cycles, sweeps);
+                mgc_discharge_tile(x, L, L.list[lst][i], phase, radial_on && cycles < 0 ? (radial_cycle_no > 1 ? -3 : -2) : cycles, sweeps);
             }
         }
     }
@@ -916,7 +917,8 @@ struct HostDev26 : HostSlabOps<HostDev26, HostBlockT<MgcTileShared26D>> {
     std::vector<uint8_t> tsrc;
     uint16_t* dt_cur = nullptr;
     bool radial_on = false, lowered = false;
-    void set_radial(bool on) { radial_on = on; }
+    int radial_cycle_no = 0;
+    void set_radial(bool on) { radial_on = on; if (on) radial_cycle_no++; }
     void dt_scans_xy(int)
     {
         HostWave w(WSr);
