@@ -8,7 +8,7 @@ ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)
 d = json.loads(open(os.path.join(ROOT, "profiles", "r6_bench_n1.json")).read().strip().splitlines()[-1])
 a, r, api, e2e, cpu = d["also"], d["roofline"], d["api_end_to_end"], d["end_to_end"], d["cpu_baseline"]
 rows = ["| | ms per step | Mvox/s | dominant kernel, `frac` | notes |", "|---|---|---|---|---|"]
-rows.append("| headline: 512³, 6-conn, diff_exp σ = 15 | **%.2f** (17.7 – 18.1 over the boxes; round 5: 18.61 on the driver's box, round 4: 35.75) | **%d** | `k_discharge_w` %.1f µs × 58 (HIP events; rocprofv3 kernel trace of the same command: `r6_kernel_stats.csv`), **%.3f**; `traffic` %.0f MB per launch = %.2f × the algorithmic bytes | build %.2f, discharges %.2f, relabels %.2f ms; 4 global relabels, 58 colour phases, 537 k tile discharges; labels = SHA-256 of the reference's label volume (`labels_match_reference`), validation block all zero |" % (
+rows.append("| headline: 512³, 6-conn, diff_exp σ = 15 | **%.2f** (17.7 – 18.2 over the boxes; round 5: 18.61 on the driver's box, round 4: 35.75) | **%d** | `k_discharge_w` %.1f µs × 58 (HIP events; rocprofv3 kernel trace of the same command: `r6_kernel_stats.csv`), **%.3f**; `traffic` %.0f MB per launch = %.2f × the algorithmic bytes | build %.2f, discharges %.2f, relabels %.2f ms; 4 global relabels, 58 colour phases, 537 k tile discharges; labels = SHA-256 of the reference's label volume (`labels_match_reference`), validation block all zero |" % (
     d["ms_per_step"], round(d["value"]), r["avg_launch_ms"] * 1e3, r["frac"], r["traffic"] / 1e6, r["traffic"] / (r["voxels_per_launch"] * 71.0),
     d["phases_ms"]["build"], d["phases_ms"]["discharge_kernels"], d["phases_ms"]["relabel_kernels"]))
 
