@@ -32,5 +32,13 @@ rows.append("| `cpu_baseline` | %.1f s | %.2f | — | the reference's BK on the 
 p = os.path.join(ROOT, "DESIGN.md")
 s = open(p).read()
 s = re.sub(r"<!-- measurement table -->.*?<!-- /measurement table -->", "<!-- measurement table -->\n" + "\n".join(rows) + "\n<!-- /measurement table -->", s, flags=re.S)
+sl = [json.loads(l) for l in open(os.path.join(ROOT, "profiles", "r6_slab_scaling_one_gpu.jsonl")) if l.startswith("{")]
+srows = ["| slabs | Σ kernel ms per slab | relabel passes | phases | exchanges | reductions |", "|---|---|---|---|---|---|"]
+for x in sl:
+    k = x["kernel_ms_per_slab"]
+    srows.append("| %d%s | %s | %s | %d | %s | %s |" % (x["slabs"], " (`mgc_maxflow`)" if x["slabs"] == 1 else "", ("%.0f" % k[0]) if len(k) == 1 else "%.0f – %.0f" % (min(k), max(k)),
+                                                       x.get("relabel_passes", x.get("relabel_launches", "–")), x["phases"], x.get("exchanges", "–"), x.get("reductions", "–")))
+s = re.sub(r"<!-- slab table -->.*?<!-- /slab table -->", "<!-- slab table -->\n" + "\n".join(srows) + "\n<!-- /slab table -->", s, flags=re.S)
 open(p, "w").write(s)
 print("\n".join(rows)[:600])
+print("\n".join(srows))
