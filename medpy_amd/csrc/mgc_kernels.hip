@@ -1510,6 +1510,27 @@ __device__ __forceinline__ void k_build_tiles(const MgcLattice& L, const MgcBuil
                 if (L.cap0) L.cap0[((int64_t)tile * MGC26_NDIR + d) * MGC_TV + t] = w; /* (as built) */
                 return w;
             };
+            /* the same for ANOTHER voxel (vz, vy, vx) of the tile (run-time coordinates; see `produce` in the pre-push) */
+            auto weight_at = [&](auto dc, int vz, int vy, int vx) __attribute__((always_inline)) -> double {
+                constexpr int d = decltype(dc)::value;
+                constexpr int c = d < 13 ? d : d + 1;
+                constexpr int dz = c / 9 - 1, dy = (c / 3) % 3 - 1, dx = c % 3 - 1;
+                constexpr uint32_t need = (dz < 0 ? 1u : (dz > 0 ? 2u : 0u)) | (dy < 0 ? 4u : (dy > 0 ? 8u : 0u)) | (dx < 0 ? 16u : (dx > 0 ? 32u : 0u));
+                const int64_t qz = z0 + vz, qy = y0 + vy, qx = x0 + vx;
+                const uint32_t nbq = (qz > 0 ? 1u : 0u) | (qz + 1 < L.dz ? 2u : 0u) | (qy > 0 ? 4u : 0u) | (qy + 1 < L.dy ? 8u : 0u) |
+                                     (qx > 0 ? 16u : 0u) | (qx + 1 < L.dx ? 32u : 0u);
+                const bool has = qz < L.dz && qy < L.dy && qx < L.dx && (nbq & need) == need;
+                double w = 0.0;
+                if (has && TERM != MGC_TERM_NONE) {
+                    const int mq = mgc_hs_index(vz, vy, vx);
+                    const double a = img[mq], b = img[mq + dz * 100 + dy * 10 + dx];
+                    const double* const lut = TABLE ? A.lut : nullptr;
+                    const int lut_n = TABLE ? A.lut_n : 0;
+                    w = d >= 13 ? mgc_boundary_g(TERM, a, b, A.p0, lut, lut_n) : mgc_boundary_g(TERM, b, a, A.p0, lut, lut_n); /* g(lower, upper) */
+                    if (A.has_spacing) w = w / A.div26[d];
+                }
+                return w;
+            };
             if (pre) {
                 /* ---- PRE-PUSH (no reference counterpart; part of the solver, not of the energy terms): with a regional term every
                  * tile holds voxels with a source link next to voxels with a sink link, and the first colour round of the solve
@@ -1523,6 +1544,43 @@ __device__ __forceinline__ void k_build_tiles(const MgcLattice& L, const MgcBuil
                 double* const dfc = pre_lds;                 /* [512] what the voxels' sink links still take */
                 double e = tr > 0.0 ? tr : 0.0;
                 dfc[t] = tr < 0.0 ? -tr : 0.0;
+                /* Every arc pair is evaluated ONCE, by its lower end: the weight of (v, dA) -- dA points to the LOWER neighbour -- is the weight of
+                 * (v + o(dA), dB = 25 - dA), which that neighbour computes anyway.  Until round 6 every voxel evaluated all 26 (twice the exp / pow of
+                 * the 13 pairs: 5.4 ms of instruction issue at 512^3).  produce(i): every voxel evaluates ITS dB-weight of pair i and leaves it in the
+                 * exchange buffer at the slot of the voxel above (the one whose dA-weight it is); the voxels whose lower neighbour lies in ANOTHER tile
+                 * (one, two or three boundary layers of the tile: 64 ... 169 of 512) get theirs evaluated directly, by the first so many threads of the
+                 * workgroup -- whole waves, not the boundary lanes of every wave.  Pair i + 1 is produced while pair i is pushed (the two barriers of a
+                 * pair are the ones the hand-off needs: none is added), into the buffer of the other parity. */
+                double* const wx = pre_lds + 5 * MGC_TV; /* [2][512] */
+                double wB_carry = 0.0;
+                auto produce = [&](auto ic) __attribute__((always_inline)) {
+                    constexpr int i = decltype(ic)::value;
+                    constexpr int dA = i, dB = 25 - i;
+                    constexpr int dz = dA / 9 - 1, dy = (dA / 3) % 3 - 1, dx = dA % 3 - 1;
+                    double* const buf = wx + (i & 1) * MGC_TV;
+                    wB_carry = weight(std::integral_constant<int, dB>{});
+                    { /* my dB-weight is the dA-weight of the voxel at t - o(dA) */
+                        const int zb = lz - dz, yb = ly - dy, xb = lx - dx;
+                        if (zb >= 0 && zb < 8 && yb >= 0 && yb < 8 && xb >= 0 && xb < 8) buf[t - (dz * 64 + dy * 8 + dx)] = wB_carry;
+                    }
+                    /* the voxels v with v + o(dA) outside the tile: layer z == zf (dz != 0), then y == yf of the other layers (dy != 0), then x == xf of what is left */
+                    constexpr int zf = dz < 0 ? 0 : 7, yf = dy < 0 ? 0 : 7, xf = dx < 0 ? 0 : 7;
+                    constexpr int zs = dz != 0 ? 7 : 8, ys = dy != 0 ? 7 : 8;
+                    constexpr int nZ = dz != 0 ? 64 : 0, nY = dy != 0 ? zs * 8 : 0, nX = dx != 0 ? zs * ys : 0;
+                    if (t < nZ + nY + nX) {
+                        int vz, vy, vx;
+                        if (t < nZ) { vz = zf; vy = t >> 3; vx = t & 7; }
+                        else if (t < nZ + nY) {
+                            const int k = t - nZ, zi = k >> 3;
+                            vz = zi + ((dz != 0 && zi >= zf) ? 1 : 0); vy = yf; vx = k & 7;
+                        } else {
+                            const int k = t - nZ - nY, zi = k / ys, yi = k % ys;
+                            vz = zi + ((dz != 0 && zi >= zf) ? 1 : 0); vy = yi + ((dy != 0 && yi >= yf) ? 1 : 0); vx = xf;
+                        }
+                        buf[vz * 64 + vy * 8 + vx] = weight_at(std::integral_constant<int, dA>{}, vz, vy, vx);
+                    }
+                };
+                produce(std::integral_constant<int, 0>{});
                 __syncthreads();
                 mgcw_static_for<13>([&](auto ic) __attribute__((always_inline)) {
                     constexpr int i = decltype(ic)::value;
@@ -1531,7 +1589,9 @@ __device__ __forceinline__ void k_build_tiles(const MgcLattice& L, const MgcBuil
                     constexpr int dz = c / 9 - 1, dy = (c / 3) % 3 - 1, dx = c % 3 - 1;
                     double* const revA = pre_lds + MGC_TV * (1 + 2 * (i & 1)); /* [512] what arrived along dA (double-buffered over the pairs) */
                     double* const revB = revA + MGC_TV;                          /* ... along dB */
-                    double wA = weight(std::integral_constant<int, dA>{}), wB = weight(std::integral_constant<int, dB>{});
+                    double wA = wx[(i & 1) * MGC_TV + t], wB = wB_carry;
+                    if (L.cap0) L.cap0[((int64_t)tile * MGC26_NDIR + dA) * MGC_TV + t] = wA; /* (as built) */
+                    if constexpr (i < 12) produce(std::integral_constant<int, i + 1>{}); /* (read at the top of the next pair, two barriers from here) */
                     const int za = lz + dz, ya = ly + dy, xa = lx + dx, zb = lz - dz, yb = ly - dy, xb = lx - dx;
                     const bool inA = za >= 0 && za < 8 && ya >= 0 && ya < 8 && xa >= 0 && xa < 8; /* my neighbour along dA lies in the tile */
                     const bool inB = zb >= 0 && zb < 8 && yb >= 0 && yb < 8 && xb >= 0 && xb < 8;
@@ -1649,7 +1709,7 @@ __global__ __launch_bounds__(MGC_TV, FULL ? MGC_BUILD_WAVES26 : (PRE6 ? 4 : ((TE
     __shared__ double scratch[MGC_TV];
     __shared__ double wf[FULL ? 1 : 3 * 576]; /* 6-neighbourhood: the forward n-link weights of the tile and its lower faces */
     __shared__ int tflag;
-    __shared__ double pre_lds[(FULL || PRE6) ? 5 * MGC_TV : 1]; /* pre-push: residual sink capacities + two double-buffered hand-off planes */
+    __shared__ double pre_lds[FULL ? 7 * MGC_TV : (PRE6 ? 5 * MGC_TV : 1)]; /* pre-push: residual sink capacities + two double-buffered hand-off planes (+ full neighbourhood: the weight exchange, two buffers) */
     k_build_tiles<FULL, TERM, PRE6, TABLE>(L, A, img, scratch, wf, &tflag, pre_lds);
 }
 
