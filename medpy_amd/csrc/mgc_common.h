@@ -34,6 +34,11 @@
 #define MGC_NDIR 6
 #define MGC_MASK_SINK 0x40      /* rmask bit 6: residual capacity to the sink > 0 */
 #define MGC_NCOUNT 32
+#define MGC_ST_SETTLED 1u      /* (full neighbourhood) every voxel of the tile that has a residual arc at all stands at label 1 or 2, i.e. as low as a voxel
+                                  with / without a sink link can ever stand: no relabel pass can lower anything here, so a pass that is sent to the tile
+                                  returns at once and nobody needs to send one.  Set by the relabel visit that found it so (together with the support
+                                  bits, which stay valid: labels only come down during a relabel); cleared wherever labels are reset (fill_heights_inf,
+                                  reset of the suspect tiles -- a discharge that raises a label makes its tile DIRTY, hence suspect) */
 #define MGC_ST_SINK 2u
 #define MGC_ST_DIRTY 4u
 #define MGC_ST_SUSPECT 8u

@@ -831,10 +831,10 @@ __global__ void k_zero_counts(MgcLattice L, uint32_t mask)
     if (sh < L.nshard) *mgc_counter(L, c, sh) = 0;
 }
 
-__global__ void k_status_or(MgcLattice L, uint32_t bits)
+__global__ void k_status_or(MgcLattice L, uint32_t bits, uint32_t clear)
 {
     const int tile = blockIdx.x * blockDim.x + threadIdx.x;
-    if (tile < L.ntiles) L.status[tile] |= bits;
+    if (tile < L.ntiles) L.status[tile] = (L.status[tile] & ~clear) | bits;
 }
 
 /* incremental global relabel: tile-level suspect closure (one thread per tile) and reset of the suspect tiles.
@@ -886,7 +886,7 @@ __global__ __launch_bounds__(MGC_TV) void k_reset_suspect(MgcLattice L, uint32_t
         }
         if ((int)threadIdx.x < n) {
             const int tile = sel[threadIdx.x];
-            L.status[tile] = (L.status[tile] & ~(MGC_ST_SUSPECT | MGC_ST_DIRTY | (FULL ? MGC26_ST_DEP_MASK : (63u << MGC_ST_DEP_SHIFT)))) | MGC_ST_ALLINF;
+            L.status[tile] = (L.status[tile] & ~(MGC_ST_SUSPECT | MGC_ST_DIRTY | MGC_ST_SETTLED | (FULL ? MGC26_ST_DEP_MASK : (63u << MGC_ST_DEP_SHIFT)))) | MGC_ST_ALLINF;
             if (bricks) mgc_enqueue_brick(x, L, list, epoch, mgc_brick_of_tile(L, tile)); /* the passes of this relabel run over bricks (k_relabel_b) */
             else mgc_enqueue(x, L, list, L.rstamp, epoch, tile);
         }
@@ -2587,7 +2587,7 @@ struct HipDevT {
         flush_zero();
         h->labels_valid = true;
         check(hipMemsetAsync(h->L.height, 0x3f, (size_t)h->L.ntiles * MGC_TV * sizeof(int32_t), h->stream));
-        hipLaunchKernelGGL(k_status_or, dim3((h->L.ntiles + 255) / 256), dim3(256), 0, h->stream, h->L, (uint32_t)MGC_ST_ALLINF); /* until a relabel lowers a label */
+        hipLaunchKernelGGL(k_status_or, dim3((h->L.ntiles + 255) / 256), dim3(256), 0, h->stream, h->L, (uint32_t)MGC_ST_ALLINF, (uint32_t)MGC_ST_SETTLED); /* until a relabel lowers a label */
         for (int sd = 0; sd < 2; ++sd) /* the neighbour slabs fill their ghost layers too: the shadows of what they hold follow */
             if (h->L.hshadow[sd]) check(hipMemsetAsync(h->L.hshadow[sd], 0x3f, (size_t)h->L.gy * h->L.gx * MGC_TF * sizeof(int32_t), h->stream));
     }

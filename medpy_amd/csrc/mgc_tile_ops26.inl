@@ -42,8 +42,10 @@ struct MgcTileShared26 {
     double  out[4][MGC_TV];  /* push hand-off: two directions per step, double buffered */
     int32_t nbr[27];      /* neighbour tile ids, index = (dz+1)*9 + (dy+1)*3 + (dx+1); 13 = self */
     int32_t nbrflag[27];
+    int32_t nbrsettled[27]; /* relabel: the neighbour tile was MGC_ST_SETTLED when the visit began */
     int32_t depflag[27];  /* relabel: some label of the tile is supported by a voxel of that neighbour tile */
     int32_t flag[2];
+    int32_t bfs_above[2]; /* mgc26_tile_bfs: the last round (of either parity) in which some voxel stood above 2 */
     int32_t satflag;      /* discharge: some arc (or sink link) of the tile was saturated               */
     uint32_t dirmask[2];  /* discharge: directions along which some active voxel can push in this sweep  */
     uint32_t pushmask;    /* discharge: directions along which a voxel of the tile DID push               */
@@ -84,6 +86,20 @@ MGC_HD int mgc26_hs_step(int d)
     return dz * 100 + dy * 10 + dx;
 }
 
+/* Does this tile's status word `st` vouch for the label behind direction (dz, dy, dx) of its voxel (z, y, x)?  It does for a voxel of the
+ * tile itself (a tile whose labels move is DIRTY) and for a voxel of a neighbour tile whose support bit is set (the tile turns suspect with
+ * that neighbour).  A label ONE DOWN behind a residual arc into any other neighbour tile is a support nobody watches -- the support bits are
+ * those of the tile's last relabel visit; a tile that settled in the first pass of a relabel (MGC_ST_SETTLED) never looked over its borders, and
+ * a neighbour may have come down to "one below" later without waking anybody -- so a voxel that saturates an arc does not keep its label
+ * on the strength of it: its tile is DIRTY. */
+MGC_HD bool mgc26_support_watched(uint32_t st, int z, int y, int xx, int dz, int dy, int dx)
+{
+    const int vz = z + dz, vy = y + dy, vx = xx + dx;
+    const int oz = vz < 0 ? -1 : (vz > 7 ? 1 : 0), oy = vy < 0 ? -1 : (vy > 7 ? 1 : 0), ox = vx < 0 ? -1 : (vx > 7 ? 1 : 0);
+    const int ni = (oz + 1) * 9 + (oy + 1) * 3 + (ox + 1);
+    return ni == 13 || ((st >> mgc26_dep_bit(ni)) & 1u) != 0;
+}
+
 MGC_HD int mgc26_colour(const MgcLattice& L, int tz, int ty, int tx) { return (((tz + L.tz_global0) & 1) << 2) | ((ty & 1) << 1) | (tx & 1); }
 
 /* every lane: 27 neighbour tile ids into LDS, flags cleared.  Needs a barrier afterwards. */
@@ -117,10 +133,19 @@ MGC_HD void mgc26_load_halo(X& x, const MgcLattice& L, int t)
     }
 }
 
-template <class X, class MaskFn>
-MGC_HD void mgc26_tile_bfs(X& x, MaskFn mask)
+/* Chaotic relaxation of the tile's own cells of x.S.hs to the fixpoint, halo frozen.  A round that changed something is followed by
+ * another one only while some voxel could still come down: a voxel with a sink link stands at 1, every other one at 2 or above, so
+ * a tile whose voxels are all at 1 or 2 (or cut off: mask 0) is done whatever the round changed -- with a regional term that is
+ * nine tiles in ten after ONE round (every voxel has a t-link; the few without a sink link stand next to one that has), and the
+ * round that would only confirm it was a third of k26_relabel_all at 512^3.  sink_tile (uniform): the tile holds a sink link at all;
+ * the others never get there and skip the bookkeeping. */
+template <bool RULE, class X, class MaskFn>
+MGC_HD bool mgc26_tile_bfs_rounds(X& x, MaskFn mask)
 {
-    for (;;) {
+    for (int round = 0;; ++round) {
+        /* "somebody is still above 2" travels beside the vote: whoever is writes the round's number into the slot of the round's
+         * parity (read behind the vote's barrier; the next writer of that slot is two barriers away).  A stale number that happens
+         * to match only costs a round. */
         const bool changed = x.any([&](int t) -> bool {
             const uint32_t m = mask(t);
             if (!m) return false;
@@ -134,32 +159,61 @@ MGC_HD void mgc26_tile_bfs(X& x, MaskFn mask)
                 const int c = ((m >> d) & 1u) ? hv + 1 : MGC_HINF;
                 cand = c < cand ? c : cand;
             }
+            if (RULE && (cand < own ? cand : own) > 2) x.S.bfs_above[round & 1] = round;
             if (cand < own) {
                 x.S.hs[me] = cand;
                 return true;
             }
             return false;
         });
-        if (!changed) break;
+        const bool settled = RULE && x.S.bfs_above[round & 1] != round;
+        if (!changed || settled) return settled;
     }
 }
 
-/* global relabel, one tile of one pass (see mgc_relabel_tile) */
+template <class X, class MaskFn>
+MGC_HD bool mgc26_tile_bfs(X& x, MaskFn mask, bool sink_tile) /* returns: every voxel with a residual arc is known to stand at 1 or 2 */
+{
+    /* (two instances of the rounds: the bookkeeping of the rule is 4 % of a round, and the relabels of a volume without a regional
+     * term run nearly all their rounds in tiles without a sink link) */
+    return sink_tile ? mgc26_tile_bfs_rounds<true>(x, mask) : mgc26_tile_bfs_rounds<false>(x, mask);
+}
+
+/* global relabel, one tile of one pass (see mgc_relabel_tile).
+ * first_pass: the pass over ALL tiles that follows fill_heights_inf (the first relabel of a solve; every relabel without the incremental
+ * closure).  Every label outside the tile is INF then -- or is being written by a neighbour in the same launch; reading INF for it is
+ * just as valid (labels only come down during a relabel) and the same on every run -- so the halo is not fetched, no label of the
+ * tile stands on a neighbour tile (no support bits), and a tile that found a finite label wakes ALL its neighbours for the second
+ * pass, where every one of them sees the others' labels and the support bits are set for good.  (Until round 6 this pass fetched
+ * 488 INFs per tile and walked the 26 directions of every border voxel to find that its neighbours are INF: 1.5 of the pass's 3.6 ms
+ * at 512^3.) */
 template <class X>
 MGC_HD void mgc26_relabel_tile(X& x, const MgcLattice& L, int tile, uint32_t next_epoch, int next_list, bool first_pass)
 {
-    if (!mgc_owned(L, tile) || (first_pass && !(L.status[tile] & 2u))) return;
+    if (!mgc_owned(L, tile) || (first_pass && !(L.status[tile] & 2u)) || (L.status[tile] & MGC_ST_SETTLED)) return;
     typename X::template Reg<uint32_t> m;
     typename X::template Reg<int> h0;
     const int64_t base = (int64_t)tile * MGC_TV;
+    const bool sink_tile = (L.status[tile] & MGC_ST_SINK) != 0;
     x.par([&](int t) { mgc26_load_nbrs(x, L, tile, t); });
     x.par([&](int t) {
+        /* a neighbour that is settled already (MGC_ST_SETTLED) is never woken.  Asked here, with the visit's other loads, not in front of
+         * the enqueue at its end (a dependent trip per visit: +3 % on the relabels of a volume without a regional term); a neighbour that
+         * settles in the meantime is sent a pass it returns from at once */
+        if (t < 27) x.S.nbrsettled[t] = (sink_tile && x.S.nbr[t] >= 0) ? (int32_t)(L.status[x.S.nbr[t]] & MGC_ST_SETTLED) : 0; /* (a tile without a sink link rarely has settled neighbours: it does not ask) */
         m[t] = L.rmask32[base + t];
         h0[t] = L.height[base + t];
         x.S.hs[mgc_hs_index(t >> 6, (t >> 3) & 7, t & 7)] = h0[t];
-        mgc26_load_halo(x, L, t);
+        if (first_pass) {
+            for (int k = t; k < 1000; k += MGC_TV) {
+                const int z = k / 100 - 1, y = (k / 10) % 10 - 1, xx = k % 10 - 1;
+                if (z < 0 || z > 7 || y < 0 || y > 7 || xx < 0 || xx > 7) x.S.hs[k] = MGC_HINF;
+            }
+        } else {
+            mgc26_load_halo(x, L, t);
+        }
     });
-    mgc26_tile_bfs(x, [&](int t) { return m[t]; });
+    const bool settled = mgc26_tile_bfs(x, [&](int t) { return m[t]; }, sink_tile);
     x.par([&](int t) {
         const int z = t >> 6, y = (t >> 3) & 7, xx = t & 7;
         const int me = mgc_hs_index(z, y, xx);
@@ -170,7 +224,9 @@ MGC_HD void mgc26_relabel_tile(X& x, const MgcLattice& L, int tile, uint32_t nex
             L.height[base + t] = h;
             x.S.flag[0] = 1; /* not "all INF" (any more) */
         }
-        if (!border || h >= MGC_HINF) return;
+        if (first_pass) return; /* (flag[0] says whether the neighbours are woken, below) */
+        /* (a voxel at 1 stands on its sink link: it has no support next door, and it wakes nobody unless it came down) */
+        if (!border || h >= MGC_HINF || (h <= 1 && !lowered)) return;
 #pragma unroll
         for (int d = 0; d < MGC26_NDIR; ++d) {
             int dz, dy, dx;
@@ -186,12 +242,13 @@ MGC_HD void mgc26_relabel_tile(X& x, const MgcLattice& L, int tile, uint32_t nex
         }
     });
     x.par([&](int t) {
-        if (t < 27 && t != 13 && x.S.nbrflag[t] && x.S.nbr[t] >= 0) mgc_enqueue(x, L, next_list, L.rstamp, next_epoch, x.S.nbr[t]);
+        if (t < 27 && t != 13 && (first_pass ? x.S.flag[0] : x.S.nbrflag[t]) && x.S.nbr[t] >= 0 && !x.S.nbrsettled[t])
+            mgc_enqueue(x, L, next_list, L.rstamp, next_epoch, x.S.nbr[t]);
         if (t == 27) {
             uint32_t dep = 0;
             for (int ni = 0; ni < 27; ++ni)
                 if (ni != 13 && x.S.depflag[ni]) dep |= 1u << mgc26_dep_bit(ni);
-            L.status[tile] = (L.status[tile] & ~(MGC26_ST_DEP_MASK | (x.S.flag[0] ? MGC_ST_ALLINF : 0u))) | dep;
+            L.status[tile] = (L.status[tile] & ~(MGC26_ST_DEP_MASK | (x.S.flag[0] ? MGC_ST_ALLINF : 0u))) | dep | (settled ? MGC_ST_SETTLED : 0u);
         }
     });
 }
@@ -225,7 +282,7 @@ MGC_HD void mgc26_reset_suspect_tile(X& x, const MgcLattice& L, int tile, uint32
         x.par([&](int t) {
             L.height[(int64_t)tile * MGC_TV + t] = MGC_HINF;
             if (t == 0) {
-                L.status[tile] = (st & ~(MGC_ST_SUSPECT | MGC_ST_DIRTY | MGC26_ST_DEP_MASK)) | MGC_ST_ALLINF;
+                L.status[tile] = (st & ~(MGC_ST_SUSPECT | MGC_ST_DIRTY | MGC_ST_SETTLED | MGC26_ST_DEP_MASK)) | MGC_ST_ALLINF;
                 mgc_enqueue(x, L, list, L.rstamp, epoch, tile);
             }
         });
@@ -307,7 +364,7 @@ MGC_HD void mgc26_discharge_tile(X& x, const MgcLattice& L, int tile, uint32_t p
 #pragma unroll
                 for (int d = 0; d < MGC26_NDIR; ++d) m |= (R(d, t) > 0.0) ? (1u << d) : 0u;
                 return m;
-            });
+            }, (L.status[tile] & 2u) != 0);
         }
         active = x.any([&](int t) -> bool {
             hme[t] = x.S.hs[mgc_hs_index(t >> 6, (t >> 3) & 7, t & 7)];
@@ -470,8 +527,8 @@ MGC_HD void mgc26_discharge_tile(X& x, const MgcLattice& L, int tile, uint32_t p
     }
     if (active) active = x.any([&](int t) -> bool { return e[t] > 0.0 && hme[t] < MGC_HINF; });
     /* DIRTY (the next global relabel recomputes the tile and whoever depends on it) iff a label rose, or a voxel that saturated an
-     * arc has no residual arc one label down left.  A voxel that keeps one of its supports keeps its distance: with 26 neighbours
-     * most do, and the tiles a small flow merely passes through stay clean.  (With an exact in-tile labelling per discharge the
+     * arc has no residual arc one label down left that the tile watches (mgc26_support_watched).  A voxel that keeps one of its supports
+     * keeps its distance: with 26 neighbours most do, and the tiles a small flow merely passes through stay clean.  (With an exact in-tile labelling per discharge the
      * stored labels are not what the pushes followed: any saturation counts there.) */
     if (stored_labels) {
         x.par([&](int t) {
@@ -480,8 +537,13 @@ MGC_HD void mgc26_discharge_tile(X& x, const MgcLattice& L, int tile, uint32_t p
                 bool kept = false;
                 if (!sat_dirty) {
                     kept = snk[t] > 0.0; /* (a label of 1 stands on the sink link) */
+                    const uint32_t stk = L.status[tile]; /* (nobody else writes it during this launch) */
 #pragma unroll
-                    for (int d = 0; d < MGC26_NDIR; ++d) kept = kept || (R(d, t) > 0.0 && x.S.hs[me + mgc26_hs_step(d)] == hme[t] - 1);
+                    for (int d = 0; d < MGC26_NDIR; ++d) {
+                        int dz, dy, dx;
+                        mgc26_offset(d, dz, dy, dx);
+                        kept = kept || (R(d, t) > 0.0 && x.S.hs[me + mgc26_hs_step(d)] == hme[t] - 1 && mgc26_support_watched(stk, t >> 6, (t >> 3) & 7, t & 7, dz, dy, dx));
+                    }
                 }
                 if (!kept) x.S.satflag = 1;
             }

@@ -502,7 +502,8 @@ MGC_HD void mgcw26_discharge_tile(W& w, const MgcLattice& L, int tile, uint32_t 
                 bool kept = (m & MGC26_MASK_SINK) != 0; /* (a label of 1 stands on the sink link) */
                 mgcw_static_for<MGC26_NDIR>([&](auto DD) MGCW_INL {
                     constexpr int D = decltype(DD)::value;
-                    kept = kept || (((m >> D) & 1u) && w.S.hs[me + mgc26_hs_step(D)] == h - 1);
+                    constexpr int C = D < 13 ? D : D + 1;
+                    kept = kept || (((m >> D) & 1u) && w.S.hs[me + mgc26_hs_step(D)] == h - 1 && mgc26_support_watched(st0, K, l >> 3, l & 7, C / 9 - 1, (C / 3) % 3 - 1, C % 3 - 1));
                 });
                 return ((satl(l, 0) >> K) & 1) && h < MGC_HINF && !kept;
             });

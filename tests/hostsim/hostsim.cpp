@@ -312,7 +312,7 @@ struct HostDev : HostSlabOps<HostDev, HostBlockT<MgcTileShared>> {
     void fill_heights_inf()
     {
         for (int64_t i = 0; i < (int64_t)L.ntiles * MGC_TV; ++i) L.height[i] = MGC_HINF;
-        for (int t = 0; t < L.ntiles; ++t) L.status[t] |= MGC_ST_ALLINF; /* until a relabel lowers a label */
+        for (int t = 0; t < L.ntiles; ++t) L.status[t] = (L.status[t] & ~MGC_ST_SETTLED) | MGC_ST_ALLINF; /* until a relabel lowers a label */
         for (int sd = 0; sd < 2; ++sd) std::fill(hshadow[sd].begin(), hshadow[sd].end(), (int32_t)MGC_HINF); /* what the neighbours hold now */
     }
     void zero_count(int i) { L.count[i] = 0; }
@@ -984,7 +984,7 @@ struct HostDev26 : HostSlabOps<HostDev26, HostBlockT<MgcTileShared26D>> {
     void fill_heights_inf()
     {
         for (int64_t i = 0; i < (int64_t)L.ntiles * MGC_TV; ++i) L.height[i] = MGC_HINF;
-        for (int t = 0; t < L.ntiles; ++t) L.status[t] |= MGC_ST_ALLINF; /* until a relabel lowers a label */
+        for (int t = 0; t < L.ntiles; ++t) L.status[t] = (L.status[t] & ~MGC_ST_SETTLED) | MGC_ST_ALLINF; /* until a relabel lowers a label */
     }
     void range_push(const char*) {}
     void range_pop() {}

@@ -237,6 +237,39 @@ def test_hostsim_incremental_relabels_leave_exact_distances(conn, gen, shape, kw
     assert p[40] == st["outer"] and p[41] == 0
 
 
+@pytest.mark.parametrize("gen,shape,kw", [
+    ("sphere", (32, 32, 32), dict(rounds=1, cycles=-1, sweeps=1)),
+    ("hard", (24, 40, 17), dict(rounds=1, cycles=-1, sweeps=2)),
+    ("sphere", (32, 32, 32), dict(rounds=1, cycles=-1, sweeps=1, wave_mode=16)),
+    ("ties", (24, 24, 24), dict(rounds=2, cycles=-1, sweeps=2, wave_mode=16)),
+])
+def test_hostsim_settled_tiles_of_a_regional_term_leave_exact_distances(gen, shape, kw):
+    """Round 6, full neighbourhood: with a regional term every voxel holds a t-link, a relabel visit that finds every voxel of a tile at 1
+    or 2 marks the tile MGC_ST_SETTLED (no later pass of that relabel looks at it, nobody wakes it; a tile that settles in the first
+    pass never looks over its borders and carries no support bits), and a voxel that saturates an arc keeps its label only on a
+    support its tile watches (mgc26_support_watched).  After EVERY global relabel the labels are the exact distances, and the cut is
+    the reference's."""
+    import sim
+    from medpy_amd import synthetic
+    from oracle import energy_numpy, pipeline
+    s = getattr(synthetic, gen)(shape)
+    r = synthetic.regional(shape)
+    w = energy_numpy.boundary_weights_offsets(s["term"], s["image"], energy_numpy.forward_offsets(3, 26), s["sigma"])
+    g = pipeline.build_graph(s["fg"], s["bg"], weights=w, connectivity=26, prob=r["prob"], alpha=r["alpha"])
+    tr = np.array([g.get_trcap(i) for i in range(s["fg"].size)])
+    g.maxflow()
+    sim.set_check_exact(1)
+    sim.prof()
+    try:
+        lab, st = sim.solve26(shape, w, tr, **kw)
+        pr = sim.prof()
+    finally:
+        sim.set_check_exact(0)
+    assert st["converged"] == 1 and st["outer"] >= 3
+    assert pr[40] == st["outer"] and pr[41] == 0
+    np.testing.assert_array_equal(lab, g.labels().reshape(shape))
+
+
 @pytest.mark.parametrize("wave_mode,n", [(3, 112)])
 def test_hostsim_floods_in_several_radial_cycles_leave_exact_distances(wave_mode, n, monkeypatch):
     """a flood cut into several cycles on radial labels (radial_rounds0 = 1, a relabel in between, labels lowered again) starts
