@@ -1903,9 +1903,188 @@ __global__ __launch_bounds__(MGC_TV) void k_cut_value(MgcLattice L, MgcBuildArgs
  * read of the merged t-links -- no label volume, no 26 byte loads per voxel.  Every other tile takes the general path.
  * The sum of a tile has a fixed order (a lane adds its eight voxels in z order, then a shuffle tree over the lanes); the
  * workgroup form spent its time in ten barriers per tile behind one dependent load (2.1 ms at 512^3). */
+/* the general path of k_cut_value26 for ONE tile, by one wave.  The tile's 10 x 10 x 10 block of label bytes goes to LDS once (100 rows of
+ * ten bytes, two rows per lane; 1 = source side or outside the volume: nothing is paid towards it), and so does the image block (as doubles,
+ * |.|'d for the maximum terms): read from the volumes per voxel and direction it was 208 scattered byte loads and up to 416 dependent image
+ * loads per lane and tile.  The n-links a z-layer of the tile pays are first LISTED -- (voxel, direction) pairs, a lane's pairs in ascending
+ * direction, the lanes in order -- then evaluated 64 at a time, one pair per lane, and then summed up by their owners in the order of the
+ * list: a tile the cut passes through pays along ~8 % of its 13 312 (voxel, direction) pairs, and evaluating g(.) under the mask of whoever
+ * pays along direction d in layer z was 208 evaluations per wave for ~11 waves' worth of pairs (config 3: 1.3 of the 1.5 ms of the cut value).
+ * The additions of a lane are the same in the same order as without the list (sink link, then the directions in ascending order, layer by
+ * layer; a shuffle tree over the lanes): the value is bit for bit the same.  A layer with more than MGC_CUT_PAIRS pairs is evaluated in place.
+ * Returns the tile's sum in lane 0. */
+#define MGC_CUT_PAIRS 512
+struct MgcCutLds {
+    uint8_t lb[1000];           /* label bytes of the block  */
+    uint16_t pair[MGC_CUT_PAIRS]; /* (lane << 5) | direction   */
+    double ib[1000];            /* image block               */
+    double w[MGC_CUT_PAIRS];    /* the pairs' capacities     */
+};
+__device__ __forceinline__ void mgc_dir_offset(int ndir, int d, int& dz, int& dy, int& dx)
+{
+    if (ndir == 6) {
+        dz = (d >> 1) == 2 ? ((d & 1) ? 1 : -1) : 0;
+        dy = (d >> 1) == 1 ? ((d & 1) ? 1 : -1) : 0;
+        dx = (d >> 1) == 0 ? ((d & 1) ? 1 : -1) : 0;
+    } else {
+        mgc26_offset(d, dz, dy, dx);
+    }
+}
+__device__ __forceinline__ double mgc_cut_tile_general(const MgcLattice& L, const MgcBuildArgs& A, const double* tr0, const uint8_t* labels, MgcCutLds& W, int tile, int lane)
+{
+    int tz, ty, tx;
+    mgc_tile_coords(L, tile, tz, ty, tx);
+    uint8_t* const lb = W.lb;
+    double* const ib = W.ib;
+    const bool from_image = !L.cap0 && A.term != MGC_TERM_NONE;
+    if (from_image) {
+        const bool take_abs = (A.term == MGC_TERM_MAXIMUM_LINEAR || A.term == MGC_TERM_MAXIMUM_EXPONENTIAL || A.term == MGC_TERM_MAXIMUM_POWER);
+        for (int k = lane; k < 1000; k += 64) {
+            const int64_t rz = (int64_t)tz * 8 + k / 100 - 1, ry = (int64_t)ty * 8 + (k / 10) % 10 - 1, rx = (int64_t)tx * 8 + k % 10 - 1;
+            double v = 0.0;
+            if (rz >= 0 && rz < L.dz && ry >= 0 && ry < L.dy && rx >= 0 && rx < L.dx) v = mgc_load_as_double(A.image, A.img_dtype, (rz * L.dy + ry) * L.dx + rx, take_abs);
+            ib[k] = v;
+        }
+    }
+    const bool has_tlinks = L.ndir != 6 || A.tflags[tile] != 0; /* (6-neighbourhood: k_build writes tr0 only for tiles that hold a t-link) */
+    const int ly = lane >> 3, lx = lane & 7;
+    const int64_t gy = (int64_t)ty * 8 + ly, gx = (int64_t)tx * 8 + lx;
+    for (int row = lane; row < 100; row += 64) {
+        const int64_t rz = (int64_t)tz * 8 + row / 10 - 1, ry = (int64_t)ty * 8 + row % 10 - 1;
+        const bool row_in = rz >= 0 && rz < L.dz && ry >= 0 && ry < L.dy;
+#pragma unroll
+        for (int k = 0; k < 10; ++k) {
+            const int64_t rx = (int64_t)tx * 8 + k - 1;
+            uint8_t v = 1;
+            if (row_in && rx >= 0 && rx < L.dx) v = labels[(rz * L.dy + ry) * L.dx + rx];
+            lb[row * 10 + k] = v;
+        }
+    }
+    __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    /* the capacity of the arc (voxel l2 of layer lz, direction d) as built: mgc_built_capacity with the two voxels from the block */
+    auto capacity = [&](int lz, int l2, int d) -> double {
+        int dz, dy, dx;
+        mgc_dir_offset(L.ndir, d, dz, dy, dx);
+        if (from_image) {
+            const int m2 = ((lz + 1) * 10 + ((l2 >> 3) + 1)) * 10 + (l2 & 7) + 1;
+            const double a = ib[m2], b = ib[m2 + (dz * 10 + dy) * 10 + dx];
+            const bool fwd = L.ndir == 6 ? (d & 1) != 0 : d >= 13;
+            double w = mgc_boundary_g(A.term, fwd ? a : b, fwd ? b : a, A.p0, A.lut, A.lut_n); /* (lower voxel, upper voxel) like the reference slices */
+            if (A.has_spacing) w = w / (L.ndir == 6 ? A.inv_axis[d >> 1] : A.div26[d]);
+            return w;
+        }
+        return mgc_built_capacity(L, A, tile, lz * 64 + l2, (int64_t)tz * 8 + lz, (int64_t)ty * 8 + (l2 >> 3), (int64_t)tx * 8 + (l2 & 7), d);
+    };
+    double s = 0.0;
+    for (int lz = 0; lz < 8; ++lz) {
+        const int64_t gz = (int64_t)tz * 8 + lz;
+        const int t = lz * 64 + lane;
+        const bool valid = gz < L.dz && gy < L.dy && gx < L.dx;
+        const double tr = (valid && has_tlinks) ? tr0[(int64_t)tile * MGC_TV + t] : 0.0;
+        const int me = ((lz + 1) * 10 + (ly + 1)) * 10 + lx + 1;
+        const bool source_side = valid && lb[me] != 0;
+        uint32_t pays = 0; /* the directions along which this voxel pays an n-link: into T (a neighbour outside the volume reads 1) */
+        if (source_side) {
+            if (L.ndir == MGC26_NDIR) { /* (constant offsets: 26 byte reads with immediate addresses) */
+                mgcw_static_for<MGC26_NDIR>([&](auto dc) __attribute__((always_inline)) {
+                    constexpr int d = decltype(dc)::value;
+                    constexpr int c = d < 13 ? d : d + 1;
+                    if (!lb[me + ((c / 9 - 1) * 10 + ((c / 3) % 3 - 1)) * 10 + (c % 3 - 1)]) pays |= 1u << d;
+                });
+            } else {
+                for (int d = 0; d < L.ndir; ++d) {
+                    int dz, dy, dx;
+                    mgc_dir_offset(L.ndir, d, dz, dy, dx);
+                    if (!lb[me + (dz * 10 + dy) * 10 + dx]) pays |= 1u << d;
+                }
+            }
+        }
+        if (__ballot(pays != 0u) == 0ull) { /* (uniform) a layer the cut does not pass through */
+            if (source_side) { if (tr < 0.0) s += -tr; }
+            else if (valid && tr > 0.0) s += tr;
+            continue;
+        }
+        const int mine = __popc(pays);
+        int before = mine; /* inclusive scan over the lanes */
+#pragma unroll
+        for (int off = 1; off < 64; off <<= 1) {
+            const int v = __shfl_up(before, off, 64);
+            if (lane >= off) before += v;
+        }
+        const int total = __shfl(before, 63, 64);
+        before -= mine;
+        if (total <= MGC_CUT_PAIRS) {
+            {
+                uint32_t m = pays;
+                for (int j = before; m; ++j) {
+                    const int d = __builtin_ctz(m);
+                    m &= m - 1u;
+                    W.pair[j] = (uint16_t)((lane << 5) | d);
+                }
+            }
+            __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+            __builtin_amdgcn_wave_barrier();
+            for (int i = lane; i < total; i += 64) {
+                const int pr = W.pair[i];
+                W.w[i] = capacity(lz, pr >> 5, pr & 31);
+            }
+            __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+            __builtin_amdgcn_wave_barrier();
+            if (source_side) { /* pays its sink link and every n-link into T */
+                if (tr < 0.0) s += -tr;
+                for (int j = before; j < before + mine; ++j) s += W.w[j];
+            } else if (valid && tr > 0.0) { /* sink side: pays its source link */
+                s += tr;
+            }
+            __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront"); /* (the next layer rewrites the list) */
+            __builtin_amdgcn_wave_barrier();
+        } else {
+            if (source_side) {
+                if (tr < 0.0) s += -tr;
+                for (uint32_t m = pays; m; m &= m - 1u) s += capacity(lz, lane, __builtin_ctz(m));
+            } else if (valid && tr > 0.0) {
+                s += tr;
+            }
+        }
+    }
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) s += __shfl_down(s, off, 64);
+    __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront"); /* (the next tile of this wave rewrites the blocks) */
+    __builtin_amdgcn_wave_barrier();
+    return s;
+}
+
+/* second launch of the two-launch form: the marked tiles (-1.0).  Wave g of W looks at the tiles g, g + W, g + 2 W, ... -- 64 of them at a
+ * time, a lane each -- and takes the marked ones in turn.  W is not a multiple of the tile grid's row or layer length (mgc_launch_cut_value26),
+ * so a run of marked tiles along any axis -- where the cut runs parallel to it for a while -- is spread over as many waves as it is long:
+ * a wave per 64 CONSECUTIVE tiles left whole rows of the sphere's caps to single waves (config 3: 1.30 ms for the ~5 % of the tiles that are
+ * marked, 0.25 ms for all the others in the first launch). */
+__device__ __forceinline__ void k_cut_value26_marked(const MgcLattice& L, const MgcBuildArgs& A, const double* tr0, const uint8_t* labels, double* part)
+{
+    __shared__ MgcCutLds lds[4];
+    const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+    const int64_t W = (int64_t)gridDim.x * 4, g = (int64_t)blockIdx.x * 4 + wv;
+    for (int64_t base = 0; base < L.ntiles; base += W * 64) {
+        const int64_t mine = base + g + (int64_t)lane * W;
+        unsigned long long todo = __ballot(mine < L.ntiles && part[mine] == -1.0);
+        while (todo) {
+            const int tile = (int)(base + g + (int64_t)__builtin_ctzll(todo) * W);
+            todo &= todo - 1ull;
+            const double s = mgc_cut_tile_general(L, A, tr0, labels, lds[wv], tile, lane);
+            if (lane == 0) part[tile] = s;
+        }
+    }
+}
+
+template <int MODE> /* 0: every tile in one launch (no label summaries); 1: the tiles that pay t-links only, the others are marked; 2: the marked tiles */
 __global__ __launch_bounds__(256) void k_cut_value26(MgcLattice L, MgcBuildArgs A, const double* tr0, const uint8_t* labels, const uint8_t* tsum, double* part)
 {
-    __shared__ uint8_t lab_lds[4][1000];
+    if constexpr (MODE == 2) {
+        k_cut_value26_marked(L, A, tr0, labels, part);
+        return;
+    }
+    __shared__ MgcCutLds lds[MODE == 0 ? 4 : 1];
     const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
     for (int tile = (int)blockIdx.x * 4 + wv; tile < L.ntiles; tile += (int)gridDim.x * 4) {
         int tz, ty, tx;
@@ -1924,28 +2103,20 @@ __global__ __launch_bounds__(256) void k_cut_value26(MgcLattice L, MgcBuildArgs 
             }
         }
         const bool general = __ballot(differs) != 0ull;
+        if (MODE == 1 && general) { /* (wave-uniform) left to the second launch: a capacity is never negative */
+            if (lane == 0) part[tile] = -1.0;
+            continue;
+        }
+        if constexpr (MODE == 0) {
+            if (general) {
+                const double sg = mgc_cut_tile_general(L, A, tr0, labels, lds[MODE == 0 ? wv : 0], tile, lane);
+                if (lane == 0) part[tile] = sg;
+                continue;
+            }
+        }
         const bool has_tlinks = L.ndir != 6 || A.tflags[tile] != 0; /* (6-neighbourhood: k_build writes tr0 only for tiles that hold a t-link) */
         const int ly = lane >> 3, lx = lane & 7;
         const int64_t gy = (int64_t)ty * 8 + ly, gx = (int64_t)tx * 8 + lx;
-        /* a tile the cut passes through: its 10 x 10 x 10 block of label bytes goes to LDS once (100 rows of ten bytes, two rows per lane; 1 = source side
-         * or outside the volume: nothing is paid towards it) -- read from the label volume per voxel and direction it was 208 scattered byte loads per
-         * lane and tile, 1.7 of the kernel's 2.06 ms on config 3 */
-        uint8_t* const lb = lab_lds[wv];
-        if (general) {
-            for (int row = lane; row < 100; row += 64) {
-                const int64_t rz = (int64_t)tz * 8 + row / 10 - 1, ry = (int64_t)ty * 8 + row % 10 - 1;
-                const bool row_in = rz >= 0 && rz < L.dz && ry >= 0 && ry < L.dy;
-#pragma unroll
-                for (int k = 0; k < 10; ++k) {
-                    const int64_t rx = (int64_t)tx * 8 + k - 1;
-                    uint8_t v = 1;
-                    if (row_in && rx >= 0 && rx < L.dx) v = labels[(rz * L.dy + ry) * L.dx + rx];
-                    lb[row * 10 + k] = v;
-                }
-            }
-            __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
-            __builtin_amdgcn_wave_barrier();
-        }
         double s = 0.0;
 #pragma unroll
         for (int lz = 0; lz < 8; ++lz) {
@@ -1953,29 +2124,8 @@ __global__ __launch_bounds__(256) void k_cut_value26(MgcLattice L, MgcBuildArgs 
             const int t = lz * 64 + lane;
             if (!(gz < L.dz && gy < L.dy && gx < L.dx)) continue;
             const double tr = has_tlinks ? tr0[(int64_t)tile * MGC_TV + t] : 0.0;
-            if (!general) {
-                if (side == 1) { if (tr < 0.0) s += -tr; } /* source side: pays its sink link (no n-link leaves the 27 tiles' common side) */
-                else if (tr > 0.0) s += tr;                /* sink side: pays its source link */
-            } else {
-                const int me = ((lz + 1) * 10 + (ly + 1)) * 10 + lx + 1;
-                if (lb[me]) { /* source side: pays its sink link and every n-link into T */
-                    if (tr < 0.0) s += -tr;
-                    for (int d = 0; d < L.ndir; ++d) {
-                        int dz, dy, dx;
-                        if (L.ndir == 6) {
-                            dz = (d >> 1) == 2 ? ((d & 1) ? 1 : -1) : 0;
-                            dy = (d >> 1) == 1 ? ((d & 1) ? 1 : -1) : 0;
-                            dx = (d >> 1) == 0 ? ((d & 1) ? 1 : -1) : 0;
-                        } else {
-                            mgc26_offset(d, dz, dy, dx);
-                        }
-                        if (!lb[me + (dz * 10 + dy) * 10 + dx]) /* (a neighbour outside the volume reads 1) */
-                            s += mgc_built_capacity(L, A, tile, t, gz, gy, gx, d);
-                    }
-                } else if (tr > 0.0) { /* sink side: pays its source link */
-                    s += tr;
-                }
-            }
+            if (side == 1) { if (tr < 0.0) s += -tr; } /* source side: pays its sink link (no n-link leaves the 27 tiles' common side) */
+            else if (tr > 0.0) s += tr;                /* sink side: pays its source link */
         }
 #pragma unroll
         for (int off = 32; off > 0; off >>= 1) s += __shfl_down(s, off, 64);
@@ -3123,6 +3273,22 @@ static void mgc_sum_partials(mgc_handle h, int64_t n, double* out)
     }
 }
 
+/* k_cut_value26: with label summaries two launches (the t-link stream at full occupancy, then the tiles the cut passes through), without
+ * them every tile takes the general path in one */
+static void mgc_launch_cut_value26(mgc_handle h, int grid, bool rows8)
+{
+    MgcLattice& L = h->L;
+    if (!rows8) {
+        hipLaunchKernelGGL(k_cut_value26<0>, dim3((grid + 3) / 4 < 8192 ? (grid + 3) / 4 : 8192), dim3(256), 0, h->stream, L, h->build_args, (const double*)h->d_tr0, (const uint8_t*)h->d_labels, (const uint8_t*)nullptr, h->d_part);
+        return;
+    }
+    const int wgs = (L.ntiles + 3) / 4;
+    hipLaunchKernelGGL(k_cut_value26<1>, dim3(wgs < 16384 ? wgs : 16384), dim3(256), 0, h->stream, L, h->build_args, (const double*)h->d_tr0, (const uint8_t*)h->d_labels, (const uint8_t*)h->d_tsum, h->d_part);
+    int wg2 = ((L.ntiles + 127) / 128) | 1; /* W = 4 wg2 waves look at ~32 tiles each; odd: W is no multiple of a power-of-two row or layer of tiles */
+    if (wg2 > 16385) wg2 = 16385;
+    hipLaunchKernelGGL(k_cut_value26<2>, dim3(wg2), dim3(256), 0, h->stream, L, h->build_args, (const double*)h->d_tr0, (const uint8_t*)h->d_labels, (const uint8_t*)h->d_tsum, h->d_part);
+}
+
 /* read-out: the label volume (C order, 0 = SINK side) and the capacity of the cut those labels define, summed into
  * h->d_scalar[slot] */
 static int mgc_launch_readout(mgc_handle h, int slot, hipEvent_t after_labels)
@@ -3138,7 +3304,7 @@ static int mgc_launch_readout(mgc_handle h, int slot, hipEvent_t after_labels)
     if (L.ndir == 6 && h->d_prob && h->d_tr0 && !L.cap0 && L.nshard == 1) {
         /* a regional term: every tile pays t-links (the tile filter below would list them all, and k_cut_value6 sums a tile behind ten
          * barriers); 6-neighbourhood tiles write tr0 only where they hold t-links -- with a regional term that is everywhere */
-        hipLaunchKernelGGL(k_cut_value26, dim3((grid + 3) / 4 < 8192 ? (grid + 3) / 4 : 8192), dim3(256), 0, h->stream, L, h->build_args, (const double*)h->d_tr0, (const uint8_t*)h->d_labels, rows8 ? (const uint8_t*)h->d_tsum : (const uint8_t*)nullptr, h->d_part);
+        mgc_launch_cut_value26(h, grid, rows8);
     }
     else if (L.ndir == 6) {
         const int fg = (L.ntiles + 255) / 256;
@@ -3149,7 +3315,7 @@ static int mgc_launch_readout(mgc_handle h, int slot, hipEvent_t after_labels)
         hipLaunchKernelGGL(k_cut_value6, dim3(grid), dim3(MGC_TV), 0, h->stream, L, h->build_args, (const double*)h->d_tr0, 6, dev.fslot(0), h->d_part, dev.fnext(0));
         dev.filter_done(0, true);
     }
-    else if (L.ndir == MGC26_NDIR) hipLaunchKernelGGL(k_cut_value26, dim3((grid + 3) / 4 < 8192 ? (grid + 3) / 4 : 8192), dim3(256), 0, h->stream, L, h->build_args, (const double*)h->d_tr0, (const uint8_t*)h->d_labels, rows8 ? (const uint8_t*)h->d_tsum : (const uint8_t*)nullptr, h->d_part);
+    else if (L.ndir == MGC26_NDIR) mgc_launch_cut_value26(h, grid, rows8);
     else hipLaunchKernelGGL(k_cut_value, dim3(grid), dim3(MGC_TV), 0, h->stream, L, h->build_args, (const double*)h->d_tr0, (const uint8_t*)h->d_labels, h->d_part);
     MGC_HIP(h, hipGetLastError());
     mgc_sum_partials(h, (int64_t)L.ntiles, h->d_scalar + slot);
