@@ -546,15 +546,20 @@ MGC_HD void mgc_discharge_tile(X& x, const MgcLattice& L, int tile, uint32_t pha
         active = x.any([&](int t) -> bool { return e[t] > 0.0 && hme[t] < MGC_HINF; });
     }
     /* DIRTY (the next global relabel recomputes the tile and whoever depends on it) iff a label rose, or a voxel that saturated an
-     * arc has no residual arc one label down left: a voxel that keeps one of its supports keeps its distance.  (With an exact
+     * arc has no residual arc one label down left: a voxel that keeps one of its supports keeps its distance.  A support in a
+     * NEIGHBOUR tile counts only if the tile's support bits name that neighbour (then the tile turns suspect with it): the bits are
+     * those of the tile's last relabel visit, and a neighbour's voxel may have come down to "one below" later in that relabel
+     * without waking anybody (only a label that can IMPROVE a neighbour wakes it) -- a support nobody watches.  (With an exact
      * in-tile labelling per discharge the stored labels are not what the pushes followed: any saturation counts there.) */
     if (stored_labels) {
         x.par([&](int t) {
             if (lostarc[t] && hme[t] < MGC_HINF) {
                 const int me = mgc_hs_index(t >> 6, (t >> 3) & 7, t & 7);
                 bool kept = snk[t] > 0.0; /* (a label of 1 stands on the sink link) */
+                const uint32_t stk = L.status[tile]; /* (nobody else writes it during this launch) */
 #pragma unroll
-                for (int d = 0; d < 6; ++d) kept = kept || (x.S.r[d][t] > 0.0 && x.S.hs[me + mgc_hs_step(d)] == hme[t] - 1);
+                for (int d = 0; d < 6; ++d) /* (a support in a neighbour tile counts only if the tile's support bits watch that neighbour: see below) */
+                    kept = kept || (x.S.r[d][t] > 0.0 && x.S.hs[me + mgc_hs_step(d)] == hme[t] - 1 && (mgc_inside(d, t >> 6, (t >> 3) & 7, t & 7) || ((stk >> (MGC_ST_DEP_SHIFT + d)) & 1u)));
                 if (!kept || any_saturation) x.S.satflag = 1;
             }
         });

@@ -650,7 +650,9 @@ MGC_HD void mgcw_discharge_impl(W& w, const MgcLattice& L, int tile, uint32_t ph
                     if constexpr (D < 4) hv = w.S.hs[mgcw_hs(l, K) + mgc_hs_step(D)];
                     else if constexpr (D == 4) { if constexpr (K > 0) hv = h(l, K - 1); else hv = hz(l, 0); }
                     else { if constexpr (K < 7) hv = h(l, K + 1); else hv = hz(l, 1); }
-                    kept = kept || (r[D](l, K) > 0.0 && hv == hk - 1);
+                    /* (a support in a neighbour tile counts only if the tile's support bits watch that neighbour: mgc_support_watched) */
+                    const bool in = D == 0 ? (l & 7) > 0 : (D == 1 ? (l & 7) < 7 : (D == 2 ? (l >> 3) > 0 : (D == 3 ? (l >> 3) < 7 : (D == 4 ? K > 0 : K < 7))));
+                    kept = kept || (r[D](l, K) > 0.0 && hv == hk - 1 && (in || (((uint32_t)st0(l, 0) >> (MGC_ST_DEP_SHIFT + D)) & 1u)));
                 });
                 return ((sat(l, 0) >> K) & 1) && hk < MGC_HINF && !kept;
             });
