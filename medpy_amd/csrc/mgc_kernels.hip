@@ -1913,7 +1913,9 @@ __global__ __launch_bounds__(MGC_TV) void k_cut_value(MgcLattice L, MgcBuildArgs
  * The additions of a lane are the same in the same order as without the list (sink link, then the directions in ascending order, layer by
  * layer; a shuffle tree over the lanes): the value is bit for bit the same.  A layer with more than MGC_CUT_PAIRS pairs is evaluated in place.
  * Returns the tile's sum in lane 0. */
-#define MGC_CUT_PAIRS 512
+#ifndef MGC_CUT_PAIRS
+#define MGC_CUT_PAIRS 512 /* (a library built with 16 runs the GPU tests through the in-place path of crowded layers as well: profiles/r6_cut_pairs_overflow_path.txt) */
+#endif
 struct MgcCutLds {
     uint8_t lb[1000];           /* label bytes of the block  */
     uint16_t pair[MGC_CUT_PAIRS]; /* (lane << 5) | direction   */

@@ -1,13 +1,8 @@
 # one GPU call of round 6 (development aid; edited per call)
 cd $GRAFT_REPO_ROOT; mkdir -p gpurun_out
-O=gpurun_out/r6_ab_timing_stride26.jsonl; : > $O
-timeout 900 python tools/gpu_ab.py --n 512 --conn 26 --regional --tag c3 --reps 5 base timing_stride=7 timing_stride=3 kernel_timing=0 base >> $O 2>&1
-timeout 900 python tools/gpu_ab.py --n 512 --conn 26 --tag m26 --reps 2 base timing_stride=7 kernel_timing=0 >> $O 2>&1
-timeout 900 python tools/gpu_ab.py --n 256 --conn 26 --regional --tag c3_256 --reps 5 base timing_stride=7 kernel_timing=0 >> $O 2>&1
-python - <<'PY'
-import json
-for l in open("gpurun_out/r6_ab_timing_stride26.jsonl"):
-    if not l.startswith("{"): print(l[:200]); continue
-    d = json.loads(l)
-    print(d["tag"], d["n"], d["variant"], d["ms"], "solve", d["solve_ms"], "dis", d["discharge_ms"], "rel", d["relabel_ms"], d["same_labels"], d["dis_tiles"], d["rel_tiles"], d["phases"], d["relabels"])
-PY
+O=gpurun_out/r6_cut_pairs_overflow_path.txt
+echo "library built with -DMGC_CUT_PAIRS=16 (mgc_cut_tile_general: layers with more than 16 paying pairs are evaluated in place): the GPU tests that compare cut values" > $O
+MEDPY_HIP_LIB=$GRAFT_REPO_ROOT/build/lib_cp16.so timeout 1500 python -m pytest tests/test_gpu_full_neighbourhood.py tests/test_gpu_large.py tests/test_gpu_parity.py tests/test_gpu_validate.py -m gpu -q -x 2>&1 | grep -E "passed|failed|rror" | tail -n 3 >> $O
+MEDPY_HIP_LIB=$GRAFT_REPO_ROOT/build/lib_cp16.so timeout 300 python tools/gpu_ab.py --lib build/lib_cp16.so --n 512 --conn 26 --regional --tag cp16 --reps 2 base 2>&1 | cut -c1-330 >> $O
+timeout 300 python tools/gpu_ab.py --n 512 --conn 26 --regional --tag tree --reps 2 base 2>&1 | cut -c1-330 >> $O
+cat $O
