@@ -19,7 +19,7 @@ def row(name, key, note):
 
 
 row("256³", "config2", "labels = the reference's (`sphere_256_6`); launch-bound (a launch is one visit deep)")
-row("512³, 26-conn + regional map", "config3", "`k26_discharge_w`; `config3_at_256` in the same line checks the reference's label hash at 256³; counter traffic 553 MB per launch = 2.2 × (`pmc_discharge26.json`)")
+row("512³, 26-conn + regional map", "config3", "`k26_discharge_w`; round 5: 44.9 (the relabel with a regional term, §6b; the cut value in two launches; every arc pair's weight evaluated once in `k_build<true>`); `config3_at_256` in the same line checks the reference's label hash at 256³; counter traffic 553 MB per launch = 2.2 × (`pmc_discharge26.json`)")
 row("weak contrast 512³", "hard", "no walls → exact labels, repeated in-plane steps (round 5: 64.4)")
 row("tie-heavy 512³ (markers everywhere)", "ties", "round 5: 697")
 row("26-conn, markers only, 512³", "conn26_markers", "round 5: 236")
