@@ -2569,9 +2569,14 @@ struct mgc_graph {
      * graphs solved on exact labels throughout (no walls: weak contrast, integer-valued images, markers everywhere), bit 1 = also for graphs
      * whose flood runs on radial labels.  Measured on MI355X (profiles/r6_ab_repeat_policy.jsonl): 512^3 ct 73.4 -> 52.1 ms, hard 63.4 -> 59.7,
      * ties 706 -> 666; the headline volume 18.2 -> 18.0 at 512^3 but 4.40 -> 4.83 ms at 256^3 (every pushing direction pays a second vote,
-     * and there the launches are a visit or two deep): on for the first kind, off for the second */
-    int repeat_steps = 1;
+     * and there the launches are a visit or two deep): on for the first kind, off for the second.  Bit 2 = graphs of the second kind ONCE THEIR
+     * FLOOD IS OVER -- the rounds on exact labels behind it are thin flows again (the last holes, the leak) -- in volumes of at least
+     * repeat_flood_min_tiles tiles, where those launches are several visits deep (profiles/r6_ab_repeat_after_flood*.jsonl: 640^3 34.8 -> 34.0 ms,
+     * 512^3 18.05 -> 17.85; 384^3 9.82 -> 9.95, 256^3 4.48 -> 4.82: off there; the estimate of a launch's length, est_phase_tiles, does not
+     * tell these apart) */
+    int repeat_steps = 5;
     int repeat_min_tiles = 0;      /* ... only for launches of at least this many tiles (parameter repeat_min_tiles) */
+    int repeat_flood_min_tiles = 200000; /* ... (bit 2) tiles of the volume: 512^3 = 262 144, 384^3 = 110 592 */
     bool repeat_now = false;       /* (during a solve) */
     int wave_min_tiles = 512;      /* shorter lists are discharged by the workgroup-per-tile kernel (measured: 128^3 4.8 -> 3.4 ms, 256^3 10.8 -> 10.5 ms,
                                       512^3 unchanged; 1024 costs 512^3 8 % more discharges) */
@@ -2997,7 +3002,8 @@ struct HipDevT {
             if (exact_sink && h->exact_sink_tiles == 1 && sweeps > h->sink_sweeps) sweeps = h->sink_sweeps;
             const int dflags = ((h->wave_kernels & 4) ? MGCW_BFS : 0) | (exact_sink ? MGCW_BFS_SINK : 0) | (h->radial_on ? MGCW_SAT_DIRTY : 0) | ((h->radial_on && h->radial_cycle_no > 1) ? MGCW_INFLOW_DIRTY : 0);
             /* repeated in-plane steps (mgcw_discharge_impl<.., MGCW_REPEAT_MAX>): decided per SOLVE (repeat_now, mgc_maxflow / mgc_solve_slabs) */
-            const bool rep = h->repeat_now && h->est_phase_tiles >= h->repeat_min_tiles;
+            const bool rep = (h->repeat_now && h->est_phase_tiles >= h->repeat_min_tiles) ||
+                             ((h->repeat_steps & 4) && h->radial_cycle_no > 0 && !h->radial_on && h->L.ntiles >= h->repeat_flood_min_tiles); /* (bit 2: the flood is over) */
             if (rep) hipLaunchKernelGGL(k_discharge_w<MGCW_REPEAT_MAX>, dim3(h->wave_grid_dis), dim3(MGCW_LANES), 0, h->stream, h->L, lst, phase, sweeps, dflags, h->tk_dis, zero_idx, h->wave_stagger);
             else hipLaunchKernelGGL(k_discharge_w<1>, dim3(h->wave_grid_dis), dim3(MGCW_LANES), 0, h->stream, h->L, lst, phase, sweeps, dflags, h->tk_dis, zero_idx, h->wave_stagger);
             h->tk_dis ^= 1;
@@ -4611,8 +4617,9 @@ int mgc_set_param(mgc_handle h, const char* name, int64_t value)
         h->L.halo_max_rec = (int)(value < T ? value : T);
     }
     else if (!strcmp(name, "wave_stagger") && value >= 0) h->wave_stagger = (int)value;
-    else if (!strcmp(name, "repeat_steps") && value >= 0 && value <= 3) h->repeat_steps = (int)value;
+    else if (!strcmp(name, "repeat_steps") && value >= 0 && value <= 7) h->repeat_steps = (int)value;
     else if (!strcmp(name, "repeat_min_tiles") && value >= 0) h->repeat_min_tiles = (int)value;
+    else if (!strcmp(name, "repeat_flood_min_tiles") && value >= 0) h->repeat_flood_min_tiles = (int)value;
     else if (!strcmp(name, "list_shards") && (value == 1 || value == MGC_NSHARD)) { /* regions per work list (MgcLattice::scount); between solves only */
         mgc_flush_zero(h);
         MGC_HIP(h, hipMemsetAsync(h->L.count, 0, MGC_NCOUNT * (1 + MGC_NSHARD) * sizeof(int32_t), h->stream));

@@ -1,18 +1,14 @@
 # one GPU call of round 6 (development aid; edited per call)
 cd $GRAFT_REPO_ROOT; mkdir -p gpurun_out
-O=gpurun_out/r6_ab_relabel26_three_lists.jsonl; : > $O
-for L in build/lib_head2.so ""; do
-  T=${L:-tree}
-  timeout 300 python tools/gpu_ab.py ${L:+--lib $L} --n 512 --conn 26 --regional --tag "$T" --reps 4 base >> $O 2>&1
-  timeout 300 python tools/gpu_ab.py ${L:+--lib $L} --n 512 --conn 26 --tag "$T" --reps 2 base >> $O 2>&1
-  timeout 300 python tools/gpu_ab.py ${L:+--lib $L} --n 512 --conn 26 --wl hard --tag "$T" --reps 2 base >> $O 2>&1
-  timeout 300 python tools/gpu_ab.py ${L:+--lib $L} --n 256 --conn 26 --regional --tag "$T" --reps 4 base >> $O 2>&1
-done
-timeout 1500 python -m pytest tests/test_gpu_full_neighbourhood.py tests/test_gpu_large.py tests/test_gpu_slabs.py -m gpu -q -x 2>&1 | grep -E "passed|failed|rror" | tail -n 3
+O=gpurun_out/r6_ab_repeat_after_flood_threshold.jsonl; : > $O
+timeout 600 python tools/gpu_ab.py --n 512 --tag s512 --reps 5 repeat_steps=1 repeat_flood_min_tiles=0 repeat_flood_min_tiles=2048 repeat_flood_min_tiles=4096 repeat_flood_min_tiles=0 repeat_steps=1 >> $O 2>&1
+timeout 600 python tools/gpu_ab.py --n 256 --tag s256 --reps 7 repeat_steps=1 repeat_flood_min_tiles=2048 repeat_flood_min_tiles=4096 >> $O 2>&1
+timeout 600 python tools/gpu_ab.py --n 384 --tag s384 --reps 5 repeat_steps=1 repeat_flood_min_tiles=0 repeat_flood_min_tiles=2048 repeat_flood_min_tiles=4096 repeat_steps=1 >> $O 2>&1
+timeout 600 python tools/gpu_ab.py --n 640 --tag s640 --reps 3 repeat_steps=1 repeat_flood_min_tiles=0 repeat_flood_min_tiles=4096 >> $O 2>&1
 python - <<'PY'
 import json
-for l in open("gpurun_out/r6_ab_relabel26_three_lists.jsonl"):
+for l in open("gpurun_out/r6_ab_repeat_after_flood_threshold.jsonl"):
     if not l.startswith("{"): print(l[:200]); continue
     d = json.loads(l)
-    print(d["tag"], d["wl"], d["n"], d["conn"], d["regional"], d["ms"], "build", d["build_ms"], "solve", d["solve_ms"], "dis", d["discharge_ms"], "rel", d["relabel_ms"], repr(d["flow"]), d["same_labels"], d["dis_tiles"], d["rel_tiles"], d["phases"])
+    print(d["tag"], d["n"], d["variant"], d["ms"], "solve", d["solve_ms"], "dis", d["discharge_ms"], "rel", d["relabel_ms"], d["same_labels"], d["dis_tiles"], d["rel_tiles"], d["phases"], d["relabels"])
 PY
