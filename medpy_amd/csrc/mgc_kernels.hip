@@ -2570,11 +2570,11 @@ struct mgc_graph {
      * whose flood runs on radial labels.  Measured on MI355X (profiles/r6_ab_repeat_policy.jsonl): 512^3 ct 73.4 -> 52.1 ms, hard 63.4 -> 59.7,
      * ties 706 -> 666; the headline volume 18.2 -> 18.0 at 512^3 but 4.40 -> 4.83 ms at 256^3 (every pushing direction pays a second vote,
      * and there the launches are a visit or two deep): on for the first kind, off for the second.  Bit 2 = graphs of the second kind ONCE THEIR
-     * FLOOD IS OVER -- the rounds on exact labels behind it are thin flows again (the last holes, the leak) -- in volumes of at least
-     * repeat_flood_min_tiles tiles, where those launches are several visits deep (profiles/r6_ab_repeat_after_flood*.jsonl: 640^3 34.8 -> 34.0 ms,
-     * 512^3 18.05 -> 17.85; 384^3 9.82 -> 9.95, 256^3 4.48 -> 4.82: off there; the estimate of a launch's length, est_phase_tiles, does not
-     * tell these apart) */
-    int repeat_steps = 5;
+     * FLOOD IS OVER (the rounds on exact labels behind it are thin flows again: the last holes, the leak), in volumes of at least
+     * repeat_flood_min_tiles tiles.  Measured and left OFF (profiles/r6_ab_repeat_after_flood*.jsonl): one object in the volume gains -- 512^3
+     * 18.05 -> 17.85 ms, 640^3 34.8 -> 34.0 -- but 384^3 and 256^3 lose 1 - 8 %, and the 2048 x 1024 x 1024 volume of sixteen objects loses 6 %
+     * on one handle (549 -> 585 ms) and 4 % on eight slabs */
+    int repeat_steps = 1;
     int repeat_min_tiles = 0;      /* ... only for launches of at least this many tiles (parameter repeat_min_tiles) */
     int repeat_flood_min_tiles = 200000; /* ... (bit 2) tiles of the volume: 512^3 = 262 144, 384^3 = 110 592 */
     bool repeat_now = false;       /* (during a solve) */

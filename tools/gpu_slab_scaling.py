@@ -42,6 +42,9 @@ if n == 1:
     g = VoxelGraph(img.shape, connectivity=conn)
     g._set_boundary("difference_exponential", img, 15.0, False)
     g._set_markers(fg, bg)
+    for kv in os.environ.get("SLAB_PARAMS", "").split(","):  # (the same knobs as the slab path below: A/Bs on one box)
+        if kv:
+            g.set_param(kv.split("=")[0], int(kv.split("=")[1]))
     best = None
     for rep in range(2):
         t0 = time.perf_counter(); g._build(); f = g.maxflow(); dt = time.perf_counter() - t0
@@ -65,7 +68,11 @@ else:
     for rep in range(2):
         t0 = time.perf_counter()
         for s in slabs: s.build()
-        st = solve_slabs(slabs, ex, **{k: int(v) for k, v in (kv.split("=") for kv in os.environ.get("SLAB_PARAMS", "").split(",") if kv)})
+        kw = {k: int(v) for k, v in (kv.split("=") for kv in os.environ.get("SLAB_PARAMS", "").split(",") if kv)}
+        for k in [k for k in kw if k not in solve_slabs.__code__.co_varnames]:  # (a knob of the handles, not of the schedule: every slab gets it)
+            for s in slabs: s.set_param(k, kw[k])
+            del kw[k]
+        st = solve_slabs(slabs, ex, **kw)
         parts = [s.finish() for s in slabs]
         dt = time.perf_counter() - t0
         sts = [s.stats() for s in slabs]
