@@ -240,6 +240,32 @@ def test_full_neighbourhood_incremental_relabel_across_slabs(gen, shape, nslabs,
     np.testing.assert_array_equal(np.concatenate([sl.finish()[0] for sl in slabs], axis=0), ref)
 
 
+@pytest.mark.parametrize("gen,shape,nslabs", [("sphere", (48, 24, 24), 3), ("hard", (40, 24, 17), 2)])
+def test_full_neighbourhood_slabs_with_a_regional_term(gen, shape, nslabs):
+    """Round 6: with a regional term the relabel passes mark tiles MGC_ST_SETTLED (every voxel at label 1 or 2) and neither visit nor
+    wake them again, the first pass of a relabel reads no halo, and discharges keep a label only on watched supports -- across slab
+    borders (ghost tiles are never settled; an owned border tile that settled returns at once when a border message wakes it):
+    many global relabels, labels = the BK oracle's."""
+    import sim
+    from medpy_amd import synthetic
+    from medpy_amd.slab import LoopbackExchange, solve_slabs
+    from oracle import energy_numpy, pipeline
+    s = getattr(synthetic, gen)(shape)
+    r = synthetic.regional(shape)
+    w = energy_numpy.boundary_weights_offsets(s["term"], s["image"], energy_numpy.forward_offsets(3, 26), s["sigma"])
+    g = pipeline.build_graph(s["fg"], s["bg"], weights=w, connectivity=26, prob=r["prob"], alpha=r["alpha"])
+    tr = np.array([g.get_trcap(i) for i in range(s["fg"].size)])
+    g.maxflow()
+    ref = g.labels().reshape(shape).astype(bool)
+    w26 = sim.weights26(shape, w)
+    slabs = [sim.SimSlab26(shape, k, nslabs) for k in range(nslabs)]
+    for sl in slabs:
+        sl.load(w26, tr)
+    st = solve_slabs(slabs, LoopbackExchange(slabs), rounds_per_relabel=1, max_sweeps=1)
+    assert st["converged"] == 1 and st["outer"] >= 3
+    np.testing.assert_array_equal(np.concatenate([sl.finish()[0] for sl in slabs], axis=0), ref)
+
+
 STORE_WORKER = r'''
 import os, sys
 import numpy as np
